@@ -1,0 +1,74 @@
+/*
+ * mobi_oracle.h -- CPU oracle for the Mobiclip frame decoder (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is a plain-C restatement of the reference decoder
+ *   /root/reference/LibMobiclip/Codec/Mobiclip/MobiclipDecoder.cs  (DecodeVXS2 and callees,
+ *   :97-259 and :400-3937; the Bitmap/RGB block :260-323 is NOT part of the graded path)
+ * used as the checker for the HIP path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product library (libmobiclip_hip.so)
+ * never links, loads or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or sample media, and the
+ * C# reference cannot run in this image (no .NET).  See DESIGN.md "Oracle pinning" for the
+ * cross-checks that substitute (self-consistency identities, generator round trips, and a
+ * dev-time differential run against a mechanical transliteration of the C# source).
+ */
+#ifndef MOBI_ORACLE_H
+#define MOBI_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MobiclipDecoder.MobiclipVersion, MD.cs:32-37 */
+enum { MOBI_VER_VXDS = 0, MOBI_VER_MODSDS = 1, MOBI_VER_MOFLEX3DS = 2 };
+
+/* "what the C# code would have thrown" -- the reference swallows all of these (MD.cs:325) */
+enum {
+  ORA_OK = 0,
+  ORA_E_INDEX = -1,     /* IndexOutOfRangeException / ArgumentException (array bounds) */
+  ORA_E_NULLREF = -2,   /* NullReferenceException: reference frame slot never decoded */
+  ORA_E_PARTCODE = -3,  /* explicit `throw new Exception()` on illegal partition code */
+  ORA_E_VERSION = -4,   /* VxDS stub (NotImplementedException) */
+};
+
+typedef struct mobi_oracle mobi_oracle;
+
+mobi_oracle *mobi_oracle_create(uint32_t width, uint32_t height, int version);
+void mobi_oracle_destroy(mobi_oracle *d);
+
+/* d.Data = data; d.Offset = *offset; d.DecodeFrame(); *offset = d.Offset.
+ * Returns ORA_OK when the reference would have reached the Bitmap stage, else the
+ * exception class.  The ring is rotated and the (possibly partial) frame kept in either case,
+ * exactly as MD.cs:102-108 + :325 leave it. */
+int mobi_oracle_decode(mobi_oracle *d, const uint8_t *data, size_t len, int32_t *offset);
+
+int mobi_oracle_stride(const mobi_oracle *d);
+uint32_t mobi_oracle_quantizer(const mobi_oracle *d);
+uint32_t mobi_oracle_yuvformat(const mobi_oracle *d);
+/* ring slot idx 0..5; NULL when that slot has never been produced.  Y: Stride*H bytes,
+ * UV: Stride*H/2 bytes (U in columns [0,Stride/2), V in [Stride/2,Stride)). */
+const uint8_t *mobi_oracle_y(const mobi_oracle *d, int idx);
+const uint8_t *mobi_oracle_uv(const mobi_oracle *d, int idx);
+/* testing hooks: direct access to the Internal[392] word array (MD.cs:28) */
+uint32_t *mobi_oracle_internal(mobi_oracle *d);
+
+/* ---- unit-level entry points (operate on caller buffers; used by the identity tests) ---- */
+/* full / reduced inverse transforms, MD.cs:3435-3798. coef: natural-order block (64 or 16 i32).
+ * variant: 64,16,3,1 for 8x8 ; 16,1 for 4x4.  Returns 0 or ORA_E_INDEX (clamp-table domain). */
+int mobi_oracle_idct8(const int32_t *coef, int variant, uint8_t *dst, int dst_len, int offset, int stride);
+int mobi_oracle_idct4(const int32_t *coef, int variant, uint8_t *dst, int dst_len, int offset, int stride);
+/* CopyBlock, MD.cs:418-456 */
+int mobi_oracle_copyblock(const uint8_t *src, int src_len, int dx, int dy, uint32_t w, uint32_t h,
+                          uint8_t *dst, int dst_len, int offset, int stride);
+/* PredictIntra for modes that do not read the bitstream (0,1,3..9,10,11,13..19), MD.cs:1883.
+ * is_uv selects the `Dst == UV[0]` V-plane fix-up (:1886).  plane modes: param given explicitly. */
+int mobi_oracle_predict(int mode, uint8_t *dst, int dst_len, int offset, int stride, int is_uv);
+int mobi_oracle_plane(int size /*16,8,4*/, int param, uint8_t *dst, int dst_len, int offset, int stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
