@@ -1,0 +1,116 @@
+/*
+ * mobiclip_hip.h -- C ABI of libmobiclip_hip.so: MI355X (gfx950) Mobiclip frame reconstruction.
+ *
+ * The reference has no FFI seam; the seam is the public surface of
+ *   LibMobiclip.Codec.Mobiclip.MobiclipDecoder   (MobiclipDecoder.cs:13-61, "MD.cs")
+ * whose callers do   d.Data = frame; d.Offset = o; d.DecodeFrame(); ... d.Offset ...
+ * (MobiConverter/Program.cs:69-71,243-250,393-395; MobiclipDecoder/Form1.cs:261-263,292-302,
+ * 359-364,463-465,525-527).  Each entry point below names the member it replaces; the C#
+ * binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Split of work: the serial VLC / Exp-Golomb parse (MD.cs bit reader and syntax, :113-259,
+ * :469-3432) runs on the host inside these calls and emits a flat per-macroblock command list;
+ * dequant + inverse transforms, intra prediction, motion compensation and residual add
+ * (MD.cs:418-456, :1883-2774, :3017-3327, :3435-3798) run as HIP kernels, one wavefront per
+ * macroblock.  There is NO CPU reconstruction path in this library: without a HIP device every
+ * create call fails.
+ */
+#ifndef MOBICLIP_HIP_H
+#define MOBICLIP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MobiclipDecoder.MobiclipVersion, MD.cs:32-37 */
+#define MOBI_VERSION_VXDS 0      /* unimplemented stub in the reference too (MD.cs:63-95) */
+#define MOBI_VERSION_MODSDS 1
+#define MOBI_VERSION_MOFLEX3DS 2
+
+/* Return codes.  0 = frame decoded.  Negative = the reference would have thrown inside
+ * DecodeVXS2 and returned a null Bitmap (MD.cs:325-328); the code says which check fired. */
+#define MOBI_OK 0
+#define MOBI_E_INDEX (-1)        /* managed array bounds: MC source window, intra neighbour at a negative
+                                    offset, VLC/CBP/quantizer table index, bitstream read past Data */
+#define MOBI_E_NULLREF (-2)      /* reference frame slot Y[ref] never decoded (MD.cs:413) */
+#define MOBI_E_PARTCODE (-3)     /* illegal partition code: explicit throw (e.g. MD.cs:625,730,827) */
+#define MOBI_E_VERSION (-4)      /* VxDS / unknown version */
+#define MOBI_E_CLAMP (-5)        /* residual add left the clamp table domain (MobiConst.cs:587; MD.cs:3551);
+                                    detected on the GPU, so the parser state has already advanced */
+#define MOBI_E_UNSUPPORTED (-6)  /* stream relies on scratch-array aliasing inside `Internal`
+                                    (coefficient run past the block, ModsDS quantizer < 12); see DESIGN.md */
+#define MOBI_E_ARG (-7)          /* bad argument / dimensions not a multiple of 16 (the reference cannot
+                                    decode those either: MD.cs:216-217) */
+#define MOBI_E_DEVICE (-8)       /* HIP error (no device, allocation, launch) */
+
+typedef struct mobi_dec mobi_dec;     /* one stream: replaces one MobiclipDecoder instance */
+typedef struct mobi_batch mobi_batch; /* N independent streams of equal geometry, decoded in lock step */
+
+/* ---- single stream ------------------------------------------------------------------------ */
+/* new MobiclipDecoder(Width, Height, Version)  (MD.cs:41-54).  device = HIP ordinal. */
+mobi_dec *mobi_create(uint32_t width, uint32_t height, int version, int device);
+void mobi_destroy(mobi_dec *d);
+/* d.Data = data (len bytes); d.Offset = *offset_inout; d.DecodeFrame(); *offset_inout = d.Offset
+ * (MD.cs:56-61, 97-259).  Synchronous: returns after the frame is reconstructed on the device. */
+int mobi_decode(mobi_dec *d, const uint8_t *data, size_t len, int32_t *offset_inout);
+/* d.Y[ring_idx] / d.UV[ring_idx]  (MD.cs:19-20), copied in the reference layout:
+ * y_out: Stride*Height bytes; uv_out: Stride*Height/2 bytes, U in columns [0,Stride/2), V in
+ * [Stride/2,Stride) of each row (MD.cs:414-415).  Either pointer may be NULL.
+ * Returns MOBI_E_NULLREF when that ring slot has never been produced. */
+int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
+int mobi_stride(const mobi_dec *d);            /* d.Stride     (MD.cs:30,50-52) */
+uint32_t mobi_quantizer(const mobi_dec *d);    /* d.Quantizer  (MD.cs:26) */
+uint32_t mobi_yuv_format(const mobi_dec *d);   /* d.YuvFormat  (MD.cs:27) */
+uint32_t mobi_width(const mobi_dec *d);        /* d.Width      (MD.cs:17) */
+uint32_t mobi_height(const mobi_dec *d);       /* d.Height     (MD.cs:18) */
+
+/* ---- batch of independent clips (the throughput path) -------------------------------------- */
+/* N decoder instances that share geometry/version; they share nothing else (MD.cs:15-39). */
+mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int version, int device);
+void mobi_batch_destroy(mobi_batch *b);
+/* One DecodeFrame() per clip: data[i]/len[i]/offsets[i] as in mobi_decode; rc[i] per clip.
+ * Parses on the host, uploads the command lists, launches, synchronises.  Returns MOBI_OK or a
+ * MOBI_E_DEVICE/ARG failure of the call itself (per-clip stream errors go to rc[]). */
+int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
+int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
+uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip);
+int mobi_batch_stride(const mobi_batch *b);
+int mobi_batch_n_clips(const mobi_batch *b);
+
+/* Pre-parsed replay: keep the command lists of whole clips resident in HBM so that a timed region
+ * contains reconstruction only (SURVEY.md 8(d) "GPU timing").
+ *  preload : parse all n_frames of `clip` (frame f = data[frame_off[f] .. frame_off[f+1])) and
+ *            stage their command lists on the host; rc per frame optional.
+ *  preload_clone: give `clip` a private copy of another clip's staged command lists (its own HBM
+ *            bytes, same content) -- lets a benchmark run more clips than it generated streams.
+ *  commit  : upload everything staged; builds the per-level launch lists across clips.
+ *  replay  : one frame step for every clip: ring rotate + reconstruction kernels for frame
+ *            `frame_idx`, asynchronously on the batch stream.  No host parse, no H2D.
+ *  sync    : wait for the stream; returns MOBI_E_CLAMP if any clip flagged a clamp-domain fault. */
+int mobi_batch_preload(mobi_batch *b, int clip, const uint8_t *data, size_t len, const uint32_t *frame_off,
+                       int n_frames, int *rc_per_frame);
+int mobi_batch_preload_clone(mobi_batch *b, int clip, int src_clip);
+int mobi_batch_commit(mobi_batch *b);
+int mobi_batch_replay(mobi_batch *b, int frame_idx);
+int mobi_batch_sync(mobi_batch *b);
+/* command-list bytes the kernels read for frame `frame_idx`, summed over clips (roofline accounting) */
+uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx);
+/* milliseconds between two internally recorded HIP events bracketing the replay launches of the last
+ * `mobi_batch_time_begin` .. `mobi_batch_time_end` region, measured on the batch's own stream */
+int mobi_batch_time_begin(mobi_batch *b);
+int mobi_batch_time_end(mobi_batch *b, float *ms_out);
+/* per-kernel-class device time (ms) accumulated since the last time_begin: [0] inter MC+IDCT kernel,
+ * [1] intra kernel launches; measured with HIP events around each launch when profiling is enabled */
+int mobi_batch_set_kernel_timing(mobi_batch *b, int enable);
+int mobi_batch_kernel_ms(mobi_batch *b, float *inter_ms, float *intra_ms, int *inter_launches, int *intra_launches);
+
+const char *mobi_error_string(int rc);
+/* library self-description: "libmobiclip_hip <ver> gfx950 ..." */
+const char *mobi_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

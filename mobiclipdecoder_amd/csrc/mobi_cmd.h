@@ -1,0 +1,79 @@
+// mobi_cmd.h -- the host->GPU command list: what the serial bitstream parser (mobi_parse.cpp)
+// emits per frame and what the reconstruction kernels (mobi_kernels.hip) consume.
+//
+// One frame of one clip =
+//   FrameHdr                       fixed, holds the dequant scale tables for this frame
+//   MbDesc   desc[n_mbs]           16 B per macroblock, raster order
+//   uint32_t payload[...]          variable: MC leaves, intra block records, residual levels
+//   uint32_t intra_items[...]      MB indices of intra MBs grouped by dependency level (host side only;
+//                                  merged across clips into per-level launch lists)
+//
+// Positions are NOT stored as MB coordinates: like the reference, everything is a linear byte
+// offset into the strided plane (MD.cs:212-217, SURVEY hard part 3); desc index -> offset is
+// (mb / mbw) * 16 * stride + (mb % mbw) * 16 because widths are multiples of 16 here.
+#ifndef MOBI_CMD_H
+#define MOBI_CMD_H
+#include <stdint.h>
+
+enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
+
+// ---- MbDesc.w1 bit fields -------------------------------------------------------------------
+//  [0]      type (MOBI_MB_*)
+//  [7:1]    n_leaves   (inter: 1..64)
+//  [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
+//  [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
+//  [31:20]  level      intra dependency level (0 for inter)
+// ---- MbDesc.w2: [9:0] n_coefs (<= 384); ---- MbDesc.w3: reserved (plane16 param for intra) ----
+struct MbDesc {
+  uint32_t payload_off; // word offset of this MB's payload inside the frame payload
+  uint32_t w1;
+  uint32_t w2;
+  uint32_t w3;
+};
+
+// ---- MC leaf: two words ---------------------------------------------------------------------
+//  w0: [3:0] x/2  [7:4] y/2  [9:8] log2(16/w)  [11:10] log2(16/h)  [14:12] ref slot 1..5
+//  w1: [15:0] dx (int16, half-pel, absolute)  [31:16] dy                         (MD.cs:400-416)
+static inline uint32_t mobi_leaf_w0(int x, int y, int wi, int hi, int ref) {
+  return (uint32_t)((x >> 1) | ((y >> 1) << 4) | (wi << 8) | (hi << 10) | (ref << 12));
+}
+static inline uint32_t mobi_leaf_w1(int dx, int dy) { return ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16); }
+
+// ---- residual level: one word ---------------------------------------------------------------
+//  [8:0]   tile position = area*64 + p, area = 0..5 (Y0..Y3,U,V)
+//            8x8 transform:  p = natural-order coefficient index (MD.cs:3426 zigzag target)
+//            4x4 transforms: p = sub*16 + natural index inside that 4x4 (sub = 0..3: TL,TR,BL,BR)
+//  [31:16] level (int16); the GPU multiplies by the dequant scale (MD.cs:3427-3429)
+static inline uint32_t mobi_coef(int area, int p, int level) {
+  return (uint32_t)(area * 64 + p) | ((uint32_t)level << 16);
+}
+
+// ---- intra MB payload: 24 block records (6 areas x 4) then the levels ------------------------
+// record for area a, slot s (s = 0 only when the area is predicted as one 8x8):
+//  [3:0]  mode 0..9 (8x8 numbering; 4x4 blocks use the same numbering, MD.cs mode-10)
+//  [4]    residual coded for this block
+//  [5]    split: the area is four 4x4 blocks (slots 0..3 all valid)
+//  [31:16] plane parameter (int16) when mode == 2                           (MD.cs:3019,3170,3255)
+// MbDesc.w3: [0] luma plane16 present, [1] chroma plane8 pair present,
+//            [31:16] plane16 param; chroma plane params live in the U/V slot-0 records with mode 9:
+//            record bit [6] = "run plane8 with param before this area" (keeps decode order).
+#define MOBI_INTRA_RECORDS 24
+static inline uint32_t mobi_intra_rec(int mode, int coded, int split, int pre_plane, int param) {
+  return (uint32_t)(mode | (coded << 4) | (split << 5) | (pre_plane << 6)) | ((uint32_t)param << 16);
+}
+
+// ---- frame header ----------------------------------------------------------------------------
+struct FrameHdr {
+  uint32_t frame_type;   // 0 = P, 1 = I
+  uint32_t n_mbs;
+  uint32_t n_intra;      // number of intra MBs
+  uint32_t n_levels;     // highest intra level (0 when no intra MBs)
+  uint32_t payload_words;
+  uint32_t quantizer;
+  uint32_t cmd_bytes;    // bytes of this frame's command list the kernels read (hdr + desc + payload)
+  uint32_t reserved;
+  int32_t scale8[64];    // dequant scale by NATURAL coefficient index, 8x8  (word >> 8, MD.cs:3907-3911)
+  int32_t scale4[16];    // same for 4x4                                     (MD.cs:3897-3902)
+};
+
+#endif

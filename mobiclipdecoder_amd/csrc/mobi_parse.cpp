@@ -1,0 +1,567 @@
+// mobi_parse.cpp -- serial bitstream parser -> per-macroblock command list (see mobi_parse.h).
+#include "mobi_parse.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/mobiclip_hip.h"
+#include "mobi_tables.h"
+
+namespace {
+inline uint32_t shl(uint32_t x, int n) { return x << (n & 31); } // C# masks shift counts to 5 bits
+inline uint32_t shr(uint32_t x, int n) { return x >> (n & 31); }
+inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; } // MD.cs:3927
+} // namespace
+
+void ParsedFrame::clear() {
+  memset(&hdr, 0, sizeof(hdr));
+  desc.clear();
+  payload.clear();
+  intra_mbs.clear();
+  level_start.clear();
+}
+
+MobiStreamParser::MobiStreamParser(uint32_t width, uint32_t height, int version) : version_(version) {
+  g_.width = (int)width;
+  g_.height = (int)height;
+  g_.stride = (width <= 256) ? 256 : (width <= 512) ? 512 : 1024; // MD.cs:50-52
+  g_.mbw = (int)width / 16;
+  g_.mbh = (int)height / 16;
+  ver_ = (version == MOBI_VERSION_MOFLEX3DS) ? 0 : 1;
+  memset(dq8_, 0, sizeof(dq8_));
+  memset(dq4_, 0, sizeof(dq4_));
+  memset(mcache_, 0, sizeof(mcache_));
+  memset(recs_, 0, sizeof(recs_));
+  mvc_.assign(2 * (g_.mbw + 2), 0);
+}
+
+// ------------------------------------------------------------------ bit reader (MD.cs:2970-3015)
+uint32_t MobiStreamParser::data_u16(long off) const { // IOUtil.ReadU16LE
+  if (off < 0 || off + 1 >= len_) fail(MOBI_E_INDEX);
+  return ((uint32_t)data_[off + 1] << 8) | data_[off];
+}
+void MobiStreamParser::fill_bits() { // FillBits: one 16-bit LE word, no refill at/after Data.Length
+  if (off_ >= len_) return;
+  uint32_t w = data_u16(off_);
+  off_ += 2;
+  nbr_ += 16;
+  win_ |= shl(w, 16 - nbr_);
+}
+void MobiStreamParser::take(int n) {
+  win_ = shl(win_, n);
+  nbr_ -= n;
+  if (nbr_ < 0) fill_bits();
+}
+uint32_t MobiStreamParser::ue() { // Elias-gamma, value = 2^z - 1 + suffix
+  int z = clz32(win_);
+  win_ = shl(win_, z);
+  win_ += win_;
+  uint32_t v = (z == 0) ? 0 : shr(win_, 32 - z);
+  v += shl(1u, z);
+  v--;
+  win_ = shl(win_, z);
+  nbr_ -= 2 * z;
+  if (--nbr_ < 0) fill_bits();
+  return v;
+}
+int MobiStreamParser::se() { // odd codes map to non-positive values (MD.cs:3009-3010)
+  int z = clz32(win_);
+  win_ = shl(win_, z);
+  win_ += win_;
+  uint32_t u = (z == 0) ? 0 : shr(win_, 32 - z);
+  u += shl(1u, z);
+  int v = (int)u;
+  if (v & 1) v = (int)(1u - u);
+  v >>= 1;
+  win_ = shl(win_, z);
+  nbr_ -= 2 * z;
+  if (--nbr_ < 0) fill_bits();
+  return v;
+}
+
+// ------------------------------------------------------------------ quantiser (MD.cs:3884-3925)
+void MobiStreamParser::setup_quant(uint32_t q) {
+  if (version_ == MOBI_VERSION_MOFLEX3DS) q = std::min<uint32_t>(std::max<uint32_t>(q, 12), 52);
+  quant_ = q; // assigned before the table index can throw
+  if (q >= sizeof(mobi_qdiv6)) fail(MOBI_E_INDEX);
+  int sh = mobi_qdiv6[q] + 8, m = mobi_qmod6[q];
+  for (int i = 0; i < 16; i++) dq4_[i] = (uint32_t)mobi_zz4[i] | shl(mobi_dq4[m * 16 + i], sh);
+  for (int i = 0; i < 64; i++) dq8_[i] = (uint32_t)mobi_zz8[i] | shl(mobi_dq8[m * 64 + i], sh - 2);
+  static const int border[8] = {1, 2, 3, 4, 8, 0x10, 0x18, 0x20}; // "no neighbour" marks, re-armed only here
+  for (int b : border) mcache_[b] = 9;
+}
+
+// ------------------------------------------------------------------ per-MB assembly
+void MobiStreamParser::begin_mb(int mb, int type) {
+  cur_mb_ = mb;
+  cur_x_ = (mb % g_.mbw) * 16;
+  cur_y_ = (mb / g_.mbw) * 16;
+  cur_off_ = (long)cur_y_ * g_.stride + cur_x_;
+  leaves_.clear();
+  coefs_.clear();
+  memset(recs_, 0, sizeof(recs_));
+  cbp6_ = t8mask_ = w3_ = 0;
+  mb_type_ = type;
+}
+void MobiStreamParser::end_mb() {
+  MbDesc d;
+  d.payload_off = (uint32_t)out_->payload.size();
+  uint32_t nl = 0;
+  if (mb_type_ == MOBI_MB_INTER) {
+    nl = (uint32_t)(leaves_.size() / 2);
+    out_->payload.insert(out_->payload.end(), leaves_.begin(), leaves_.end());
+  } else {
+    out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
+  }
+  out_->payload.insert(out_->payload.end(), coefs_.begin(), coefs_.end());
+  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14);
+  d.w2 = (uint32_t)coefs_.size();
+  d.w3 = w3_;
+  out_->desc.push_back(d);
+}
+long MobiStreamParser::area_offset(int area, int sub) const {
+  const long S = g_.stride;
+  long o = (area < 4) ? cur_off_ + (area >> 1) * 8 * S + (area & 1) * 8 : cur_off_ / 2 + (area == 5 ? S / 2 : 0);
+  return o + (sub >> 1) * 4 * S + (sub & 1) * 4;
+}
+
+// ------------------------------------------------------------------ motion (MD.cs:400-456)
+// Would CopyBlock throw?  Rows are visited top to bottom, so first row / last row bound the rest.
+void MobiStreamParser::check_window(long pos, int w, int h, int phase, long plane_len) const {
+  if (pos < 0) fail(MOBI_E_INDEX);
+  long last = pos + (long)(h - 1) * g_.stride;
+  long hi; // highest index touched (phase 0: Array.Copy end is exclusive)
+  switch (phase) {
+    case 0: hi = last + w - 1; break;
+    case 1: hi = last + w; break;
+    case 2: hi = last + w - 1 + g_.stride; break;
+    default: hi = last + w + g_.stride; break;
+  }
+  if (hi >= plane_len) fail(MOBI_E_INDEX);
+}
+void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, int dy, int mv_slot) {
+  const long S = g_.stride;
+  const int w = 16 >> wi, h = 16 >> hi;
+  mvc_[mv_slot] = dx; // every leaf overwrites the MB's exported MV (MD.cs:411-412)
+  mvc_[mv_slot + 1] = dy;
+  if (ref > std::min(5, frames_started_ - 1)) fail(MOBI_E_NULLREF); // Y[ref] == null
+  long off = cur_off_ + (long)y * S + x;
+  check_window(off + (long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * g_.height);
+  int cdx = dx >> 1, cdy = dy >> 1;
+  long cpos = off / 2 + (long)(cdy >> 1) * S + (cdx >> 1);
+  int cph = (cdx & 1) | ((cdy & 1) << 1);
+  check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
+  check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
+  if (dx < -32768 || dx > 32767 || dy < -32768 || dy > 32767) fail(MOBI_E_UNSUPPORTED);
+  leaves_.push_back(mobi_leaf_w0(x, y, wi, hi, ref));
+  leaves_.push_back(mobi_leaf_w1(dx, dy));
+}
+// ReadPBlock*/SwitchPBlock* (MD.cs:469-1746) as one table-driven routine; x,y are MB-relative.
+void MobiStreamParser::pblock(int wi, int hi, int x, int y, int mv_slot) {
+  const int s = wi * 4 + hi, w = 16 >> wi, h = 16 >> hi;
+  uint32_t code = mobi_part_lut[ver_][s][win_ >> mobi_part_shift[ver_][s]];
+  if (code >= mobi_part_nbits_len[ver_][s]) fail(MOBI_E_INDEX);
+  take(mobi_part_bits[ver_][s][code]);
+  if (code == 0) {
+    mc_leaf(wi, hi, x, y, 1, predx_, predy_, mv_slot);
+  } else if (code <= 5) {
+    int dx = se();
+    int dy = se();
+    mc_leaf(wi, hi, x, y, (int)code, dx + predx_, dy + predy_, mv_slot);
+  } else if (code == 6 || code == 7) {
+    if (s != 0) fail(MOBI_E_PARTCODE);
+    mb_type_ = MOBI_MB_INTRA;
+    if (code == 6) intra_full(); else intra_sub();
+    return;
+  } else if (code == 8) {
+    if (h == 2) fail(MOBI_E_PARTCODE);
+    pblock(wi, hi + 1, x, y, mv_slot);
+    pblock(wi, hi + 1, x, y + h / 2, mv_slot);
+  } else if (code == 9) {
+    if (w == 2) fail(MOBI_E_PARTCODE);
+    pblock(wi + 1, hi, x, y, mv_slot);
+    pblock(wi + 1, hi, x + w / 2, y, mv_slot);
+  }
+  if (s == 0) p_residual();
+}
+
+// ------------------------------------------------------------------ residual (MD.cs:3330-3432)
+void MobiStreamParser::resid_block(int area, int sub, bool is8) {
+  const int N = is8 ? 64 : 16;
+  const uint32_t *dq = is8 ? dq8_ : dq4_;
+  // Below q=12 the dequant word's scale bits leak into its zigzag byte (MD.cs:3907-3911 vs :3426) and
+  // the reference result depends on scratch aliasing inside Internal[]; outside the parity domain.
+  if (quant_ < 12) fail(MOBI_E_UNSUPPORTED);
+  const uint16_t *A = vlc_table_ == 1 ? mobi_vx2table1_a : mobi_vx2table0_a;
+  const uint8_t *B = vlc_table_ == 1 ? mobi_vx2table1_b : mobi_vx2table0_b;
+  int p = 0;
+  struct { uint8_t idx; int16_t level; } tmp[64];
+  int n = 0;
+  for (;;) {
+    int skip, value;
+    uint32_t e;
+    if ((win_ >> 25) == 3) { // escape prefix 0000011
+      win_ <<= 7;
+      bool c = (win_ >> 31) == 1;
+      win_ <<= 1;
+      if (!c) { // "0": table code, level += B[last<<6|run]
+        nbr_ -= 8;
+        if (nbr_ < 0) fill_bits();
+        e = A[win_ >> 20];
+        value = (int)((e >> 4) & 0x1F) + B[e >> 9];
+        win_ = shl(win_, (int)(e & 0xF) - 1);
+        if (win_ >> 31) value = -value;
+        win_ <<= 1;
+        nbr_ -= (int)(e & 0xF);
+        if (nbr_ < 0) fill_bits();
+        skip = (int)((e >> 9) & 0x3F);
+        e >>= 15;
+      } else {
+        c = (win_ >> 31) == 1;
+        win_ <<= 1;
+        nbr_ -= 9;
+        if (nbr_ < 0) fill_bits();
+        if (!c) { // "10": table code, run += B[0x80 + level + (last<<6)]
+          e = A[win_ >> 20];
+          value = (int)((e >> 4) & 0x1F);
+          skip = (int)((e >> 9) & 0x3F) + B[0x80 + value + ((e >> 15) << 6)];
+          win_ = shl(win_, (int)(e & 0xF) - 1);
+          if (win_ >> 31) value = -value;
+          win_ <<= 1;
+          nbr_ -= (int)(e & 0xF);
+          if (nbr_ < 0) fill_bits();
+          e >>= 15;
+        } else { // "11": raw last(1) run(6) level(s12)
+          e = win_ >> 31;
+          win_ <<= 1;
+          skip = (int)(win_ >> 26);
+          win_ <<= 6;
+          nbr_ -= 7;
+          if (nbr_ < 0) fill_bits();
+          value = (int32_t)win_ >> 20;
+          win_ <<= 12;
+          nbr_ -= 12;
+          if (nbr_ < 0) fill_bits();
+        }
+      }
+    } else {
+      e = A[win_ >> 20];
+      value = (int)((e >> 4) & 0x1F);
+      win_ = shl(win_, (int)(e & 0xF) - 1);
+      if (win_ >> 31) value = -value;
+      win_ <<= 1;
+      nbr_ -= (int)(e & 0xF);
+      if (nbr_ < 0) fill_bits();
+      skip = (int)((e >> 9) & 0x3F);
+      e >>= 15;
+    }
+    p += skip;
+    if (p >= N) fail(MOBI_E_UNSUPPORTED); // the reference would walk past the dequant words (Internal[] aliasing)
+    uint32_t word = dq[p++];
+    if (value != 0) {
+      tmp[n].idx = (uint8_t)(word & 0xFF);
+      tmp[n].level = (int16_t)value;
+      n++;
+    }
+    if (e & 1) break;
+  }
+  // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the
+  // reduced transforms only look at part of the block, so drop what they would not see.  (For q >= 12
+  // nothing is ever dropped: scan positions 0, 0..2, 0..9 map inside the respective regions.)
+  int vis = 3;
+  if (is8) vis = (p <= 1) ? 0 : (p <= 3) ? 1 : (p <= 10) ? 2 : 3;
+  else vis = (p <= 1) ? 0 : 3;
+  for (int i = 0; i < n; i++) {
+    int idx = tmp[i].idx;
+    bool keep = vis == 3 || (vis == 0 && idx == 0) || (vis == 1 && (idx == 0 || idx == 1 || idx == 8)) ||
+                (vis == 2 && (idx & 7) < 4 && (idx >> 3) < 4);
+    if (!keep) continue;
+    coefs_.push_back(mobi_coef(area, is8 ? idx : sub * 16 + idx, tmp[i].level));
+  }
+}
+void MobiStreamParser::resid_area(int area) { // loc_11652C, MD.cs:2909-2929
+  if (win_ >> 31) {
+    win_ += win_;
+    nbr_--;
+    t8mask_ |= 1u << area;
+    resid_block(area, 0, true);
+  } else {
+    uint32_t u = ue();
+    if (u >= sizeof(mobi_cbp4_inter)) fail(MOBI_E_INDEX);
+    uint32_t m = mobi_cbp4_inter[u];
+    for (int sub = 0; sub < 4; sub++)
+      if ((m >> sub) & 1) resid_block(area, sub, false);
+  }
+}
+void MobiStreamParser::p_residual() { // loc_1161A0, MD.cs:1818-1833
+  uint32_t u = ue();
+  if (u >= sizeof(mobi_cbp_inter)) fail(MOBI_E_INDEX);
+  cbp6_ = mobi_cbp_inter[u];
+  for (int area = 0; area < 6; area++)
+    if ((cbp6_ >> area) & 1) resid_area(area);
+}
+
+// ------------------------------------------------------------------ intra syntax
+// Reads PredictIntra (MD.cs:1883-2774) / the plane predictors (:3017-3327) make outside the block:
+// the top row needs Offset-Stride >= 0, the left column Offset-1 >= 0; anything else is in range.
+void MobiStreamParser::check_intra_reads(int mode, long off, bool) const {
+  static const bool top[10] = {1, 0, 1, 0, 0, 1, 1, 1, 1, 0}, left[10] = {0, 1, 1, 0, 1, 1, 1, 1, 0, 0};
+  if (top[mode] && off < g_.stride) fail(MOBI_E_INDEX);
+  if (left[mode] && off < 1) fail(MOBI_E_INDEX);
+}
+// predicted-mode code shared by loc_116220 / loc_116368 / sub_1163DC (MD.cs:1840-1859, 2785-2804, 2841-2858)
+int MobiStreamParser::pmode(int ci, bool four) {
+  int pred = std::min(mcache_[ci - 8], mcache_[ci - 1]);
+  if (pred == 9) pred = 3;
+  int v = (int)(win_ >> 28), nb = 1, mode = pred;
+  if (v >= pred) v++;
+  if (v < 9) { mode = v; nb = 4; }
+  if (four) mcache_[ci] = (uint8_t)mode;
+  else mcache_[ci] = mcache_[ci + 1] = mcache_[ci + 8] = mcache_[ci + 9] = (uint8_t)mode;
+  take(nb);
+  return mode;
+}
+static inline int16_t param16(int p, bool &ok) {
+  ok = p >= -32768 && p <= 32767;
+  return (int16_t)p;
+}
+// sub_116508 (MD.cs:2869-2896) or a bare PredictIntra: one 8x8 area whose mode is already known
+void MobiStreamParser::intra_area_fixed(int area, int mode, bool coded) {
+  if (!coded) {
+    check_intra_reads(mode, area_offset(area, 0), false);
+    recs_[area * 4] |= mobi_intra_rec(mode, 0, 0, 0, 0);
+    return;
+  }
+  if (win_ >> 31) {
+    win_ += win_;
+    nbr_--;
+    check_intra_reads(mode, area_offset(area, 0), false);
+    recs_[area * 4] |= mobi_intra_rec(mode, 1, 0, 0, 0);
+    cbp6_ |= 1u << area;
+    t8mask_ |= 1u << area;
+    resid_block(area, 0, true);
+  } else {
+    uint32_t u = ue();
+    if (u >= sizeof(mobi_cbp4_intra)) fail(MOBI_E_INDEX);
+    uint32_t m4 = mobi_cbp4_intra[u];
+    for (int sub = 0; sub < 4; sub++) {
+      check_intra_reads(mode, area_offset(area, sub), true);
+      int c = (m4 >> sub) & 1;
+      recs_[area * 4 + sub] |= mobi_intra_rec(mode, c, 1, 0, 0);
+      if (c) {
+        cbp6_ |= 1u << area;
+        resid_block(area, sub, false);
+      }
+    }
+  }
+}
+void MobiStreamParser::intra_chroma(uint32_t cbp) { // loc_116290, MD.cs:1864-1880
+  int m = (int)(win_ >> 29);
+  take(3);
+  if (m == 2) {
+    m = 9;
+    for (int area = 4; area < 6; area++) {
+      bool ok;
+      int16_t p = param16(se(), ok);
+      check_intra_reads(2, area_offset(area, 0), false);
+      if (!ok) fail(MOBI_E_UNSUPPORTED);
+      recs_[area * 4] |= mobi_intra_rec(0, 0, 0, 1, p);
+    }
+  }
+  intra_area_fixed(4, m, (cbp >> 4) & 1);
+  intra_area_fixed(5, m, (cbp >> 5) & 1);
+}
+void MobiStreamParser::intra_full() { // DecIntraFullBlockPMode, MD.cs:1759-1786
+  uint32_t u = ue();
+  if (u >= sizeof(mobi_cbp_intra)) fail(MOBI_E_INDEX);
+  uint32_t cbp = mobi_cbp_intra[u];
+  int m = (int)(win_ >> 29);
+  take(3);
+  if (m == 2) {
+    m = 9;
+    bool ok;
+    int16_t p = param16(se(), ok);
+    check_intra_reads(2, cur_off_, false);
+    if (!ok) fail(MOBI_E_UNSUPPORTED);
+    w3_ = 1u | ((uint32_t)(uint16_t)p << 16);
+  }
+  for (int k = 0; k < 4; k++) intra_area_fixed(k, m, (cbp >> k) & 1);
+  intra_chroma(cbp);
+}
+void MobiStreamParser::intra_sub() { // DecIntraSubBlockPMode, MD.cs:1789-1807
+  uint32_t u = ue();
+  if (u >= sizeof(mobi_cbp_intra)) fail(MOBI_E_INDEX);
+  uint32_t cbp = mobi_cbp_intra[u];
+  static const int ci[4] = {9, 0xB, 0x19, 0x1B}, d5[4] = {0, 1, 8, 9};
+  for (int k = 0; k < 4; k++) {
+    bool coded = (cbp >> k) & 1;
+    bool whole = true;
+    if (coded) { // loc_116368, MD.cs:2776
+      if (win_ >> 31) { win_ <<= 1; nbr_--; }
+      else whole = false;
+    }
+    if (whole) {
+      int m = pmode(ci[k], false);
+      int p = 0;
+      if (m == 2) { // the predictor itself reads its parameter (MD.cs:1915-1919)
+        bool ok;
+        p = param16(se(), ok);
+        if (!ok) fail(MOBI_E_UNSUPPORTED);
+      }
+      check_intra_reads(m, area_offset(k, 0), false);
+      recs_[k * 4] |= mobi_intra_rec(m, coded, 0, 0, p);
+      if (coded) {
+        cbp6_ |= 1u << k;
+        t8mask_ |= 1u << k;
+        resid_block(k, 0, true);
+      }
+    } else {
+      uint32_t u4 = ue();
+      if (u4 >= sizeof(mobi_cbp4_intra)) fail(MOBI_E_INDEX);
+      uint32_t m4 = mobi_cbp4_intra[u4];
+      for (int sub = 0; sub < 4; sub++) {
+        int m = pmode(ci[k] + d5[sub], true);
+        int p = 0;
+        if (m == 2) {
+          bool ok;
+          p = param16(se(), ok);
+          if (!ok) fail(MOBI_E_UNSUPPORTED);
+        }
+        check_intra_reads(m, area_offset(k, sub), true);
+        int c = (m4 >> sub) & 1;
+        recs_[k * 4 + sub] |= mobi_intra_rec(m, c, 1, 0, p);
+        if (c) {
+          cbp6_ |= 1u << k;
+          resid_block(k, sub, false);
+        }
+      }
+    }
+  }
+  intra_chroma(cbp);
+}
+
+// ------------------------------------------------------------------ frames (MD.cs:97-259)
+void MobiStreamParser::parse_p(ParsedFrame &out) {
+  if (--nbr_ < 0) fill_bits();
+  if (version_ == MOBI_VERSION_MOFLEX3DS) {
+    uint32_t q = quant_;
+    int dq = se();
+    if (q == 0) setup_quant(q);
+    else if (dq != 0) setup_quant(q + (uint32_t)dq);
+  } else {
+    int dq = se();
+    if (dq != 0) setup_quant(quant_ + (uint32_t)dq);
+  }
+  vlc_table_ = 0;
+  std::fill(mvc_.begin(), mvc_.end(), 0);
+  out.hdr.frame_type = 0;
+  for (int mb = 0; mb < g_.mbw * g_.mbh; mb++) {
+    int mx = mb % g_.mbw;
+    const int *e = &mvc_[2 * mx]; // entries: left, top, top-right (MD.cs:163-169)
+    auto med3 = [](int a, int b, int c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); };
+    predx_ = med3(e[0], e[2], e[4]);
+    predy_ = med3(e[1], e[3], e[5]);
+    int slot = 2 * (mx + 1);
+    mvc_[slot] = mvc_[slot + 1] = 0;
+    begin_mb(mb, MOBI_MB_INTER);
+    pblock(0, 0, 0, 0, slot);
+    end_mb();
+  }
+}
+void MobiStreamParser::parse_i(ParsedFrame &out) {
+  yuvfmt_ = win_ >> 31;
+  win_ += win_;
+  vlc_table_ = (int)(win_ >> 31);
+  win_ += win_;
+  nbr_ -= 3;
+  if (nbr_ < 0) fill_bits();
+  uint32_t q = win_ >> 26;
+  take(6);
+  if (quant_ != q) setup_quant(q);
+  out.hdr.frame_type = 1;
+  for (int mb = 0; mb < g_.mbw * g_.mbh; mb++) {
+    bool sub = (win_ >> 31) == 1;
+    win_ += win_;
+    nbr_--;
+    if (nbr_ < 0) fill_bits();
+    begin_mb(mb, MOBI_MB_INTRA);
+    if (sub) intra_sub(); else intra_full();
+    end_mb();
+  }
+}
+
+// Dependency levels: an intra MB may run once every raster-earlier MB whose pixels its halo touches
+// has run.  Inter MBs all run first (level 0).  Raster-later owners are "not yet decoded" = 0 in the
+// reference (fresh plane, MD.cs:107) and are masked by the kernel, so they are not dependencies.
+void MobiStreamParser::finish_levels(ParsedFrame &out) {
+  const int n = (int)out.desc.size();
+  const long S = g_.stride;
+  std::vector<uint16_t> level(n, 0);
+  int maxl = 0, n_intra = 0;
+  for (int mb = 0; mb < n; mb++) {
+    if ((out.desc[mb].w1 & 1) != MOBI_MB_INTRA) continue;
+    n_intra++;
+    long off = (long)(mb / g_.mbw) * 16 * S + (mb % g_.mbw) * 16;
+    int lv = 0;
+    auto dep = [&](int o) {
+      if (o >= 0 && o < mb && level[o] > lv) lv = level[o];
+    };
+    for (int c = -1; c <= MOBI_HALO_Y_RIGHT; c++) dep(g_.owner_luma(off - S + c));
+    for (int r = 0; r < 16; r++) {
+      dep(g_.owner_luma(off + r * S - 1));
+      dep(g_.owner_luma(off + r * S + 16)); // right halo: one owner per row (an MB is 16 wide, halo is 8)
+    }
+    for (int v = 0; v < 2; v++) {
+      long base = off / 2 + v * (S / 2);
+      for (int c = -1; c <= MOBI_HALO_C_RIGHT; c++) dep(g_.owner_chroma(base - S + c));
+      for (int r = 0; r < 8; r++) {
+        dep(g_.owner_chroma(base + r * S - 1));
+        dep(g_.owner_chroma(base + r * S + 8));
+      }
+    }
+    level[mb] = (uint16_t)(lv + 1);
+    if (lv + 1 > maxl) maxl = lv + 1;
+    out.desc[mb].w1 |= (uint32_t)(lv + 1) << 20;
+  }
+  out.level_start.assign(maxl + 2, 0);
+  for (int mb = 0; mb < n; mb++)
+    if (level[mb]) out.level_start[level[mb] + 1]++;
+  for (int l = 1; l <= maxl + 1 && l < (int)out.level_start.size(); l++) out.level_start[l] += out.level_start[l - 1];
+  out.intra_mbs.resize(n_intra);
+  std::vector<uint32_t> cursor(out.level_start.begin(), out.level_start.end());
+  for (int mb = 0; mb < n; mb++)
+    if (level[mb]) out.intra_mbs[cursor[level[mb]]++] = (uint32_t)mb;
+  out.hdr.n_mbs = (uint32_t)n;
+  out.hdr.n_intra = (uint32_t)n_intra;
+  out.hdr.n_levels = (uint32_t)maxl;
+  out.hdr.payload_words = (uint32_t)out.payload.size();
+  out.hdr.quantizer = quant_;
+  out.hdr.cmd_bytes = (uint32_t)out.cmd_bytes();
+  for (int i = 0; i < 64; i++) out.hdr.scale8[dq8_[i] & 63] = (int32_t)(dq8_[i] >> 8);
+  for (int i = 0; i < 16; i++) out.hdr.scale4[dq4_[i] & 15] = (int32_t)(dq4_[i] >> 8);
+}
+
+int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offset, ParsedFrame &out) {
+  out.clear();
+  if (version_ != MOBI_VERSION_MODSDS && version_ != MOBI_VERSION_MOFLEX3DS) return MOBI_E_VERSION;
+  data_ = data;
+  len_ = (long)len;
+  off_ = *offset;
+  out_ = &out;
+  int rc = MOBI_OK;
+  frames_started_++; // ring rotation + fresh planes happen before anything can throw (MD.cs:102-108)
+  try {
+    nbr_ = 0;
+    win_ = data_u16(off_);
+    off_ += 2;
+    win_ <<= 16;
+    bool iframe = (win_ >> 31) == 1;
+    win_ += win_;
+    if (iframe) parse_i(out); else parse_p(out);
+    finish_levels(out);
+  } catch (const Err &e) {
+    rc = e.code;
+  }
+  *offset = off_;
+  return rc;
+}

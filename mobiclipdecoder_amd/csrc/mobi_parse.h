@@ -1,0 +1,116 @@
+// mobi_parse.h -- host half of one decoder instance: serial bitstream parse -> command list.
+//
+// Mirrors the parse side of LibMobiclip.Codec.Mobiclip.MobiclipDecoder (MobiclipDecoder.cs,
+// "MD.cs"): bit reader (:2970-3015), frame headers (:113-143, :224-236), MV prediction
+// (:163-208), the partition tree (:469-1746), residual CBP/VLC (:1818-1833, :2909-2968,
+// :3330-3432), intra macroblock syntax (:1759-1880, :2776-2902) and the quantiser tables
+// (:3884-3925).  It writes no pixels: every reconstruction step becomes a command (mobi_cmd.h).
+#ifndef MOBI_PARSE_H
+#define MOBI_PARSE_H
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "mobi_cmd.h"
+
+struct ParsedFrame {
+  FrameHdr hdr;
+  std::vector<MbDesc> desc;
+  std::vector<uint32_t> payload;
+  std::vector<uint32_t> intra_mbs;   // MB indices, grouped by level (ascending), raster order inside a level
+  std::vector<uint32_t> level_start; // size n_levels+2: intra_mbs[level_start[L] .. level_start[L+1]) for L = 1..n_levels
+  void clear();
+  size_t cmd_bytes() const { return sizeof(FrameHdr) + desc.size() * sizeof(MbDesc) + payload.size() * 4; }
+};
+
+// Geometry helpers shared by the parser (dependency levels) and the kernels (availability):
+// which macroblock owns the pixel at linear address `a` of the Y / UV plane; -1 = padding / outside.
+struct MobiGeom {
+  int width, height, stride, mbw, mbh;
+  int owner_luma(long a) const {
+    if (a < 0) return -1;
+    long row = a / stride, col = a % stride;
+    if (col >= width || row >= height) return -1;
+    return (int)((row >> 4) * mbw + (col >> 4));
+  }
+  int owner_chroma(long a) const {
+    if (a < 0) return -1;
+    long row = a / stride, col = a % stride;
+    long x = col >= stride / 2 ? col - stride / 2 : col;
+    if (x >= width / 2 || row >= height / 2) return -1;
+    return (int)((row >> 3) * mbw + (x >> 3));
+  }
+};
+// halo the intra kernel loads around a macroblock (must match mobi_kernels.hip)
+enum { MOBI_HALO_Y_RIGHT = 23, MOBI_HALO_C_RIGHT = 15 };
+
+class MobiStreamParser {
+ public:
+  MobiStreamParser(uint32_t width, uint32_t height, int version);
+  // d.Data=data; d.Offset=*offset; DecodeFrame(); *offset=d.Offset.  Returns MOBI_OK or MOBI_E_*.
+  // On error `out` is not to be executed; the ring still advances (MD.cs:102-108 ran already).
+  int parse_frame(const uint8_t *data, size_t len, int32_t *offset, ParsedFrame &out);
+
+  uint32_t quantizer() const { return quant_; }
+  uint32_t yuv_format() const { return yuvfmt_; }
+  int frames_started() const { return frames_started_; }
+  const MobiGeom &geom() const { return g_; }
+  int version() const { return version_; }
+
+ private:
+  struct Err { int code; };
+  [[noreturn]] void fail(int code) const { throw Err{code}; }
+  // bit reader
+  uint32_t data_u16(long off) const;
+  void fill_bits();
+  void take(int n);
+  uint32_t ue();
+  int se();
+  // syntax
+  void setup_quant(uint32_t q);
+  void parse_p(ParsedFrame &out);
+  void parse_i(ParsedFrame &out);
+  void pblock(int wi, int hi, int x, int y, int mv_slot);
+  void mc_leaf(int wi, int hi, int x, int y, int ref, int dx, int dy, int mv_slot);
+  void check_window(long pos, int w, int h, int phase, long plane_len) const;
+  void p_residual();
+  void resid_area(int area);
+  void resid_block(int area, int sub, bool is8);
+  void intra_full();
+  void intra_sub();
+  void intra_chroma(uint32_t cbp);
+  void intra_area_fixed(int area, int mode, bool coded);
+  int pmode(int ci, bool four);
+  void check_intra_reads(int mode, long off, bool four) const;
+  long area_offset(int area, int sub) const;
+  void begin_mb(int mb, int type);
+  void end_mb();
+  void finish_levels(ParsedFrame &out);
+
+  MobiGeom g_;
+  int version_, ver_; // ver_: table index 0 = Moflex3DS, 1 = ModsDS
+  // stream
+  const uint8_t *data_ = nullptr;
+  long len_ = 0;
+  int off_ = 0;
+  uint32_t win_ = 0; // r3
+  int nbr_ = 0;      // nrBitsRemaining
+  // persistent decoder state
+  uint32_t quant_ = 0, yuvfmt_ = 0;
+  uint32_t dq8_[64], dq4_[16]; // Internal[10..73], Internal[74..89]
+  uint8_t mcache_[40];         // bytes of Internal[0..9]
+  int vlc_table_ = 0;          // Internal[218]
+  int frames_started_ = 0;
+  std::vector<int> mvc_; // MV row cache, Internal[221..]
+  int predx_ = 0, predy_ = 0;
+  // current frame / MB being built
+  ParsedFrame *out_ = nullptr;
+  int cur_mb_ = 0, cur_x_ = 0, cur_y_ = 0;
+  long cur_off_ = 0;
+  std::vector<uint32_t> leaves_, coefs_;
+  uint32_t recs_[MOBI_INTRA_RECORDS];
+  uint32_t cbp6_ = 0, t8mask_ = 0, w3_ = 0;
+  int mb_type_ = 0;
+};
+
+#endif
