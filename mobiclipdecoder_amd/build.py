@@ -1,0 +1,94 @@
+"""Build every native artefact in-tree (no JIT cache, no pip install).
+
+  libmobiclip_hip.so      product: host parser + C ABI + gfx950 kernels          (hipcc)
+  libmobi_streamgen.so    synthetic bitstream generator (input source)           (g++)
+  oracle/_build/libmobi_oracle.so   CPU oracle = TEST INFRASTRUCTURE             (gcc)
+  tests/tools/libmobi_cmdinterp.so  CPU command-list interpreter = TEST TOOL     (g++)
+
+hipcc cross-compiles gfx950 without a GPU.  The built .so files are git-ignored but travel to the
+GPU box with the gpurun snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "mobiclipdecoder_amd")
+CSRC = os.path.join(PKG, "csrc")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+
+LIB_HIP = os.path.join(PKG, "libmobiclip_hip.so")
+LIB_GEN = os.path.join(PKG, "libmobi_streamgen.so")
+LIB_ORACLE = os.path.join(ROOT, "oracle", "_build", "libmobi_oracle.so")
+LIB_INTERP = os.path.join(ROOT, "tests", "tools", "libmobi_cmdinterp.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _hdrs(d):
+    return [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
+
+
+def build_hip(force=False):
+    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_kernels.hip")]
+    deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h")]
+    if not force and not _newer(LIB_HIP, deps):
+        return LIB_HIP
+    obj = os.path.join(PKG, "_obj")
+    os.makedirs(obj, exist_ok=True)
+    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
+    objs = []
+    for s in srcs[:2]:
+        o = os.path.join(obj, os.path.basename(s) + ".o")
+        _run(["g++"] + host_flags + ["-c", s, "-o", o])
+        objs.append(o)
+    ko = os.path.join(obj, "mobi_kernels.o")
+    _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", srcs[2], "-o", ko])
+    objs.append(ko)
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_HIP])
+    return LIB_HIP
+
+
+def build_gen(force=False):
+    src = os.path.join(CSRC, "mobi_streamgen.cpp")
+    if force or _newer(LIB_GEN, [src] + _hdrs(CSRC)):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", LIB_GEN])
+    return LIB_GEN
+
+
+def build_oracle(force=False):
+    odir = os.path.join(ROOT, "oracle")
+    src = os.path.join(odir, "mobi_oracle.c")
+    if force or _newer(LIB_ORACLE, [src] + _hdrs(odir)):
+        os.makedirs(os.path.dirname(LIB_ORACLE), exist_ok=True)
+        _run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-fwrapv", "-Wall", src, "-o", LIB_ORACLE])
+    return LIB_ORACLE
+
+
+def build_interp(force=False):
+    src = os.path.join(ROOT, "tests", "tools", "mobi_cmd_interp.cpp")
+    parse = os.path.join(CSRC, "mobi_parse.cpp")
+    if force or _newer(LIB_INTERP, [src, parse] + _hdrs(CSRC)):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, parse, "-o", LIB_INTERP])
+    return LIB_INTERP
+
+
+def build_all(force=False):
+    return [build_hip(force), build_gen(force), build_oracle(force), build_interp(force)]
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("ok")

@@ -1,0 +1,499 @@
+// mobi_abi.cpp -- C ABI of libmobiclip_hip.so (include/mobiclip_hip.h): owns the HIP buffers, runs the
+// host bitstream parse and launches the reconstruction kernels.  There is no CPU reconstruction path:
+// every entry point that produces pixels goes through mobi_launch_inter / mobi_launch_intra.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mobiclip_hip.h"
+#include "mobi_cmd.h"
+#include "mobi_kernels.h"
+#include "mobi_parse.h"
+
+namespace {
+
+constexpr size_t kGuard = 4096; // slack on both ends of the plane arena: MC fetches whole aligned dwords
+constexpr size_t kAlign = 16;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define HIP_TRY(expr)                                                             \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s: %s", #expr, hipGetErrorString(e_)); \
+      return MOBI_E_DEVICE;                                                       \
+    }                                                                             \
+  } while (0)
+thread_local char g_last_hip_error[256] = "";
+
+struct PinnedBuf { // growable pinned host staging buffer
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return MOBI_OK;
+    if (p) hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max(n, (size_t)1 << 20);
+    HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+    cap = want;
+    return MOBI_OK;
+  }
+  ~PinnedBuf() { if (p) hipHostFree(p); }
+};
+struct DevBuf {
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return MOBI_OK;
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max(n, (size_t)1 << 20);
+    HIP_TRY(hipMalloc((void **)&p, want));
+    cap = want;
+    return MOBI_OK;
+  }
+  ~DevBuf() { if (p) hipFree(p); }
+};
+
+// serialise one parsed frame as [FrameHdr][MbDesc x n][payload], 16-byte aligned; returns bytes written
+size_t blob_size(const ParsedFrame &f) { return align_up(f.cmd_bytes(), kAlign); }
+void blob_write(const ParsedFrame &f, uint8_t *dst) {
+  memcpy(dst, &f.hdr, sizeof(FrameHdr));
+  memcpy(dst + sizeof(FrameHdr), f.desc.data(), f.desc.size() * sizeof(MbDesc));
+  memcpy(dst + sizeof(FrameHdr) + f.desc.size() * sizeof(MbDesc), f.payload.data(), f.payload.size() * 4);
+}
+
+struct LevelPlan { // launch plan of one frame step: items of level L are items[start[L] .. start[L+1])
+  std::vector<uint32_t> items;
+  std::vector<uint32_t> start; // size n_levels + 2, index 0 unused
+  bool any_inter = false;
+  uint64_t cmd_bytes = 0;
+  void build(const std::vector<const ParsedFrame *> &frames) {
+    uint32_t maxl = 0;
+    any_inter = false;
+    cmd_bytes = 0;
+    for (auto *f : frames)
+      if (f) {
+        maxl = std::max(maxl, f->hdr.n_levels);
+        if (f->hdr.n_intra < f->hdr.n_mbs) any_inter = true;
+        cmd_bytes += f->hdr.cmd_bytes;
+      }
+    start.assign(maxl + 2, 0);
+    items.clear();
+    for (uint32_t L = 1; L <= maxl; L++) {
+      start[L] = (uint32_t)items.size();
+      for (size_t c = 0; c < frames.size(); c++) {
+        const ParsedFrame *f = frames[c];
+        if (!f || L > f->hdr.n_levels) continue;
+        for (uint32_t i = f->level_start[L]; i < f->level_start[L + 1]; i++) items.push_back(MOBI_ITEM(c, f->intra_mbs[i]));
+      }
+    }
+    start[maxl + 1] = (uint32_t)items.size();
+  }
+  uint32_t n_levels() const { return start.empty() ? 0 : (uint32_t)start.size() - 2; }
+};
+
+} // namespace
+
+struct mobi_batch {
+  int n = 0, device = 0, version = 0;
+  MobiGeom g{};
+  hipStream_t stream = nullptr;
+  uint8_t *arena = nullptr; // guard | clips x 6 slots | guard
+  size_t slot_bytes = 0, clip_bytes = 0;
+  int ring_base = 0;
+  int frames_started = 0;
+  std::vector<std::unique_ptr<MobiStreamParser>> parsers;
+  std::vector<ParsedFrame> cur; // per clip, current frame (batch_decode)
+  int *d_fault = nullptr;
+  std::vector<int> h_fault;
+  // per-call staging (batch_decode)
+  PinnedBuf h_stage;
+  DevBuf d_cmd, d_off, d_items;
+  size_t dummy_bytes = 0;
+  std::vector<uint8_t> dummy; // a frame whose MBs are all "intra" with no launch items: nothing is written
+  // preloaded replay
+  std::vector<std::vector<ParsedFrame>> staged; // [clip][frame]
+  std::vector<std::vector<int>> staged_rc;
+  int n_frames_loaded = 0;
+  DevBuf r_cmd, r_off, r_items;
+  std::vector<LevelPlan> r_plan;        // per frame
+  std::vector<size_t> r_items_off;      // per frame: word offset of its items in r_items
+  bool committed = false;
+  // timing
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  bool ktiming = false;
+  struct EvPair { hipEvent_t a, b; int kind; };
+  std::vector<EvPair> evs;
+  std::vector<hipEvent_t> ev_pool;
+  float acc_ms[2] = {0, 0};
+  int acc_launches[2] = {0, 0};
+
+  MobiReconArgs args(const uint8_t *cmd, const uint64_t *off) const {
+    MobiReconArgs a;
+    a.planes = arena + kGuard;
+    a.cmd = cmd;
+    a.frame_off = off;
+    a.fault = d_fault;
+    a.clip_bytes = clip_bytes;
+    a.slot_bytes = (uint32_t)slot_bytes;
+    a.ring_base = ring_base;
+    a.width = g.width; a.height = g.height; a.stride = g.stride; a.mbw = g.mbw;
+    a.n_mbs = g.mbw * g.mbh;
+    a.n_clips = n;
+    return a;
+  }
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+  }
+  int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev) {
+    if (plan.any_inter) {
+      EvPair ep{nullptr, nullptr, 0};
+      if (ktiming) { ep.a = get_event(); ep.b = get_event(); hipEventRecord(ep.a, stream); }
+      if (mobi_launch_inter(&a, stream) != 0) return MOBI_E_DEVICE;
+      if (ktiming) { hipEventRecord(ep.b, stream); evs.push_back(ep); }
+    }
+    for (uint32_t L = 1; L <= plan.n_levels(); L++) {
+      int cnt = (int)(plan.start[L + 1] - plan.start[L]);
+      if (cnt <= 0) continue;
+      EvPair ep{nullptr, nullptr, 1};
+      if (ktiming) { ep.a = get_event(); ep.b = get_event(); hipEventRecord(ep.a, stream); }
+      if (mobi_launch_intra(&a, items_dev + plan.start[L], cnt, stream) != 0) return MOBI_E_DEVICE;
+      if (ktiming) { hipEventRecord(ep.b, stream); evs.push_back(ep); }
+    }
+    return MOBI_OK;
+  }
+  void drain_events() {
+    for (auto &e : evs) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { acc_ms[e.kind] += ms; acc_launches[e.kind]++; }
+      ev_pool.push_back(e.a);
+      ev_pool.push_back(e.b);
+    }
+    evs.clear();
+  }
+  ~mobi_batch() {
+    if (stream) hipStreamSynchronize(stream);
+    drain_events();
+    for (auto e : ev_pool) hipEventDestroy(e);
+    if (ev_begin) hipEventDestroy(ev_begin);
+    if (ev_end) hipEventDestroy(ev_end);
+    if (arena) hipFree(arena);
+    if (d_fault) hipFree(d_fault);
+    if (stream) hipStreamDestroy(stream);
+  }
+};
+
+struct mobi_dec { mobi_batch *b; };
+
+extern "C" {
+
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter, mobi_recon_intra; no CPU reconstruction path)"; }
+
+const char *mobi_error_string(int rc) {
+  switch (rc) {
+    case MOBI_OK: return "ok";
+    case MOBI_E_INDEX: return "index out of range (reference would throw IndexOutOfRange/ArgumentException)";
+    case MOBI_E_NULLREF: return "reference frame slot is null";
+    case MOBI_E_PARTCODE: return "illegal partition code";
+    case MOBI_E_VERSION: return "unsupported codec version";
+    case MOBI_E_CLAMP: return "residual left the clamp-table domain";
+    case MOBI_E_UNSUPPORTED: return "stream depends on Internal[] scratch aliasing (outside the parity domain)";
+    case MOBI_E_ARG: return "bad argument";
+    case MOBI_E_DEVICE: return g_last_hip_error[0] ? g_last_hip_error : "HIP error";
+    default: return "unknown";
+  }
+}
+
+mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int version, int device) {
+  if (n_clips < 1 || n_clips >= (1 << 19) || width == 0 || height == 0 || (width & 15) || (height & 15) || width > 1024 ||
+      (width / 16) * (height / 16) > 8191)
+    return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    snprintf(g_last_hip_error, sizeof(g_last_hip_error), "no usable HIP device (count=%d, requested %d)", ndev, device);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  auto b = std::make_unique<mobi_batch>();
+  b->n = n_clips;
+  b->device = device;
+  b->version = version;
+  for (int i = 0; i < n_clips; i++) b->parsers.emplace_back(new MobiStreamParser(width, height, version));
+  b->g = b->parsers[0]->geom();
+  b->slot_bytes = (size_t)b->g.stride * b->g.height * 3 / 2;
+  b->clip_bytes = 6 * b->slot_bytes;
+  b->cur.resize(n_clips);
+  b->h_fault.assign(n_clips, 0);
+  size_t total = kGuard * 2 + b->clip_bytes * (size_t)n_clips;
+  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipMalloc((void **)&b->arena, total) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(b->arena, 0, total, b->stream) != hipSuccess) return nullptr; // padding must read 0 forever (MD.cs:107)
+  if (hipMalloc((void **)&b->d_fault, sizeof(int) * n_clips) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(b->d_fault, 0, sizeof(int) * n_clips, b->stream) != hipSuccess) return nullptr;
+  if (hipEventCreate(&b->ev_begin) != hipSuccess || hipEventCreate(&b->ev_end) != hipSuccess) return nullptr;
+  // dummy frame: every MB typed intra, no launch items
+  const int n_mbs = b->g.mbw * b->g.mbh;
+  b->dummy_bytes = align_up(sizeof(FrameHdr) + (size_t)n_mbs * sizeof(MbDesc), kAlign);
+  b->dummy.assign(b->dummy_bytes, 0);
+  FrameHdr h;
+  memset(&h, 0, sizeof(h));
+  h.n_mbs = (uint32_t)n_mbs;
+  h.n_intra = (uint32_t)n_mbs;
+  memcpy(b->dummy.data(), &h, sizeof(h));
+  for (int i = 0; i < n_mbs; i++) {
+    MbDesc d{0, MOBI_MB_INTRA, 0, 0};
+    memcpy(b->dummy.data() + sizeof(FrameHdr) + (size_t)i * sizeof(MbDesc), &d, sizeof(d));
+  }
+  if (hipStreamSynchronize(b->stream) != hipSuccess) return nullptr;
+  return b.release();
+}
+
+void mobi_batch_destroy(mobi_batch *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  delete b;
+}
+
+int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
+  if (!b || !data || !len || !offsets || !rc) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  const int n = b->n;
+  // 1. host: serial VLC parse of one frame per clip -> command lists
+  std::vector<const ParsedFrame *> ok(n, nullptr);
+  bool any_version_error = false;
+  for (int i = 0; i < n; i++) {
+    rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]);
+    if (rc[i] == MOBI_OK) ok[i] = &b->cur[i];
+    if (rc[i] == MOBI_E_VERSION) any_version_error = true;
+  }
+  if (any_version_error) return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
+  b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
+  b->frames_started++;
+  LevelPlan plan;
+  plan.build(ok);
+  // 2. stage [dummy][clip blobs][frame_off table][items] and upload
+  size_t cmd_bytes = b->dummy_bytes;
+  std::vector<uint64_t> off(n, 0);
+  for (int i = 0; i < n; i++)
+    if (ok[i]) { off[i] = cmd_bytes; cmd_bytes += blob_size(*ok[i]); }
+  const size_t off_bytes = align_up(sizeof(uint64_t) * n, kAlign), item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
+  if (int e = b->h_stage.reserve(cmd_bytes + off_bytes + item_bytes)) return e;
+  if (int e = b->d_cmd.reserve(cmd_bytes)) return e;
+  if (int e = b->d_off.reserve(off_bytes)) return e;
+  if (int e = b->d_items.reserve(item_bytes)) return e;
+  uint8_t *hs = b->h_stage.p;
+  memcpy(hs, b->dummy.data(), b->dummy_bytes);
+  for (int i = 0; i < n; i++)
+    if (ok[i]) blob_write(*ok[i], hs + off[i]);
+  memcpy(hs + cmd_bytes, off.data(), sizeof(uint64_t) * n);
+  if (!plan.items.empty()) memcpy(hs + cmd_bytes + off_bytes, plan.items.data(), plan.items.size() * 4);
+  HIP_TRY(hipMemcpyAsync(b->d_cmd.p, hs, cmd_bytes, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_off.p, hs + cmd_bytes, off_bytes, hipMemcpyHostToDevice, b->stream));
+  if (!plan.items.empty())
+    HIP_TRY(hipMemcpyAsync(b->d_items.p, hs + cmd_bytes + off_bytes, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
+  // 3. device: reconstruction
+  MobiReconArgs a = b->args(b->d_cmd.p, (const uint64_t *)b->d_off.p);
+  if (int e = b->launch_plan(a, plan, (const uint32_t *)b->d_items.p)) return e;
+  HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->drain_events();
+  for (int i = 0; i < n; i++)
+    if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = MOBI_E_CLAMP;
+  return MOBI_OK;
+}
+
+int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out) {
+  if (!b || clip < 0 || clip >= b->n || ring_idx < 0 || ring_idx > 5) return MOBI_E_ARG;
+  if (ring_idx >= b->frames_started) return MOBI_E_NULLREF;
+  HIP_TRY(hipSetDevice(b->device));
+  const uint8_t *slot = b->arena + kGuard + (size_t)clip * b->clip_bytes + (size_t)((b->ring_base + 6 - ring_idx) % 6) * b->slot_bytes;
+  const size_t ysz = (size_t)b->g.stride * b->g.height;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (y_out) HIP_TRY(hipMemcpy(y_out, slot, ysz, hipMemcpyDeviceToHost));
+  if (uv_out) HIP_TRY(hipMemcpy(uv_out, slot + ysz, ysz / 2, hipMemcpyDeviceToHost));
+  return MOBI_OK;
+}
+uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) { return (b && clip >= 0 && clip < b->n) ? b->parsers[clip]->quantizer() : 0; }
+int mobi_batch_stride(const mobi_batch *b) { return b ? b->g.stride : 0; }
+int mobi_batch_n_clips(const mobi_batch *b) { return b ? b->n : 0; }
+
+// ---- pre-parsed replay -----------------------------------------------------------------------------
+int mobi_batch_preload(mobi_batch *b, int clip, const uint8_t *data, size_t len, const uint32_t *frame_off, int n_frames, int *rc_per_frame) {
+  if (!b || clip < 0 || clip >= b->n || !data || !frame_off || n_frames < 1) return MOBI_E_ARG;
+  if (b->staged.empty()) { b->staged.resize(b->n); b->staged_rc.resize(b->n); }
+  b->committed = false;
+  auto &dst = b->staged[clip];
+  auto &rcs = b->staged_rc[clip];
+  dst.assign(n_frames, ParsedFrame());
+  rcs.assign(n_frames, MOBI_OK);
+  MobiStreamParser parser((uint32_t)b->g.width, (uint32_t)b->g.height, b->version); // fresh decoder state for this clip
+  int worst = MOBI_OK;
+  for (int f = 0; f < n_frames; f++) {
+    if (frame_off[f + 1] > len || frame_off[f] > frame_off[f + 1]) return MOBI_E_ARG;
+    int32_t off = (int32_t)frame_off[f];
+    int rc = parser.parse_frame(data, frame_off[f + 1], &off, dst[f]);
+    rcs[f] = rc;
+    if (rc_per_frame) rc_per_frame[f] = rc;
+    if (rc != MOBI_OK && worst == MOBI_OK) worst = rc;
+  }
+  return worst;
+}
+int mobi_batch_preload_clone(mobi_batch *b, int clip, int src_clip) {
+  if (!b || b->staged.empty() || clip < 0 || clip >= b->n || src_clip < 0 || src_clip >= b->n || b->staged[src_clip].empty()) return MOBI_E_ARG;
+  b->committed = false;
+  b->staged[clip] = b->staged[src_clip];
+  b->staged_rc[clip] = b->staged_rc[src_clip];
+  return MOBI_OK;
+}
+int mobi_batch_commit(mobi_batch *b) {
+  if (!b || b->staged.empty()) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  const int n = b->n;
+  int nf = -1;
+  for (int c = 0; c < n; c++) {
+    if (b->staged[c].empty()) return MOBI_E_ARG; // every clip must be loaded or cloned
+    if (nf < 0) nf = (int)b->staged[c].size();
+    if ((int)b->staged[c].size() != nf) return MOBI_E_ARG;
+  }
+  size_t cmd_bytes = b->dummy_bytes, n_items = 0;
+  std::vector<uint64_t> off((size_t)nf * n, 0);
+  b->r_plan.assign(nf, LevelPlan());
+  b->r_items_off.assign(nf, 0);
+  for (int f = 0; f < nf; f++) {
+    std::vector<const ParsedFrame *> ok(n, nullptr);
+    for (int c = 0; c < n; c++)
+      if (b->staged_rc[c][f] == MOBI_OK) {
+        ok[c] = &b->staged[c][f];
+        off[(size_t)f * n + c] = cmd_bytes;
+        cmd_bytes += blob_size(*ok[c]);
+      }
+    b->r_plan[f].build(ok);
+    b->r_items_off[f] = n_items;
+    n_items += b->r_plan[f].items.size();
+  }
+  if (int e = b->r_cmd.reserve(cmd_bytes)) return e;
+  if (int e = b->r_off.reserve(off.size() * sizeof(uint64_t))) return e;
+  if (int e = b->r_items.reserve(n_items * 4 + 16)) return e;
+  // upload through a bounded pinned window
+  const size_t win = (size_t)64 << 20;
+  if (int e = b->h_stage.reserve(win)) return e;
+  auto upload = [&](uint8_t *dst, const uint8_t *src, size_t bytes) -> int {
+    for (size_t done = 0; done < bytes; done += win) {
+      size_t chunk = std::min(win, bytes - done);
+      memcpy(b->h_stage.p, src + done, chunk);
+      HIP_TRY(hipMemcpyAsync(dst + done, b->h_stage.p, chunk, hipMemcpyHostToDevice, b->stream));
+      HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    return MOBI_OK;
+  };
+  if (int e = upload(b->r_cmd.p, b->dummy.data(), b->dummy_bytes)) return e;
+  std::vector<uint8_t> tmp;
+  for (int f = 0; f < nf; f++)
+    for (int c = 0; c < n; c++)
+      if (b->staged_rc[c][f] == MOBI_OK) {
+        const ParsedFrame &pf = b->staged[c][f];
+        tmp.assign(blob_size(pf), 0);
+        blob_write(pf, tmp.data());
+        if (int e = upload(b->r_cmd.p + off[(size_t)f * n + c], tmp.data(), tmp.size())) return e;
+      }
+  if (int e = upload(b->r_off.p, (const uint8_t *)off.data(), off.size() * sizeof(uint64_t))) return e;
+  for (int f = 0; f < nf; f++)
+    if (!b->r_plan[f].items.empty())
+      if (int e = upload(b->r_items.p + b->r_items_off[f] * 4, (const uint8_t *)b->r_plan[f].items.data(), b->r_plan[f].items.size() * 4)) return e;
+  b->n_frames_loaded = nf;
+  b->committed = true;
+  return MOBI_OK;
+}
+int mobi_batch_replay(mobi_batch *b, int frame_idx) {
+  if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
+  b->ring_base = (b->ring_base + 1) % 6;
+  b->frames_started++;
+  MobiReconArgs a = b->args(b->r_cmd.p, (const uint64_t *)b->r_off.p + (size_t)frame_idx * b->n);
+  return b->launch_plan(a, b->r_plan[frame_idx], (const uint32_t *)b->r_items.p + b->r_items_off[frame_idx]);
+}
+int mobi_batch_sync(mobi_batch *b) {
+  if (!b) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * b->n, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * b->n, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->drain_events();
+  for (int i = 0; i < b->n; i++)
+    if (b->h_fault[i]) return MOBI_E_CLAMP;
+  return MOBI_OK;
+}
+uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx) {
+  if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return 0;
+  return b->r_plan[frame_idx].cmd_bytes;
+}
+int mobi_batch_time_begin(mobi_batch *b) {
+  if (!b) return MOBI_E_ARG;
+  b->acc_ms[0] = b->acc_ms[1] = 0;
+  b->acc_launches[0] = b->acc_launches[1] = 0;
+  HIP_TRY(hipEventRecord(b->ev_begin, b->stream));
+  return MOBI_OK;
+}
+int mobi_batch_time_end(mobi_batch *b, float *ms_out) {
+  if (!b || !ms_out) return MOBI_E_ARG;
+  HIP_TRY(hipEventRecord(b->ev_end, b->stream));
+  HIP_TRY(hipEventSynchronize(b->ev_end));
+  HIP_TRY(hipEventElapsedTime(ms_out, b->ev_begin, b->ev_end));
+  b->drain_events();
+  return MOBI_OK;
+}
+int mobi_batch_set_kernel_timing(mobi_batch *b, int enable) {
+  if (!b) return MOBI_E_ARG;
+  b->ktiming = enable != 0;
+  return MOBI_OK;
+}
+int mobi_batch_kernel_ms(mobi_batch *b, float *inter_ms, float *intra_ms, int *inter_launches, int *intra_launches) {
+  if (!b) return MOBI_E_ARG;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->drain_events();
+  if (inter_ms) *inter_ms = b->acc_ms[0];
+  if (intra_ms) *intra_ms = b->acc_ms[1];
+  if (inter_launches) *inter_launches = b->acc_launches[0];
+  if (intra_launches) *intra_launches = b->acc_launches[1];
+  return MOBI_OK;
+}
+
+// ---- single stream = batch of one --------------------------------------------------------------------
+mobi_dec *mobi_create(uint32_t width, uint32_t height, int version, int device) {
+  mobi_batch *b = mobi_batch_create(1, width, height, version, device);
+  if (!b) return nullptr;
+  return new mobi_dec{b};
+}
+void mobi_destroy(mobi_dec *d) {
+  if (!d) return;
+  mobi_batch_destroy(d->b);
+  delete d;
+}
+int mobi_decode(mobi_dec *d, const uint8_t *data, size_t len, int32_t *offset_inout) {
+  if (!d || !data || !offset_inout) return MOBI_E_ARG;
+  int rc = MOBI_OK;
+  const uint8_t *dp[1] = {data};
+  size_t lp[1] = {len};
+  int e = mobi_batch_decode(d->b, dp, lp, offset_inout, &rc);
+  return e != MOBI_OK ? e : rc;
+}
+int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out) { return d ? mobi_batch_get_planes(d->b, 0, ring_idx, y_out, uv_out) : MOBI_E_ARG; }
+int mobi_stride(const mobi_dec *d) { return d ? d->b->g.stride : 0; }
+uint32_t mobi_quantizer(const mobi_dec *d) { return d ? d->b->parsers[0]->quantizer() : 0; }
+uint32_t mobi_yuv_format(const mobi_dec *d) { return d ? d->b->parsers[0]->yuv_format() : 0; }
+uint32_t mobi_width(const mobi_dec *d) { return d ? (uint32_t)d->b->g.width : 0; }
+uint32_t mobi_height(const mobi_dec *d) { return d ? (uint32_t)d->b->g.height : 0; }
+
+} // extern "C"

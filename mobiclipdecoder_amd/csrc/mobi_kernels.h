@@ -1,0 +1,28 @@
+// mobi_kernels.h -- launch interface between the C-ABI layer (mobi_abi.cpp) and mobi_kernels.hip.
+#ifndef MOBI_KERNELS_H
+#define MOBI_KERNELS_H
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+// Everything one reconstruction launch needs.  HBM layout:
+//   planes : [clip][slot 0..5][ Y: stride*height | UV: stride*height/2 ]   (the reference's own plane
+//            layout, MD.cs:107-108,414-415, so linear offsets in the command list apply unchanged)
+//   cmd    : command lists; frame_off[clip] = byte offset of that clip's FrameHdr for the current frame
+// Ring: position r (0 = frame being written, 1..5 = references, MD.cs:102-106) lives in slot
+//   (ring_base + 6 - r) % 6 ; every clip of a batch rotates in lock step, so ring_base is a scalar.
+struct MobiReconArgs {
+  uint8_t *planes;
+  const uint8_t *cmd;
+  const uint64_t *frame_off;
+  int *fault;           // [clip] clamp-table domain faults (MOBI_E_CLAMP)
+  uint64_t clip_bytes;  // 6 * slot_bytes
+  uint32_t slot_bytes;  // stride*height*3/2
+  int ring_base;
+  int width, height, stride, mbw, n_mbs, n_clips;
+};
+
+extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);
+extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
+// intra launch item: (clip << 13) | mb
+#define MOBI_ITEM(clip, mb) (((uint32_t)(clip) << 13) | (uint32_t)(mb))
+#endif

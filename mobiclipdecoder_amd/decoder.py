@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference decoder class over the C ABI (include/mobiclip_hip.h).
+
+``MobiclipDecoder`` keeps the public surface of LibMobiclip.Codec.Mobiclip.MobiclipDecoder
+(MobiclipDecoder.cs:13-61): ctor ``(Width, Height, Version)``, fields ``Data`` / ``Offset`` /
+``Width`` / ``Height`` / ``Stride`` / ``Quantizer`` / ``YuvFormat``, plane accessors ``Y[i]`` /
+``UV[i]`` and ``DecodeFrame()``.  The callers' contract (MobiConverter/Program.cs:69-71,243-250):
+
+    d.Data = frame; d.Offset = 0; d.DecodeFrame(); audio_start = d.Offset - 2
+
+Differences, on purpose: ``DecodeFrame`` returns the planes (Y, UV) instead of a System.Drawing
+Bitmap (the RGB conversion MD.cs:260-323 is outside the graded path), and where the reference
+swallows every exception and returns null (MD.cs:325-328) this returns ``None`` and leaves the
+reason in ``last_error``.  Reconstruction runs only on the GPU; there is no CPU fallback.
+"""
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MobiclipVersion(enum.IntEnum):  # MD.cs:32-37
+    VxDS = 0
+    ModsDS = 1
+    Moflex3DS = 2
+
+
+class MobiclipError(RuntimeError):
+    pass
+
+
+# names must match include/mobiclip_hip.h (tests/test_abi_symbols.py checks the header against the .so)
+_SIGS = {
+    "mobi_create": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "mobi_destroy": (None, [C.c_void_p]),
+    "mobi_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)]),
+    "mobi_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mobi_stride": (C.c_int, [C.c_void_p]),
+    "mobi_quantizer": (C.c_uint32, [C.c_void_p]),
+    "mobi_yuv_format": (C.c_uint32, [C.c_void_p]),
+    "mobi_width": (C.c_uint32, [C.c_void_p]),
+    "mobi_height": (C.c_uint32, [C.c_void_p]),
+    "mobi_batch_create": (C.c_void_p, [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "mobi_batch_destroy": (None, [C.c_void_p]),
+    "mobi_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mobi_batch_quantizer": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "mobi_batch_stride": (C.c_int, [C.c_void_p]),
+    "mobi_batch_n_clips": (C.c_int, [C.c_void_p]),
+    "mobi_batch_preload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "mobi_batch_preload_clone": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mobi_batch_commit": (C.c_int, [C.c_void_p]),
+    "mobi_batch_replay": (C.c_int, [C.c_void_p, C.c_int]),
+    "mobi_batch_sync": (C.c_int, [C.c_void_p]),
+    "mobi_batch_cmd_bytes": (C.c_uint64, [C.c_void_p, C.c_int]),
+    "mobi_batch_time_begin": (C.c_int, [C.c_void_p]),
+    "mobi_batch_time_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mobi_batch_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mobi_batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mobi_error_string": (C.c_char_p, [C.c_int]),
+    "mobi_build_info": (C.c_char_p, []),
+}
+
+LIB_PATH = os.path.join(_HERE, "libmobiclip_hip.so")
+
+
+def load_library():
+    """dlopen libmobiclip_hip.so and bind every entry point.  Raises if it was not built: the HIP
+    library is the only implementation, there is nothing to fall back to."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} missing: run `python -m mobiclipdecoder_amd.build` (or __graft_entry__.build())")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def error_string(rc):
+    return load_library().mobi_error_string(rc).decode()
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    if a.dtype != np.uint8:
+        a = a.view(np.uint8)
+    return np.ascontiguousarray(a)
+
+
+class _PlaneRing:
+    """d.Y[i] / d.UV[i] (MD.cs:19-20): device ring slot i copied to a numpy array on access."""
+
+    def __init__(self, dec, which):
+        self._dec, self._which = dec, which
+
+    def __getitem__(self, idx):
+        return self._dec._plane(idx, self._which)
+
+    def __len__(self):
+        return 6
+
+
+class MobiclipDecoder:
+    def __init__(self, Width, Height, Version, device=0):
+        self._lib = load_library()
+        self.Width, self.Height, self.Version = int(Width), int(Height), MobiclipVersion(Version)
+        self._h = self._lib.mobi_create(self.Width, self.Height, int(self.Version), device)
+        if not self._h:
+            raise MobiclipError(
+                f"mobi_create({Width},{Height},{Version},dev={device}) failed: {error_string(-8)} "
+                "(dimensions must be multiples of 16; a HIP device is required)")
+        self.Data = None
+        self.Offset = 0
+        self.last_error = 0
+        self.Y = _PlaneRing(self, 0)
+        self.UV = _PlaneRing(self, 1)
+
+    # -- reference fields -------------------------------------------------------------------
+    @property
+    def Stride(self):
+        return self._lib.mobi_stride(self._h)
+
+    @property
+    def Quantizer(self):
+        return self._lib.mobi_quantizer(self._h)
+
+    @property
+    def YuvFormat(self):
+        return self._lib.mobi_yuv_format(self._h)
+
+    # -- reference method -------------------------------------------------------------------
+    def DecodeFrame(self):
+        """MD.cs:56-61.  Returns (Y, UV) of the new frame, or None where the reference returns null."""
+        if self.Data is None:
+            self.last_error = -2
+            return None
+        buf = _as_u8(self.Data)
+        off = C.c_int32(int(self.Offset))
+        rc = self._lib.mobi_decode(self._h, buf.ctypes.data, buf.size, C.byref(off))
+        self.Offset = off.value
+        self.last_error = rc
+        if rc != 0:
+            return None
+        return self._plane(0, 0), self._plane(0, 1)
+
+    def _plane(self, idx, which):
+        S, H = self.Stride, self.Height
+        y = np.empty(S * H, np.uint8) if which == 0 else None
+        uv = np.empty(S * H // 2, np.uint8) if which == 1 else None
+        rc = self._lib.mobi_get_planes(self._h, idx, y.ctypes.data if y is not None else None,
+                                       uv.ctypes.data if uv is not None else None)
+        if rc == -2:
+            return None  # null slot, like the reference's unfilled ring entries
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return (y.reshape(H, S) if which == 0 else uv.reshape(H // 2, S))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mobi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MobiclipBatch:
+    """N independent decoder instances of equal geometry decoded in lock step on one GPU
+    (decoder instances share nothing: MD.cs:15-39).  Also the pre-parsed replay path used for
+    throughput measurement."""
+
+    def __init__(self, n_clips, Width, Height, Version, device=0):
+        self._lib = load_library()
+        self.n, self.Width, self.Height, self.Version = int(n_clips), int(Width), int(Height), MobiclipVersion(Version)
+        self._h = self._lib.mobi_batch_create(self.n, self.Width, self.Height, int(self.Version), device)
+        if not self._h:
+            raise MobiclipError(f"mobi_batch_create failed: {error_string(-8)}")
+        self.Stride = self._lib.mobi_batch_stride(self._h)
+
+    def decode(self, datas, offsets):
+        """One DecodeFrame() per clip.  datas: list of byte buffers; offsets: list of ints.
+        Returns (rc list, new offsets list)."""
+        bufs = [_as_u8(d) for d in datas]
+        ptrs = (C.c_void_p * self.n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * self.n)(*[b.size for b in bufs])
+        offs = (C.c_int32 * self.n)(*[int(o) for o in offsets])
+        rcs = (C.c_int * self.n)()
+        e = self._lib.mobi_batch_decode(self._h, ptrs, lens, offs, rcs)
+        if e != 0:
+            raise MobiclipError(error_string(e))
+        return list(rcs), list(offs)
+
+    def planes(self, clip, idx=0):
+        S, H = self.Stride, self.Height
+        y = np.empty(S * H, np.uint8)
+        uv = np.empty(S * H // 2, np.uint8)
+        rc = self._lib.mobi_batch_get_planes(self._h, clip, idx, y.ctypes.data, uv.ctypes.data)
+        if rc == -2:
+            return None
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return y.reshape(H, S), uv.reshape(H // 2, S)
+
+    def quantizer(self, clip):
+        return self._lib.mobi_batch_quantizer(self._h, clip)
+
+    # -- replay ---------------------------------------------------------------------------------
+    def preload(self, clip, data, frame_off):
+        buf = _as_u8(data)
+        fo = np.ascontiguousarray(frame_off, dtype=np.uint32)
+        n_frames = fo.size - 1
+        rcs = (C.c_int * n_frames)()
+        self._lib.mobi_batch_preload(self._h, clip, buf.ctypes.data, buf.size, fo.ctypes.data, n_frames, rcs)
+        return list(rcs)
+
+    def preload_clone(self, clip, src):
+        rc = self._lib.mobi_batch_preload_clone(self._h, clip, src)
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+
+    def commit(self):
+        rc = self._lib.mobi_batch_commit(self._h)
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+
+    def replay(self, frame_idx):
+        rc = self._lib.mobi_batch_replay(self._h, frame_idx)
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+
+    def sync(self):
+        return self._lib.mobi_batch_sync(self._h)
+
+    def cmd_bytes(self, frame_idx):
+        return int(self._lib.mobi_batch_cmd_bytes(self._h, frame_idx))
+
+    def time_begin(self):
+        self._lib.mobi_batch_time_begin(self._h)
+
+    def time_end(self):
+        ms = C.c_float()
+        rc = self._lib.mobi_batch_time_end(self._h, C.byref(ms))
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return ms.value
+
+    def set_kernel_timing(self, on):
+        self._lib.mobi_batch_set_kernel_timing(self._h, 1 if on else 0)
+
+    def kernel_ms(self):
+        a, b, na, nb = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+        self._lib.mobi_batch_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(na), C.byref(nb))
+        return {"inter_ms": a.value, "intra_ms": b.value, "inter_launches": na.value, "intra_launches": nb.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mobi_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,68 @@
+"""ctypes binding of libmobi_streamgen.so (csrc/mobi_streamgen.h): seeded synthetic bitstreams.
+
+The reference ships no sample media, so tests and the benchmark feed on these streams
+(SURVEY.md 8(d)).  This is an input source, not part of the decode path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class GenParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("version", C.c_int32), ("seed", C.c_uint64),
+        ("n_frames", C.c_int32), ("quantizer", C.c_int32), ("iframe_interval", C.c_int32),
+        ("pm_skip", C.c_int32), ("pm_split1", C.c_int32), ("pm_deep", C.c_int32), ("pm_intra", C.c_int32),
+        ("pm_multiref", C.c_int32), ("mv_range", C.c_int32), ("cbp_prob", C.c_int32), ("t8_prob", C.c_int32),
+        ("dense_prob", C.c_int32), ("max_coefs", C.c_int32), ("scan_span", C.c_int32),
+        ("intra_sub_prob", C.c_int32), ("plane_prob", C.c_int32), ("intra_dc_only", C.c_int32),
+        ("edge_mode", C.c_int32), ("escape_prob", C.c_int32), ("qdelta_prob", C.c_int32), ("table1_prob", C.c_int32),
+    ]
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmobi_streamgen.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} missing: run `python -m mobiclipdecoder_amd.build` (or __graft_entry__.build())")
+        lib = C.CDLL(path)
+        lib.mobi_gen_default_params.argtypes = [C.POINTER(GenParams), C.c_int, C.c_uint64]
+        lib.mobi_gen_default_params.restype = None
+        lib.mobi_gen_clip.argtypes = [C.POINTER(GenParams), C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.mobi_gen_clip.restype = C.c_int64
+        _LIB = lib
+    return _LIB
+
+
+BASE_SEED = 0x4D4F4249  # "MOBI" 
+
+
+def default_params(config="B", seed=BASE_SEED, **overrides):
+    """SURVEY.md 8(d) distribution for config 'A' (256x192 ModsDS), 'B' (640x480 Moflex3DS), 'C' (848x480)."""
+    p = GenParams()
+    _lib().mobi_gen_default_params(C.byref(p), ord(config), seed)
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def generate_clip(p):
+    """-> (bytes ndarray, frame_off uint32[n_frames+1])."""
+    lib = _lib()
+    fo = np.zeros(p.n_frames + 1, np.uint32)
+    need = lib.mobi_gen_clip(C.byref(p), None, 0, fo.ctypes.data)
+    if need == -1:
+        raise ValueError("bad generator parameters")
+    n = -need if need < 0 else need
+    buf = np.zeros(max(int(n), 2), np.uint8)
+    got = lib.mobi_gen_clip(C.byref(p), buf.ctypes.data, buf.size, fo.ctypes.data)
+    if got != n:
+        raise RuntimeError(f"generator size mismatch {got} != {n}")
+    return buf[: int(n)], fo

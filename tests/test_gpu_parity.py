@@ -1,0 +1,105 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact Y/U/V planes,
+post-call Offset and Quantizer, on seeded synthetic streams."""
+import numpy as np
+import pytest
+
+from mobiclipdecoder_amd import MobiclipBatch, MobiclipDecoder, MobiclipVersion, default_params, generate_clip
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+from tests.oracle_binding import OracleDecoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_stream(params, whole_file=False):
+    data, fo = generate_clip(params)
+    gpu = MobiclipDecoder(params.width, params.height, params.version)
+    ora = OracleDecoder(params.width, params.height, params.version)
+    assert gpu.Stride == ora.Stride
+    for f in range(params.n_frames):
+        if whole_file:  # MOC5 style: Data = whole file, Offset = frame start (Form1.cs:292-302)
+            gpu.Data = ora.Data = data
+        else:           # Moflex/Mods style: one buffer per frame, Offset = 0 (Program.cs:69-71)
+            gpu.Data = ora.Data = data[fo[f]:fo[f + 1]]
+        gpu.Offset = ora.Offset = int(fo[f]) if whole_file else 0
+        g = gpu.DecodeFrame()
+        o = ora.DecodeFrame()
+        assert gpu.last_error == ora.last_error == 0, (f, gpu.last_error, ora.last_error)
+        assert gpu.Offset == ora.Offset, f
+        assert gpu.Quantizer == ora.Quantizer, f
+        assert np.array_equal(g[0], o[0]), f"Y mismatch frame {f}: {np.argwhere(g[0] != o[0])[:4].tolist()}"
+        assert np.array_equal(g[1], o[1]), f"UV mismatch frame {f}: {np.argwhere(g[1] != o[1])[:4].tolist()}"
+    # the whole ring, not just slot 0
+    for r in range(6):
+        gy, oy = gpu.Y[r], ora.y(r)
+        assert (gy is None) == (oy is None)
+        if gy is not None:
+            assert np.array_equal(gy, oy) and np.array_equal(gpu.UV[r], ora.uv(r))
+    gpu.close()
+
+
+@pytest.mark.parametrize("cfg,seed", [("A", 0), ("A", 1), ("B", 0), ("B", 1), ("C", 0)])
+def test_default_streams_bit_exact(cfg, seed):
+    _run_stream(default_params(cfg, BASE_SEED + seed, n_frames=9))
+
+
+@pytest.mark.parametrize("cfg", ["A", "B"])
+def test_rich_streams_bit_exact(cfg):
+    p = default_params(cfg, BASE_SEED + 77, n_frames=10, pm_intra=150, pm_deep=150, pm_multiref=300,
+                       qdelta_prob=300, table1_prob=500, escape_prob=100, iframe_interval=6)
+    _run_stream(p, whole_file=True)
+
+
+def test_edge_mvs_pad_and_wrap():
+    _run_stream(default_params("A", BASE_SEED + 5, n_frames=8, edge_mode=1, mv_range=40))
+    _run_stream(default_params("B", BASE_SEED + 6, n_frames=8, edge_mode=1, mv_range=40))
+
+
+def test_batch_and_replay_match_single():
+    nclips, nfr = 5, 7
+    ps = [default_params("A", BASE_SEED + 100 + i, n_frames=nfr, pm_intra=100) for i in range(nclips)]
+    clips = [generate_clip(p) for p in ps]
+    oras = [OracleDecoder(256, 192, MobiclipVersion.ModsDS) for _ in range(nclips)]
+    b = MobiclipBatch(nclips, 256, 192, MobiclipVersion.ModsDS)
+    for f in range(nfr):
+        rcs, offs = b.decode([c[0] for c in clips], [int(c[1][f]) for c in clips])
+        for i in range(nclips):
+            oras[i].Data, oras[i].Offset = clips[i][0], int(clips[i][1][f])
+            o = oras[i].DecodeFrame()
+            assert rcs[i] == 0 and offs[i] == oras[i].Offset
+            y, uv = b.planes(i)
+            assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (f, i)
+    b.close()
+    # replay path: pre-parsed command lists resident in HBM, cloned clip included
+    b = MobiclipBatch(nclips + 1, 256, 192, MobiclipVersion.ModsDS)
+    for i in range(nclips):
+        assert all(r == 0 for r in b.preload(i, clips[i][0], clips[i][1]))
+    b.preload_clone(nclips, 2)
+    b.commit()
+    for f in range(nfr):
+        b.replay(f)
+    assert b.sync() == 0
+    for i in range(nclips + 1):
+        src = i if i < nclips else 2
+        y, uv = b.planes(i)
+        assert np.array_equal(y, oras[src].y(0)) and np.array_equal(uv, oras[src].uv(0)), i
+    assert b.cmd_bytes(1) > 0
+    b.close()
+
+
+def test_error_codes_match_oracle_class():
+    """Streams the reference would throw on: null reference slot (P-frame first), truncated data."""
+    p = default_params("A", BASE_SEED + 9, n_frames=3)
+    data, fo = generate_clip(p)
+    gpu = MobiclipDecoder(256, 192, MobiclipVersion.ModsDS)
+    ora = OracleDecoder(256, 192, MobiclipVersion.ModsDS)
+    # P-frame with nothing in the ring -> NullReference in CopyBlock
+    gpu.Data = ora.Data = data[fo[1]:fo[2]]
+    gpu.Offset = ora.Offset = 0
+    assert gpu.DecodeFrame() is None and ora.DecodeFrame() is None
+    assert gpu.last_error == ora.last_error == -2
+    # a good I-frame afterwards still decodes identically (ring rotated on both sides)
+    gpu.Data = ora.Data = data[fo[0]:fo[1]]
+    gpu.Offset = ora.Offset = 0
+    g, o = gpu.DecodeFrame(), ora.DecodeFrame()
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    gpu.close()
