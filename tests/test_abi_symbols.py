@@ -1,0 +1,58 @@
+"""CPU: libmobiclip_hip.so loads without a GPU and exports every symbol include/mobiclip_hip.h declares;
+creating a decoder without a device fails loudly (no CPU fallback exists)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mobiclip_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mobi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from mobiclipdecoder_amd import decoder
+    lib = decoder.load_library()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mobiclip_hip.h but not exported"
+        assert n in decoder._SIGS, f"{n} has no ctypes signature in decoder._SIGS"
+    assert set(decoder._SIGS) <= set(names)
+
+
+def test_library_contains_gfx950_code_object_and_no_oracle():
+    path = os.path.join(ROOT, "mobiclipdecoder_amd", "libmobiclip_hip.so")
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob and b"mobi_recon_inter" in blob and b"mobi_recon_intra" in blob
+    assert b"mobi_oracle" not in blob and b"cmdinterp" not in blob  # the checker is never linked into the product
+    ldd = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "libamdhip64" in ldd and "oracle" not in ldd
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import mobiclipdecoder_amd as m
+    with pytest.raises(m.MobiclipError):
+        m.MobiclipDecoder(256, 192, m.MobiclipVersion.ModsDS)
+    with pytest.raises(m.MobiclipError):
+        m.MobiclipBatch(4, 256, 192, m.MobiclipVersion.ModsDS)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mobiclipdecoder_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f == "build.py":
+                continue  # build.py compiles the checker (allowed); it never loads or calls it
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_binding" not in txt and "mobi_oracle" not in txt and "cmdinterp" not in txt, os.path.join(dp, f)
