@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded Mpixels/s of Mobiclip P-frame reconstruction on MI355X (BASELINE.json metric).
+
+A "step" = one P-frame of every resident clip: the reconstruction kernels (MC + dequant/IDCT +
+intra) run over pre-parsed command lists that already sit in HBM (the serial VLC
+parse and PCIe cannot feed a TB/s kernel, so they are outside the timed region; end-to-end numbers
+are in DESIGN.md).  Workload = BASELINE config "640x480 3DS Moflex stream" at a batch large enough to
+leave the Infinity Cache: `--clips` independent clips per GPU (weak scaling: per-GPU work fixed).
+
+  python bench.py                      # 1 GPU, defaults finish in well under a minute
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
+
+Clips shard across ranks with no data-path collective (decoder instances share nothing,
+MobiclipDecoder.cs:15-39); torch.distributed is used only for the barrier / max-over-ranks timing.
+
+Prints ONE JSON line (rank 0).  `roofline` = algorithmic bytes of the dominant kernel
+(mobi_recon_inter) per launch / its average duration from HIP events recorded on the launch stream
+inside the timed region.  `cpu_baseline` = the CPU oracle (a C restatement of the reference decoder;
+the C# original cannot run here) on this host, single thread, same stream, parse + reconstruction.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_PFRAMES = 32         # P-frames per generated clip (1 I + 32 P)
+
+
+def cpu_baseline(params, data, fo, budget_s):
+    """Oracle ("port" of MobiclipDecoder.cs) timed on one host core on the same stream."""
+    from tests.oracle_binding import OracleDecoder  # checker used here ONLY as the reported CPU baseline
+    px, t_used, n = 0, 0.0, 0
+    while t_used < budget_s:
+        d = OracleDecoder(params.width, params.height, params.version)
+        t0 = time.perf_counter()
+        for f in range(params.n_frames):
+            d.Data, d.Offset = data[: fo[f + 1]], int(fo[f])
+            assert d.DecodeFrame() is not None
+        t_used += time.perf_counter() - t0
+        px += params.width * params.height * params.n_frames
+        n += 1
+        d.close()
+    return {"value": round(px / t_used / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x ({params.n_frames}-frame {params.width}x{params.height} clip, 1 I + {params.n_frames - 1} P), "
+                      f"VLC parse + reconstruction, planes only, {t_used:.1f} s on 1 thread of {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--clips", type=int, default=512, help="independent clips resident per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct generated streams per GPU (others are private HBM copies)")
+    ap.add_argument("--config", default="B", choices=["A", "B", "C"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU reconstruction path to time")
+
+    import mobiclipdecoder_amd as m
+    from mobiclipdecoder_amd.streamgen import BASE_SEED
+
+    cfg_idx = "ABC".index(args.config)
+    distinct = max(1, min(args.distinct, args.clips))
+    streams = []
+    for i in range(distinct):
+        p = m.default_params(args.config, BASE_SEED + cfg_idx + 1000 * rank + i, n_frames=1 + N_PFRAMES)
+        streams.append((p,) + m.generate_clip(p))
+    p0 = streams[0][0]
+    W, H = p0.width, p0.height
+
+    b = m.MobiclipBatch(args.clips, W, H, p0.version, device=local)
+    for i, (p, data, fo) in enumerate(streams):
+        rcs = b.preload(i, data, fo)
+        assert all(r == 0 for r in rcs), rcs
+    for c in range(distinct, args.clips):
+        b.preload_clone(c, c % distinct)
+    b.commit()
+
+    # warm-up: the I-frame (frame 0) then W P-frames, in stream order
+    b.replay(0)
+    step_frames = [1 + (i % N_PFRAMES) for i in range(args.warmup + args.steps)]
+    for f in step_frames[: args.warmup]:
+        b.replay(f)
+    assert b.sync() == 0, "clamp-domain fault during warm-up"
+
+    b.set_kernel_timing(not args.no_kernel_events)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    b.time_begin()
+    t0 = time.perf_counter()
+    for f in step_frames[args.warmup:]:
+        b.replay(f)
+    stream_ms = b.time_end()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert b.sync() == 0, "clamp-domain fault in the timed region"
+    km = b.kernel_ms()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        steps = args.steps
+        total_px = world * args.clips * steps * W * H
+        timed = step_frames[args.warmup:]
+        cmd_bytes = sum(b.cmd_bytes(f) for f in timed) / steps          # per launch, all clips of this GPU
+        algo_bytes = args.clips * 3.0 * W * H + cmd_bytes                # ref read 1.5WH + write 1.5WH + commands
+        roof = None
+        if km["inter_launches"]:
+            avg_ms = km["inter_ms"] / km["inter_launches"]
+            ach = algo_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "mobi_recon_inter", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_ms, 5),
+                    "launches": km["inter_launches"],
+                    "intra_kernel_ms_per_step": round(km["intra_ms"] / steps, 5),
+                    "intra_launches_per_step": round(km["intra_launches"] / steps, 2)}
+            prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(prof):  # HBM bytes per launch from a separate rocprofv3 --pmc run (see profiles/README.md)
+                try:
+                    t = json.load(open(prof)).get(f"{args.config}:{args.clips}")
+                    if t:
+                        roof["traffic"] = t["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = t.get("source")
+                except Exception:
+                    pass
+        base = None
+        if world == 1 and args.cpu_seconds > 0:
+            base = cpu_baseline(*streams[0], args.cpu_seconds)
+        out = {
+            "metric": "decoded Mpixels/s @ 640x480 P-frames" if args.config == "B" else f"decoded Mpixels/s P-frames (config {args.config})",
+            "value": round(total_px / elapsed / 1e6, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} {'Moflex3DS' if p0.version == 2 else 'ModsDS'} P-frame reconstruction "
+                                   f"(SURVEY 8d generator mix), {args.clips} independent clips per GPU, "
+                                   f"{distinct} distinct streams, command lists resident in HBM",
+                       "clips_per_gpu": args.clips, "parallelism": f"clips sharded over {world} GPU(s), no collective",
+                       "stream_ms_per_step": round(stream_ms / steps, 4)},
+            "roofline": roof, "cpu_baseline": base,
+        }
+        print(json.dumps(out), flush=True)
+    b.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,7 @@ struct PinnedBuf { // growable pinned host staging buffer
   size_t cap = 0;
   int reserve(size_t n) {
     if (n <= cap) return MOBI_OK;
-    if (p) hipHostFree(p);
+    if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
     size_t want = std::max(n, (size_t)1 << 20);
@@ -45,14 +45,14 @@ struct PinnedBuf { // growable pinned host staging buffer
     cap = want;
     return MOBI_OK;
   }
-  ~PinnedBuf() { if (p) hipHostFree(p); }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
 };
 struct DevBuf {
   uint8_t *p = nullptr;
   size_t cap = 0;
   int reserve(size_t n) {
     if (n <= cap) return MOBI_OK;
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
     size_t want = std::max(n, (size_t)1 << 20);
@@ -60,7 +60,7 @@ struct DevBuf {
     cap = want;
     return MOBI_OK;
   }
-  ~DevBuf() { if (p) hipFree(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
 // serialise one parsed frame as [FrameHdr][MbDesc x n][payload], 16-byte aligned; returns bytes written
@@ -121,8 +121,9 @@ struct mobi_batch {
   size_t dummy_bytes = 0;
   std::vector<uint8_t> dummy; // a frame whose MBs are all "intra" with no launch items: nothing is written
   // preloaded replay
-  std::vector<std::vector<ParsedFrame>> staged; // [clip][frame]
-  std::vector<std::vector<int>> staged_rc;
+  // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
+  std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
+  std::vector<std::shared_ptr<std::vector<int>>> staged_rc;
   int n_frames_loaded = 0;
   DevBuf r_cmd, r_off, r_items;
   std::vector<LevelPlan> r_plan;        // per frame
@@ -154,23 +155,23 @@ struct mobi_batch {
   hipEvent_t get_event() {
     if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
   }
   int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev) {
     if (plan.any_inter) {
       EvPair ep{nullptr, nullptr, 0};
-      if (ktiming) { ep.a = get_event(); ep.b = get_event(); hipEventRecord(ep.a, stream); }
+      if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
       if (mobi_launch_inter(&a, stream) != 0) return MOBI_E_DEVICE;
-      if (ktiming) { hipEventRecord(ep.b, stream); evs.push_back(ep); }
+      if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
     for (uint32_t L = 1; L <= plan.n_levels(); L++) {
       int cnt = (int)(plan.start[L + 1] - plan.start[L]);
       if (cnt <= 0) continue;
       EvPair ep{nullptr, nullptr, 1};
-      if (ktiming) { ep.a = get_event(); ep.b = get_event(); hipEventRecord(ep.a, stream); }
+      if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
       if (mobi_launch_intra(&a, items_dev + plan.start[L], cnt, stream) != 0) return MOBI_E_DEVICE;
-      if (ktiming) { hipEventRecord(ep.b, stream); evs.push_back(ep); }
+      if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
     return MOBI_OK;
   }
@@ -184,14 +185,14 @@ struct mobi_batch {
     evs.clear();
   }
   ~mobi_batch() {
-    if (stream) hipStreamSynchronize(stream);
+    if (stream) (void)hipStreamSynchronize(stream);
     drain_events();
-    for (auto e : ev_pool) hipEventDestroy(e);
-    if (ev_begin) hipEventDestroy(ev_begin);
-    if (ev_end) hipEventDestroy(ev_end);
-    if (arena) hipFree(arena);
-    if (d_fault) hipFree(d_fault);
-    if (stream) hipStreamDestroy(stream);
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (ev_begin) (void)hipEventDestroy(ev_begin);
+    if (ev_end) (void)hipEventDestroy(ev_end);
+    if (arena) (void)hipFree(arena);
+    if (d_fault) (void)hipFree(d_fault);
+    if (stream) (void)hipStreamDestroy(stream);
   }
 };
 
@@ -262,7 +263,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
 
 void mobi_batch_destroy(mobi_batch *b) {
   if (!b) return;
-  hipSetDevice(b->device);
+  (void)hipSetDevice(b->device);
   delete b;
 }
 
@@ -335,10 +336,10 @@ int mobi_batch_preload(mobi_batch *b, int clip, const uint8_t *data, size_t len,
   if (!b || clip < 0 || clip >= b->n || !data || !frame_off || n_frames < 1) return MOBI_E_ARG;
   if (b->staged.empty()) { b->staged.resize(b->n); b->staged_rc.resize(b->n); }
   b->committed = false;
-  auto &dst = b->staged[clip];
-  auto &rcs = b->staged_rc[clip];
-  dst.assign(n_frames, ParsedFrame());
-  rcs.assign(n_frames, MOBI_OK);
+  b->staged[clip] = std::make_shared<std::vector<ParsedFrame>>(n_frames);
+  b->staged_rc[clip] = std::make_shared<std::vector<int>>(n_frames, MOBI_OK);
+  auto &dst = *b->staged[clip];
+  auto &rcs = *b->staged_rc[clip];
   MobiStreamParser parser((uint32_t)b->g.width, (uint32_t)b->g.height, b->version); // fresh decoder state for this clip
   int worst = MOBI_OK;
   for (int f = 0; f < n_frames; f++) {
@@ -352,7 +353,7 @@ int mobi_batch_preload(mobi_batch *b, int clip, const uint8_t *data, size_t len,
   return worst;
 }
 int mobi_batch_preload_clone(mobi_batch *b, int clip, int src_clip) {
-  if (!b || b->staged.empty() || clip < 0 || clip >= b->n || src_clip < 0 || src_clip >= b->n || b->staged[src_clip].empty()) return MOBI_E_ARG;
+  if (!b || b->staged.empty() || clip < 0 || clip >= b->n || src_clip < 0 || src_clip >= b->n || !b->staged[src_clip]) return MOBI_E_ARG;
   b->committed = false;
   b->staged[clip] = b->staged[src_clip];
   b->staged_rc[clip] = b->staged_rc[src_clip];
@@ -364,9 +365,9 @@ int mobi_batch_commit(mobi_batch *b) {
   const int n = b->n;
   int nf = -1;
   for (int c = 0; c < n; c++) {
-    if (b->staged[c].empty()) return MOBI_E_ARG; // every clip must be loaded or cloned
-    if (nf < 0) nf = (int)b->staged[c].size();
-    if ((int)b->staged[c].size() != nf) return MOBI_E_ARG;
+    if (!b->staged[c] || b->staged[c]->empty()) return MOBI_E_ARG; // every clip must be loaded or cloned
+    if (nf < 0) nf = (int)b->staged[c]->size();
+    if ((int)b->staged[c]->size() != nf) return MOBI_E_ARG;
   }
   size_t cmd_bytes = b->dummy_bytes, n_items = 0;
   std::vector<uint64_t> off((size_t)nf * n, 0);
@@ -375,8 +376,8 @@ int mobi_batch_commit(mobi_batch *b) {
   for (int f = 0; f < nf; f++) {
     std::vector<const ParsedFrame *> ok(n, nullptr);
     for (int c = 0; c < n; c++)
-      if (b->staged_rc[c][f] == MOBI_OK) {
-        ok[c] = &b->staged[c][f];
+      if ((*b->staged_rc[c])[f] == MOBI_OK) {
+        ok[c] = &(*b->staged[c])[f];
         off[(size_t)f * n + c] = cmd_bytes;
         cmd_bytes += blob_size(*ok[c]);
       }
@@ -403,8 +404,8 @@ int mobi_batch_commit(mobi_batch *b) {
   std::vector<uint8_t> tmp;
   for (int f = 0; f < nf; f++)
     for (int c = 0; c < n; c++)
-      if (b->staged_rc[c][f] == MOBI_OK) {
-        const ParsedFrame &pf = b->staged[c][f];
+      if ((*b->staged_rc[c])[f] == MOBI_OK) {
+        const ParsedFrame &pf = (*b->staged[c])[f];
         tmp.assign(blob_size(pf), 0);
         blob_write(pf, tmp.data());
         if (int e = upload(b->r_cmd.p + off[(size_t)f * n + c], tmp.data(), tmp.size())) return e;
