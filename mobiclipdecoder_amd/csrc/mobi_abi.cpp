@@ -63,12 +63,31 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
-// serialise one parsed frame as [FrameHdr][MbDesc x n][payload], 16-byte aligned; returns bytes written
-size_t blob_size(const ParsedFrame &f) { return align_up(f.cmd_bytes(), kAlign); }
-void blob_write(const ParsedFrame &f, uint8_t *dst) {
-  memcpy(dst, &f.hdr, sizeof(FrameHdr));
-  memcpy(dst + sizeof(FrameHdr), f.desc.data(), f.desc.size() * sizeof(MbDesc));
-  memcpy(dst + sizeof(FrameHdr) + f.desc.size() * sizeof(MbDesc), f.payload.data(), f.payload.size() * 4);
+// One frame step on the device = [MbDesc table: n_clips * n_mbs][payload arena: all clips back to back].
+// Clips whose parse failed (nullptr) get descriptors typed "intra" that no launch list references, so
+// nothing of theirs is ever written (the reference leaves a partial frame; content is unspecified here).
+size_t step_payload_words(const std::vector<const ParsedFrame *> &frames) {
+  size_t w = 0;
+  for (auto *f : frames)
+    if (f) w += f->payload.size();
+  return w;
+}
+void step_write(const std::vector<const ParsedFrame *> &frames, int n_mbs, MbDesc *desc, uint32_t *payload) {
+  size_t base = 0;
+  for (size_t c = 0; c < frames.size(); c++) {
+    MbDesc *dd = desc + c * (size_t)n_mbs;
+    const ParsedFrame *f = frames[c];
+    if (!f) {
+      for (int i = 0; i < n_mbs; i++) dd[i] = MbDesc{0, MOBI_MB_INTRA, 0, 0};
+      continue;
+    }
+    for (int i = 0; i < n_mbs; i++) {
+      dd[i] = f->desc[i];
+      dd[i].payload_off += (uint32_t)base;
+    }
+    if (!f->payload.empty()) memcpy(payload + base, f->payload.data(), f->payload.size() * 4);
+    base += f->payload.size();
+  }
 }
 
 struct LevelPlan { // launch plan of one frame step: items of level L are items[start[L] .. start[L+1])
@@ -117,17 +136,17 @@ struct mobi_batch {
   std::vector<int> h_fault;
   // per-call staging (batch_decode)
   PinnedBuf h_stage;
-  DevBuf d_cmd, d_off, d_items;
-  size_t dummy_bytes = 0;
-  std::vector<uint8_t> dummy; // a frame whose MBs are all "intra" with no launch items: nothing is written
+  DevBuf d_cmd, d_items;
+  int32_t *d_scale = nullptr; // [MOBI_SCALE_QMAX][MOBI_SCALE_STRIDE]
   // preloaded replay
   // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
   std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
   std::vector<std::shared_ptr<std::vector<int>>> staged_rc;
   int n_frames_loaded = 0;
-  DevBuf r_cmd, r_off, r_items;
+  DevBuf r_cmd, r_items;
   std::vector<LevelPlan> r_plan;        // per frame
   std::vector<size_t> r_items_off;      // per frame: word offset of its items in r_items
+  std::vector<size_t> r_desc_off, r_payload_off; // per frame: byte offsets inside r_cmd
   bool committed = false;
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -138,11 +157,12 @@ struct mobi_batch {
   float acc_ms[2] = {0, 0};
   int acc_launches[2] = {0, 0};
 
-  MobiReconArgs args(const uint8_t *cmd, const uint64_t *off) const {
+  MobiReconArgs args(const uint8_t *desc, const uint8_t *payload) const {
     MobiReconArgs a;
     a.planes = arena + kGuard;
-    a.cmd = cmd;
-    a.frame_off = off;
+    a.desc = (const MbDesc *)desc;
+    a.payload = (const uint32_t *)payload;
+    a.scale = d_scale;
     a.fault = d_fault;
     a.clip_bytes = clip_bytes;
     a.slot_bytes = (uint32_t)slot_bytes;
@@ -192,6 +212,7 @@ struct mobi_batch {
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (arena) (void)hipFree(arena);
     if (d_fault) (void)hipFree(d_fault);
+    if (d_scale) (void)hipFree(d_scale);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -244,18 +265,11 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   if (hipMalloc((void **)&b->d_fault, sizeof(int) * n_clips) != hipSuccess) return nullptr;
   if (hipMemsetAsync(b->d_fault, 0, sizeof(int) * n_clips, b->stream) != hipSuccess) return nullptr;
   if (hipEventCreate(&b->ev_begin) != hipSuccess || hipEventCreate(&b->ev_end) != hipSuccess) return nullptr;
-  // dummy frame: every MB typed intra, no launch items
-  const int n_mbs = b->g.mbw * b->g.mbh;
-  b->dummy_bytes = align_up(sizeof(FrameHdr) + (size_t)n_mbs * sizeof(MbDesc), kAlign);
-  b->dummy.assign(b->dummy_bytes, 0);
-  FrameHdr h;
-  memset(&h, 0, sizeof(h));
-  h.n_mbs = (uint32_t)n_mbs;
-  h.n_intra = (uint32_t)n_mbs;
-  memcpy(b->dummy.data(), &h, sizeof(h));
-  for (int i = 0; i < n_mbs; i++) {
-    MbDesc d{0, MOBI_MB_INTRA, 0, 0};
-    memcpy(b->dummy.data() + sizeof(FrameHdr) + (size_t)i * sizeof(MbDesc), &d, sizeof(d));
+  {
+    std::vector<int32_t> tab((size_t)MOBI_SCALE_QMAX * MOBI_SCALE_STRIDE, 0);
+    for (int q = 0; q < MOBI_SCALE_QMAX; q++) mobi_build_scale_table(q, &tab[(size_t)q * MOBI_SCALE_STRIDE]);
+    if (hipMalloc((void **)&b->d_scale, tab.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(b->d_scale, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   }
   if (hipStreamSynchronize(b->stream) != hipSuccess) return nullptr;
   return b.release();
@@ -284,28 +298,22 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->frames_started++;
   LevelPlan plan;
   plan.build(ok);
-  // 2. stage [dummy][clip blobs][frame_off table][items] and upload
-  size_t cmd_bytes = b->dummy_bytes;
-  std::vector<uint64_t> off(n, 0);
-  for (int i = 0; i < n; i++)
-    if (ok[i]) { off[i] = cmd_bytes; cmd_bytes += blob_size(*ok[i]); }
-  const size_t off_bytes = align_up(sizeof(uint64_t) * n, kAlign), item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
-  if (int e = b->h_stage.reserve(cmd_bytes + off_bytes + item_bytes)) return e;
-  if (int e = b->d_cmd.reserve(cmd_bytes)) return e;
-  if (int e = b->d_off.reserve(off_bytes)) return e;
+  // 2. stage [desc table][payload arena][items] and upload
+  const int n_mbs = b->g.mbw * b->g.mbh;
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc), kAlign);
+  const size_t pay_bytes = align_up(step_payload_words(ok) * 4 + 4, kAlign);
+  const size_t item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
+  if (int e = b->h_stage.reserve(desc_bytes + pay_bytes + item_bytes)) return e;
+  if (int e = b->d_cmd.reserve(desc_bytes + pay_bytes)) return e;
   if (int e = b->d_items.reserve(item_bytes)) return e;
   uint8_t *hs = b->h_stage.p;
-  memcpy(hs, b->dummy.data(), b->dummy_bytes);
-  for (int i = 0; i < n; i++)
-    if (ok[i]) blob_write(*ok[i], hs + off[i]);
-  memcpy(hs + cmd_bytes, off.data(), sizeof(uint64_t) * n);
-  if (!plan.items.empty()) memcpy(hs + cmd_bytes + off_bytes, plan.items.data(), plan.items.size() * 4);
-  HIP_TRY(hipMemcpyAsync(b->d_cmd.p, hs, cmd_bytes, hipMemcpyHostToDevice, b->stream));
-  HIP_TRY(hipMemcpyAsync(b->d_off.p, hs + cmd_bytes, off_bytes, hipMemcpyHostToDevice, b->stream));
+  step_write(ok, n_mbs, (MbDesc *)hs, (uint32_t *)(hs + desc_bytes));
+  if (!plan.items.empty()) memcpy(hs + desc_bytes + pay_bytes, plan.items.data(), plan.items.size() * 4);
+  HIP_TRY(hipMemcpyAsync(b->d_cmd.p, hs, desc_bytes + pay_bytes, hipMemcpyHostToDevice, b->stream));
   if (!plan.items.empty())
-    HIP_TRY(hipMemcpyAsync(b->d_items.p, hs + cmd_bytes + off_bytes, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_items.p, hs + desc_bytes + pay_bytes, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
   // 3. device: reconstruction
-  MobiReconArgs a = b->args(b->d_cmd.p, (const uint64_t *)b->d_off.p);
+  MobiReconArgs a = b->args(b->d_cmd.p, b->d_cmd.p + desc_bytes);
   if (int e = b->launch_plan(a, plan, (const uint32_t *)b->d_items.p)) return e;
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
@@ -369,24 +377,26 @@ int mobi_batch_commit(mobi_batch *b) {
     if (nf < 0) nf = (int)b->staged[c]->size();
     if ((int)b->staged[c]->size() != nf) return MOBI_E_ARG;
   }
-  size_t cmd_bytes = b->dummy_bytes, n_items = 0;
-  std::vector<uint64_t> off((size_t)nf * n, 0);
+  const int n_mbs = b->g.mbw * b->g.mbh;
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc), kAlign);
+  size_t cmd_bytes = 0, n_items = 0;
   b->r_plan.assign(nf, LevelPlan());
   b->r_items_off.assign(nf, 0);
+  b->r_desc_off.assign(nf, 0);
+  b->r_payload_off.assign(nf, 0);
+  std::vector<std::vector<const ParsedFrame *>> per_frame(nf, std::vector<const ParsedFrame *>(n, nullptr));
   for (int f = 0; f < nf; f++) {
-    std::vector<const ParsedFrame *> ok(n, nullptr);
+    auto &ok = per_frame[f];
     for (int c = 0; c < n; c++)
-      if ((*b->staged_rc[c])[f] == MOBI_OK) {
-        ok[c] = &(*b->staged[c])[f];
-        off[(size_t)f * n + c] = cmd_bytes;
-        cmd_bytes += blob_size(*ok[c]);
-      }
+      if ((*b->staged_rc[c])[f] == MOBI_OK) ok[c] = &(*b->staged[c])[f];
+    b->r_desc_off[f] = cmd_bytes;
+    b->r_payload_off[f] = cmd_bytes + desc_bytes;
+    cmd_bytes += desc_bytes + align_up(step_payload_words(ok) * 4 + 4, kAlign);
     b->r_plan[f].build(ok);
     b->r_items_off[f] = n_items;
     n_items += b->r_plan[f].items.size();
   }
   if (int e = b->r_cmd.reserve(cmd_bytes)) return e;
-  if (int e = b->r_off.reserve(off.size() * sizeof(uint64_t))) return e;
   if (int e = b->r_items.reserve(n_items * 4 + 16)) return e;
   // upload through a bounded pinned window
   const size_t win = (size_t)64 << 20;
@@ -400,20 +410,15 @@ int mobi_batch_commit(mobi_batch *b) {
     }
     return MOBI_OK;
   };
-  if (int e = upload(b->r_cmd.p, b->dummy.data(), b->dummy_bytes)) return e;
   std::vector<uint8_t> tmp;
-  for (int f = 0; f < nf; f++)
-    for (int c = 0; c < n; c++)
-      if ((*b->staged_rc[c])[f] == MOBI_OK) {
-        const ParsedFrame &pf = (*b->staged[c])[f];
-        tmp.assign(blob_size(pf), 0);
-        blob_write(pf, tmp.data());
-        if (int e = upload(b->r_cmd.p + off[(size_t)f * n + c], tmp.data(), tmp.size())) return e;
-      }
-  if (int e = upload(b->r_off.p, (const uint8_t *)off.data(), off.size() * sizeof(uint64_t))) return e;
-  for (int f = 0; f < nf; f++)
+  for (int f = 0; f < nf; f++) {
+    const size_t bytes = (f + 1 < nf ? b->r_desc_off[f + 1] : cmd_bytes) - b->r_desc_off[f];
+    tmp.assign(bytes, 0);
+    step_write(per_frame[f], n_mbs, (MbDesc *)tmp.data(), (uint32_t *)(tmp.data() + desc_bytes));
+    if (int e = upload(b->r_cmd.p + b->r_desc_off[f], tmp.data(), bytes)) return e;
     if (!b->r_plan[f].items.empty())
       if (int e = upload(b->r_items.p + b->r_items_off[f] * 4, (const uint8_t *)b->r_plan[f].items.data(), b->r_plan[f].items.size() * 4)) return e;
+  }
   b->n_frames_loaded = nf;
   b->committed = true;
   return MOBI_OK;
@@ -422,7 +427,7 @@ int mobi_batch_replay(mobi_batch *b, int frame_idx) {
   if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
   b->ring_base = (b->ring_base + 1) % 6;
   b->frames_started++;
-  MobiReconArgs a = b->args(b->r_cmd.p, (const uint64_t *)b->r_off.p + (size_t)frame_idx * b->n);
+  MobiReconArgs a = b->args(b->r_cmd.p + b->r_desc_off[frame_idx], b->r_cmd.p + b->r_payload_off[frame_idx]);
   return b->launch_plan(a, b->r_plan[frame_idx], (const uint32_t *)b->r_items.p + b->r_items_off[frame_idx]);
 }
 int mobi_batch_sync(mobi_batch *b) {

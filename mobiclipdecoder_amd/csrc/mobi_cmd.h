@@ -2,8 +2,7 @@
 // emits per frame and what the reconstruction kernels (mobi_kernels.hip) consume.
 //
 // One frame of one clip =
-//   FrameHdr                       fixed, holds the dequant scale tables for this frame
-//   MbDesc   desc[n_mbs]           16 B per macroblock, raster order
+//   MbDesc   desc[n_mbs]           16 B per macroblock, raster order (leaf 0 of inter MBs is inline)
 //   uint32_t payload[...]          variable: MC leaves, intra block records, residual levels
 //   uint32_t intra_items[...]      MB indices of intra MBs grouped by dependency level (host side only;
 //                                  merged across clips into per-level launch lists)
@@ -17,15 +16,18 @@
 
 enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 
-// ---- MbDesc.w1 bit fields -------------------------------------------------------------------
-//  [0]      type (MOBI_MB_*)
-//  [7:1]    n_leaves   (inter: 1..64)
-//  [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
-//  [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
-//  [31:20]  level      intra dependency level (0 for inter)
-// ---- MbDesc.w2: [9:0] n_coefs (<= 384); ---- MbDesc.w3: reserved (plane16 param for intra) ----
+// ---- MbDesc: 16 B per macroblock; on the device one flat table per frame step, index = clip*n_mbs + mb,
+//      so a wave's first load already tells it everything it needs to start fetching pixels ------------
+// w0  payload word offset (host: inside the clip's payload; device: inside the frame step's payload arena)
+// w1  [0]      type (MOBI_MB_*)
+//     [7:1]    n_leaves   (inter: 1..64; leaf 0 is INLINE in w2/w3, leaves 1.. are the first payload words)
+//     [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
+//     [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
+//     [25:20]  quantizer  of the frame (selects the dequant scale table, MD.cs:3884-3912)
+// w2  [9:0]    n_coefs (<= 384)      [24:10] inter: leaf 0 word 0 (mobi_leaf_w0)
+// w3  inter: leaf 0 word 1 (MV) ;  intra: [0] plane16 present, [31:16] plane16 parameter
 struct MbDesc {
-  uint32_t payload_off; // word offset of this MB's payload inside the frame payload
+  uint32_t payload_off;
   uint32_t w1;
   uint32_t w2;
   uint32_t w3;
@@ -62,18 +64,22 @@ static inline uint32_t mobi_intra_rec(int mode, int coded, int split, int pre_pl
   return (uint32_t)(mode | (coded << 4) | (split << 5) | (pre_plane << 6)) | ((uint32_t)param << 16);
 }
 
-// ---- frame header ----------------------------------------------------------------------------
+// ---- per-frame info kept on the host (launch planning, accounting); the kernels never read it ----------
 struct FrameHdr {
   uint32_t frame_type;   // 0 = P, 1 = I
   uint32_t n_mbs;
   uint32_t n_intra;      // number of intra MBs
-  uint32_t n_levels;     // highest intra level (0 when no intra MBs)
+  uint32_t n_levels;     // highest intra dependency level (0 when no intra MBs)
   uint32_t payload_words;
   uint32_t quantizer;
-  uint32_t cmd_bytes;    // bytes of this frame's command list the kernels read (hdr + desc + payload)
+  uint32_t cmd_bytes;    // bytes of this frame's command list the kernels read (desc + payload)
   uint32_t reserved;
-  int32_t scale8[64];    // dequant scale by NATURAL coefficient index, 8x8  (word >> 8, MD.cs:3907-3911)
-  int32_t scale4[16];    // same for 4x4                                     (MD.cs:3897-3902)
 };
+
+// Dequant scale tables by NATURAL coefficient index for one quantizer: scale = dequant word >> 8
+// (MD.cs:3897-3911; 4x4: tbl<<(q/6), 8x8: tbl<<(q/6-2)).  Valid for q in [12,53] (no zigzag-byte leak).
+// Layout of one entry of the device table: int[80] = scale8[64] then scale4[16].
+#define MOBI_SCALE_STRIDE 80
+#define MOBI_SCALE_QMAX 54
 
 #endif

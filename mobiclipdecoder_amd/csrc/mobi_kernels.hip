@@ -75,13 +75,13 @@ __device__ __forceinline__ void zero_coefs(int *coef, int lane) {
 #pragma unroll
   for (int i = 0; i < 6; i++) coef[lane + 64 * i] = 0;
 }
-__device__ __forceinline__ void scatter_coefs(const FrameHdr *h, const uint32_t *cw, int n, uint32_t t8, int *coef, int lane) {
-  for (int i = lane; i < n; i += 64) {
-    const uint32_t e = cw[i];
-    const int t = e & 0x1FF, level = (int32_t)e >> 16, area = t >> 6, p = t & 63;
-    const int scale = ((t8 >> area) & 1) ? h->scale8[p] : h->scale4[p & 15];
-    coef[t] = scale * level;
-  }
+__device__ __forceinline__ void scatter_one(const int32_t *sc, uint32_t e, uint32_t t8, int *coef) {
+  const int t = e & 0x1FF, level = (int32_t)e >> 16, area = t >> 6, p = t & 63;
+  const int scale = ((t8 >> area) & 1) ? sc[p] : sc[64 + (p & 15)];
+  coef[t] = scale * level;
+}
+__device__ __forceinline__ void scatter_coefs(const int32_t *sc, const uint32_t *cw, int first, int n, uint32_t t8, int *coef, int lane) {
+  for (int i = first + lane; i < n; i += 64) scatter_one(sc, cw[i], t8, coef);
 }
 // pass 1 of area b by lane r (0..7): 8x8 -> coefficient group r; 4x4 -> sub-block r>>1, groups (r&1)*2+{0,1}
 __device__ __forceinline__ void idct_pass1(const int *c, int *t, bool is8, int r) {
@@ -141,42 +141,62 @@ __device__ __forceinline__ void idct_pass2(const int *t, bool is8, int r, uint8_
 extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs A) {
   __shared__ uint32_t lds[WAVES][96 + 384 + 384]; // per wave: pred tiles (384 B), coef, tmp
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const long gm = (long)blockIdx.x * WAVES + wave;
+  // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so give each XCD
+  // one contiguous run of macroblocks (whole clips): neighbours that share 128-B lines of the output and the
+  // overlapping MC windows of the reference then meet in ONE L2 instead of eight.
+  const int per_xcd = gridDim.x >> 3;
+  const long vb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const long gm = vb * WAVES + wave;
   if (gm >= (long)A.n_clips * A.n_mbs) return;
-  const int clip = (int)(gm / A.n_mbs), mb = (int)(gm % A.n_mbs);
-  const uint8_t *cmd = A.cmd + A.frame_off[clip];
-  const FrameHdr *hdr = (const FrameHdr *)cmd;
-  const MbDesc *desc = (const MbDesc *)(cmd + sizeof(FrameHdr)) + mb;
-  const uint32_t w1 = desc->w1;
+  const uint4 d = *(const uint4 *)(A.desc + gm);
+  const uint32_t w1 = d.y;
   if ((w1 & 1) != MOBI_MB_INTER) return;
-  const uint32_t *pl = (const uint32_t *)(cmd + sizeof(FrameHdr) + (size_t)A.n_mbs * sizeof(MbDesc)) + desc->payload_off;
-  const int nl = (w1 >> 1) & 0x7F, cbp6 = (w1 >> 8) & 0x3F, t8 = (w1 >> 14) & 0x3F, ncoef = desc->w2 & 0x3FF;
+  const int clip = (int)(gm / A.n_mbs), mb = (int)(gm - (long)clip * A.n_mbs);
+  const int nl = (w1 >> 1) & 0x7F, cbp6 = (w1 >> 8) & 0x3F, t8 = (w1 >> 14) & 0x3F, ncoef = d.z & 0x3FF;
+  const uint32_t *pl = A.payload + d.x;          // leaves 1..nl-1, then the residual levels
+  const uint32_t *cw = pl + 2 * (nl - 1);
   const int S = A.stride;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
   const size_t ysz = (size_t)S * A.height;
-  const long off = (long)(mb / A.mbw) * 16 * S + (mb % A.mbw) * 16;
+  const int mby = mb / A.mbw;
+  const long off = (long)mby * 16 * S + (mb - mby * A.mbw) * 16;
+  // first 64 residual levels travel together with the pixel fetches
+  const uint32_t c_first = (cbp6 && lane < ncoef) ? cw[lane] : 0;
 
   // ---- motion compensation: lane -> luma row lane>>2, px (lane&3)*4 ; lanes 0..31 -> chroma ----
   const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
   const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
   uint32_t ypred = 0, cpred = 0;
-  for (int l = 0; l < nl; l++) {
-    const uint32_t w0 = pl[2 * l], mvw = pl[2 * l + 1];
-    const int lx = (w0 & 15) * 2, ly = ((w0 >> 4) & 15) * 2, lw = 16 >> ((w0 >> 8) & 3), lh = 16 >> ((w0 >> 10) & 3);
+  uint32_t w0 = (d.z >> 10) & 0x7FFF, mvw = d.w;
+  if (nl == 1) { // one 16x16 leaf (the common case): no masks
     const int ref = (w0 >> 12) & 7;
     const int dx = (int16_t)(mvw & 0xFFFF), dy = (int16_t)(mvw >> 16);
     const uint8_t *ry = clip_base + (size_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes;
-    const uint8_t *ruv = ry + ysz;
-    if (yrow >= ly && yrow < ly + lh && yc4 + 4 > lx && yc4 < lx + lw) {
-      const uint32_t v = mc_word(ry + off + (long)(yrow + (dy >> 1)) * S + yc4 + (dx >> 1), S, (dx & 1) | ((dy & 1) << 1));
-      const uint32_t m = seg_mask(yc4, lx, lw);
-      ypred = (ypred & ~m) | (v & m);
-    }
-    const int cdx = dx >> 1, cdy = dy >> 1, cx = lx >> 1, cy = ly >> 1, cw = lw >> 1, ch = lh >> 1;
-    if (lane < 32 && crow >= cy && crow < cy + ch && cc4 + 4 > cx && cc4 < cx + cw) {
-      const uint32_t v = mc_word(ruv + off / 2 + cv * (S >> 1) + (long)(crow + (cdy >> 1)) * S + cc4 + (cdx >> 1), S, (cdx & 1) | ((cdy & 1) << 1));
-      const uint32_t m = seg_mask(cc4, cx, cw);
-      cpred = (cpred & ~m) | (v & m);
+    ypred = mc_word(ry + off + (long)(yrow + (dy >> 1)) * S + yc4 + (dx >> 1), S, (dx & 1) | ((dy & 1) << 1));
+    const int cdx = dx >> 1, cdy = dy >> 1;
+    if (lane < 32)
+      cpred = mc_word(ry + ysz + off / 2 + cv * (S >> 1) + (long)(crow + (cdy >> 1)) * S + cc4 + (cdx >> 1), S, (cdx & 1) | ((cdy & 1) << 1));
+  } else {
+    for (int l = 0;;) {
+      const int lx = (w0 & 15) * 2, ly = ((w0 >> 4) & 15) * 2, lw = 16 >> ((w0 >> 8) & 3), lh = 16 >> ((w0 >> 10) & 3);
+      const int ref = (w0 >> 12) & 7;
+      const int dx = (int16_t)(mvw & 0xFFFF), dy = (int16_t)(mvw >> 16);
+      const uint8_t *ry = clip_base + (size_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes;
+      const uint8_t *ruv = ry + ysz;
+      if (yrow >= ly && yrow < ly + lh && yc4 + 4 > lx && yc4 < lx + lw) {
+        const uint32_t v = mc_word(ry + off + (long)(yrow + (dy >> 1)) * S + yc4 + (dx >> 1), S, (dx & 1) | ((dy & 1) << 1));
+        const uint32_t m = seg_mask(yc4, lx, lw);
+        ypred = (ypred & ~m) | (v & m);
+      }
+      const int cdx = dx >> 1, cdy = dy >> 1, cx = lx >> 1, cy = ly >> 1, cw2 = lw >> 1, ch = lh >> 1;
+      if (lane < 32 && crow >= cy && crow < cy + ch && cc4 + 4 > cx && cc4 < cx + cw2) {
+        const uint32_t v = mc_word(ruv + off / 2 + cv * (S >> 1) + (long)(crow + (cdy >> 1)) * S + cc4 + (cdx >> 1), S, (cdx & 1) | ((cdy & 1) << 1));
+        const uint32_t m = seg_mask(cc4, cx, cw2);
+        cpred = (cpred & ~m) | (v & m);
+      }
+      if (++l >= nl) break;
+      w0 = pl[2 * (l - 1)];
+      mvw = pl[2 * (l - 1) + 1];
     }
   }
 
@@ -186,11 +206,13 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
     uint8_t *ty = (uint8_t *)L;          // 16 x 16
     uint8_t *tc = ty + 256;              // U 8x8 then V 8x8
     int *coef = (int *)(L + 96), *tmp = coef + 384;
+    const int32_t *sc = A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE;
     ((uint32_t *)ty)[yrow * 4 + (lane & 3)] = ypred;
     if (lane < 32) ((uint32_t *)tc)[cv * 16 + crow * 2 + (lane & 1)] = cpred;
     zero_coefs(coef, lane);
     wave_sync();
-    scatter_coefs(hdr, pl + 2 * nl, ncoef, t8, coef, lane);
+    if (lane < ncoef) scatter_one(sc, c_first, t8, coef);
+    scatter_coefs(sc, cw, 64, ncoef, t8, coef, lane);
     wave_sync();
     const int b = lane >> 3, r = lane & 7;
     const bool act = lane < 48 && ((cbp6 >> b) & 1);
@@ -263,11 +285,10 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   if (it >= n_items) return;
   const uint32_t item = items[it];
   const int clip = (int)(item >> 13), mb = (int)(item & 0x1FFF);
-  const uint8_t *cmd = A.cmd + A.frame_off[clip];
-  const FrameHdr *hdr = (const FrameHdr *)cmd;
-  const MbDesc *desc = (const MbDesc *)(cmd + sizeof(FrameHdr)) + mb;
+  const MbDesc *desc = A.desc + (long)clip * A.n_mbs + mb;
   const uint32_t w1 = desc->w1, w3 = desc->w3;
-  const uint32_t *rec = (const uint32_t *)(cmd + sizeof(FrameHdr) + (size_t)A.n_mbs * sizeof(MbDesc)) + desc->payload_off;
+  const uint32_t *rec = A.payload + desc->payload_off;
+  const int32_t *sc = A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE;
   const int t8 = (w1 >> 14) & 0x3F, ncoef = desc->w2 & 0x3FF;
   const int S = A.stride;
   const Geo g{A.width, A.height, S, A.mbw, 31 - __builtin_clz((unsigned)S)};
@@ -304,7 +325,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     const int o = g.owner_chroma(a);
     if (o >= 0 && o < mb) (v ? tcv : tcu)[(r + 1) * TP + 4 + c] = uv0[a];
   }
-  scatter_coefs(hdr, rec + MOBI_INTRA_RECORDS, ncoef, t8, coef, lane);
+  scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 0, ncoef, t8, coef, lane);
   wave_sync();
 
   // ---- block records, in decode order ----
@@ -347,7 +368,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const long waves = (long)a->n_clips * a->n_mbs;
   if (waves <= 0) return 0;
-  const unsigned grid = (unsigned)((waves + WAVES - 1) / WAVES);
+  const unsigned grid = (unsigned)(((waves + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of blocks per XCD
   hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, *a);
   return (int)hipGetLastError();
 }

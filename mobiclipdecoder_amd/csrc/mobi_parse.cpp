@@ -107,16 +107,18 @@ void MobiStreamParser::end_mb() {
   MbDesc d;
   d.payload_off = (uint32_t)out_->payload.size();
   uint32_t nl = 0;
+  d.w2 = (uint32_t)coefs_.size();
+  d.w3 = w3_;
   if (mb_type_ == MOBI_MB_INTER) {
     nl = (uint32_t)(leaves_.size() / 2);
-    out_->payload.insert(out_->payload.end(), leaves_.begin(), leaves_.end());
+    d.w2 |= leaves_[0] << 10; // leaf 0 rides in the descriptor
+    d.w3 = leaves_[1];
+    out_->payload.insert(out_->payload.end(), leaves_.begin() + 2, leaves_.end());
   } else {
     out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
   }
   out_->payload.insert(out_->payload.end(), coefs_.begin(), coefs_.end());
-  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14);
-  d.w2 = (uint32_t)coefs_.size();
-  d.w3 = w3_;
+  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14) | ((quant_ & 63) << 20);
   out_->desc.push_back(d);
 }
 long MobiStreamParser::area_offset(int area, int sub) const {
@@ -521,7 +523,6 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     }
     level[mb] = (uint16_t)(lv + 1);
     if (lv + 1 > maxl) maxl = lv + 1;
-    out.desc[mb].w1 |= (uint32_t)(lv + 1) << 20;
   }
   out.level_start.assign(maxl + 2, 0);
   for (int mb = 0; mb < n; mb++)
@@ -537,8 +538,6 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
   out.hdr.payload_words = (uint32_t)out.payload.size();
   out.hdr.quantizer = quant_;
   out.hdr.cmd_bytes = (uint32_t)out.cmd_bytes();
-  for (int i = 0; i < 64; i++) out.hdr.scale8[dq8_[i] & 63] = (int32_t)(dq8_[i] >> 8);
-  for (int i = 0; i < 16; i++) out.hdr.scale4[dq4_[i] & 15] = (int32_t)(dq4_[i] >> 8);
 }
 
 int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offset, ParsedFrame &out) {
@@ -564,4 +563,14 @@ int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offs
   }
   *offset = off_;
   return rc;
+}
+
+// Dequant scales by natural coefficient index for quantizer q (MD.cs:3892-3911), the table the kernels index
+// with MbDesc.w1[25:20].  q outside [12,53] is never used by a residual (resid_block rejects it).
+void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]) {
+  memset(out, 0, sizeof(int32_t) * MOBI_SCALE_STRIDE);
+  if (q < 0 || q >= (int)sizeof(mobi_qdiv6)) return;
+  const int sh = mobi_qdiv6[q] + 8, m = mobi_qmod6[q];
+  for (int i = 0; i < 64; i++) out[mobi_zz8[i]] = (int32_t)((((uint32_t)mobi_dq8[m * 64 + i]) << (sh - 2)) >> 8);
+  for (int i = 0; i < 16; i++) out[64 + mobi_zz4[i]] = (int32_t)((((uint32_t)mobi_dq4[m * 16 + i]) << sh) >> 8);
 }

@@ -20,7 +20,7 @@ struct ParsedFrame {
   std::vector<uint32_t> intra_mbs;   // MB indices, grouped by level (ascending), raster order inside a level
   std::vector<uint32_t> level_start; // size n_levels+2: intra_mbs[level_start[L] .. level_start[L+1]) for L = 1..n_levels
   void clear();
-  size_t cmd_bytes() const { return sizeof(FrameHdr) + desc.size() * sizeof(MbDesc) + payload.size() * 4; }
+  size_t cmd_bytes() const { return desc.size() * sizeof(MbDesc) + payload.size() * 4; }
 };
 
 // Geometry helpers shared by the parser (dependency levels) and the kernels (availability):
@@ -43,6 +43,8 @@ struct MobiGeom {
 };
 // halo the intra kernel loads around a macroblock (must match mobi_kernels.hip)
 enum { MOBI_HALO_Y_RIGHT = 23, MOBI_HALO_C_RIGHT = 15 };
+
+void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]);
 
 class MobiStreamParser {
  public:

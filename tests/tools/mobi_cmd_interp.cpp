@@ -41,12 +41,14 @@ inline uint32_t ld4(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; 
 inline void st4(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 
 // ---- residual: dequantise into the coefficient tile, inverse transform, add ---------------------
-void dequant_into(const FrameHdr &h, const uint32_t *coefs, int n, uint32_t t8mask, int coef_tile[6 * 64]) {
+void dequant_into(int q, const uint32_t *coefs, int n, uint32_t t8mask, int coef_tile[6 * 64]) {
   memset(coef_tile, 0, sizeof(int) * 6 * 64);
+  int32_t sc[MOBI_SCALE_STRIDE];
+  mobi_build_scale_table(q, sc);
   for (int i = 0; i < n; i++) {
     uint32_t e = coefs[i];
     int t = e & 0x1FF, level = (int32_t)e >> 16, area = t >> 6, p = t & 63;
-    int scale = ((t8mask >> area) & 1) ? h.scale8[p] : h.scale4[p & 15];
+    int scale = ((t8mask >> area) & 1) ? sc[p] : sc[64 + (p & 15)];
     coef_tile[t] = scale * level;
   }
 }
@@ -92,7 +94,7 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
   const long off = (long)(mb / g.mbw) * 16 * S + (mb % g.mbw) * 16;
   uint8_t ty[16 * TP], tc[2][8 * TP]; // prediction tiles (interior only; pitch TP, origin at byte 0)
   for (int l = 0; l < nl; l++) {
-    uint32_t w0 = pl[2 * l], w1 = pl[2 * l + 1];
+    uint32_t w0 = l ? pl[2 * (l - 1)] : (d.w2 >> 10) & 0x7FFF, w1 = l ? pl[2 * (l - 1) + 1] : d.w3; // leaf 0 is in the descriptor
     int lx = (w0 & 15) * 2, ly = ((w0 >> 4) & 15) * 2, lw = 16 >> ((w0 >> 8) & 3), lh = 16 >> ((w0 >> 10) & 3), ref = (w0 >> 12) & 7;
     int dx = (int16_t)(w1 & 0xFFFF), dy = (int16_t)(w1 >> 16);
     const uint8_t *ry = I.Y(ref), *ruv = I.UV(ref);
@@ -131,7 +133,7 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
   }
   if (cbp6) {
     int coef[6 * 64];
-    dequant_into(I.pf.hdr, pl + 2 * nl, ncoef, t8, coef);
+    dequant_into((d.w1 >> 20) & 63, pl + 2 * (nl - 1), ncoef, t8, coef);
     for (int a = 0; a < 6; a++) {
       if (!((cbp6 >> a) & 1)) continue;
       uint8_t *t = a < 4 ? ty + (a >> 1) * 8 * TP + (a & 1) * 8 : tc[a - 4];
@@ -203,7 +205,7 @@ void exec_intra(Interp &I, int mb, const MbDesc &d) {
       for (int c = 8; c <= MOBI_HALO_C_RIGHT; c++) tc[v][(r + 1) * TP + 4 + c] = chroma(base + r * S + c);
   }
   int coef[6 * 64];
-  dequant_into(I.pf.hdr, rec + MOBI_INTRA_RECORDS, ncoef, t8, coef);
+  dequant_into((d.w1 >> 20) & 63, rec + MOBI_INTRA_RECORDS, ncoef, t8, coef);
   if (d.w3 & 1) run_block(I, ty, 0, 0, 16, 2, (int16_t)(d.w3 >> 16), false, nullptr, false, 0, off, false);
   for (int a = 0; a < 6; a++) {
     uint8_t *tile = a < 4 ? ty : tc[a - 4];
