@@ -80,11 +80,13 @@ def main():
     import mobiclipdecoder_amd as m
     from mobiclipdecoder_amd.streamgen import BASE_SEED
 
+    # experiment hook: BENCH_GEN="pm_split1=0,pm_deep=0" overrides generator fields (non-default => not the headline workload)
+    gen_over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("BENCH_GEN", "").split(",") if kv)}
     cfg_idx = "ABC".index(args.config)
     distinct = max(1, min(args.distinct, args.clips))
     streams = []
     for i in range(distinct):
-        p = m.default_params(args.config, BASE_SEED + cfg_idx + 1000 * rank + i, n_frames=1 + N_PFRAMES)
+        p = m.default_params(args.config, BASE_SEED + cfg_idx + 1000 * rank + i, n_frames=1 + N_PFRAMES, **gen_over)
         streams.append((p,) + m.generate_clip(p))
     p0 = streams[0][0]
     W, H = p0.width, p0.height
@@ -162,7 +164,7 @@ def main():
             "config": {"workload": f"{W}x{H} {'Moflex3DS' if p0.version == 2 else 'ModsDS'} P-frame reconstruction "
                                    f"(SURVEY 8d generator mix), {args.clips} independent clips per GPU, "
                                    f"{distinct} distinct streams, command lists resident in HBM",
-                       "clips_per_gpu": args.clips, "parallelism": f"clips sharded over {world} GPU(s), no collective",
+                       "generator_overrides": gen_over or None, "clips_per_gpu": args.clips, "parallelism": f"clips sharded over {world} GPU(s), no collective",
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             "roofline": roof, "cpu_baseline": base,
         }

@@ -170,6 +170,8 @@ struct mobi_batch {
     a.width = g.width; a.height = g.height; a.stride = g.stride; a.mbw = g.mbw;
     a.n_mbs = g.mbw * g.mbh;
     a.n_clips = n;
+    a.magic_n_mbs = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.n_mbs);
+    a.magic_mbw = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.mbw);
     return a;
   }
   hipEvent_t get_event() {

@@ -3,7 +3,7 @@
 //
 // One frame of one clip =
 //   MbDesc   desc[n_mbs]           16 B per macroblock, raster order (leaf 0 of inter MBs is inline)
-//   uint32_t payload[...]          variable: MC leaves, intra block records, residual levels
+//   uint32_t payload[...]          variable: MV cell maps, intra block records, residual levels
 //   uint32_t intra_items[...]      MB indices of intra MBs grouped by dependency level (host side only;
 //                                  merged across clips into per-level launch lists)
 //
@@ -14,13 +14,20 @@
 #define MOBI_CMD_H
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#define MOBI_CMD_FN static __host__ __device__ __forceinline__
+#else
+#define MOBI_CMD_FN static inline
+#endif
+
 enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 
 // ---- MbDesc: 16 B per macroblock; on the device one flat table per frame step, index = clip*n_mbs + mb,
 //      so a wave's first load already tells it everything it needs to start fetching pixels ------------
 // w0  payload word offset (host: inside the clip's payload; device: inside the frame step's payload arena)
 // w1  [0]      type (MOBI_MB_*)
-//     [7:1]    n_leaves   (inter: 1..64; leaf 0 is INLINE in w2/w3, leaves 1.. are the first payload words)
+//     [7:1]    n_leaves   (inter: 1 = the single 16x16 leaf INLINE in w2/w3; >1 = the payload starts with the
+//                          64-word MV cell map instead)
 //     [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
 //     [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
 //     [25:20]  quantizer  of the frame (selects the dequant scale table, MD.cs:3884-3912)
@@ -33,13 +40,28 @@ struct MbDesc {
   uint32_t w3;
 };
 
-// ---- MC leaf: two words ---------------------------------------------------------------------
+// ---- MC leaf (single-leaf macroblocks: inline in the descriptor) ------------------------------
 //  w0: [3:0] x/2  [7:4] y/2  [9:8] log2(16/w)  [11:10] log2(16/h)  [14:12] ref slot 1..5
 //  w1: [15:0] dx (int16, half-pel, absolute)  [31:16] dy                         (MD.cs:400-416)
 static inline uint32_t mobi_leaf_w0(int x, int y, int wi, int hi, int ref) {
   return (uint32_t)((x >> 1) | ((y >> 1) << 4) | (wi << 8) | (hi << 10) | (ref << 12));
 }
 static inline uint32_t mobi_leaf_w1(int dx, int dy) { return ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16); }
+
+// ---- MV cell map (macroblocks with more than one leaf): 64 words, first thing in the payload ---
+// The partition tree bottoms out at 2x2 luma (MD.cs:1683-1746), so an 8x8 grid of 2x2-pixel cells
+// (= one chroma sample each) says for every pixel which leaf moved it.  cell[(y/2)*8 + x/2] =
+//  [13:0] dx (signed 14)  [27:14] dy (signed 14)  [30:28] ref slot 1..5
+// Every lane fetches the cells under its own pixels, so all reference reads of a macroblock are in
+// flight together, however deep the tree was.
+#define MOBI_MV_CELLS 64
+#define MOBI_MV_LIMIT 8191
+MOBI_CMD_FN uint32_t mobi_cell(int dx, int dy, int ref) {
+  return ((uint32_t)dx & 0x3FFFu) | (((uint32_t)dy & 0x3FFFu) << 14) | ((uint32_t)ref << 28);
+}
+MOBI_CMD_FN int mobi_cell_dx(uint32_t c) { return (int)(c << 18) >> 18; }
+MOBI_CMD_FN int mobi_cell_dy(uint32_t c) { return (int)(c << 4) >> 18; }
+MOBI_CMD_FN int mobi_cell_ref(uint32_t c) { return (int)(c >> 28) & 7; }
 
 // ---- residual level: one word ---------------------------------------------------------------
 //  [8:0]   tile position = area*64 + p, area = 0..5 (Y0..Y3,U,V)

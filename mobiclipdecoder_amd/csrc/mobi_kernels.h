@@ -22,6 +22,7 @@ struct MobiReconArgs {
   uint32_t slot_bytes;      // stride*height*3/2
   int ring_base;
   int width, height, stride, mbw, n_mbs, n_clips;
+  uint32_t magic_n_mbs, magic_mbw; // floor(2^32 / d) for the in-kernel divisions (no 64-bit divides on the GPU)
 };
 
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);

@@ -138,65 +138,74 @@ __device__ __forceinline__ void idct_pass2(const int *t, bool is8, int r, uint8_
 // =====================================================================================================
 // inter macroblocks
 // =====================================================================================================
+// q = x / d, r = x % d with magic = floor(2^32 / d): the estimate is at most one short
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t magic, uint32_t &r) {
+  uint32_t q = __umulhi(x, magic);
+  r = x - q * d;
+  if (r >= d) { q++; r -= d; }
+  return q;
+}
+
+// One wavefront per macroblock, four macroblocks (64 x 16 luma pixels) per workgroup, no workgroup barriers:
+// a wave lives for one macroblock, so the hardware scheduler does the load balancing and latency hiding.
+// XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so XCD x gets one
+// contiguous run of macroblocks (whole clips) -- neighbours that share output lines and overlapping MC
+// windows then meet in ONE L2 while they are in flight together.
 extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs A) {
   __shared__ uint32_t lds[WAVES][96 + 384 + 384]; // per wave: pred tiles (384 B), coef, tmp
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so give each XCD
-  // one contiguous run of macroblocks (whole clips): neighbours that share 128-B lines of the output and the
-  // overlapping MC windows of the reference then meet in ONE L2 instead of eight.
-  const int per_xcd = gridDim.x >> 3;
-  const long vb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const long gm = vb * WAVES + wave;
-  if (gm >= (long)A.n_clips * A.n_mbs) return;
+  const uint32_t total = (uint32_t)A.n_clips * (uint32_t)A.n_mbs;
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t gm = ((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
+  if (gm >= total) return;
   const uint4 d = *(const uint4 *)(A.desc + gm);
   const uint32_t w1 = d.y;
   if ((w1 & 1) != MOBI_MB_INTER) return;
-  const int clip = (int)(gm / A.n_mbs), mb = (int)(gm - (long)clip * A.n_mbs);
+  uint32_t mb, mbx;
+  const uint32_t clip = fastdiv(gm, (uint32_t)A.n_mbs, A.magic_n_mbs, mb);
+  const uint32_t mby = fastdiv(mb, (uint32_t)A.mbw, A.magic_mbw, mbx);
   const int nl = (w1 >> 1) & 0x7F, cbp6 = (w1 >> 8) & 0x3F, t8 = (w1 >> 14) & 0x3F, ncoef = d.z & 0x3FF;
-  const uint32_t *pl = A.payload + d.x;          // leaves 1..nl-1, then the residual levels
-  const uint32_t *cw = pl + 2 * (nl - 1);
+  const uint32_t *pl = A.payload + d.x;
+  const uint32_t *cw = pl + (nl > 1 ? MOBI_MV_CELLS : 0); // residual levels follow the MV cell map
   const int S = A.stride;
+  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
-  const size_t ysz = (size_t)S * A.height;
-  const int mby = mb / A.mbw;
-  const long off = (long)mby * 16 * S + (mb - mby * A.mbw) * 16;
+  const int off = (int)(mby * 16 * (uint32_t)S + mbx * 16);
+  const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
+  const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
   // first 64 residual levels travel together with the pixel fetches
   const uint32_t c_first = (cbp6 && lane < ncoef) ? cw[lane] : 0;
 
   // ---- motion compensation: lane -> luma row lane>>2, px (lane&3)*4 ; lanes 0..31 -> chroma ----
-  const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
-  const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
   uint32_t ypred = 0, cpred = 0;
-  uint32_t w0 = (d.z >> 10) & 0x7FFF, mvw = d.w;
-  if (nl == 1) { // one 16x16 leaf (the common case): no masks
-    const int ref = (w0 >> 12) & 7;
-    const int dx = (int16_t)(mvw & 0xFFFF), dy = (int16_t)(mvw >> 16);
-    const uint8_t *ry = clip_base + (size_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes;
-    ypred = mc_word(ry + off + (long)(yrow + (dy >> 1)) * S + yc4 + (dx >> 1), S, (dx & 1) | ((dy & 1) << 1));
+  if (nl == 1) { // one 16x16 leaf, inline in the descriptor
+    const int ref = (d.z >> 22) & 7;
+    const int dx = (int16_t)(d.w & 0xFFFF), dy = (int16_t)(d.w >> 16);
+    const uint8_t *ry = clip_base + (uint32_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes;
+    ypred = mc_word(ry + (off + (yrow + (dy >> 1)) * S + yc4 + (dx >> 1)), S, (dx & 1) | ((dy & 1) << 1));
     const int cdx = dx >> 1, cdy = dy >> 1;
     if (lane < 32)
-      cpred = mc_word(ry + ysz + off / 2 + cv * (S >> 1) + (long)(crow + (cdy >> 1)) * S + cc4 + (cdx >> 1), S, (cdx & 1) | ((cdy & 1) << 1));
-  } else {
-    for (int l = 0;;) {
-      const int lx = (w0 & 15) * 2, ly = ((w0 >> 4) & 15) * 2, lw = 16 >> ((w0 >> 8) & 3), lh = 16 >> ((w0 >> 10) & 3);
-      const int ref = (w0 >> 12) & 7;
-      const int dx = (int16_t)(mvw & 0xFFFF), dy = (int16_t)(mvw >> 16);
-      const uint8_t *ry = clip_base + (size_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes;
-      const uint8_t *ruv = ry + ysz;
-      if (yrow >= ly && yrow < ly + lh && yc4 + 4 > lx && yc4 < lx + lw) {
-        const uint32_t v = mc_word(ry + off + (long)(yrow + (dy >> 1)) * S + yc4 + (dx >> 1), S, (dx & 1) | ((dy & 1) << 1));
-        const uint32_t m = seg_mask(yc4, lx, lw);
-        ypred = (ypred & ~m) | (v & m);
+      cpred = mc_word(ry + ysz + ((off >> 1) + cv * (S >> 1) + (crow + (cdy >> 1)) * S + cc4 + (cdx >> 1)), S, (cdx & 1) | ((cdy & 1) << 1));
+  } else { // MV cell map: every lane looks up the cells under its own pixels, then all fetches fly together
+    const uint2 yc = *(const uint2 *)(pl + (yrow >> 1) * 8 + (yc4 >> 1));
+    uint4 cc = uint4{0, 0, 0, 0};
+    if (lane < 32) cc = *(const uint4 *)(pl + crow * 8 + cc4);
+    const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
+    const uint8_t *ra = clip_base + (uint32_t)((A.ring_base + 6 - mobi_cell_ref(yc.x)) % 6) * A.slot_bytes;
+    const uint8_t *rb = clip_base + (uint32_t)((A.ring_base + 6 - mobi_cell_ref(yc.y)) % 6) * A.slot_bytes;
+    const uint32_t va = mc_word(ra + (off + (yrow + (dya >> 1)) * S + yc4 + (dxa >> 1)), S, (dxa & 1) | ((dya & 1) << 1));
+    const uint32_t vb = mc_word(rb + (off + (yrow + (dyb >> 1)) * S + yc4 + (dxb >> 1)), S, (dxb & 1) | ((dyb & 1) << 1));
+    ypred = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
+    if (lane < 32) {
+      const int cbase = (off >> 1) + cv * (S >> 1) + crow * S + cc4;
+      const uint32_t cell[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int cdx = mobi_cell_dx(cell[k]) >> 1, cdy = mobi_cell_dy(cell[k]) >> 1;
+        const uint8_t *rc = clip_base + (uint32_t)((A.ring_base + 6 - mobi_cell_ref(cell[k])) % 6) * A.slot_bytes + ysz;
+        const uint32_t v = mc_word(rc + (cbase + (cdy >> 1) * S + (cdx >> 1)), S, (cdx & 1) | ((cdy & 1) << 1));
+        cpred |= v & (0xFFu << (8 * k));
       }
-      const int cdx = dx >> 1, cdy = dy >> 1, cx = lx >> 1, cy = ly >> 1, cw2 = lw >> 1, ch = lh >> 1;
-      if (lane < 32 && crow >= cy && crow < cy + ch && cc4 + 4 > cx && cc4 < cx + cw2) {
-        const uint32_t v = mc_word(ruv + off / 2 + cv * (S >> 1) + (long)(crow + (cdy >> 1)) * S + cc4 + (cdx >> 1), S, (cdx & 1) | ((cdy & 1) << 1));
-        const uint32_t m = seg_mask(cc4, cx, cw2);
-        cpred = (cpred & ~m) | (v & m);
-      }
-      if (++l >= nl) break;
-      w0 = pl[2 * (l - 1)];
-      mvw = pl[2 * (l - 1) + 1];
     }
   }
 
@@ -230,9 +239,9 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
   }
 
   // ---- store: 16 B per row per MB (4 adjacent MBs per workgroup -> 64 B runs) ----
-  uint8_t *y0 = clip_base + (size_t)(A.ring_base % 6) * A.slot_bytes;
-  *(uint32_t *)(y0 + off + (long)yrow * S + yc4) = ypred;
-  if (lane < 32) *(uint32_t *)(y0 + ysz + off / 2 + cv * (S >> 1) + (long)crow * S + cc4) = cpred;
+  uint8_t *y0 = clip_base + (uint32_t)(A.ring_base % 6) * A.slot_bytes;
+  *(uint32_t *)(y0 + (off + yrow * S + yc4)) = ypred;
+  if (lane < 32) *(uint32_t *)(y0 + ysz + ((off >> 1) + cv * (S >> 1) + crow * S + cc4)) = cpred;
 }
 
 // =====================================================================================================
@@ -368,7 +377,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const long waves = (long)a->n_clips * a->n_mbs;
   if (waves <= 0) return 0;
-  const unsigned grid = (unsigned)(((waves + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of blocks per XCD
+  const unsigned grid = (unsigned)(((waves + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, *a);
   return (int)hipGetLastError();
 }

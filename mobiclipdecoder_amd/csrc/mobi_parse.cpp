@@ -111,9 +111,9 @@ void MobiStreamParser::end_mb() {
   d.w3 = w3_;
   if (mb_type_ == MOBI_MB_INTER) {
     nl = (uint32_t)(leaves_.size() / 2);
-    d.w2 |= leaves_[0] << 10; // leaf 0 rides in the descriptor
+    d.w2 |= leaves_[0] << 10; // the leaf of a single-leaf MB rides in the descriptor
     d.w3 = leaves_[1];
-    out_->payload.insert(out_->payload.end(), leaves_.begin() + 2, leaves_.end());
+    if (nl > 1) out_->payload.insert(out_->payload.end(), cells_, cells_ + MOBI_MV_CELLS);
   } else {
     out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
   }
@@ -154,9 +154,12 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
   int cph = (cdx & 1) | ((cdy & 1) << 1);
   check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
   check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
-  if (dx < -32768 || dx > 32767 || dy < -32768 || dy > 32767) fail(MOBI_E_UNSUPPORTED);
+  if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) fail(MOBI_E_UNSUPPORTED);
   leaves_.push_back(mobi_leaf_w0(x, y, wi, hi, ref));
   leaves_.push_back(mobi_leaf_w1(dx, dy));
+  const uint32_t cell = mobi_cell(dx, dy, ref);
+  for (int cy = y >> 1; cy < (y + h) >> 1; cy++)
+    for (int cx = x >> 1; cx < (x + w) >> 1; cx++) cells_[cy * 8 + cx] = cell;
 }
 // ReadPBlock*/SwitchPBlock* (MD.cs:469-1746) as one table-driven routine; x,y are MB-relative.
 void MobiStreamParser::pblock(int wi, int hi, int x, int y, int mv_slot) {

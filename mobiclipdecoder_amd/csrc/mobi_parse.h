@@ -111,6 +111,7 @@ class MobiStreamParser {
   long cur_off_ = 0;
   std::vector<uint32_t> leaves_, coefs_;
   uint32_t recs_[MOBI_INTRA_RECORDS];
+  uint32_t cells_[MOBI_MV_CELLS];
   uint32_t cbp6_ = 0, t8mask_ = 0, w3_ = 0;
   int mb_type_ = 0;
 };

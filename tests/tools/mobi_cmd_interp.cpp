@@ -93,47 +93,50 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
   const int nl = (d.w1 >> 1) & 0x7F, cbp6 = (d.w1 >> 8) & 0x3F, t8 = (d.w1 >> 14) & 0x3F, ncoef = d.w2 & 0x3FF;
   const long off = (long)(mb / g.mbw) * 16 * S + (mb % g.mbw) * 16;
   uint8_t ty[16 * TP], tc[2][8 * TP]; // prediction tiles (interior only; pitch TP, origin at byte 0)
-  for (int l = 0; l < nl; l++) {
-    uint32_t w0 = l ? pl[2 * (l - 1)] : (d.w2 >> 10) & 0x7FFF, w1 = l ? pl[2 * (l - 1) + 1] : d.w3; // leaf 0 is in the descriptor
-    int lx = (w0 & 15) * 2, ly = ((w0 >> 4) & 15) * 2, lw = 16 >> ((w0 >> 8) & 3), lh = 16 >> ((w0 >> 10) & 3), ref = (w0 >> 12) & 7;
-    int dx = (int16_t)(w1 & 0xFFFF), dy = (int16_t)(w1 >> 16);
-    const uint8_t *ry = I.Y(ref), *ruv = I.UV(ref);
-    for (int lane = 0; lane < 64; lane++) { // luma: lane -> row lane>>2, 4 px at (lane&3)*4
-      int row = lane >> 2, c4 = (lane & 3) * 4;
-      if (row < ly || row >= ly + lh || c4 + 4 <= lx || c4 >= lx + lw) continue;
-      long pos = off + (long)(row + (dy >> 1)) * S + c4 + (dx >> 1);
-      // the 4-px word may stick out of the leaf's validated window by up to 2 px: guard like the HBM slack
-      uint8_t a[8] = {0}, b[8] = {0};
-      const long len = S * g.height;
-      for (int k = 0; k < 5; k++) {
-        long p0 = pos + k, p1 = pos + S + k;
-        a[k] = (p0 >= 0 && p0 < len) ? ry[p0] : 0;
-        b[k] = (p1 >= 0 && p1 < len) ? ry[p1] : 0;
-      }
-      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), (dx & 1) | ((dy & 1) << 1));
-      for (int k = 0; k < 4; k++)
-        if (c4 + k >= lx && c4 + k < lx + lw) ty[row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
+  // per-lane MV: the inline leaf (nl == 1) or the cell under each pixel (nl > 1)
+  auto mv_at = [&](int cellx, int celly, int &dx, int &dy, int &ref) {
+    if (nl == 1) {
+      uint32_t w0 = (d.w2 >> 10) & 0x7FFF;
+      ref = (w0 >> 12) & 7; dx = (int16_t)(d.w3 & 0xFFFF); dy = (int16_t)(d.w3 >> 16);
+    } else {
+      uint32_t c = pl[celly * 8 + cellx];
+      dx = mobi_cell_dx(c); dy = mobi_cell_dy(c); ref = mobi_cell_ref(c);
     }
-    int cdx = dx >> 1, cdy = dy >> 1, cx = lx >> 1, cy = ly >> 1, cw = lw >> 1, ch = lh >> 1;
-    for (int lane = 0; lane < 32; lane++) { // chroma: lanes 0..15 U, 16..31 V; row (lane&15)>>1, 4 px at (lane&1)*4
-      int v01 = lane >> 4, row = (lane & 15) >> 1, c4 = (lane & 1) * 4;
-      if (row < cy || row >= cy + ch || c4 + 4 <= cx || c4 >= cx + cw) continue;
-      long pos = off / 2 + v01 * (S / 2) + (long)(row + (cdy >> 1)) * S + c4 + (cdx >> 1);
+  };
+  auto fetch5 = [&](const uint8_t *plane, long len, long pos, uint8_t *a, uint8_t *b) {
+    for (int k = 0; k < 5; k++) { // the 4-px word may stick out of a leaf's validated window: guard like the HBM slack
+      long p0 = pos + k, p1 = pos + S + k;
+      a[k] = (p0 >= 0 && p0 < len) ? plane[p0] : 0;
+      b[k] = (p1 >= 0 && p1 < len) ? plane[p1] : 0;
+    }
+  };
+  for (int lane = 0; lane < 64; lane++) { // luma: lane -> row lane>>2, 4 px at (lane&3)*4 = two cells
+    int row = lane >> 2, c4 = (lane & 3) * 4;
+    for (int half = 0; half < 2; half++) {
+      int dx, dy, ref;
+      mv_at(c4 / 2 + half, row >> 1, dx, dy, ref);
       uint8_t a[8] = {0}, b[8] = {0};
-      const long len = S * g.height / 2;
-      for (int k = 0; k < 5; k++) {
-        long p0 = pos + k, p1 = pos + S + k;
-        a[k] = (p0 >= 0 && p0 < len) ? ruv[p0] : 0;
-        b[k] = (p1 >= 0 && p1 < len) ? ruv[p1] : 0;
-      }
-      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), (cdx & 1) | ((cdy & 1) << 1));
-      for (int k = 0; k < 4; k++)
-        if (c4 + k >= cx && c4 + k < cx + cw) tc[v01][row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
+      fetch5(I.Y(ref), S * g.height, off + (long)(row + (dy >> 1)) * S + c4 + (dx >> 1), a, b);
+      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), (dx & 1) | ((dy & 1) << 1));
+      for (int k = 2 * half; k < 2 * half + 2; k++) ty[row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
     }
   }
+  for (int lane = 0; lane < 32; lane++) { // chroma: lanes 0..15 U, 16..31 V; one cell per chroma sample
+    int v01 = lane >> 4, row = (lane & 15) >> 1, c4 = (lane & 1) * 4;
+    for (int k = 0; k < 4; k++) {
+      int dx, dy, ref;
+      mv_at(c4 + k, row, dx, dy, ref);
+      int cdx = dx >> 1, cdy = dy >> 1;
+      uint8_t a[8] = {0}, b[8] = {0};
+      fetch5(I.UV(ref), S * g.height / 2, off / 2 + v01 * (S / 2) + (long)(row + (cdy >> 1)) * S + c4 + (cdx >> 1), a, b);
+      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), (cdx & 1) | ((cdy & 1) << 1));
+      tc[v01][row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
+    }
+  }
+  const uint32_t *cw = pl + (nl > 1 ? MOBI_MV_CELLS : 0);
   if (cbp6) {
     int coef[6 * 64];
-    dequant_into((d.w1 >> 20) & 63, pl + 2 * (nl - 1), ncoef, t8, coef);
+    dequant_into((d.w1 >> 20) & 63, cw, ncoef, t8, coef);
     for (int a = 0; a < 6; a++) {
       if (!((cbp6 >> a) & 1)) continue;
       uint8_t *t = a < 4 ? ty + (a >> 1) * 8 * TP + (a & 1) * 8 : tc[a - 4];
