@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -130,6 +131,7 @@ struct mobi_batch {
   size_t slot_bytes = 0, clip_bytes = 0;
   int ring_base = 0;
   int frames_started = 0;
+  int debug = 0;
   std::vector<std::unique_ptr<MobiStreamParser>> parsers;
   std::vector<ParsedFrame> cur; // per clip, current frame (batch_decode)
   int *d_fault = nullptr;
@@ -172,6 +174,11 @@ struct mobi_batch {
     a.n_clips = n;
     a.magic_n_mbs = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.n_mbs);
     a.magic_mbw = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.mbw);
+    a.debug = debug;
+    a.opr = (uint32_t)(a.mbw + 7) / 8;
+    a.opc = a.opr * (uint32_t)g.mbh;
+    a.magic_opr = (uint32_t)(((uint64_t)1 << 32) / a.opr);
+    a.magic_opc = (uint32_t)(((uint64_t)1 << 32) / a.opc);
     return a;
   }
   hipEvent_t get_event() {
@@ -252,6 +259,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   auto b = std::make_unique<mobi_batch>();
   b->n = n_clips;
+  if (const char *dbg = getenv("MOBI_DEBUG")) b->debug = atoi(dbg); // kernel ablation switch for profiling only
   b->device = device;
   b->version = version;
   for (int i = 0; i < n_clips; i++) b->parsers.emplace_back(new MobiStreamParser(width, height, version));

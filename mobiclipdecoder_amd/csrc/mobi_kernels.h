@@ -23,6 +23,8 @@ struct MobiReconArgs {
   int ring_base;
   int width, height, stride, mbw, n_mbs, n_clips;
   uint32_t magic_n_mbs, magic_mbw; // floor(2^32 / d) for the in-kernel divisions (no 64-bit divides on the GPU)
+  uint32_t opr, opc, magic_opr, magic_opc; // octets (8 MBs) per MB row / per clip, and their magics
+  int debug;                       // profiling aid (env MOBI_DEBUG): 0 = normal
 };
 
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);

@@ -161,6 +161,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
   const uint4 d = *(const uint4 *)(A.desc + gm);
   const uint32_t w1 = d.y;
   if ((w1 & 1) != MOBI_MB_INTER) return;
+  if (A.debug == 1) return; // profiling ablation (env MOBI_DEBUG): launch + descriptor only
   uint32_t mb, mbx;
   const uint32_t clip = fastdiv(gm, (uint32_t)A.n_mbs, A.magic_n_mbs, mb);
   const uint32_t mby = fastdiv(mb, (uint32_t)A.mbw, A.magic_mbw, mbx);
@@ -239,6 +240,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
   }
 
   // ---- store: 16 B per row per MB (4 adjacent MBs per workgroup -> 64 B runs) ----
+  if (A.debug == 2) return; // profiling ablation: no stores
   uint8_t *y0 = clip_base + (uint32_t)(A.ring_base % 6) * A.slot_bytes;
   *(uint32_t *)(y0 + (off + yrow * S + yc4)) = ypred;
   if (lane < 32) *(uint32_t *)(y0 + ysz + ((off >> 1) + cv * (S >> 1) + crow * S + cc4)) = cpred;
