@@ -78,15 +78,14 @@ def main():
         raise SystemExit("bench.py needs a HIP device: there is no CPU reconstruction path to time")
 
     import mobiclipdecoder_amd as m
-    from mobiclipdecoder_amd.streamgen import BASE_SEED
+    from mobiclipdecoder_amd import sharding
 
     # experiment hook: BENCH_GEN="pm_split1=0,pm_deep=0" overrides generator fields (non-default => not the headline workload)
     gen_over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("BENCH_GEN", "").split(",") if kv)}
-    cfg_idx = "ABC".index(args.config)
     distinct = max(1, min(args.distinct, args.clips))
     streams = []
     for i in range(distinct):
-        p = m.default_params(args.config, BASE_SEED + cfg_idx + 1000 * rank + i, n_frames=1 + N_PFRAMES, **gen_over)
+        p = m.default_params(args.config, sharding.stream_seed(args.config, rank, i), n_frames=1 + N_PFRAMES, **gen_over)
         streams.append((p,) + m.generate_clip(p))
     p0 = streams[0][0]
     W, H = p0.width, p0.height
@@ -122,14 +121,10 @@ def main():
     assert b.sync() == 0, "clamp-domain fault in the timed region"
     km = b.kernel_ms()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(dist, elapsed, device=f"cuda:{local}")
 
     if rank == 0:
         steps = args.steps
-        total_px = world * args.clips * steps * W * H
         timed = step_frames[args.warmup:]
         cmd_bytes = sum(b.cmd_bytes(f) for f in timed) / steps          # per launch, all clips of this GPU
         algo_bytes = args.clips * 3.0 * W * H + cmd_bytes                # ref read 1.5WH + write 1.5WH + commands
@@ -157,7 +152,7 @@ def main():
             base = cpu_baseline(*streams[0], args.cpu_seconds)
         out = {
             "metric": "decoded Mpixels/s @ 640x480 P-frames" if args.config == "B" else f"decoded Mpixels/s P-frames (config {args.config})",
-            "value": round(total_px / elapsed / 1e6, 1), "unit": "Mpixels/s",
+            "value": round(sharding.whole_job_mpix_per_s(world, args.clips, steps, W, H, elapsed), 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
