@@ -140,6 +140,7 @@ struct mobi_batch {
   PinnedBuf h_stage;
   DevBuf d_cmd, d_items;
   int32_t *d_scale = nullptr; // [MOBI_SCALE_QMAX][MOBI_SCALE_STRIDE]
+  unsigned long long *d_prof = nullptr; // MOBI_DEBUG=9: in-kernel cycle accumulators
   // preloaded replay
   // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
   std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
@@ -161,6 +162,7 @@ struct mobi_batch {
 
   MobiReconArgs args(const uint8_t *desc, const uint8_t *payload) const {
     MobiReconArgs a;
+    memset(&a, 0, sizeof(a));
     a.planes = arena + kGuard;
     a.desc = (const MbDesc *)desc;
     a.payload = (const uint32_t *)payload;
@@ -172,13 +174,15 @@ struct mobi_batch {
     a.width = g.width; a.height = g.height; a.stride = g.stride; a.mbw = g.mbw;
     a.n_mbs = g.mbw * g.mbh;
     a.n_clips = n;
-    a.magic_n_mbs = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.n_mbs);
-    a.magic_mbw = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)a.mbw);
+    auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); }; // d == 1 must not wrap to 0
+    a.magic_n_mbs = magic((uint32_t)a.n_mbs);
+    a.magic_mbw = magic((uint32_t)a.mbw);
     a.debug = debug;
-    a.opr = (uint32_t)(a.mbw + 7) / 8;
-    a.opc = a.opr * (uint32_t)g.mbh;
-    a.magic_opr = (uint32_t)(((uint64_t)1 << 32) / a.opr);
-    a.magic_opc = (uint32_t)(((uint64_t)1 << 32) / a.opc);
+    a.prof = d_prof;
+    a.qpr = (uint32_t)(a.mbw + 3) / 4;
+    a.qpc = a.qpr * (uint32_t)g.mbh;
+    a.magic_qpr = magic(a.qpr);
+    a.magic_qpc = magic(a.qpc);
     return a;
   }
   hipEvent_t get_event() {
@@ -222,6 +226,7 @@ struct mobi_batch {
     if (arena) (void)hipFree(arena);
     if (d_fault) (void)hipFree(d_fault);
     if (d_scale) (void)hipFree(d_scale);
+    if (d_prof) (void)hipFree(d_prof);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -229,6 +234,15 @@ struct mobi_batch {
 struct mobi_dec { mobi_batch *b; };
 
 extern "C" {
+
+// profiling aid, not part of the public header: copy out the MOBI_DEBUG=9 per-wave cycle records
+// (uint32 x 4 per macroblock: descriptor, pixels+MC, residual, store drain) of the last inter launch
+int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
+  if (!b || !b->d_prof) return MOBI_E_ARG;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->d_prof, n_words * 4, hipMemcpyDeviceToHost));
+  return MOBI_OK;
+}
 
 const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter, mobi_recon_intra; no CPU reconstruction path)"; }
 
@@ -281,6 +295,11 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMalloc((void **)&b->d_scale, tab.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(b->d_scale, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   }
+  if (b->debug == 9) {
+    const size_t pbytes = (size_t)n_clips * (b->g.mbw * b->g.mbh) * 16;
+    if (hipMalloc((void **)&b->d_prof, pbytes) != hipSuccess) return nullptr;
+    if (hipMemset(b->d_prof, 0, pbytes) != hipSuccess) return nullptr;
+  }
   if (hipStreamSynchronize(b->stream) != hipSuccess) return nullptr;
   return b.release();
 }
@@ -310,7 +329,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   plan.build(ok);
   // 2. stage [desc table][payload arena][items] and upload
   const int n_mbs = b->g.mbw * b->g.mbh;
-  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc), kAlign);
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 64, kAlign); // +64: a quad reads 4 descriptors at once
   const size_t pay_bytes = align_up(step_payload_words(ok) * 4 + 4, kAlign);
   const size_t item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
   if (int e = b->h_stage.reserve(desc_bytes + pay_bytes + item_bytes)) return e;
@@ -388,7 +407,7 @@ int mobi_batch_commit(mobi_batch *b) {
     if ((int)b->staged[c]->size() != nf) return MOBI_E_ARG;
   }
   const int n_mbs = b->g.mbw * b->g.mbh;
-  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc), kAlign);
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 64, kAlign); // +64: a quad reads 4 descriptors at once
   size_t cmd_bytes = 0, n_items = 0;
   b->r_plan.assign(nf, LevelPlan());
   b->r_items_off.assign(nf, 0);

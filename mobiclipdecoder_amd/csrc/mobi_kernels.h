@@ -12,20 +12,25 @@
 //   desc / payload : the command list of one frame step, all clips (mobi_cmd.h)
 // Ring: position r (0 = frame being written, 1..5 = references, MD.cs:102-106) lives in slot
 //   (ring_base + 6 - r) % 6 ; every clip of a batch rotates in lock step, so ring_base is a scalar.
-struct MobiReconArgs {
-  uint8_t *planes;
-  const MbDesc *desc;       // flat table of this frame step: [clip * n_mbs + mb]
-  const uint32_t *payload;  // payload arena of this frame step (MbDesc.payload_off indexes it)
-  const int32_t *scale;     // [quantizer][MOBI_SCALE_STRIDE] dequant scales by natural coefficient index
-  int *fault;               // [clip] clamp-table domain faults (MOBI_E_CLAMP)
-  uint64_t clip_bytes;      // 6 * slot_bytes
-  uint32_t slot_bytes;      // stride*height*3/2
-  int ring_base;
-  int width, height, stride, mbw, n_mbs, n_clips;
-  uint32_t magic_n_mbs, magic_mbw; // floor(2^32 / d) for the in-kernel divisions (no 64-bit divides on the GPU)
-  uint32_t opr, opc, magic_opr, magic_opc; // octets (8 MBs) per MB row / per clip, and their magics
-  int debug;                       // profiling aid (env MOBI_DEBUG): 0 = normal
+struct MobiReconArgs { // field order is part of the kernel ABI: mobi_recon_inter reads the kernarg block as two 16-dword tuples
+  uint8_t *planes;          // dwords 0-1
+  const MbDesc *desc;       // 2-3   flat table of this frame step: [clip * n_mbs + mb]
+  const uint32_t *payload;  // 4-5   payload arena of this frame step (MbDesc.payload_off indexes it)
+  const int32_t *scale;     // 6-7   [quantizer][MOBI_SCALE_STRIDE] dequant scales by natural coefficient index
+  int *fault;               // 8-9   [clip] clamp-table domain faults (MOBI_E_CLAMP)
+  uint64_t clip_bytes;      // 10-11 6 * slot_bytes
+  uint32_t slot_bytes;      // 12    stride*height*3/2
+  int ring_base;            // 13
+  int width, height;        // 14, 15
+  int stride, mbw, n_mbs, n_clips;          // 16-19
+  uint32_t magic_n_mbs, magic_mbw;          // 20, 21  floor(2^32 / d): no integer divides on the GPU
+  uint32_t qpr, qpc, magic_qpr, magic_qpc;  // 22-25  quads (4 adjacent MBs = one wave) per MB row / per clip
+  int debug;                                // 26     profiling aid (env MOBI_DEBUG): 0 = normal
+  uint32_t inter_per_xcd;                   // 27     inter launch: workgroups per XCD (= gridDim.x / 8)
+  int pad0, pad1;                           // 28-29
+  unsigned long long *prof;                 // 30-31  profiling accumulators (MOBI_DEBUG=9), else null
 };
+static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");
 
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);

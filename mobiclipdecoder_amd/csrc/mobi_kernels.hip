@@ -45,20 +45,35 @@ struct Geo { // stride is 256/512/1024 (MD.cs:50-52): divide/modulo by shifts
   }
 };
 
-// four reference pixels (+1 for the half-pel neighbour) starting at an arbitrary byte address,
-// fetched as two aligned dwords and funnel-shifted
-__device__ __forceinline__ void load5(const uint8_t *p, uint32_t &a, uint32_t &b) {
-  const uintptr_t ad = (uintptr_t)p;
-  const uint32_t *q = (const uint32_t *)(ad & ~(uintptr_t)3);
-  const uint32_t sh = (uint32_t)(ad & 3) * 8;
-  const uint64_t v = (((uint64_t)q[1] << 32) | q[0]) >> sh;
-  a = (uint32_t)v;
-  b = (uint32_t)(v >> 8);
+// ---- reference fetch: a lane needs 5 consecutive bytes (4 pixels + the half-pel neighbour) of a row, and
+// the same of the row below, at an arbitrary byte offset `o` of a 4-byte-aligned plane.  They are fetched as
+// aligned dword pairs (global_load_dwordx2, never flat) and cut out with v_alignbyte.  All loads of a
+// macroblock are issued before the first one is consumed: no control flow sits between them.
+typedef uint2 __attribute__((aligned(4))) uint2_a4;
+struct Win { uint2 r0, r1; uint32_t sh; }; // row, row below, byte shift 0..3
+__device__ __forceinline__ Win fetch_win(const uint32_t *plane32, int o, int S) {
+  Win w;
+  const uint32_t *q = plane32 + (o >> 2);
+  w.r0 = *(const uint2_a4 *)q;
+  w.r1 = *(const uint2_a4 *)(q + (S >> 2));
+  w.sh = (uint32_t)o & 3;
+  return w;
 }
-__device__ __forceinline__ uint32_t mc_word(const uint8_t *p, int stride, int phase) {
-  uint32_t a, b, c = 0, d = 0;
-  load5(p, a, b);
-  if (phase & 2) load5(p + stride, c, d);
+__device__ __forceinline__ uint32_t cut(uint2 r, uint32_t sh) { return __builtin_amdgcn_alignbyte(r.y, r.x, sh); }
+__device__ __forceinline__ uint32_t cut1(uint2 r, uint32_t sh) { return sh == 3 ? r.y : __builtin_amdgcn_alignbyte(r.y, r.x, sh + 1); }
+// CopyBlock arithmetic on four packed pixels, phase known per lane: no branches (MD.cs:424-452)
+__device__ __forceinline__ uint32_t mc4_select(const Win &w, int phase) {
+  const uint32_t M = 0x7F7F7F7Fu;
+  const uint32_t a = cut(w.r0, w.sh), b = cut1(w.r0, w.sh), c = cut(w.r1, w.sh), d = cut1(w.r1, w.sh);
+  const uint32_t ha = (a >> 1) & M, hb = (b >> 1) & M, hc = (c >> 1) & M, hd = (d >> 1) & M;
+  const uint32_t p1 = ha + hb, p2 = ha + hc, p3 = ((p1 >> 1) & M) + (((hc + hd) >> 1) & M);
+  return phase == 0 ? a : phase == 1 ? p1 : phase == 2 ? p2 : p3;
+}
+// the same with a wave-uniform phase (single-leaf macroblocks): scalar branch, only the needed terms
+__device__ __forceinline__ uint32_t mc4_uniform(const Win &w, int phase) {
+  const uint32_t a = cut(w.r0, w.sh);
+  if (phase == 0) return a;
+  const uint32_t b = (phase & 1) ? cut1(w.r0, w.sh) : 0, c = (phase & 2) ? cut(w.r1, w.sh) : 0, d = phase == 3 ? cut1(w.r1, w.sh) : 0;
   return mobi_mc4(a, b, c, d, phase);
 }
 // byte mask of the pixels [c4, c4+4) that fall inside [lo, lo+len)
@@ -146,104 +161,219 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
   return q;
 }
 
-// One wavefront per macroblock, four macroblocks (64 x 16 luma pixels) per workgroup, no workgroup barriers:
-// a wave lives for one macroblock, so the hardware scheduler does the load balancing and latency hiding.
-// XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so XCD x gets one
-// contiguous run of macroblocks (whole clips) -- neighbours that share output lines and overlapping MC
-// windows then meet in ONE L2 while they are in flight together.
+// ---- mobi_recon_inter: one wavefront per QUAD of four horizontally adjacent macroblocks (64 x 16 luma) ----
+// Measured on MI355X (tools/ubench/valu.hip, MOBI_DEBUG=9 cycle records): integer wave64 VALU ops cost ~4
+// SIMD cycles, a memory round trip ~3.4k cycles under load, and with one macroblock per wave the kernel was
+// VALU-bound at ~330 instructions per macroblock, most of them in an inverse transform that kept <= 48 of 64
+// lanes busy for ~1.8 coded 8x8 areas.  Hence:
+//   * all global reads of the four macroblocks -- descriptors, MC windows as whole 16-byte chunks (one lane
+//     per window row x chunk: ~18 cache lines per load instead of 4 x 16), MV cell maps, first residual
+//     levels, dequant scales -- are issued together as asynchronous global->LDS copies
+//     (global_load_lds: "LDS staging of the macroblock + MC halo"), then waited for once;
+//   * motion compensation runs per macroblock out of LDS;
+//   * ONE batched inverse transform serves the coded areas of all four macroblocks, 8 areas x 8 rows = 64
+//     lanes per pass;
+//   * the quad leaves as whole 64-byte luma rows / 8-byte chroma rows.
+// A wave lives for one quad (no loop-carried state, no workgroup barriers).  XCD-aware order: the dispatcher
+// deals consecutive workgroups round-robin to the 8 XCDs, so XCD x gets one contiguous run of quads.
+namespace {
+enum {
+  Q_WIN_MB = 1120,               // per MB: luma window 17 rows x 32 B (544) + chroma 2 x 9 rows x 32 B (576);
+                                 // a multi-leaf MB keeps its 256-byte MV cell map here instead
+  Q_WIN = 0,                     // 4 x Q_WIN_MB = 4480
+  Q_COEF = 0, Q_TMP = 2048,      // coefficient tile + transposed intermediate (8 areas x 64 ints each): alias the
+                                 // windows, which are dead once motion compensation is done
+  Q_CW = 4480,                   // first 64 residual level words per MB (4 x 256)
+  Q_OUT_Y = 5504,                // out tile: luma 16 rows x 64 B
+  Q_OUT_C = 6528,                //           chroma 2 planes x 8 rows x 32 B
+  Q_SCALE = 7040,                // dequant scales of the frame quantizer (80 ints)
+  Q_TAB = 7360,                  // coded-area table: entry -> (mb*6 + area), 24 bytes
+  Q_DESC = 7392,                 // the four descriptors (64 B)
+  Q_BYTES = 7680
+};
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+// lane i lands at dst + i*BYTES; dst must be wave-uniform (it travels in M0)
+#define MOBI_DMA(BYTES, src, dst) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), BYTES, 0, 0)
+} // namespace
+
 extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs A) {
-  __shared__ uint32_t lds[WAVES][96 + 384 + 384]; // per wave: pred tiles (384 B), coef, tmp
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES][Q_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t total = (uint32_t)A.n_clips * (uint32_t)A.n_mbs;
-  const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t gm = ((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
-  if (gm >= total) return;
-  const uint4 d = *(const uint4 *)(A.desc + gm);
-  const uint32_t w1 = d.y;
-  if ((w1 & 1) != MOBI_MB_INTER) return;
-  if (A.debug == 1) return; // profiling ablation (env MOBI_DEBUG): launch + descriptor only
-  uint32_t mb, mbx;
-  const uint32_t clip = fastdiv(gm, (uint32_t)A.n_mbs, A.magic_n_mbs, mb);
-  const uint32_t mby = fastdiv(mb, (uint32_t)A.mbw, A.magic_mbw, mbx);
-  const int nl = (w1 >> 1) & 0x7F, cbp6 = (w1 >> 8) & 0x3F, t8 = (w1 >> 14) & 0x3F, ncoef = d.z & 0x3FF;
-  const uint32_t *pl = A.payload + d.x;
-  const uint32_t *cw = pl + (nl > 1 ? MOBI_MV_CELLS : 0); // residual levels follow the MV cell map
+  const uint32_t qi = ((blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
+  if (qi >= A.qpc * (uint32_t)A.n_clips) return;
+  if (A.debug == 1) return;
+  uint32_t rem, qx;
+  const uint32_t clip = fastdiv(qi, A.qpc, A.magic_qpc, rem);
+  const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, qx);
+  const uint32_t mbx0 = qx * 4, mbw = (uint32_t)A.mbw;
+  const int nmb = (int)(mbw - mbx0 < 4 ? mbw - mbx0 : 4);
   const int S = A.stride;
-  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height;
+  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height, slot_w = A.slot_bytes >> 2, ysz_w = ysz >> 2;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
-  const int off = (int)(mby * 16 * (uint32_t)S + mbx * 16);
+  const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16);
+  uint8_t *L = lds_all[wave];
   const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
   const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-  // first 64 residual levels travel together with the pixel fetches
-  const uint32_t c_first = (cbp6 && lane < ncoef) ? cw[lane] : 0;
+  const int wr = lane >> 1, wk = lane & 1;                           // window row, 16-byte chunk (luma: lanes 0..33)
+  const int cpl = lane >= 18 ? 1 : 0, crw = (lane - cpl * 18) >> 1; // chroma window: plane, row (lanes 0..35)
 
-  // ---- motion compensation: lane -> luma row lane>>2, px (lane&3)*4 ; lanes 0..31 -> chroma ----
-  uint32_t ypred = 0, cpred = 0;
-  if (nl == 1) { // one 16x16 leaf, inline in the descriptor
-    const int ref = (d.z >> 22) & 7;
-    const int dx = (int16_t)(d.w & 0xFFFF), dy = (int16_t)(d.w >> 16);
-    const uint8_t *ry = clip_base + (uint32_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes;
-    ypred = mc_word(ry + (off + (yrow + (dy >> 1)) * S + yc4 + (dx >> 1)), S, (dx & 1) | ((dy & 1) << 1));
-    const int cdx = dx >> 1, cdy = dy >> 1;
-    if (lane < 32)
-      cpred = mc_word(ry + ysz + ((off >> 1) + cv * (S >> 1) + (crow + (cdy >> 1)) * S + cc4 + (cdx >> 1)), S, (cdx & 1) | ((cdy & 1) << 1));
-  } else { // MV cell map: every lane looks up the cells under its own pixels, then all fetches fly together
-    const uint2 yc = *(const uint2 *)(pl + (yrow >> 1) * 8 + (yc4 >> 1));
-    uint4 cc = uint4{0, 0, 0, 0};
-    if (lane < 32) cc = *(const uint4 *)(pl + crow * 8 + cc4);
-    const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
-    const uint8_t *ra = clip_base + (uint32_t)((A.ring_base + 6 - mobi_cell_ref(yc.x)) % 6) * A.slot_bytes;
-    const uint8_t *rb = clip_base + (uint32_t)((A.ring_base + 6 - mobi_cell_ref(yc.y)) % 6) * A.slot_bytes;
-    const uint32_t va = mc_word(ra + (off + (yrow + (dya >> 1)) * S + yc4 + (dxa >> 1)), S, (dxa & 1) | ((dya & 1) << 1));
-    const uint32_t vb = mc_word(rb + (off + (yrow + (dyb >> 1)) * S + yc4 + (dxb >> 1)), S, (dxb & 1) | ((dyb & 1) << 1));
-    ypred = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
-    if (lane < 32) {
-      const int cbase = (off >> 1) + cv * (S >> 1) + crow * S + cc4;
-      const uint32_t cell[4] = {cc.x, cc.y, cc.z, cc.w};
+  // ---- stage A: every global read of the quad, asynchronously into LDS ----
+  const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0));
+  uint32_t m24 = 0, t24 = 0, inter_mask = 0; // coded 8x8 areas / one-8x8-transform flags of the quad: bit mb*6 + area
+  int quant = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int cdx = mobi_cell_dx(cell[k]) >> 1, cdy = mobi_cell_dy(cell[k]) >> 1;
-        const uint8_t *rc = clip_base + (uint32_t)((A.ring_base + 6 - mobi_cell_ref(cell[k])) % 6) * A.slot_bytes + ysz;
-        const uint32_t v = mc_word(rc + (cbase + (cdy >> 1) * S + (cdx >> 1)), S, (cdx & 1) | ((cdy & 1) << 1));
-        cpred |= v & (0xFFu << (8 * k));
+  for (int g = 0; g < 4; g++) {
+    uint4 d = dp[g]; // the table has slack for the last quad
+    const bool inter = g < nmb && (d.y & 1) == MOBI_MB_INTER;
+    if (lane == 0) *(uint4 *)(L + Q_DESC + g * 16) = inter ? d : uint4{0, MOBI_MB_INTRA, 0, 0};
+    if (!inter) continue;
+    inter_mask |= 1u << g;
+    const int nl = (d.y >> 1) & 0x7F, cbp6 = (d.y >> 8) & 0x3F, ncoef = d.z & 0x3FF;
+    m24 |= (uint32_t)cbp6 << (6 * g);
+    t24 |= ((d.y >> 14) & 0x3F) << (6 * g);
+    quant = (d.y >> 20) & 63;
+    const uint32_t *pl = A.payload + d.x;
+    uint8_t *win = L + Q_WIN + g * Q_WIN_MB;
+    if (nl == 1) {
+      const int ref = (d.z >> 22) & 7;
+      const int dx = (int16_t)(d.w & 0xFFFF), dy = (int16_t)(d.w >> 16), cdx = dx >> 1, cdy = dy >> 1;
+      const uint8_t *ry = clip_base + (uint32_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes; // 16-byte aligned
+      const int off = off0 + g * 16;
+      const int ypos = off + (dy >> 1) * S + (dx >> 1), cpos = (off >> 1) + (cdy >> 1) * S + (cdx >> 1);
+      if (lane < 34) MOBI_DMA(16, ry + ((ypos & ~15) + wr * S + wk * 16), win);
+      if (lane < 36) MOBI_DMA(16, ry + ysz + ((cpos & ~15) + cpl * (S >> 1) + crw * S + wk * 16), win + 544);
+    } else {
+      if (lane < 16) MOBI_DMA(16, pl + lane * 4, win); // 64 MV cells
+    }
+    if (cbp6) {
+      const uint32_t *cw = pl + (nl > 1 ? MOBI_MV_CELLS : 0);
+      if (lane < ncoef) MOBI_DMA(4, cw + lane, L + Q_CW + g * 256);
+    }
+  }
+  if (inter_mask == 0) return;
+  if (m24 && lane < 20) MOBI_DMA(16, A.scale + quant * MOBI_SCALE_STRIDE + lane * 4, L + Q_SCALE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wave_sync();
+
+  // ---- stage B: motion compensation, one macroblock at a time, out of LDS into the quad's out tile ----
+  for (int g = 0; g < 4; g++) {
+    const uint4 dv = *(const uint4 *)(L + Q_DESC + g * 16);
+    const uint4 d = uint4{(uint32_t)__builtin_amdgcn_readfirstlane(dv.x), (uint32_t)__builtin_amdgcn_readfirstlane(dv.y),
+                          (uint32_t)__builtin_amdgcn_readfirstlane(dv.z), (uint32_t)__builtin_amdgcn_readfirstlane(dv.w)};
+    if ((d.y & 1) != MOBI_MB_INTER) continue;
+    const int nl = (d.y >> 1) & 0x7F;
+    const uint8_t *win = L + Q_WIN + g * Q_WIN_MB;
+    const int off = off0 + g * 16;
+    uint32_t ypred, cpred = 0;
+    if (nl == 1) {
+      const int dx = (int16_t)(d.w & 0xFFFF), dy = (int16_t)(d.w >> 16), cdx = dx >> 1, cdy = dy >> 1;
+      const int ys = (off + (dy >> 1) * S + (dx >> 1)) & 15, cs = ((off >> 1) + (cdy >> 1) * S + (cdx >> 1)) & 15;
+      Win w;
+      const uint32_t *p0 = (const uint32_t *)(win + yrow * 32 + ((ys + yc4) & ~3));
+      w.r0 = uint2{p0[0], p0[1]};
+      w.r1 = uint2{p0[8], p0[9]};
+      w.sh = (uint32_t)ys & 3;
+      ypred = mc4_uniform(w, (dx & 1) | ((dy & 1) << 1));
+      const uint32_t *p1 = (const uint32_t *)(win + 544 + (cv * 9 + crow) * 32 + ((cs + cc4) & ~3));
+      w.r0 = uint2{p1[0], p1[1]};
+      w.r1 = uint2{p1[8], p1[9]};
+      w.sh = (uint32_t)cs & 3;
+      cpred = mc4_uniform(w, (cdx & 1) | ((cdy & 1) << 1));
+    } else { // MV cell map: every lane looks up the cells under its own pixels, then all its fetches fly together
+      const uint32_t *cells = (const uint32_t *)win;
+      const uint32_t *clip32 = (const uint32_t *)clip_base;
+      const int ybase = off + yrow * S + yc4, cbase = (off >> 1) + cv * (S >> 1) + crow * S + cc4;
+      const uint2 yc = uint2{cells[(yrow >> 1) * 8 + (yc4 >> 1)], cells[(yrow >> 1) * 8 + (yc4 >> 1) + 1]};
+      const uint32_t *ccp = cells + crow * 8 + cc4;
+      const uint32_t cell[4] = {ccp[0], ccp[1], ccp[2], ccp[3]};
+      auto slot_of = [&](uint32_t c) { int sl = A.ring_base - mobi_cell_ref(c); return (uint32_t)(sl < 0 ? sl + 6 : sl) * slot_w; };
+      // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits
+      // (leaves at least 8 wide) they are the same cell: one window instead of two / four
+      const bool ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
+      const bool csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
+      const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
+      const Win wa = fetch_win(clip32 + slot_of(yc.x), ybase + (dya >> 1) * S + (dxa >> 1), S);
+      Win wb = wa;
+      if (ysplit) wb = fetch_win(clip32 + slot_of(yc.y), ybase + (dyb >> 1) * S + (dxb >> 1), S);
+      const int qx0 = mobi_cell_dx(cell[0]) >> 1, qy0 = mobi_cell_dy(cell[0]) >> 1;
+      const Win wq = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + (qy0 >> 1) * S + (qx0 >> 1), S);
+      const uint32_t va = mc4_select(wa, (dxa & 1) | ((dya & 1) << 1));
+      const uint32_t vb = ysplit ? mc4_select(wb, (dxb & 1) | ((dyb & 1) << 1)) : va;
+      ypred = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
+      cpred = mc4_select(wq, (qx0 & 1) | ((qy0 & 1) << 1));
+      if (csplit) {
+        cpred &= 0xFFu;
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+          const int qx1 = mobi_cell_dx(cell[k]) >> 1, qy1 = mobi_cell_dy(cell[k]) >> 1;
+          const Win wn = fetch_win(clip32 + slot_of(cell[k]) + ysz_w, cbase + (qy1 >> 1) * S + (qx1 >> 1), S);
+          cpred |= mc4_select(wn, (qx1 & 1) | ((qy1 & 1) << 1)) & (0xFFu << (8 * k));
+        }
       }
     }
+    *(uint32_t *)(L + Q_OUT_Y + yrow * 64 + g * 16 + yc4) = ypred;
+    if (lane < 32) *(uint32_t *)(L + Q_OUT_C + cv * 256 + crow * 32 + g * 8 + cc4) = cpred;
   }
 
-  // ---- residual ----
-  if (cbp6) {
-    uint32_t *L = lds[wave];
-    uint8_t *ty = (uint8_t *)L;          // 16 x 16
-    uint8_t *tc = ty + 256;              // U 8x8 then V 8x8
-    int *coef = (int *)(L + 96), *tmp = coef + 384;
-    const int32_t *sc = A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE;
-    ((uint32_t *)ty)[yrow * 4 + (lane & 3)] = ypred;
-    if (lane < 32) ((uint32_t *)tc)[cv * 16 + crow * 2 + (lane & 1)] = cpred;
-    zero_coefs(coef, lane);
-    wave_sync();
-    if (lane < ncoef) scatter_one(sc, c_first, t8, coef);
-    scatter_coefs(sc, cw, 64, ncoef, t8, coef, lane);
-    wave_sync();
-    const int b = lane >> 3, r = lane & 7;
-    const bool act = lane < 48 && ((cbp6 >> b) & 1);
-    if (act) idct_pass1(coef + 64 * b, tmp + 64 * b, (t8 >> b) & 1, r);
-    wave_sync();
+  // ---- stage C: one batched inverse transform for the coded areas of the whole quad ----
+  if (m24) {
+    const int n_ent = __builtin_popcount(m24);
+    int *coef = (int *)(L + Q_COEF), *tmp = (int *)(L + Q_TMP);
+    const int32_t *sc = (const int32_t *)(L + Q_SCALE);
+    wave_sync(); // windows are dead from here on: the coefficient tile takes their place
+    if (lane < 24 && ((m24 >> lane) & 1)) L[Q_TAB + __builtin_popcount(m24 & ((1u << lane) - 1))] = (uint8_t)lane;
     int fault = 0;
-    if (act) {
-      uint8_t *px = b < 4 ? ty + (b >> 1) * 8 * 16 + (b & 1) * 8 : tc + (b - 4) * 64;
-      idct_pass2(tmp + 64 * b, (t8 >> b) & 1, r, px, b < 4 ? 16 : 8, 0xF, &fault);
+    for (int pass = 0; pass * 8 < n_ent; pass++) {
+      {
+        uint4 z = uint4{0, 0, 0, 0};
+        *(uint4 *)(L + Q_COEF + lane * 32) = z;
+        *(uint4 *)(L + Q_COEF + lane * 32 + 16) = z;
+      }
+      wave_sync();
+      for (int g = 0; g < 4; g++) {
+        const int cbp6 = (m24 >> (6 * g)) & 0x3F;
+        if (!cbp6) continue;
+        const uint4 dv = *(const uint4 *)(L + Q_DESC + g * 16);
+        const int ncoef = __builtin_amdgcn_readfirstlane(dv.z) & 0x3FF, nl = (__builtin_amdgcn_readfirstlane(dv.y) >> 1) & 0x7F;
+        const uint32_t *cw = A.payload + (uint32_t)__builtin_amdgcn_readfirstlane(dv.x) + (nl > 1 ? MOBI_MV_CELLS : 0);
+        for (int i = lane; i < ncoef; i += 64) {
+          const uint32_t e = i < 64 ? *(const uint32_t *)(L + Q_CW + g * 256 + i * 4) : cw[i];
+          const int t = e & 0x1FF, level = (int32_t)e >> 16, k = g * 6 + (t >> 6), p = t & 63;
+          const int slot = __builtin_popcount(m24 & ((1u << k) - 1)) - pass * 8;
+          if (slot >= 0 && slot < 8) coef[slot * 64 + p] = (((t24 >> k) & 1) ? sc[p] : sc[64 + (p & 15)]) * level;
+        }
+      }
+      wave_sync();
+      const int e = lane >> 3, r = lane & 7, idx = pass * 8 + e;
+      const bool act = idx < n_ent;
+      const int k = act ? L[Q_TAB + idx] : 0;
+      const int g = (k * 43) >> 8, a = k - g * 6; // k / 6 for k < 24
+      const bool is8 = (t24 >> k) & 1;
+      if (act) idct_pass1(coef + 64 * e, tmp + 64 * e, is8, r);
+      wave_sync();
+      if (act) {
+        uint8_t *px = a < 4 ? L + Q_OUT_Y + (a >> 1) * 8 * 64 + g * 16 + (a & 1) * 8 : L + Q_OUT_C + (a - 4) * 256 + g * 8;
+        idct_pass2(tmp + 64 * e, is8, r, px, a < 4 ? 64 : 32, 0xF, &fault);
+      }
+      wave_sync();
     }
-    wave_sync();
     if (fault) atomicOr(&A.fault[clip], 1);
-    ypred = ((uint32_t *)ty)[yrow * 4 + (lane & 3)];
-    if (lane < 32) cpred = ((uint32_t *)tc)[cv * 16 + crow * 2 + (lane & 1)];
+  } else {
+    wave_sync();
   }
+  if (A.debug == 2) return;
 
-  // ---- store: 16 B per row per MB (4 adjacent MBs per workgroup -> 64 B runs) ----
-  if (A.debug == 2) return; // profiling ablation: no stores
+  // ---- stage D: the quad leaves as whole rows: 64 B of luma, 8 B per macroblock of chroma ----
   uint8_t *y0 = clip_base + (uint32_t)(A.ring_base % 6) * A.slot_bytes;
-  *(uint32_t *)(y0 + (off + yrow * S + yc4)) = ypred;
-  if (lane < 32) *(uint32_t *)(y0 + ysz + ((off >> 1) + cv * (S >> 1) + crow * S + cc4)) = cpred;
+  {
+    const int g = lane & 3;
+    if ((inter_mask >> g) & 1) {
+      *(uint4 *)(y0 + (off0 + yrow * S + g * 16)) = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + g * 16);
+      const int pl = lane >> 5, row = (lane >> 2) & 7;
+      *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + row * S + g * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + g * 8);
+    }
+  }
 }
 
 // =====================================================================================================
@@ -377,10 +507,12 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
 // launch wrappers (called from mobi_abi.cpp)
 // =====================================================================================================
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
-  const long waves = (long)a->n_clips * a->n_mbs;
-  if (waves <= 0) return 0;
-  const unsigned grid = (unsigned)(((waves + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
-  hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, *a);
+  const long quads = (long)a->qpc * a->n_clips;
+  if (quads <= 0) return 0;
+  const unsigned grid = (unsigned)(((quads + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
+  MobiReconArgs b = *a;
+  b.inter_per_xcd = grid / 8;
+  hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, b);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
