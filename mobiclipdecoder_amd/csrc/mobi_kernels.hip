@@ -203,6 +203,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
   const uint32_t qi = ((blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
   if (qi >= A.qpc * (uint32_t)A.n_clips) return;
   if (A.debug == 1) return;
+  const unsigned long long t0 = A.prof ? __builtin_readcyclecounter() : 0;
   uint32_t rem, qx;
   const uint32_t clip = fastdiv(qi, A.qpc, A.magic_qpc, rem);
   const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, qx);
@@ -222,11 +223,23 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
   const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0));
   uint32_t m24 = 0, t24 = 0, inter_mask = 0; // coded 8x8 areas / one-8x8-transform flags of the quad: bit mb*6 + area
   int quant = 0;
+  uint4 dd[4]; // all four descriptors in ONE scalar round trip (64 contiguous bytes; the table has slack for the last quad)
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 dv;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dv) : "s"(dp));
+#pragma unroll
+    for (int g = 0; g < 4; g++) dd[g] = uint4{dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]};
+  }
+#else
+  for (int g = 0; g < 4; g++) dd[g] = dp[g];
+#endif
 #pragma unroll
   for (int g = 0; g < 4; g++) {
-    uint4 d = dp[g]; // the table has slack for the last quad
-    const bool inter = g < nmb && (d.y & 1) == MOBI_MB_INTER;
-    if (lane == 0) *(uint4 *)(L + Q_DESC + g * 16) = inter ? d : uint4{0, MOBI_MB_INTRA, 0, 0};
+    if (!(g < nmb && (dd[g].y & 1) == MOBI_MB_INTER)) dd[g] = uint4{0, MOBI_MB_INTRA, 0, 0};
+    const uint4 d = dd[g];
+    const bool inter = (d.y & 1) == MOBI_MB_INTER;
     if (!inter) continue;
     inter_mask |= 1u << g;
     const int nl = (d.y >> 1) & 0x7F, cbp6 = (d.y >> 8) & 0x3F, ncoef = d.z & 0x3FF;
@@ -253,14 +266,15 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
   }
   if (inter_mask == 0) return;
   if (m24 && lane < 20) MOBI_DMA(16, A.scale + quant * MOBI_SCALE_STRIDE + lane * 4, L + Q_SCALE);
+  const unsigned long long t1 = A.prof ? __builtin_readcyclecounter() : 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
+  const unsigned long long t2 = A.prof ? __builtin_readcyclecounter() : 0;
 
   // ---- stage B: motion compensation, one macroblock at a time, out of LDS into the quad's out tile ----
+#pragma unroll
   for (int g = 0; g < 4; g++) {
-    const uint4 dv = *(const uint4 *)(L + Q_DESC + g * 16);
-    const uint4 d = uint4{(uint32_t)__builtin_amdgcn_readfirstlane(dv.x), (uint32_t)__builtin_amdgcn_readfirstlane(dv.y),
-                          (uint32_t)__builtin_amdgcn_readfirstlane(dv.z), (uint32_t)__builtin_amdgcn_readfirstlane(dv.w)};
+    const uint4 d = dd[g];
     if ((d.y & 1) != MOBI_MB_INTER) continue;
     const int nl = (d.y >> 1) & 0x7F;
     const uint8_t *win = L + Q_WIN + g * Q_WIN_MB;
@@ -316,6 +330,8 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
     if (lane < 32) *(uint32_t *)(L + Q_OUT_C + cv * 256 + crow * 32 + g * 8 + cc4) = cpred;
   }
 
+  unsigned long long t3 = 0;
+  if (A.prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t3 = __builtin_readcyclecounter(); }
   // ---- stage C: one batched inverse transform for the coded areas of the whole quad ----
   if (m24) {
     const int n_ent = __builtin_popcount(m24);
@@ -331,12 +347,12 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
         *(uint4 *)(L + Q_COEF + lane * 32 + 16) = z;
       }
       wave_sync();
+#pragma unroll
       for (int g = 0; g < 4; g++) {
         const int cbp6 = (m24 >> (6 * g)) & 0x3F;
         if (!cbp6) continue;
-        const uint4 dv = *(const uint4 *)(L + Q_DESC + g * 16);
-        const int ncoef = __builtin_amdgcn_readfirstlane(dv.z) & 0x3FF, nl = (__builtin_amdgcn_readfirstlane(dv.y) >> 1) & 0x7F;
-        const uint32_t *cw = A.payload + (uint32_t)__builtin_amdgcn_readfirstlane(dv.x) + (nl > 1 ? MOBI_MV_CELLS : 0);
+        const int ncoef = dd[g].z & 0x3FF, nl = (dd[g].y >> 1) & 0x7F;
+        const uint32_t *cw = A.payload + dd[g].x + (nl > 1 ? MOBI_MV_CELLS : 0);
         for (int i = lane; i < ncoef; i += 64) {
           const uint32_t e = i < 64 ? *(const uint32_t *)(L + Q_CW + g * 256 + i * 4) : cw[i];
           const int t = e & 0x1FF, level = (int32_t)e >> 16, k = g * 6 + (t >> 6), p = t & 63;
@@ -363,6 +379,8 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
     wave_sync();
   }
   if (A.debug == 2) return;
+  unsigned long long t4 = 0;
+  if (A.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t4 = __builtin_readcyclecounter(); }
 
   // ---- stage D: the quad leaves as whole rows: 64 B of luma, 8 B per macroblock of chroma ----
   uint8_t *y0 = clip_base + (uint32_t)(A.ring_base % 6) * A.slot_bytes;
@@ -374,6 +392,8 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
       *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + row * S + g * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + g * 8);
     }
   }
+  if (A.prof && lane == 0) // MOBI_DEBUG=9: where does a wave's life go (shader clock): issue, DMA wait, MC, IDCT
+    ((uint4 *)A.prof)[qi] = uint4{(uint32_t)(t1 - t0), (uint32_t)(t2 - t1), (uint32_t)(t3 - t2) | ((uint32_t)__builtin_popcount(m24) << 24), (uint32_t)(t4 - t3)};
 }
 
 // =====================================================================================================

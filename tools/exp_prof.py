@@ -15,17 +15,13 @@ def run(tag, **kw):
     b.commit(); b.replay(0)
     for f in range(1, 6): b.replay(f)
     b.sync()
-    rec = np.zeros((clips * 1200, 4), np.uint32)
+    rec = np.zeros((clips * 300, 4), np.uint32)
     lib.mobi_debug_read_prof(b._h, rec.ctypes.data, rec.size)
-    multi = (rec[:, 0] >> 31).astype(bool); coded = (rec[:, 2] >> 31).astype(bool)
-    r = rec & 0x7FFFFFFF
+    nent = rec[:, 2] >> 24
+    r = rec.copy(); r[:, 2] &= 0xFFFFFF
     live = r.sum(1) > 0
-    print(f"{tag}: inter MBs {live.sum()}; mean cycles: desc {r[live,0].mean():.0f}  pixels+MC {r[live,1].mean():.0f}  residual {r[live,2].mean():.0f}  store-drain {r[live,3].mean():.0f}  total {r[live].sum(1).mean():.0f}")
-    for name, msk in (("single-leaf", live & ~multi), ("multi-leaf", live & multi)):
-        if msk.any(): print(f"    {name:12s} n={msk.sum():7d} pixels+MC mean {r[msk,1].mean():.0f} p50 {np.median(r[msk,1]):.0f} p90 {np.percentile(r[msk,1],90):.0f}")
-    for name, msk in (("uncoded", live & ~coded), ("coded", live & coded)):
-        if msk.any(): print(f"    {name:12s} n={msk.sum():7d} residual mean {r[msk,2].mean():.0f} p50 {np.median(r[msk,2]):.0f} p90 {np.percentile(r[msk,2],90):.0f}")
-    print(f"    desc p50 {np.median(r[live,0]):.0f} p90 {np.percentile(r[live,0],90):.0f}; store-drain p50 {np.median(r[live,3]):.0f} p90 {np.percentile(r[live,3],90):.0f}", flush=True)
+    print(f"{tag}: quads {live.sum()}; mean cycles: issue {r[live,0].mean():.0f}  dma-wait {r[live,1].mean():.0f}  MC(4 MBs) {r[live,2].mean():.0f}  IDCT {r[live,3].mean():.0f}  total {r[live].sum(1).mean():.0f}; coded areas/quad {nent[live].mean():.1f} (>8: {(nent[live]>8).mean()*100:.0f}%)")
+    print(f"    p50/p90: issue {np.median(r[live,0]):.0f}/{np.percentile(r[live,0],90):.0f} dma {np.median(r[live,1]):.0f}/{np.percentile(r[live,1],90):.0f} MC {np.median(r[live,2]):.0f}/{np.percentile(r[live,2],90):.0f} IDCT {np.median(r[live,3]):.0f}/{np.percentile(r[live,3],90):.0f}", flush=True)
     b.close()
 run('default')
 run('pure copy', pm_split1=0, pm_deep=0, cbp_prob=0, pm_intra=0)
