@@ -18,6 +18,7 @@
 
 namespace {
 
+constexpr size_t kPaySlack = 2048; // lanes of the inter kernel with nothing to fetch re-read up to ~1 KB past their macroblock's payload
 constexpr size_t kGuard = 4096; // slack on both ends of the plane arena: MC fetches whole aligned dwords
 constexpr size_t kAlign = 16;
 
@@ -290,7 +291,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   if (hipMemsetAsync(b->d_fault, 0, sizeof(int) * n_clips, b->stream) != hipSuccess) return nullptr;
   if (hipEventCreate(&b->ev_begin) != hipSuccess || hipEventCreate(&b->ev_end) != hipSuccess) return nullptr;
   {
-    std::vector<int32_t> tab((size_t)MOBI_SCALE_QMAX * MOBI_SCALE_STRIDE, 0);
+    std::vector<int32_t> tab((size_t)64 * MOBI_SCALE_STRIDE, 0); // 64 rows: the 6-bit quantizer field of any descriptor stays inside
     for (int q = 0; q < MOBI_SCALE_QMAX; q++) mobi_build_scale_table(q, &tab[(size_t)q * MOBI_SCALE_STRIDE]);
     if (hipMalloc((void **)&b->d_scale, tab.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(b->d_scale, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
@@ -330,7 +331,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // 2. stage [desc table][payload arena][items] and upload
   const int n_mbs = b->g.mbw * b->g.mbh;
   const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 64, kAlign); // +64: a quad reads 4 descriptors at once
-  const size_t pay_bytes = align_up(step_payload_words(ok) * 4 + 4, kAlign);
+  const size_t pay_bytes = align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
   const size_t item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
   if (int e = b->h_stage.reserve(desc_bytes + pay_bytes + item_bytes)) return e;
   if (int e = b->d_cmd.reserve(desc_bytes + pay_bytes)) return e;
@@ -420,7 +421,7 @@ int mobi_batch_commit(mobi_batch *b) {
       if ((*b->staged_rc[c])[f] == MOBI_OK) ok[c] = &(*b->staged[c])[f];
     b->r_desc_off[f] = cmd_bytes;
     b->r_payload_off[f] = cmd_bytes + desc_bytes;
-    cmd_bytes += desc_bytes + align_up(step_payload_words(ok) * 4 + 4, kAlign);
+    cmd_bytes += desc_bytes + align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
     b->r_plan[f].build(ok);
     b->r_items_off[f] = n_items;
     n_items += b->r_plan[f].items.size();

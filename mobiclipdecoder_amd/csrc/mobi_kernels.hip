@@ -162,146 +162,210 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
 }
 
 // ---- mobi_recon_inter: one wavefront per QUAD of four horizontally adjacent macroblocks (64 x 16 luma) ----
-// Measured on MI355X (tools/ubench/valu.hip, MOBI_DEBUG=9 cycle records): integer wave64 VALU ops cost ~4
-// SIMD cycles, a memory round trip ~3.4k cycles under load, and with one macroblock per wave the kernel was
-// VALU-bound at ~330 instructions per macroblock, most of them in an inverse transform that kept <= 48 of 64
-// lanes busy for ~1.8 coded 8x8 areas.  Hence:
-//   * all global reads of the four macroblocks -- descriptors, MC windows as whole 16-byte chunks (one lane
-//     per window row x chunk: ~18 cache lines per load instead of 4 x 16), MV cell maps, first residual
-//     levels, dequant scales -- are issued together as asynchronous global->LDS copies
-//     (global_load_lds: "LDS staging of the macroblock + MC halo"), then waited for once;
-//   * motion compensation runs per macroblock out of LDS;
+// Measured on MI355X (tools/ubench/valu.hip, salu.hip, MOBI_DEBUG=9 cycle records): a wave64 integer VALU op
+// occupies a SIMD for ~3-4 cycles, a SCALAR op for ~4.3 (one scalar issue slot per SIMD visit) and the two
+// overlap only partly; a memory round trip is ~3.4k cycles under load.  The previous version of this kernel
+// ran ~700 VALU + ~650 SALU instructions per quad and was bound by instruction issue, most of the scalar ones
+// being per-macroblock decode (bit fields, address arithmetic, exec masks, branches) repeated four times.
+// Hence the shape of this one: NOTHING is done per macroblock in scalar code.
+//   * lane = (g, j): g = lane >> 4 is the macroblock of the quad the lane works for, in every stage.
+//     Each lane loads ITS macroblock's descriptor and decodes it with vector ops: one instruction stream
+//     serves the four macroblocks at once.
+//   * all global reads of the quad -- MC windows as whole 16-byte chunks, MV cell maps, residual levels,
+//     dequant scales -- are six full-wave asynchronous global->LDS copies (global_load_lds_dwordx4: "LDS
+//     staging of the macroblock + MC halo"), waited for once.  Lanes with nothing to fetch re-read a line
+//     some other lane already touches instead of being masked off (exec-mask juggling is scalar work).
+//   * motion compensation of all single-leaf macroblocks: 4 + 2 vector iterations (4 luma rows x 4 MBs,
+//     one chroma plane x 4 MBs), the half-pel phase a per-lane select; multi-leaf macroblocks (MV cell map)
+//     are redone one at a time by the whole wave;
 //   * ONE batched inverse transform serves the coded areas of all four macroblocks, 8 areas x 8 rows = 64
-//     lanes per pass;
+//     lanes per pass; the residual levels of the four macroblocks are scattered together (16 lanes each);
 //   * the quad leaves as whole 64-byte luma rows / 8-byte chroma rows.
 // A wave lives for one quad (no loop-carried state, no workgroup barriers).  XCD-aware order: the dispatcher
 // deals consecutive workgroups round-robin to the 8 XCDs, so XCD x gets one contiguous run of quads.
 namespace {
-enum {
-  Q_WIN_MB = 1120,               // per MB: luma window 17 rows x 32 B (544) + chroma 2 x 9 rows x 32 B (576);
-                                 // a multi-leaf MB keeps its 256-byte MV cell map here instead
-  Q_WIN = 0,                     // 4 x Q_WIN_MB = 4480
-  Q_COEF = 0, Q_TMP = 2048,      // coefficient tile + transposed intermediate (8 areas x 64 ints each): alias the
-                                 // windows, which are dead once motion compensation is done
-  Q_CW = 4480,                   // first 64 residual level words per MB (4 x 256)
-  Q_OUT_Y = 5504,                // out tile: luma 16 rows x 64 B
-  Q_OUT_C = 6528,                //           chroma 2 planes x 8 rows x 32 B
-  Q_SCALE = 7040,                // dequant scales of the frame quantizer (80 ints)
-  Q_TAB = 7360,                  // coded-area table: entry -> (mb*6 + area), 24 bytes
-  Q_DESC = 7392,                 // the four descriptors (64 B)
-  Q_BYTES = 7680
+enum {                           // per-wave LDS map.  A DMA round r puts lane i's 16 bytes at R_r + 16 * i, i = g*16 + j
+  Q_R0 = 0,                      // luma window rows 0..15, bytes 0..15 of the row  (j = row);  multi-leaf MB: its 64 MV cells
+  Q_R1 = 1024,                   // luma window rows 0..15, bytes 16..31
+  Q_R2 = 2048,                   // U window rows 0..7 (j = row*2 + 16-byte half)
+  Q_R3 = 3072,                   // V window rows 0..7
+  Q_R4 = 4096,                   // j 0,1: luma row 16; 2,3: U row 8; 4,5: V row 8; j 6..15 of g 0,1: dequant scales (20 chunks)
+  Q_R5 = 5120,                   // first 64 residual level words of MB g (j = chunk of 4)
+  Q_COEF = 0, Q_TMP = 2048,      // coefficient tile (8 areas x 64 ints) + transposed intermediate: alias R0..R3, dead after MC
+  Q_TAB = Q_R4,                  // coded-area table: entry -> g*8 + area (row 16 of MB 0 is dead after MC)
+  Q_OUT_Y = 6144,                // out tile: luma 16 rows x 64 B
+  Q_OUT_C = 7168,                //           chroma 2 planes x 8 rows x 32 B
+  Q_META = 7680,                 // per quad: cbp6[4], t8mask[4], flags[4]
+  Q_BYTES = 7696
 };
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
-// lane i lands at dst + i*BYTES; dst must be wave-uniform (it travels in M0)
-#define MOBI_DMA(BYTES, src, dst) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), BYTES, 0, 0)
+// lane i lands at dst + IMM + i*16; dst must be wave-uniform (it travels in M0); IMM = constant byte offset added to BOTH
+// the source address and the LDS address
+#define MOBI_DMA16(src, dst, IMM) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), 16, IMM, 0)
+
+__device__ __forceinline__ uint32_t lds32(const uint8_t *L, int byte_off) { return *(const uint32_t *)(L + byte_off); }
+// CopyBlock on four packed pixels (MD.cs:424-452): x0,x1 = aligned dwords holding the row, y0,y1 the row below,
+// sh = byte shift 0..3, sh8 = 8*sh; the phase arrives as three lane masks
+__device__ __forceinline__ uint32_t mc4_lane(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t sh, uint32_t sh8,
+                                             bool ph0, bool ph1, bool ph2) {
+  const uint32_t M = 0x7F7F7F7Fu;
+  const uint32_t a = __builtin_amdgcn_alignbyte(x1, x0, sh), c = __builtin_amdgcn_alignbyte(y1, y0, sh);
+  const uint32_t b = __builtin_amdgcn_alignbyte(x1 >> sh8, a, 1), d = __builtin_amdgcn_alignbyte(y1 >> sh8, c, 1);
+  const uint32_t ha = (a >> 1) & M, hb = (b >> 1) & M, hc = (c >> 1) & M, hd = (d >> 1) & M;
+  const uint32_t p1 = ha + hb, p2 = ha + hc, p3 = ((p1 >> 1) & M) + (((hc + hd) >> 1) & M);
+  return ph0 ? a : ph1 ? p1 : ph2 ? p2 : p3;
+}
+// pass 2 of one area by lane r, tracking the range of pred+residual instead of testing every sample
+__device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint8_t *px, int pitch, int &lo, int &hi) {
+  int in[8], out[8];
+  if (is8) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) in[m] = t[8 * r + m];
+    mobi_bfly8(in, out);
+    uint8_t *row = px + r * pitch;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int v = (int)row[j] + (out[j] >> 6);
+      lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+      row[j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  } else {
+    const int s = r >> 1;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const int i = (r & 1) * 2 + g;
+#pragma unroll
+      for (int m = 0; m < 4; m++) in[m] = t[16 * s + 4 * i + m];
+      mobi_bfly4(in, out);
+      uint8_t *row = px + ((s >> 1) * 4 + i) * pitch + (s & 1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int v = (int)row[j] + (out[j] >> 6);
+        lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+        row[j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+    }
+  }
+}
 } // namespace
 
-extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs A) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES][Q_BYTES];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t qi = ((blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
-  if (qi >= A.qpc * (uint32_t)A.n_clips) return;
-  if (A.debug == 1) return;
-  const unsigned long long t0 = A.prof ? __builtin_readcyclecounter() : 0;
+template <bool PROF>
+__device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t *L, uint32_t qi, int lane) {
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  if (PROF) t0 = __builtin_readcyclecounter();
   uint32_t rem, qx;
   const uint32_t clip = fastdiv(qi, A.qpc, A.magic_qpc, rem);
   const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, qx);
   const uint32_t mbx0 = qx * 4, mbw = (uint32_t)A.mbw;
   const int nmb = (int)(mbw - mbx0 < 4 ? mbw - mbx0 : 4);
-  const int S = A.stride;
+  const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S);
   const uint32_t ysz = (uint32_t)S * (uint32_t)A.height, slot_w = A.slot_bytes >> 2, ysz_w = ysz >> 2;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
   const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16);
-  uint8_t *L = lds_all[wave];
-  const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
-  const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-  const int wr = lane >> 1, wk = lane & 1;                           // window row, 16-byte chunk (luma: lanes 0..33)
-  const int cpl = lane >= 18 ? 1 : 0, crw = (lane - cpl * 18) >> 1; // chroma window: plane, row (lanes 0..35)
+  const int g = lane >> 4, j = lane & 15;
 
-  // ---- stage A: every global read of the quad, asynchronously into LDS ----
-  const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0));
-  uint32_t m24 = 0, t24 = 0, inter_mask = 0; // coded 8x8 areas / one-8x8-transform flags of the quad: bit mb*6 + area
-  int quant = 0;
-  uint4 dd[4]; // all four descriptors in ONE scalar round trip (64 contiguous bytes; the table has slack for the last quad)
-#if defined(__HIP_DEVICE_COMPILE__)
+  // ---- stage A: decode this lane's macroblock, then every global read of the quad, asynchronously into LDS ----
+  const uint4 d = *(const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last quad
+  const bool valid = g < nmb && (d.y & 1) == MOBI_MB_INTER;
+  const int nl = (d.y >> 1) & 0x7F;
+  const bool single = valid && nl == 1, multi = valid && nl > 1;
+  const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
+  L[Q_META + g] = (uint8_t)cbp6;
+  L[Q_META + 4 + g] = (uint8_t)((d.y >> 14) & 0x3F);
+  L[Q_META + 8 + g] = (uint8_t)((valid ? 1 : 0) | (multi ? 2 : 0));
+  const int dx = (int)(d.w << 16) >> 16, dy = (int)d.w >> 16, cdx = dx >> 1, cdy = dy >> 1;
+  int sl = A.ring_base - (int)((d.z >> 22) & 7);
+  sl = sl < 0 ? sl + 6 : sl;
+  const uint32_t refoff = __umul24((uint32_t)sl, A.slot_bytes); // slot_bytes < 2^24: checked by mobi_launch_inter
+  const int off = off0 + g * 16;
+  const int ypos = off + ((dy >> 1) << lgS) + (dx >> 1), cpos = (off >> 1) + ((cdy >> 1) << lgS) + (cdx >> 1);
+  const int step = single ? S : multi ? 16 : 0; // a lane without a window keeps re-reading the start of its region
+  const int hS = single ? S >> 1 : 0;
+  const uint32_t ywin = single ? refoff + (uint32_t)(ypos & ~15) : 0u;
+  const uint32_t cwin = single ? refoff + ysz + (uint32_t)(cpos & ~15) : 0u;
+  const uint8_t *lbase = multi ? (const uint8_t *)(A.payload + d.x) : clip_base; // multi-leaf: the payload opens with the MV cell map
   {
-    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-    u32x16 dv;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dv) : "s"(dp));
-#pragma unroll
-    for (int g = 0; g < 4; g++) dd[g] = uint4{dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]};
+    const uint8_t *p0 = lbase + (ywin + (uint32_t)(j * step));
+    MOBI_DMA16(p0, L + Q_R0, 0);
+    MOBI_DMA16(p0, L + Q_R1 - 16, 16); // the instruction offset moves the LDS side as well as the global side
+    const uint8_t *p2 = lbase + (cwin + (uint32_t)((j >> 1) * step + (j & 1) * 16));
+    MOBI_DMA16(p2, L + Q_R2, 0);
+    MOBI_DMA16(p2 + hS, L + Q_R3, 0);
+    // leftovers: window rows 16 (luma) / 8 (U, V); the spare lanes of MBs 0 and 1 bring the dequant scales of the clip's quantizer
+    const int h = j >> 1;
+    const uint32_t o4 = (h == 0 ? ywin + 16u * step : h == 1 ? cwin + 8u * step : cwin + hS + 8u * step) + (uint32_t)(j & 1) * 16u;
+    const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63)); // per clip (MD.cs:113-143): MB 0's copy
+    const uint8_t *p4 = lbase + (j < 6 ? o4 : 0u);
+    if (j >= 6 && g < 2) p4 = (const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + (g * 10 + j - 6) * 16;
+    MOBI_DMA16(p4, L + Q_R4, 0);
+    const uint32_t cwo = d.x + (multi ? MOBI_MV_CELLS : 0);
+    const uint8_t *p5 = (const uint8_t *)A.payload + ((uint32_t)(j * 4) < ncoef ? (cwo + j * 4) * 4u : 0u);
+    MOBI_DMA16(p5, L + Q_R5, 0);
   }
-#else
-  for (int g = 0; g < 4; g++) dd[g] = dp[g];
-#endif
-#pragma unroll
-  for (int g = 0; g < 4; g++) {
-    if (!(g < nmb && (dd[g].y & 1) == MOBI_MB_INTER)) dd[g] = uint4{0, MOBI_MB_INTRA, 0, 0};
-    const uint4 d = dd[g];
-    const bool inter = (d.y & 1) == MOBI_MB_INTER;
-    if (!inter) continue;
-    inter_mask |= 1u << g;
-    const int nl = (d.y >> 1) & 0x7F, cbp6 = (d.y >> 8) & 0x3F, ncoef = d.z & 0x3FF;
-    m24 |= (uint32_t)cbp6 << (6 * g);
-    t24 |= ((d.y >> 14) & 0x3F) << (6 * g);
-    quant = (d.y >> 20) & 63;
-    const uint32_t *pl = A.payload + d.x;
-    uint8_t *win = L + Q_WIN + g * Q_WIN_MB;
-    if (nl == 1) {
-      const int ref = (d.z >> 22) & 7;
-      const int dx = (int16_t)(d.w & 0xFFFF), dy = (int16_t)(d.w >> 16), cdx = dx >> 1, cdy = dy >> 1;
-      const uint8_t *ry = clip_base + (uint32_t)((A.ring_base + 6 - ref) % 6) * A.slot_bytes; // 16-byte aligned
-      const int off = off0 + g * 16;
-      const int ypos = off + (dy >> 1) * S + (dx >> 1), cpos = (off >> 1) + (cdy >> 1) * S + (cdx >> 1);
-      if (lane < 34) MOBI_DMA(16, ry + ((ypos & ~15) + wr * S + wk * 16), win);
-      if (lane < 36) MOBI_DMA(16, ry + ysz + ((cpos & ~15) + cpl * (S >> 1) + crw * S + wk * 16), win + 544);
-    } else {
-      if (lane < 16) MOBI_DMA(16, pl + lane * 4, win); // 64 MV cells
-    }
-    if (cbp6) {
-      const uint32_t *cw = pl + (nl > 1 ? MOBI_MV_CELLS : 0);
-      if (lane < ncoef) MOBI_DMA(4, cw + lane, L + Q_CW + g * 256);
-    }
-  }
-  if (inter_mask == 0) return;
-  if (m24 && lane < 20) MOBI_DMA(16, A.scale + quant * MOBI_SCALE_STRIDE + lane * 4, L + Q_SCALE);
-  const unsigned long long t1 = A.prof ? __builtin_readcyclecounter() : 0;
+  if (PROF) t1 = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
-  const unsigned long long t2 = A.prof ? __builtin_readcyclecounter() : 0;
+  if (PROF) t2 = __builtin_readcyclecounter();
+  const uint32_t m32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META));      // coded 8x8 areas: bit g*8 + area
+  const uint32_t t32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META + 4));  // ... that use one 8x8 transform
+  const uint32_t f32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META + 8));  // byte g: bit 0 inter, bit 1 multi-leaf
+  if ((f32 & 0x01010101u) == 0) return;
 
-  // ---- stage B: motion compensation, one macroblock at a time, out of LDS into the quad's out tile ----
+  // ---- stage B: motion compensation out of LDS into the quad's out tile ----
+  {
+    // single-leaf macroblocks, all at once (the other lanes compute garbage into tiles nobody stores, or that B2 overwrites)
+    const int ys = ypos & 15, cs = cpos & 15;
+    const int yph = (dx & 1) | ((dy & 1) << 1), cph = (cdx & 1) | ((cdy & 1) << 1);
+    {
+      const int rr = j >> 2, q = j & 3, w0 = (ys + 4 * q) >> 2, w1 = w0 + 1;
+      const int a0 = Q_R0 + (w0 >> 2) * 1024 + g * 256 + rr * 16 + (w0 & 3) * 4, a1 = Q_R0 + (w1 >> 2) * 1024 + g * 256 + rr * 16 + (w1 & 3) * 4;
+      const int b0 = Q_R4 + g * 256 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + (w1 >> 2) * 16 + (w1 & 3) * 4;
+      const uint32_t sh = ys & 3, sh8 = sh * 8;
+      const bool ph0 = yph == 0, ph1 = yph == 1, ph2 = yph == 2;
+      const int o = Q_OUT_Y + rr * 64 + g * 16 + q * 4;
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
-    const uint4 d = dd[g];
-    if ((d.y & 1) != MOBI_MB_INTER) continue;
-    const int nl = (d.y >> 1) & 0x7F;
-    const uint8_t *win = L + Q_WIN + g * Q_WIN_MB;
-    const int off = off0 + g * 16;
-    uint32_t ypred, cpred = 0;
-    if (nl == 1) {
-      const int dx = (int16_t)(d.w & 0xFFFF), dy = (int16_t)(d.w >> 16), cdx = dx >> 1, cdy = dy >> 1;
-      const int ys = (off + (dy >> 1) * S + (dx >> 1)) & 15, cs = ((off >> 1) + (cdy >> 1) * S + (cdx >> 1)) & 15;
-      Win w;
-      const uint32_t *p0 = (const uint32_t *)(win + yrow * 32 + ((ys + yc4) & ~3));
-      w.r0 = uint2{p0[0], p0[1]};
-      w.r1 = uint2{p0[8], p0[9]};
-      w.sh = (uint32_t)ys & 3;
-      ypred = mc4_uniform(w, (dx & 1) | ((dy & 1) << 1));
-      const uint32_t *p1 = (const uint32_t *)(win + 544 + (cv * 9 + crow) * 32 + ((cs + cc4) & ~3));
-      w.r0 = uint2{p1[0], p1[1]};
-      w.r1 = uint2{p1[8], p1[9]};
-      w.sh = (uint32_t)cs & 3;
-      cpred = mc4_uniform(w, (cdx & 1) | ((cdy & 1) << 1));
-    } else { // MV cell map: every lane looks up the cells under its own pixels, then all its fetches fly together
-      const uint32_t *cells = (const uint32_t *)win;
+      for (int t = 0; t < 4; t++) {
+        const uint32_t x0 = lds32(L, a0 + 64 * t), x1 = lds32(L, a1 + 64 * t);
+        uint32_t y0, y1;
+        if (t < 3) { y0 = lds32(L, a0 + 64 * t + 16); y1 = lds32(L, a1 + 64 * t + 16); }
+        else { y0 = lds32(L, rr == 3 ? b0 : a0 + 64 * 3 + 16); y1 = lds32(L, rr == 3 ? b1 : a1 + 64 * 3 + 16); }
+        *(uint32_t *)(L + o + 256 * t) = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
+      }
+    }
+    {
+      const int row = j >> 1, q = j & 1, w0 = (cs + 4 * q) >> 2, w1 = w0 + 1;
+      const int a0 = Q_R2 + g * 256 + row * 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, a1 = Q_R2 + g * 256 + row * 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
+      const int b0 = Q_R4 + g * 256 + 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
+      const int n0 = row == 7 ? b0 : a0 + 32, n1 = row == 7 ? b1 : a1 + 32;
+      const uint32_t sh = cs & 3, sh8 = sh * 8;
+      const bool ph0 = cph == 0, ph1 = cph == 1, ph2 = cph == 2;
+      const int o = Q_OUT_C + row * 32 + g * 8 + q * 4;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t x0 = lds32(L, a0 + 1024 * u), x1 = lds32(L, a1 + 1024 * u);
+        const uint32_t y0 = lds32(L, row == 7 ? n0 + 32 * u : n0 + 1024 * u), y1 = lds32(L, row == 7 ? n1 + 32 * u : n1 + 1024 * u);
+        *(uint32_t *)(L + o + 256 * u) = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
+      }
+    }
+  }
+  // B2: multi-leaf macroblocks, one at a time by the whole wave.  Every lane looks up the MV cells under its own
+  // pixels (the map sits in LDS), then all its fetches fly together.
+  {
+    const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
+    const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
+    uint32_t mm = (f32 >> 1) & 0x01010101u;
+    while (mm) {
+      const int gm = (__builtin_ctz(mm)) >> 3;
+      mm &= mm - 1;
+      const uint32_t *cells = (const uint32_t *)(L + Q_R0 + gm * 256);
       const uint32_t *clip32 = (const uint32_t *)clip_base;
-      const int ybase = off + yrow * S + yc4, cbase = (off >> 1) + cv * (S >> 1) + crow * S + cc4;
+      const int offm = off0 + gm * 16;
+      const int ybase = offm + yrow * S + yc4, cbase = (offm >> 1) + cv * (S >> 1) + crow * S + cc4;
       const uint2 yc = uint2{cells[(yrow >> 1) * 8 + (yc4 >> 1)], cells[(yrow >> 1) * 8 + (yc4 >> 1) + 1]};
       const uint32_t *ccp = cells + crow * 8 + cc4;
       const uint32_t cell[4] = {ccp[0], ccp[1], ccp[2], ccp[3]};
-      auto slot_of = [&](uint32_t c) { int sl = A.ring_base - mobi_cell_ref(c); return (uint32_t)(sl < 0 ? sl + 6 : sl) * slot_w; };
+      auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return (uint32_t)(s2 < 0 ? s2 + 6 : s2) * slot_w; };
       // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits
       // (leaves at least 8 wide) they are the same cell: one window instead of two / four
       const bool ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
@@ -314,8 +378,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
       const Win wq = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + (qy0 >> 1) * S + (qx0 >> 1), S);
       const uint32_t va = mc4_select(wa, (dxa & 1) | ((dya & 1) << 1));
       const uint32_t vb = ysplit ? mc4_select(wb, (dxb & 1) | ((dyb & 1) << 1)) : va;
-      ypred = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
-      cpred = mc4_select(wq, (qx0 & 1) | ((qy0 & 1) << 1));
+      uint32_t cpred = mc4_select(wq, (qx0 & 1) | ((qy0 & 1) << 1));
       if (csplit) {
         cpred &= 0xFFu;
 #pragma unroll
@@ -325,76 +388,80 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs
           cpred |= mc4_select(wn, (qx1 & 1) | ((qy1 & 1) << 1)) & (0xFFu << (8 * k));
         }
       }
+      *(uint32_t *)(L + Q_OUT_Y + yrow * 64 + gm * 16 + yc4) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
+      if (lane < 32) *(uint32_t *)(L + Q_OUT_C + cv * 256 + crow * 32 + gm * 8 + cc4) = cpred;
     }
-    *(uint32_t *)(L + Q_OUT_Y + yrow * 64 + g * 16 + yc4) = ypred;
-    if (lane < 32) *(uint32_t *)(L + Q_OUT_C + cv * 256 + crow * 32 + g * 8 + cc4) = cpred;
   }
+  if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t3 = __builtin_readcyclecounter(); }
 
-  unsigned long long t3 = 0;
-  if (A.prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t3 = __builtin_readcyclecounter(); }
   // ---- stage C: one batched inverse transform for the coded areas of the whole quad ----
-  if (m24) {
-    const int n_ent = __builtin_popcount(m24);
+  wave_sync(); // windows are dead from here on: the coefficient tile takes their place
+  if (m32) {
+    const int n_ent = __builtin_popcount(m32);
     int *coef = (int *)(L + Q_COEF), *tmp = (int *)(L + Q_TMP);
-    const int32_t *sc = (const int32_t *)(L + Q_SCALE);
-    wave_sync(); // windows are dead from here on: the coefficient tile takes their place
-    if (lane < 24 && ((m24 >> lane) & 1)) L[Q_TAB + __builtin_popcount(m24 & ((1u << lane) - 1))] = (uint8_t)lane;
-    int fault = 0;
+    if (lane < 32 && ((m32 >> lane) & 1)) L[Q_TAB + __builtin_popcount(m32 & ((1u << lane) - 1))] = (uint8_t)lane;
+    const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
+    int lo = 0, hi = 0;
     for (int pass = 0; pass * 8 < n_ent; pass++) {
       {
-        uint4 z = uint4{0, 0, 0, 0};
-        *(uint4 *)(L + Q_COEF + lane * 32) = z;
-        *(uint4 *)(L + Q_COEF + lane * 32 + 16) = z;
+        const uint4 z = uint4{0, 0, 0, 0};
+        *(uint4 *)(L + Q_COEF + lane * 16) = z;
+        *(uint4 *)(L + Q_COEF + 1024 + lane * 16) = z;
       }
       wave_sync();
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int cbp6 = (m24 >> (6 * g)) & 0x3F;
-        if (!cbp6) continue;
-        const int ncoef = dd[g].z & 0x3FF, nl = (dd[g].y >> 1) & 0x7F;
-        const uint32_t *cw = A.payload + dd[g].x + (nl > 1 ? MOBI_MV_CELLS : 0);
-        for (int i = lane; i < ncoef; i += 64) {
-          const uint32_t e = i < 64 ? *(const uint32_t *)(L + Q_CW + g * 256 + i * 4) : cw[i];
-          const int t = e & 0x1FF, level = (int32_t)e >> 16, k = g * 6 + (t >> 6), p = t & 63;
-          const int slot = __builtin_popcount(m24 & ((1u << k) - 1)) - pass * 8;
-          if (slot >= 0 && slot < 8) coef[slot * 64 + p] = (((t24 >> k) & 1) ? sc[p] : sc[64 + (p & 15)]) * level;
+      // residual levels of the four macroblocks together: lane (g, j) takes levels j, j+16, ... of macroblock g
+      for (uint32_t i = (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 16) {
+        if (i < ncoef) {
+          const uint32_t e = i < 64 ? lds32(L, Q_R5 + g * 256 + (int)i * 4) : cw[i];
+          const int t = e & 0x1FF, level = (int32_t)e >> 16, k = g * 8 + (t >> 6), p = t & 63;
+          const int slot = __builtin_popcount(m32 & ((1u << k) - 1)) - pass * 8;
+          const int si = ((t32 >> k) & 1) ? p : 64 + (p & 15);                       // scale8[p] / scale4[p & 15]
+          const int scale = (int)lds32(L, Q_R4 + 96 + si * 4 + (si >= 40 ? 96 : 0)); // two runs of 10 chunks, see Q_R4
+          if ((unsigned)slot < 8u) coef[slot * 64 + p] = scale * level;
         }
       }
       wave_sync();
       const int e = lane >> 3, r = lane & 7, idx = pass * 8 + e;
       const bool act = idx < n_ent;
       const int k = act ? L[Q_TAB + idx] : 0;
-      const int g = (k * 43) >> 8, a = k - g * 6; // k / 6 for k < 24
-      const bool is8 = (t24 >> k) & 1;
+      const int ge = k >> 3, a = k & 7;
+      const bool is8 = (t32 >> k) & 1;
       if (act) idct_pass1(coef + 64 * e, tmp + 64 * e, is8, r);
       wave_sync();
       if (act) {
-        uint8_t *px = a < 4 ? L + Q_OUT_Y + (a >> 1) * 8 * 64 + g * 16 + (a & 1) * 8 : L + Q_OUT_C + (a - 4) * 256 + g * 8;
-        idct_pass2(tmp + 64 * e, is8, r, px, a < 4 ? 64 : 32, 0xF, &fault);
+        uint8_t *px = a < 4 ? L + Q_OUT_Y + (a >> 1) * 8 * 64 + ge * 16 + (a & 1) * 8 : L + Q_OUT_C + (a - 4) * 256 + ge * 8;
+        idct_pass2_q(tmp + 64 * e, is8, r, px, a < 4 ? 64 : 32, lo, hi);
       }
       wave_sync();
     }
-    if (fault) atomicOr(&A.fault[clip], 1);
-  } else {
-    wave_sync();
+    if (lo < -64 || hi > 319) atomicOr(&A.fault[clip], 1); // clamp table domain (MobiConst.cs:587)
   }
-  if (A.debug == 2) return;
-  unsigned long long t4 = 0;
-  if (A.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t4 = __builtin_readcyclecounter(); }
+  if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t4 = __builtin_readcyclecounter(); }
 
   // ---- stage D: the quad leaves as whole rows: 64 B of luma, 8 B per macroblock of chroma ----
-  uint8_t *y0 = clip_base + (uint32_t)(A.ring_base % 6) * A.slot_bytes;
+  uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
   {
-    const int g = lane & 3;
-    if ((inter_mask >> g) & 1) {
-      *(uint4 *)(y0 + (off0 + yrow * S + g * 16)) = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + g * 16);
+    const int gq = lane & 3, yrow = lane >> 2;
+    if ((f32 >> (8 * gq)) & 1) {
+      *(uint4 *)(y0 + (off0 + yrow * S + gq * 16)) = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + gq * 16);
       const int pl = lane >> 5, row = (lane >> 2) & 7;
-      *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + row * S + g * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + g * 8);
+      *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + row * S + gq * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + gq * 8);
     }
   }
-  if (A.prof && lane == 0) // MOBI_DEBUG=9: where does a wave's life go (shader clock): issue, DMA wait, MC, IDCT
-    ((uint4 *)A.prof)[qi] = uint4{(uint32_t)(t1 - t0), (uint32_t)(t2 - t1), (uint32_t)(t3 - t2) | ((uint32_t)__builtin_popcount(m24) << 24), (uint32_t)(t4 - t3)};
+  if (PROF && lane == 0) // MOBI_DEBUG=9: where does a wave's life go (shader clock): issue, DMA wait, MC, IDCT
+    ((uint4 *)A.prof)[qi] = uint4{(uint32_t)(t1 - t0), (uint32_t)(t2 - t1), (uint32_t)(t3 - t2) | ((uint32_t)__builtin_popcount(m32) << 24), (uint32_t)(t4 - t3)};
 }
+
+template <bool PROF>
+__device__ __forceinline__ void recon_inter_entry(const MobiReconArgs &A) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES][Q_BYTES];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t qi = ((blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
+  if (qi >= A.qpc * (uint32_t)A.n_clips) return;
+  recon_inter_quad<PROF>(A, lds_all[wave], qi, lane);
+}
+extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs A) { recon_inter_entry<false>(A); }
+extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter_prof(MobiReconArgs A) { recon_inter_entry<true>(A); }
 
 // =====================================================================================================
 // intra macroblocks of one dependency level
@@ -529,10 +596,12 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const long quads = (long)a->qpc * a->n_clips;
   if (quads <= 0) return 0;
+  if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue; // 24-bit multiply in the kernel
   const unsigned grid = (unsigned)(((quads + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
-  hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, b);
+  if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * WAVES), 0, s, b);
+  else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, b);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
