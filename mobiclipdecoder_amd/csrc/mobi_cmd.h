@@ -2,7 +2,7 @@
 // emits per frame and what the reconstruction kernels (mobi_kernels.hip) consume.
 //
 // One frame of one clip =
-//   MbDesc   desc[n_mbs]           16 B per macroblock, raster order (leaf 0 of inter MBs is inline)
+//   MbDesc   desc[n_mbs]           32 B per macroblock, raster order (leaves of 1- and 2-leaf inter MBs are inline)
 //   uint32_t payload[...]          variable: MV cell maps, intra block records, residual levels
 //   uint32_t intra_items[...]      MB indices of intra MBs grouped by dependency level (host side only;
 //                                  merged across clips into per-level launch lists)
@@ -22,23 +22,33 @@
 
 enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 
-// ---- MbDesc: 16 B per macroblock; on the device one flat table per frame step, index = clip*n_mbs + mb,
+// ---- MbDesc: 32 B per macroblock; on the device one flat table per frame step, index = clip*n_mbs + mb,
 //      so a wave's first load already tells it everything it needs to start fetching pixels ------------
 // w0  payload word offset (host: inside the clip's payload; device: inside the frame step's payload arena)
 // w1  [0]      type (MOBI_MB_*)
-//     [7:1]    n_leaves   (inter: 1 = the single 16x16 leaf INLINE in w2/w3; >1 = the payload starts with the
-//                          64-word MV cell map instead)
+//     [7:1]    n_leaves   (inter: 1 = the single 16x16 leaf INLINE in w2/w3; 2 with a DUAL kind in w5 = both
+//                          leaves inline; otherwise the payload starts with the 64-word MV cell map)
 //     [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
 //     [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
 //     [25:20]  quantizer  of the frame (selects the dequant scale table, MD.cs:3884-3912)
 // w2  [9:0]    n_coefs (<= 384)      [24:10] inter: leaf 0 word 0 (mobi_leaf_w0)
 // w3  inter: leaf 0 word 1 (MV) ;  intra: [0] plane16 present, [31:16] plane16 parameter
+// w4  DUAL: leaf 1 word 1 (MV)
+// w5  [2:0] DUAL: ref slot of leaf 1   [4:3] MOBI_DUAL_* : the macroblock is exactly two halves (partition codes
+//     8 / 9 at the 16x16 level with two plain leaves, MD.cs:585-600 -- by far the most common split), leaf 0 =
+//     top / left, leaf 1 = bottom / right; no cell map is emitted for it
+// w6, w7 reserved (0)
 struct MbDesc {
   uint32_t payload_off;
   uint32_t w1;
   uint32_t w2;
   uint32_t w3;
+  uint32_t w4;
+  uint32_t w5;
+  uint32_t w6;
+  uint32_t w7;
 };
+enum { MOBI_DUAL_NONE = 0, MOBI_DUAL_TB = 1, MOBI_DUAL_LR = 2 }; // two 16x8 (top, bottom) / two 8x16 (left, right)
 
 // ---- MC leaf (single-leaf macroblocks: inline in the descriptor) ------------------------------
 //  w0: [3:0] x/2  [7:4] y/2  [9:8] log2(16/w)  [11:10] log2(16/h)  [14:12] ref slot 1..5
@@ -48,7 +58,7 @@ static inline uint32_t mobi_leaf_w0(int x, int y, int wi, int hi, int ref) {
 }
 static inline uint32_t mobi_leaf_w1(int dx, int dy) { return ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16); }
 
-// ---- MV cell map (macroblocks with more than one leaf): 64 words, first thing in the payload ---
+// ---- MV cell map (macroblocks with more than one leaf that are not DUAL): 64 words, first thing in the payload ---
 // The partition tree bottoms out at 2x2 luma (MD.cs:1683-1746), so an 8x8 grid of 2x2-pixel cells
 // (= one chroma sample each) says for every pixel which leaf moved it.  cell[(y/2)*8 + x/2] =
 //  [13:0] dx (signed 14)  [27:14] dy (signed 14)  [30:28] ref slot 1..5

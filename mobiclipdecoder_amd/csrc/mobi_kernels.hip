@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mobi_cmd.h"
 #include "mobi_kernels.h"
 #include "mobi_recon_math.h"
@@ -266,24 +268,48 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   const int g = lane >> 4, j = lane & 15;
 
   // ---- stage A: decode this lane's macroblock, then every global read of the quad, asynchronously into LDS ----
-  const uint4 d = *(const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last quad
+  const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last quad
+  const uint4 d = dp[0], d2 = dp[1];
   const bool valid = g < nmb && (d.y & 1) == MOBI_MB_INTER;
-  const int nl = (d.y >> 1) & 0x7F;
-  const bool single = valid && nl == 1, multi = valid && nl > 1;
+  const int nl = (d.y >> 1) & 0x7F, kind2 = (d2.y >> 3) & 3;
+  const bool single = valid && nl == 1, dual = valid && kind2 != 0, multi = valid && nl > 1 && kind2 == 0;
   const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
   L[Q_META + g] = (uint8_t)cbp6;
   L[Q_META + 4 + g] = (uint8_t)((d.y >> 14) & 0x3F);
   L[Q_META + 8 + g] = (uint8_t)((valid ? 1 : 0) | (multi ? 2 : 0));
-  const int dx = (int)(d.w << 16) >> 16, dy = (int)d.w >> 16, cdx = dx >> 1, cdy = dy >> 1;
-  int sl = A.ring_base - (int)((d.z >> 22) & 7);
-  sl = sl < 0 ? sl + 6 : sl;
-  const uint32_t refoff = __umul24((uint32_t)sl, A.slot_bytes); // slot_bytes < 2^24: checked by mobi_launch_inter
+  const bool any_dual = __builtin_amdgcn_ballot_w64(dual) != 0;
+  // Leaf parameters as this lane needs them: one set for its luma rows 0..7 (iterations t = 0,1), one for rows
+  // 8..15 (t = 2,3), one for its chroma samples.  Single-leaf: all three are the inline leaf.  DUAL (two halves,
+  // both inline): top/bottom switches between t = 1 and 2, left/right by the lane's column.
+  struct Leaf { int dx, dy; uint32_t refoff; };
+  auto leaf_of = [&](uint32_t mv, uint32_t ref, bool ok) {
+    int sl = A.ring_base - (int)ref;
+    sl = sl < 0 ? sl + 6 : sl;
+    Leaf r;
+    r.dx = ok ? (int)(mv << 16) >> 16 : 0; // lanes without a motion vector keep to their own macroblock position
+    r.dy = ok ? (int)mv >> 16 : 0;
+    r.refoff = ok ? __umul24((uint32_t)sl, A.slot_bytes) : 0u; // slot_bytes < 2^24: checked by mobi_launch_inter
+    return r;
+  };
+  const Leaf PA = leaf_of(d.w, (d.z >> 22) & 7, single || dual);
+  Leaf P01 = PA, P23 = PA, PC = PA;
+  if (any_dual) {
+    const Leaf PB = leaf_of(d2.x, d2.y & 7, dual);
+    const bool lr = kind2 == MOBI_DUAL_LR, tb = kind2 == MOBI_DUAL_TB;
+    const bool b01 = dual && lr && (j & 2), b23 = dual && (tb || (lr && (j & 2))), bc = dual && (lr ? (j & 1) != 0 : j >= 8);
+    auto pick = [](bool b, const Leaf &x, const Leaf &y) { return Leaf{b ? x.dx : y.dx, b ? x.dy : y.dy, b ? x.refoff : y.refoff}; };
+    P01 = pick(b01, PB, PA);
+    P23 = pick(b23, PB, PA);
+    PC = pick(bc, PB, PA);
+  }
   const int off = off0 + g * 16;
-  const int ypos = off + ((dy >> 1) << lgS) + (dx >> 1), cpos = (off >> 1) + ((cdy >> 1) << lgS) + (cdx >> 1);
+  const int ypos = off + ((P01.dy >> 1) << lgS) + (P01.dx >> 1), ypos23 = off + ((P23.dy >> 1) << lgS) + (P23.dx >> 1);
+  const int cdx = PC.dx >> 1, cdy = PC.dy >> 1;
+  const int cpos = (off >> 1) + ((cdy >> 1) << lgS) + (cdx >> 1);
   const int step = single ? S : multi ? 16 : 0; // a lane without a window keeps re-reading the start of its region
   const int hS = single ? S >> 1 : 0;
-  const uint32_t ywin = single ? refoff + (uint32_t)(ypos & ~15) : 0u;
-  const uint32_t cwin = single ? refoff + ysz + (uint32_t)(cpos & ~15) : 0u;
+  const uint32_t ywin = single ? P01.refoff + (uint32_t)(ypos & ~15) : 0u;
+  const uint32_t cwin = single ? PC.refoff + ysz + (uint32_t)(cpos & ~15) : 0u;
   const uint8_t *lbase = multi ? (const uint8_t *)(A.payload + d.x) : clip_base; // multi-leaf: the payload opens with the MV cell map
   {
     const uint8_t *p0 = lbase + (ywin + (uint32_t)(j * step));
@@ -303,37 +329,60 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
     const uint8_t *p5 = (const uint8_t *)A.payload + ((uint32_t)(j * 4) < ncoef ? (cwo + j * 4) * 4u : 0u);
     MOBI_DMA16(p5, L + Q_R5, 0);
   }
+  // DUAL macroblocks: 8-wide / 8-high halves do not fit the window layout; their lanes fetch their own 2 x 8 bytes
+  // per iteration straight into registers, in flight together with the DMA rounds.
+  uint2 fx[6], fy[6]; // only read by DUAL lanes
+  if (dual) {
+    const int rr = j >> 2, q = j & 3;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const uint32_t o = (t < 2 ? P01.refoff : P23.refoff) + (uint32_t)(((t < 2 ? ypos : ypos23) + (4 * t + rr) * S + 4 * q) & ~3);
+      fx[t] = *(const uint2_a4 *)(clip_base + o);
+      fy[t] = *(const uint2_a4 *)(clip_base + o + S);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t o = PC.refoff + ysz + (uint32_t)((cpos + u * (S >> 1) + (j >> 1) * S + 4 * (j & 1)) & ~3);
+      fx[4 + u] = *(const uint2_a4 *)(clip_base + o);
+      fy[4 + u] = *(const uint2_a4 *)(clip_base + o + S);
+    }
+  }
   if (PROF) t1 = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
   if (PROF) t2 = __builtin_readcyclecounter();
   const uint32_t m32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META));      // coded 8x8 areas: bit g*8 + area
   const uint32_t t32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META + 4));  // ... that use one 8x8 transform
-  const uint32_t f32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META + 8));  // byte g: bit 0 inter, bit 1 multi-leaf
+  const uint32_t f32 = __builtin_amdgcn_readfirstlane(lds32(L, Q_META + 8));  // byte g: bit 0 inter, bit 1 multi-leaf (cell map)
   if ((f32 & 0x01010101u) == 0) return;
 
-  // ---- stage B: motion compensation out of LDS into the quad's out tile ----
-  {
-    // single-leaf macroblocks, all at once (the other lanes compute garbage into tiles nobody stores, or that B2 overwrites)
-    const int ys = ypos & 15, cs = cpos & 15;
-    const int yph = (dx & 1) | ((dy & 1) << 1), cph = (cdx & 1) | ((cdy & 1) << 1);
+  // ---- stage B: motion compensation into the quad's out tile ----
+  // single-leaf macroblocks out of the LDS windows, DUAL ones out of their registers, all at once (the other lanes
+  // compute garbage into tiles nobody stores, or that B2 overwrites)
+  auto stage_b = [&](auto with_dual) {
+    constexpr bool DUAL = decltype(with_dual)::value;
     {
+      const int ys = ypos & 15;
       const int rr = j >> 2, q = j & 3, w0 = (ys + 4 * q) >> 2, w1 = w0 + 1;
       const int a0 = Q_R0 + (w0 >> 2) * 1024 + g * 256 + rr * 16 + (w0 & 3) * 4, a1 = Q_R0 + (w1 >> 2) * 1024 + g * 256 + rr * 16 + (w1 & 3) * 4;
       const int b0 = Q_R4 + g * 256 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + (w1 >> 2) * 16 + (w1 & 3) * 4;
-      const uint32_t sh = ys & 3, sh8 = sh * 8;
-      const bool ph0 = yph == 0, ph1 = yph == 1, ph2 = yph == 2;
+      const int ph01 = (P01.dx & 1) | ((P01.dy & 1) << 1), ph23 = (P23.dx & 1) | ((P23.dy & 1) << 1);
+      const uint32_t sh01 = ypos & 3, sh23 = ypos23 & 3;
+      const bool p0a = ph01 == 0, p1a = ph01 == 1, p2a = ph01 == 2, p0b = ph23 == 0, p1b = ph23 == 1, p2b = ph23 == 2;
       const int o = Q_OUT_Y + rr * 64 + g * 16 + q * 4;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        const uint32_t x0 = lds32(L, a0 + 64 * t), x1 = lds32(L, a1 + 64 * t);
-        uint32_t y0, y1;
+        uint32_t x0 = lds32(L, a0 + 64 * t), x1 = lds32(L, a1 + 64 * t), y0, y1;
         if (t < 3) { y0 = lds32(L, a0 + 64 * t + 16); y1 = lds32(L, a1 + 64 * t + 16); }
         else { y0 = lds32(L, rr == 3 ? b0 : a0 + 64 * 3 + 16); y1 = lds32(L, rr == 3 ? b1 : a1 + 64 * 3 + 16); }
-        *(uint32_t *)(L + o + 256 * t) = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
+        if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
+        const bool second = DUAL && t >= 2;
+        const uint32_t sh = second ? sh23 : sh01;
+        *(uint32_t *)(L + o + 256 * t) = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
       }
     }
     {
+      const int cs = cpos & 15, cph = (cdx & 1) | ((cdy & 1) << 1);
       const int row = j >> 1, q = j & 1, w0 = (cs + 4 * q) >> 2, w1 = w0 + 1;
       const int a0 = Q_R2 + g * 256 + row * 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, a1 = Q_R2 + g * 256 + row * 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
       const int b0 = Q_R4 + g * 256 + 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
@@ -343,12 +392,15 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       const int o = Q_OUT_C + row * 32 + g * 8 + q * 4;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const uint32_t x0 = lds32(L, a0 + 1024 * u), x1 = lds32(L, a1 + 1024 * u);
-        const uint32_t y0 = lds32(L, row == 7 ? n0 + 32 * u : n0 + 1024 * u), y1 = lds32(L, row == 7 ? n1 + 32 * u : n1 + 1024 * u);
+        uint32_t x0 = lds32(L, a0 + 1024 * u), x1 = lds32(L, a1 + 1024 * u);
+        uint32_t y0 = lds32(L, row == 7 ? n0 + 32 * u : n0 + 1024 * u), y1 = lds32(L, row == 7 ? n1 + 32 * u : n1 + 1024 * u);
+        if (DUAL) { x0 = dual ? fx[4 + u].x : x0; x1 = dual ? fx[4 + u].y : x1; y0 = dual ? fy[4 + u].x : y0; y1 = dual ? fy[4 + u].y : y1; }
         *(uint32_t *)(L + o + 256 * u) = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
       }
     }
-  }
+  };
+  if (any_dual) stage_b(std::true_type{});
+  else stage_b(std::false_type{});
   // B2: multi-leaf macroblocks, one at a time by the whole wave.  Every lane looks up the MV cells under its own
   // pixels (the map sits in LDS), then all its fetches fly together.
   {
@@ -371,22 +423,27 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       const bool ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
       const bool csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
       const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
+      // every fetch of the macroblock is issued before the first one is used
       const Win wa = fetch_win(clip32 + slot_of(yc.x), ybase + (dya >> 1) * S + (dxa >> 1), S);
-      Win wb = wa;
+      Win wb; // only read when ysplit (copying wa here would wait for its loads)
       if (ysplit) wb = fetch_win(clip32 + slot_of(yc.y), ybase + (dyb >> 1) * S + (dxb >> 1), S);
-      const int qx0 = mobi_cell_dx(cell[0]) >> 1, qy0 = mobi_cell_dy(cell[0]) >> 1;
-      const Win wq = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + (qy0 >> 1) * S + (qx0 >> 1), S);
+      int qx[4], qy[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { qx[k] = mobi_cell_dx(cell[k]) >> 1; qy[k] = mobi_cell_dy(cell[k]) >> 1; }
+      Win wq[4];
+      wq[0] = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + (qy[0] >> 1) * S + (qx[0] >> 1), S);
+      if (csplit) {
+#pragma unroll
+        for (int k = 1; k < 4; k++) wq[k] = fetch_win(clip32 + slot_of(cell[k]) + ysz_w, cbase + (qy[k] >> 1) * S + (qx[k] >> 1), S);
+      }
+      asm volatile("" ::: "memory"); // keep the loads above the arithmetic
       const uint32_t va = mc4_select(wa, (dxa & 1) | ((dya & 1) << 1));
       const uint32_t vb = ysplit ? mc4_select(wb, (dxb & 1) | ((dyb & 1) << 1)) : va;
-      uint32_t cpred = mc4_select(wq, (qx0 & 1) | ((qy0 & 1) << 1));
+      uint32_t cpred = mc4_select(wq[0], (qx[0] & 1) | ((qy[0] & 1) << 1));
       if (csplit) {
         cpred &= 0xFFu;
 #pragma unroll
-        for (int k = 1; k < 4; k++) {
-          const int qx1 = mobi_cell_dx(cell[k]) >> 1, qy1 = mobi_cell_dy(cell[k]) >> 1;
-          const Win wn = fetch_win(clip32 + slot_of(cell[k]) + ysz_w, cbase + (qy1 >> 1) * S + (qx1 >> 1), S);
-          cpred |= mc4_select(wn, (qx1 & 1) | ((qy1 & 1) << 1)) & (0xFFu << (8 * k));
-        }
+        for (int k = 1; k < 4; k++) cpred |= mc4_select(wq[k], (qx[k] & 1) | ((qy[k] & 1) << 1)) & (0xFFu << (8 * k));
       }
       *(uint32_t *)(L + Q_OUT_Y + yrow * 64 + gm * 16 + yc4) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
       if (lane < 32) *(uint32_t *)(L + Q_OUT_C + cv * 256 + crow * 32 + gm * 8 + cc4) = cpred;

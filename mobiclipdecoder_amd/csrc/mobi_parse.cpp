@@ -104,7 +104,7 @@ void MobiStreamParser::begin_mb(int mb, int type) {
   mb_type_ = type;
 }
 void MobiStreamParser::end_mb() {
-  MbDesc d;
+  MbDesc d{};
   d.payload_off = (uint32_t)out_->payload.size();
   uint32_t nl = 0;
   d.w2 = (uint32_t)coefs_.size();
@@ -113,7 +113,18 @@ void MobiStreamParser::end_mb() {
     nl = (uint32_t)(leaves_.size() / 2);
     d.w2 |= leaves_[0] << 10; // the leaf of a single-leaf MB rides in the descriptor
     d.w3 = leaves_[1];
-    if (nl > 1) out_->payload.insert(out_->payload.end(), cells_, cells_ + MOBI_MV_CELLS);
+    int dual = MOBI_DUAL_NONE;
+    if (nl == 2) { // two halves: both leaves ride in the descriptor (leaf word 0: x/2 | y/2<<4 | wi<<8 | hi<<10 | ref<<12)
+      const uint32_t a = leaves_[0] & 0xFFF, b = leaves_[2] & 0xFFF;
+      if (a == (0u | (1u << 10)) && b == ((4u << 4) | (1u << 10))) dual = MOBI_DUAL_TB;
+      if (a == (0u | (1u << 8)) && b == (4u | (1u << 8))) dual = MOBI_DUAL_LR;
+    }
+    if (dual) {
+      d.w4 = leaves_[3];
+      d.w5 = ((leaves_[2] >> 12) & 7) | ((uint32_t)dual << 3);
+    } else if (nl > 1) {
+      out_->payload.insert(out_->payload.end(), cells_, cells_ + MOBI_MV_CELLS);
+    }
   } else {
     out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
   }

@@ -94,8 +94,11 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
   const long off = (long)(mb / g.mbw) * 16 * S + (mb % g.mbw) * 16;
   uint8_t ty[16 * TP], tc[2][8 * TP]; // prediction tiles (interior only; pitch TP, origin at byte 0)
   // per-lane MV: the inline leaf (nl == 1) or the cell under each pixel (nl > 1)
+  const int dual = (d.w5 >> 3) & 3; // two inline halves: no cell map in the payload
   auto mv_at = [&](int cellx, int celly, int &dx, int &dy, int &ref) {
-    if (nl == 1) {
+    if (dual && (dual == MOBI_DUAL_TB ? celly >= 4 : cellx >= 4)) {
+      ref = d.w5 & 7; dx = (int16_t)(d.w4 & 0xFFFF); dy = (int16_t)(d.w4 >> 16);
+    } else if (nl == 1 || dual) {
       uint32_t w0 = (d.w2 >> 10) & 0x7FFF;
       ref = (w0 >> 12) & 7; dx = (int16_t)(d.w3 & 0xFFFF); dy = (int16_t)(d.w3 >> 16);
     } else {
@@ -133,7 +136,7 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
       tc[v01][row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
     }
   }
-  const uint32_t *cw = pl + (nl > 1 ? MOBI_MV_CELLS : 0);
+  const uint32_t *cw = pl + (nl > 1 && !dual ? MOBI_MV_CELLS : 0);
   if (cbp6) {
     int coef[6 * 64];
     dequant_into((d.w1 >> 20) & 63, cw, ncoef, t8, coef);
