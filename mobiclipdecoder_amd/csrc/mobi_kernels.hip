@@ -27,6 +27,10 @@ namespace {
 enum { TP = 32 };                     // intra tile pitch: interior col c at byte 4+c, halo col -1 at byte 3
 enum { HALO_Y_RIGHT = 23, HALO_C_RIGHT = 15 }; // must match MOBI_HALO_* in mobi_parse.h
 enum { WAVES = 4 };
+#ifndef QWAVES
+#define QWAVES 1
+#endif
+enum { INTER_WAVES = QWAVES }; // waves per workgroup of the inter kernel
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
@@ -52,6 +56,7 @@ struct Geo { // stride is 256/512/1024 (MD.cs:50-52): divide/modulo by shifts
 // aligned dword pairs (global_load_dwordx2, never flat) and cut out with v_alignbyte.  All loads of a
 // macroblock are issued before the first one is consumed: no control flow sits between them.
 typedef uint2 __attribute__((aligned(4))) uint2_a4;
+typedef uint4 __attribute__((aligned(4))) uint4_a4;
 struct Win { uint2 r0, r1; uint32_t sh; }; // row, row below, byte shift 0..3
 __device__ __forceinline__ Win fetch_win(const uint32_t *plane32, int o, int S) {
   Win w;
@@ -100,7 +105,9 @@ __device__ __forceinline__ void scatter_one(const int32_t *sc, uint32_t e, uint3
 __device__ __forceinline__ void scatter_coefs(const int32_t *sc, const uint32_t *cw, int first, int n, uint32_t t8, int *coef, int lane) {
   for (int i = first + lane; i < n; i += 64) scatter_one(sc, cw[i], t8, coef);
 }
-// pass 1 of area b by lane r (0..7): 8x8 -> coefficient group r; 4x4 -> sub-block r>>1, groups (r&1)*2+{0,1}
+// pass 1 of area b by lane r (0..7): 8x8 -> coefficient group r; 4x4 -> sub-block r>>1, groups (r&1)*2+{0,1}.
+// t may be c itself (in-place transpose): every read of the area is issued before its first write, and the 8
+// lanes of an area always take the same branch (LDS executes a wave's instructions in order)
 __device__ __forceinline__ void idct_pass1(const int *c, int *t, bool is8, int r) {
   int in[8], out[8];
   if (is8) {
@@ -108,20 +115,19 @@ __device__ __forceinline__ void idct_pass1(const int *c, int *t, bool is8, int r
     for (int m = 0; m < 8; m++) in[m] = c[8 * r + m];
     if (r == 0) in[0] += 32;
     mobi_bfly8(in, out);
+    wave_sync();
 #pragma unroll
     for (int m = 0; m < 8; m++) t[8 * m + r] = out[m];
   } else {
-    const int s = r >> 1;
+    const int s = r >> 1, k0 = (r & 1) * 2;
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-      const int k = (r & 1) * 2 + g;
+    for (int m = 0; m < 8; m++) in[m] = c[16 * s + 4 * k0 + m]; // groups k0 and k0+1
+    if (k0 == 0) in[0] += 32;
+    mobi_bfly4(in, out);
+    mobi_bfly4(in + 4, out + 4);
+    wave_sync();
 #pragma unroll
-      for (int m = 0; m < 4; m++) in[m] = c[16 * s + 4 * k + m];
-      if (k == 0) in[0] += 32;
-      mobi_bfly4(in, out);
-#pragma unroll
-      for (int m = 0; m < 4; m++) t[16 * s + 4 * m + k] = out[m];
-    }
+    for (int m = 0; m < 4; m++) { t[16 * s + 4 * m + k0] = out[m]; t[16 * s + 4 * m + k0 + 1] = out[4 + m]; }
   }
 }
 // pass 2 of area b by lane r: adds the residual into the 8x8 pixel area at `px` (pitch in bytes)
@@ -187,18 +193,18 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
 // deals consecutive workgroups round-robin to the 8 XCDs, so XCD x gets one contiguous run of quads.
 namespace {
 enum {                           // per-wave LDS map.  A DMA round r puts lane i's 16 bytes at R_r + 16 * i, i = g*16 + j
-  Q_R0 = 0,                      // luma window rows 0..15, bytes 0..15 of the row  (j = row);  multi-leaf MB: its 64 MV cells
+  Q_R0 = 0,                      // luma window rows 0..15, bytes 0..15 of the row  (j = row)
   Q_R1 = 1024,                   // luma window rows 0..15, bytes 16..31
   Q_R2 = 2048,                   // U window rows 0..7 (j = row*2 + 16-byte half)
   Q_R3 = 3072,                   // V window rows 0..7
   Q_R4 = 4096,                   // j 0,1: luma row 16; 2,3: U row 8; 4,5: V row 8; j 6..15 of g 0,1: dequant scales (20 chunks)
-  Q_R5 = 5120,                   // first 64 residual level words of MB g (j = chunk of 4)
-  Q_COEF = 0, Q_TMP = 2048,      // coefficient tile (8 areas x 64 ints) + transposed intermediate: alias R0..R3, dead after MC
-  Q_TAB = Q_R4,                  // coded-area table: entry -> g*8 + area (row 16 of MB 0 is dead after MC)
-  Q_OUT_Y = 6144,                // out tile: luma 16 rows x 64 B
-  Q_OUT_C = 7168,                //           chroma 2 planes x 8 rows x 32 B
-  Q_META = 7680,                 // per quad: cbp6[4], t8mask[4], flags[4]
-  Q_BYTES = 7696
+  // after motion compensation the windows are dead and the same bytes are reused:
+  Q_OUT_Y = 0,                   // out tile: luma 16 rows x 64 B
+  Q_OUT_C = 1024,                //           chroma 2 planes x 8 rows x 32 B
+  Q_COEF = 1536,                 // coefficient tile, 8 areas x 64 ints; transposed in place between the two passes
+  Q_TAB = Q_R4,                  // coded-area table: entry -> g*8 + area (row 16 of MB 0)
+  Q_META = 5120,                 // per quad: cbp6[4], t8mask[4], flags[4]
+  Q_BYTES = 5136                 // 5.5 KB allocated: 29 waves per CU fit the 160 KB
 };
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
@@ -306,11 +312,11 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   const int ypos = off + ((P01.dy >> 1) << lgS) + (P01.dx >> 1), ypos23 = off + ((P23.dy >> 1) << lgS) + (P23.dx >> 1);
   const int cdx = PC.dx >> 1, cdy = PC.dy >> 1;
   const int cpos = (off >> 1) + ((cdy >> 1) << lgS) + (cdx >> 1);
-  const int step = single ? S : multi ? 16 : 0; // a lane without a window keeps re-reading the start of its region
+  const int step = single ? S : 0; // a lane without a window keeps re-reading the start of its clip
   const int hS = single ? S >> 1 : 0;
   const uint32_t ywin = single ? P01.refoff + (uint32_t)(ypos & ~15) : 0u;
   const uint32_t cwin = single ? PC.refoff + ysz + (uint32_t)(cpos & ~15) : 0u;
-  const uint8_t *lbase = multi ? (const uint8_t *)(A.payload + d.x) : clip_base; // multi-leaf: the payload opens with the MV cell map
+  const uint8_t *lbase = clip_base;
   {
     const uint8_t *p0 = lbase + (ywin + (uint32_t)(j * step));
     MOBI_DMA16(p0, L + Q_R0, 0);
@@ -325,9 +331,15 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
     const uint8_t *p4 = lbase + (j < 6 ? o4 : 0u);
     if (j >= 6 && g < 2) p4 = (const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + (g * 10 + j - 6) * 16;
     MOBI_DMA16(p4, L + Q_R4, 0);
-    const uint32_t cwo = d.x + (multi ? MOBI_MV_CELLS : 0);
-    const uint8_t *p5 = (const uint8_t *)A.payload + ((uint32_t)(j * 4) < ncoef ? (cwo + j * 4) * 4u : 0u);
-    MOBI_DMA16(p5, L + Q_R5, 0);
+  }
+  // residual level words: lane (g, j) scatters words j, j+16, j+32, ... of macroblock g, so they go straight into its registers
+  const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
+  uint32_t cwr[4] = {0, 0, 0, 0};
+  if ((uint32_t)j < ncoef) cwr[0] = cw[j];
+  if (__builtin_amdgcn_ballot_w64(ncoef > 16) != 0) {
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if ((uint32_t)(16 * k + j) < ncoef) cwr[k] = cw[16 * k + j];
   }
   // DUAL macroblocks: 8-wide / 8-high halves do not fit the window layout; their lanes fetch their own 2 x 8 bytes
   // per iteration straight into registers, in flight together with the DMA rounds.
@@ -359,6 +371,8 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   // ---- stage B: motion compensation into the quad's out tile ----
   // single-leaf macroblocks out of the LDS windows, DUAL ones out of their registers, all at once (the other lanes
   // compute garbage into tiles nobody stores, or that B2 overwrites)
+  uint32_t mcv[6]; // 4 luma + 2 chroma words of this lane: the out tile takes the place of the windows, so nothing is
+                   // written before every window read has been issued (LDS executes a wave's instructions in order)
   auto stage_b = [&](auto with_dual) {
     constexpr bool DUAL = decltype(with_dual)::value;
     {
@@ -369,7 +383,6 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       const int ph01 = (P01.dx & 1) | ((P01.dy & 1) << 1), ph23 = (P23.dx & 1) | ((P23.dy & 1) << 1);
       const uint32_t sh01 = ypos & 3, sh23 = ypos23 & 3;
       const bool p0a = ph01 == 0, p1a = ph01 == 1, p2a = ph01 == 2, p0b = ph23 == 0, p1b = ph23 == 1, p2b = ph23 == 2;
-      const int o = Q_OUT_Y + rr * 64 + g * 16 + q * 4;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         uint32_t x0 = lds32(L, a0 + 64 * t), x1 = lds32(L, a1 + 64 * t), y0, y1;
@@ -378,7 +391,7 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
         if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
         const bool second = DUAL && t >= 2;
         const uint32_t sh = second ? sh23 : sh01;
-        *(uint32_t *)(L + o + 256 * t) = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
+        mcv[t] = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
       }
     }
     {
@@ -389,20 +402,27 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       const int n0 = row == 7 ? b0 : a0 + 32, n1 = row == 7 ? b1 : a1 + 32;
       const uint32_t sh = cs & 3, sh8 = sh * 8;
       const bool ph0 = cph == 0, ph1 = cph == 1, ph2 = cph == 2;
-      const int o = Q_OUT_C + row * 32 + g * 8 + q * 4;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         uint32_t x0 = lds32(L, a0 + 1024 * u), x1 = lds32(L, a1 + 1024 * u);
         uint32_t y0 = lds32(L, row == 7 ? n0 + 32 * u : n0 + 1024 * u), y1 = lds32(L, row == 7 ? n1 + 32 * u : n1 + 1024 * u);
         if (DUAL) { x0 = dual ? fx[4 + u].x : x0; x1 = dual ? fx[4 + u].y : x1; y0 = dual ? fy[4 + u].x : y0; y1 = dual ? fy[4 + u].y : y1; }
-        *(uint32_t *)(L + o + 256 * u) = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
+        mcv[4 + u] = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
       }
     }
   };
   if (any_dual) stage_b(std::true_type{});
   else stage_b(std::false_type{});
-  // B2: multi-leaf macroblocks, one at a time by the whole wave.  Every lane looks up the MV cells under its own
-  // pixels (the map sits in LDS), then all its fetches fly together.
+  wave_sync();
+  {
+    const int oy = Q_OUT_Y + (j >> 2) * 64 + g * 16 + (j & 3) * 4, oc = Q_OUT_C + (j >> 1) * 32 + g * 8 + (j & 1) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; t++) *(uint32_t *)(L + oy + 256 * t) = mcv[t];
+#pragma unroll
+    for (int u = 0; u < 2; u++) *(uint32_t *)(L + oc + 256 * u) = mcv[4 + u];
+  }
+  // B2: multi-leaf macroblocks (deeper partition trees; rare), one at a time by the whole wave.  Every lane looks up the
+  // MV cells under its own pixels, then all its fetches fly together.
   {
     const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
     const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
@@ -410,13 +430,13 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
     while (mm) {
       const int gm = (__builtin_ctz(mm)) >> 3;
       mm &= mm - 1;
-      const uint32_t *cells = (const uint32_t *)(L + Q_R0 + gm * 256);
+      const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm * 16); // the MV cell map opens the payload
       const uint32_t *clip32 = (const uint32_t *)clip_base;
       const int offm = off0 + gm * 16;
       const int ybase = offm + yrow * S + yc4, cbase = (offm >> 1) + cv * (S >> 1) + crow * S + cc4;
-      const uint2 yc = uint2{cells[(yrow >> 1) * 8 + (yc4 >> 1)], cells[(yrow >> 1) * 8 + (yc4 >> 1) + 1]};
-      const uint32_t *ccp = cells + crow * 8 + cc4;
-      const uint32_t cell[4] = {ccp[0], ccp[1], ccp[2], ccp[3]};
+      const uint2 yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
+      const uint4_a4 c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+      const uint32_t cell[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
       auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return (uint32_t)(s2 < 0 ? s2 + 6 : s2) * slot_w; };
       // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits
       // (leaves at least 8 wide) they are the same cell: one window instead of two / four
@@ -455,9 +475,8 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   wave_sync(); // windows are dead from here on: the coefficient tile takes their place
   if (m32) {
     const int n_ent = __builtin_popcount(m32);
-    int *coef = (int *)(L + Q_COEF), *tmp = (int *)(L + Q_TMP);
+    int *coef = (int *)(L + Q_COEF), *tmp = coef;
     if (lane < 32 && ((m32 >> lane) & 1)) L[Q_TAB + __builtin_popcount(m32 & ((1u << lane) - 1))] = (uint8_t)lane;
-    const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
     int lo = 0, hi = 0;
     for (int pass = 0; pass * 8 < n_ent; pass++) {
       {
@@ -467,16 +486,21 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       }
       wave_sync();
       // residual levels of the four macroblocks together: lane (g, j) takes levels j, j+16, ... of macroblock g
-      for (uint32_t i = (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 16) {
-        if (i < ncoef) {
-          const uint32_t e = i < 64 ? lds32(L, Q_R5 + g * 256 + (int)i * 4) : cw[i];
-          const int t = e & 0x1FF, level = (int32_t)e >> 16, k = g * 8 + (t >> 6), p = t & 63;
-          const int slot = __builtin_popcount(m32 & ((1u << k) - 1)) - pass * 8;
-          const int si = ((t32 >> k) & 1) ? p : 64 + (p & 15);                       // scale8[p] / scale4[p & 15]
-          const int scale = (int)lds32(L, Q_R4 + 96 + si * 4 + (si >= 40 ? 96 : 0)); // two runs of 10 chunks, see Q_R4
-          if ((unsigned)slot < 8u) coef[slot * 64 + p] = scale * level;
-        }
+      auto scatter = [&](uint32_t e) {
+        const int t = e & 0x1FF, level = (int32_t)e >> 16, k = g * 8 + (t >> 6), p = t & 63;
+        const int slot = __builtin_popcount(m32 & ((1u << k) - 1)) - pass * 8;
+        const int si = ((t32 >> k) & 1) ? p : 64 + (p & 15);                       // scale8[p] / scale4[p & 15]
+        const int scale = (int)lds32(L, Q_R4 + 96 + si * 4 + (si >= 40 ? 96 : 0)); // two runs of 10 chunks, see Q_R4
+        if ((unsigned)slot < 8u) coef[slot * 64 + p] = scale * level;
+      };
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool mine = (uint32_t)(16 * k + j) < ncoef;
+        if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
+        if (mine) scatter(cwr[k]);
       }
+      for (uint32_t i = 64u + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 16)
+        if (i < ncoef) scatter(cw[i]);
       wave_sync();
       const int e = lane >> 3, r = lane & 7, idx = pass * 8 + e;
       const bool act = idx < n_ent;
@@ -511,14 +535,14 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
 
 template <bool PROF>
 __device__ __forceinline__ void recon_inter_entry(const MobiReconArgs &A) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES][Q_BYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_all[INTER_WAVES][Q_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const uint32_t qi = ((blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3)) * WAVES + wave;
+  const uint32_t qi = ((blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3)) * INTER_WAVES + wave;
   if (qi >= A.qpc * (uint32_t)A.n_clips) return;
   recon_inter_quad<PROF>(A, lds_all[wave], qi, lane);
 }
-extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter(MobiReconArgs A) { recon_inter_entry<false>(A); }
-extern "C" __global__ __launch_bounds__(256) void mobi_recon_inter_prof(MobiReconArgs A) { recon_inter_entry<true>(A); }
+extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter(MobiReconArgs A) { recon_inter_entry<false>(A); }
+extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter_prof(MobiReconArgs A) { recon_inter_entry<true>(A); }
 
 // =====================================================================================================
 // intra macroblocks of one dependency level
@@ -654,11 +678,11 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const long quads = (long)a->qpc * a->n_clips;
   if (quads <= 0) return 0;
   if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue; // 24-bit multiply in the kernel
-  const unsigned grid = (unsigned)(((quads + WAVES - 1) / WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
+  const unsigned grid = (unsigned)(((quads + INTER_WAVES - 1) / INTER_WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
-  if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * WAVES), 0, s, b);
-  else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * WAVES), 0, s, b);
+  if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * INTER_WAVES), 0, s, b);
+  else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * INTER_WAVES), 0, s, b);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
