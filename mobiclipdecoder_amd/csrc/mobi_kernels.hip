@@ -312,21 +312,23 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   const int ypos = off + ((P01.dy >> 1) << lgS) + (P01.dx >> 1), ypos23 = off + ((P23.dy >> 1) << lgS) + (P23.dx >> 1);
   const int cdx = PC.dx >> 1, cdy = PC.dy >> 1;
   const int cpos = (off >> 1) + ((cdy >> 1) << lgS) + (cdx >> 1);
-  const int step = single ? S : 0; // a lane without a window keeps re-reading the start of its clip
+  // a lane without a window keeps re-reading the start of its clip.  (Row offsets by shifts: the pitch is a power of
+  // two, and a 32-bit integer multiply costs four VALU slots.)
   const int hS = single ? S >> 1 : 0;
+  auto rowoff = [&](int rows) { return single ? (uint32_t)rows << lgS : 0u; };
   const uint32_t ywin = single ? P01.refoff + (uint32_t)(ypos & ~15) : 0u;
   const uint32_t cwin = single ? PC.refoff + ysz + (uint32_t)(cpos & ~15) : 0u;
   const uint8_t *lbase = clip_base;
   {
-    const uint8_t *p0 = lbase + (ywin + (uint32_t)(j * step));
+    const uint8_t *p0 = lbase + (ywin + rowoff(j));
     MOBI_DMA16(p0, L + Q_R0, 0);
     MOBI_DMA16(p0, L + Q_R1 - 16, 16); // the instruction offset moves the LDS side as well as the global side
-    const uint8_t *p2 = lbase + (cwin + (uint32_t)((j >> 1) * step + (j & 1) * 16));
+    const uint8_t *p2 = lbase + (cwin + rowoff(j >> 1) + (uint32_t)(j & 1) * 16u);
     MOBI_DMA16(p2, L + Q_R2, 0);
     MOBI_DMA16(p2 + hS, L + Q_R3, 0);
     // leftovers: window rows 16 (luma) / 8 (U, V); the spare lanes of MBs 0 and 1 bring the dequant scales of the clip's quantizer
     const int h = j >> 1;
-    const uint32_t o4 = (h == 0 ? ywin + 16u * step : h == 1 ? cwin + 8u * step : cwin + hS + 8u * step) + (uint32_t)(j & 1) * 16u;
+    const uint32_t o4 = (h == 0 ? ywin + rowoff(16) : h == 1 ? cwin + rowoff(8) : cwin + hS + rowoff(8)) + (uint32_t)(j & 1) * 16u;
     const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63)); // per clip (MD.cs:113-143): MB 0's copy
     const uint8_t *p4 = lbase + (j < 6 ? o4 : 0u);
     if (j >= 6 && g < 2) p4 = (const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + (g * 10 + j - 6) * 16;
@@ -348,13 +350,13 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
     const int rr = j >> 2, q = j & 3;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const uint32_t o = (t < 2 ? P01.refoff : P23.refoff) + (uint32_t)(((t < 2 ? ypos : ypos23) + (4 * t + rr) * S + 4 * q) & ~3);
+      const uint32_t o = (t < 2 ? P01.refoff : P23.refoff) + (uint32_t)(((t < 2 ? ypos : ypos23) + ((4 * t + rr) << lgS) + 4 * q) & ~3);
       fx[t] = *(const uint2_a4 *)(clip_base + o);
       fy[t] = *(const uint2_a4 *)(clip_base + o + S);
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      const uint32_t o = PC.refoff + ysz + (uint32_t)((cpos + u * (S >> 1) + (j >> 1) * S + 4 * (j & 1)) & ~3);
+      const uint32_t o = PC.refoff + ysz + (uint32_t)((cpos + u * (S >> 1) + ((j >> 1) << lgS) + 4 * (j & 1)) & ~3);
       fx[4 + u] = *(const uint2_a4 *)(clip_base + o);
       fy[4 + u] = *(const uint2_a4 *)(clip_base + o + S);
     }
@@ -433,28 +435,28 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm * 16); // the MV cell map opens the payload
       const uint32_t *clip32 = (const uint32_t *)clip_base;
       const int offm = off0 + gm * 16;
-      const int ybase = offm + yrow * S + yc4, cbase = (offm >> 1) + cv * (S >> 1) + crow * S + cc4;
+      const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
       const uint2 yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
       const uint4_a4 c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
       const uint32_t cell[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
-      auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return (uint32_t)(s2 < 0 ? s2 + 6 : s2) * slot_w; };
+      auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return __umul24((uint32_t)(s2 < 0 ? s2 + 6 : s2), slot_w); };
       // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits
       // (leaves at least 8 wide) they are the same cell: one window instead of two / four
       const bool ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
       const bool csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
       const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
       // every fetch of the macroblock is issued before the first one is used
-      const Win wa = fetch_win(clip32 + slot_of(yc.x), ybase + (dya >> 1) * S + (dxa >> 1), S);
+      const Win wa = fetch_win(clip32 + slot_of(yc.x), ybase + ((dya >> 1) << lgS) + (dxa >> 1), S);
       Win wb; // only read when ysplit (copying wa here would wait for its loads)
-      if (ysplit) wb = fetch_win(clip32 + slot_of(yc.y), ybase + (dyb >> 1) * S + (dxb >> 1), S);
+      if (ysplit) wb = fetch_win(clip32 + slot_of(yc.y), ybase + ((dyb >> 1) << lgS) + (dxb >> 1), S);
       int qx[4], qy[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) { qx[k] = mobi_cell_dx(cell[k]) >> 1; qy[k] = mobi_cell_dy(cell[k]) >> 1; }
       Win wq[4];
-      wq[0] = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + (qy[0] >> 1) * S + (qx[0] >> 1), S);
+      wq[0] = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + ((qy[0] >> 1) << lgS) + (qx[0] >> 1), S);
       if (csplit) {
 #pragma unroll
-        for (int k = 1; k < 4; k++) wq[k] = fetch_win(clip32 + slot_of(cell[k]) + ysz_w, cbase + (qy[k] >> 1) * S + (qx[k] >> 1), S);
+        for (int k = 1; k < 4; k++) wq[k] = fetch_win(clip32 + slot_of(cell[k]) + ysz_w, cbase + ((qy[k] >> 1) << lgS) + (qx[k] >> 1), S);
       }
       asm volatile("" ::: "memory"); // keep the loads above the arithmetic
       const uint32_t va = mc4_select(wa, (dxa & 1) | ((dya & 1) << 1));
@@ -491,7 +493,7 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
         const int slot = __builtin_popcount(m32 & ((1u << k) - 1)) - pass * 8;
         const int si = ((t32 >> k) & 1) ? p : 64 + (p & 15);                       // scale8[p] / scale4[p & 15]
         const int scale = (int)lds32(L, Q_R4 + 96 + si * 4 + (si >= 40 ? 96 : 0)); // two runs of 10 chunks, see Q_R4
-        if ((unsigned)slot < 8u) coef[slot * 64 + p] = scale * level;
+        if ((unsigned)slot < 8u) coef[slot * 64 + p] = __mul24(scale, level); // scale < 2^24, level 16 bits: exact, and full rate
       };
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -524,9 +526,9 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   {
     const int gq = lane & 3, yrow = lane >> 2;
     if ((f32 >> (8 * gq)) & 1) {
-      *(uint4 *)(y0 + (off0 + yrow * S + gq * 16)) = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + gq * 16);
+      *(uint4 *)(y0 + (off0 + (yrow << lgS) + gq * 16)) = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + gq * 16);
       const int pl = lane >> 5, row = (lane >> 2) & 7;
-      *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + row * S + gq * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + gq * 8);
+      *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + gq * 8);
     }
   }
   if (PROF && lane == 0) // MOBI_DEBUG=9: where does a wave's life go (shader clock): issue, DMA wait, MC, IDCT
