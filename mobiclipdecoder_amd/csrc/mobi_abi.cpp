@@ -142,6 +142,9 @@ struct mobi_batch {
   DevBuf d_cmd, d_items;
   int32_t *d_scale = nullptr; // [MOBI_SCALE_QMAX][MOBI_SCALE_STRIDE]
   unsigned long long *d_prof = nullptr; // MOBI_DEBUG=9: in-kernel cycle accumulators
+  uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
+  uint32_t step_tag = 0;                // bumped once per frame step, never 0
+  bool merged_intra = true;             // all intra levels of a step in ONE launch (MOBI_INTRA_LEVELS=1: one launch per level)
   // preloaded replay
   // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
   std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
@@ -178,7 +181,8 @@ struct mobi_batch {
     auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); }; // d == 1 must not wrap to 0
     a.magic_n_mbs = magic((uint32_t)a.n_mbs);
     a.magic_mbw = magic((uint32_t)a.mbw);
-    a.debug = debug;
+    a.step_tag = step_tag;
+    a.done = merged_intra ? d_done : nullptr;
     a.prof = d_prof;
     a.qpr = (uint32_t)(a.mbw + 3) / 4;
     a.qpc = a.qpr * (uint32_t)g.mbh;
@@ -198,6 +202,16 @@ struct mobi_batch {
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
       if (mobi_launch_inter(&a, stream) != 0) return MOBI_E_DEVICE;
       if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
+    }
+    if (merged_intra && plan.n_levels() >= 1) { // every level in one launch: items are sorted by level, waves wait on their own dependencies
+      const int cnt = (int)(plan.start[plan.n_levels() + 1] - plan.start[1]);
+      if (cnt > 0) {
+        EvPair ep{nullptr, nullptr, 1};
+        if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
+        if (mobi_launch_intra(&a, items_dev + plan.start[1], cnt, stream) != 0) return MOBI_E_DEVICE;
+        if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
+      }
+      return MOBI_OK;
     }
     for (uint32_t L = 1; L <= plan.n_levels(); L++) {
       int cnt = (int)(plan.start[L + 1] - plan.start[L]);
@@ -228,6 +242,7 @@ struct mobi_batch {
     if (d_fault) (void)hipFree(d_fault);
     if (d_scale) (void)hipFree(d_scale);
     if (d_prof) (void)hipFree(d_prof);
+    if (d_done) (void)hipFree(d_done);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -296,6 +311,12 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMalloc((void **)&b->d_scale, tab.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(b->d_scale, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   }
+  {
+    const size_t dbytes = (size_t)n_clips * b->g.mbw * b->g.mbh * 4;
+    if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
+    if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
+    if (const char *lv = getenv("MOBI_INTRA_LEVELS")) b->merged_intra = atoi(lv) == 0;
+  }
   if (b->debug == 9) {
     const size_t pbytes = (size_t)n_clips * (b->g.mbw * b->g.mbh) * 16;
     if (hipMalloc((void **)&b->d_prof, pbytes) != hipSuccess) return nullptr;
@@ -325,6 +346,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   }
   if (any_version_error) return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
+  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->frames_started++;
   LevelPlan plan;
   plan.build(ok);
@@ -350,7 +372,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->drain_events();
   for (int i = 0; i < n; i++)
-    if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = MOBI_E_CLAMP;
+    if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP; // bit 1: an intra dependency never arrived
   return MOBI_OK;
 }
 
@@ -456,6 +478,7 @@ int mobi_batch_commit(mobi_batch *b) {
 int mobi_batch_replay(mobi_batch *b, int frame_idx) {
   if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
   b->ring_base = (b->ring_base + 1) % 6;
+  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->frames_started++;
   MobiReconArgs a = b->args(b->r_cmd.p + b->r_desc_off[frame_idx], b->r_cmd.p + b->r_payload_off[frame_idx]);
   return b->launch_plan(a, b->r_plan[frame_idx], (const uint32_t *)b->r_items.p + b->r_items_off[frame_idx]);
@@ -468,7 +491,7 @@ int mobi_batch_sync(mobi_batch *b) {
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->drain_events();
   for (int i = 0; i < b->n; i++)
-    if (b->h_fault[i]) return MOBI_E_CLAMP;
+    if (b->h_fault[i]) return (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
   return MOBI_OK;
 }
 uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx) {

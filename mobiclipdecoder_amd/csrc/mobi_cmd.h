@@ -37,7 +37,10 @@ enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 // w5  [2:0] DUAL: ref slot of leaf 1   [4:3] MOBI_DUAL_* : the macroblock is exactly two halves (partition codes
 //     8 / 9 at the 16x16 level with two plain leaves, MD.cs:585-600 -- by far the most common split), leaf 0 =
 //     top / left, leaf 1 = bottom / right; no cell map is emitted for it
-// w6, w7 reserved (0)
+// w6, w7 reserved (0) for inter macroblocks
+// intra: w4..w7 hold up to 8 uint16 macroblock indices (MOBI_DEP_NONE = unused): the INTRA macroblocks of the same
+//        frame whose pixels this one's prediction halo reads.  The intra kernel runs all dependency levels of a
+//        frame step in one launch and waits on exactly these (mobi_kernels.hip).
 struct MbDesc {
   uint32_t payload_off;
   uint32_t w1;
@@ -48,6 +51,8 @@ struct MbDesc {
   uint32_t w6;
   uint32_t w7;
 };
+#define MOBI_DEP_NONE 0xFFFFu
+#define MOBI_INTRA_DEPS 8
 enum { MOBI_DUAL_NONE = 0, MOBI_DUAL_TB = 1, MOBI_DUAL_LR = 2 }; // two 16x8 (top, bottom) / two 8x16 (left, right)
 
 // ---- MC leaf (single-leaf macroblocks: inline in the descriptor) ------------------------------

@@ -25,9 +25,9 @@ struct MobiReconArgs { // field order is part of the kernel ABI: mobi_recon_inte
   int stride, mbw, n_mbs, n_clips;          // 16-19
   uint32_t magic_n_mbs, magic_mbw;          // 20, 21  floor(2^32 / d): no integer divides on the GPU
   uint32_t qpr, qpc, magic_qpr, magic_qpc;  // 22-25  quads (4 adjacent MBs = one wave) per MB row / per clip
-  int debug;                                // 26     profiling aid (env MOBI_DEBUG): 0 = normal
+  uint32_t step_tag;                        // 26     frame-step counter (never 0): done[] == step_tag means "reconstructed in this step"
   uint32_t inter_per_xcd;                   // 27     inter launch: workgroups per XCD (= gridDim.x / 8)
-  int pad0, pad1;                           // 28-29
+  uint32_t *done;                           // 28-29  [clip * n_mbs + mb] completion tags of intra macroblocks; null = one launch per level
   unsigned long long *prof;                 // 30-31  profiling accumulators (MOBI_DEBUG=9), else null
 };
 static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");

@@ -607,6 +607,27 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   uint8_t *uv0 = y0 + (size_t)S * A.height;
   const long off = (long)(mb / A.mbw) * 16 * S + (mb % A.mbw) * 16;
 
+  // All dependency levels of a frame step run in ONE launch (A.done != null): items are sorted by level, workgroups are
+  // dispatched in order, and a wave waits here until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this
+  // step's tag.  Hand-off across CUs: producer stores pixels write-through (sc1), drains them, then publishes its
+  // tag (sc1); the consumer polls the tag with sc1 loads and reads the halo with sc1 loads, so neither a stale L1
+  // line nor a dirty L2 line can sit in between (MI355X_MICROARCH.md, inter-workgroup visibility).
+  if (A.done) {
+    if (lane < MOBI_INTRA_DEPS) {
+      const uint32_t wv = (&desc->w4)[lane >> 1];
+      const uint32_t dep = (wv >> (16 * (lane & 1))) & 0xFFFFu;
+      if (dep != MOBI_DEP_NONE) {
+        const uint32_t *f = A.done + (size_t)clip * A.n_mbs + dep;
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.step_tag) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 21)) { atomicOr(&A.fault[clip], 2); break; } // a producer that never ran: report, do not hang
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
   uint32_t *L = lds[wave];
   uint8_t *ty = (uint8_t *)L;                 // 17 rows x TP
   uint8_t *tcu = (uint8_t *)(L + 136);        // 9 rows x TP
@@ -624,7 +645,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     else { r = (i - 41) >> 3; c = 16 + ((i - 41) & 7); }
     const long a = off + (long)r * S + c;
     const int o = g.owner_luma(a);
-    if (o >= 0 && o < mb) ty[(r + 1) * TP + 4 + c] = y0[a];
+    if (o >= 0 && o < mb) ty[(r + 1) * TP + 4 + c] = __hip_atomic_load(y0 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (int i = lane; i < 2 * (17 + 8 + 64); i += 64) {
     const int v = i >= 89, j = v ? i - 89 : i;
@@ -634,7 +655,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     else { r = (j - 25) >> 3; c = 8 + ((j - 25) & 7); }
     const long a = off / 2 + v * (S >> 1) + (long)r * S + c;
     const int o = g.owner_chroma(a);
-    if (o >= 0 && o < mb) (v ? tcv : tcu)[(r + 1) * TP + 4 + c] = uv0[a];
+    if (o >= 0 && o < mb) (v ? tcv : tcu)[(r + 1) * TP + 4 + c] = __hip_atomic_load(uv0 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 0, ncoef, t8, coef, lane);
   wave_sync();
@@ -665,11 +686,15 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   // ---- store interiors ----
   {
     const int row = lane >> 2, c4 = (lane & 3) * 4;
-    *(uint32_t *)(y0 + off + (long)row * S + c4) = *(const uint32_t *)(ty + (row + 1) * TP + 4 + c4);
+    __hip_atomic_store((uint32_t *)(y0 + off + (long)row * S + c4), *(const uint32_t *)(ty + (row + 1) * TP + 4 + c4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < 32) {
       const int v = lane >> 4, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-      *(uint32_t *)(uv0 + off / 2 + v * (S >> 1) + (long)crow * S + cc4) = *(const uint32_t *)((v ? tcv : tcu) + (crow + 1) * TP + 4 + cc4);
+      __hip_atomic_store((uint32_t *)(uv0 + off / 2 + v * (S >> 1) + (long)crow * S + cc4), *(const uint32_t *)((v ? tcv : tcu) + (crow + 1) * TP + 4 + cc4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+  if (A.done) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pixels have left this CU before the tag does
+    if (lane == 0) __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + mb, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

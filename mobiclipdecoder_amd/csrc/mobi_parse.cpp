@@ -519,8 +519,15 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     n_intra++;
     long off = (long)(mb / g_.mbw) * 16 * S + (mb % g_.mbw) * 16;
     int lv = 0;
+    uint16_t deps[MOBI_INTRA_DEPS];
+    int n_deps = 0;
     auto dep = [&](int o) {
-      if (o >= 0 && o < mb && level[o] > lv) lv = level[o];
+      if (o < 0 || o >= mb || level[o] == 0) return; // only raster-earlier INTRA macroblocks of this frame matter
+      if (level[o] > lv) lv = level[o];
+      for (int k = 0; k < n_deps; k++)
+        if (deps[k] == o) return;
+      if (n_deps == MOBI_INTRA_DEPS) fail(MOBI_E_UNSUPPORTED); // cannot happen: the halo touches at most 7 macroblocks
+      deps[n_deps++] = (uint16_t)o;
     };
     for (int c = -1; c <= MOBI_HALO_Y_RIGHT; c++) dep(g_.owner_luma(off - S + c));
     for (int r = 0; r < 16; r++) {
@@ -537,6 +544,12 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     }
     level[mb] = (uint16_t)(lv + 1);
     if (lv + 1 > maxl) maxl = lv + 1;
+    for (int k = n_deps; k < MOBI_INTRA_DEPS; k++) deps[k] = MOBI_DEP_NONE;
+    MbDesc &d = out.desc[mb];
+    d.w4 = deps[0] | ((uint32_t)deps[1] << 16);
+    d.w5 = deps[2] | ((uint32_t)deps[3] << 16);
+    d.w6 = deps[4] | ((uint32_t)deps[5] << 16);
+    d.w7 = deps[6] | ((uint32_t)deps[7] << 16);
   }
   out.level_start.assign(maxl + 2, 0);
   for (int mb = 0; mb < n; mb++)
