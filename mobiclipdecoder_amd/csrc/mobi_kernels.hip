@@ -550,6 +550,22 @@ extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter_
 // intra macroblocks of one dependency level
 // =====================================================================================================
 namespace {
+// byte load that bypasses this CU's L1 (sc1): issued now, valid only after ld_wait6() -- the compiler puts a full wait
+// behind every __hip_atomic_load, which serialises the halo into six round trips
+__device__ __forceinline__ uint32_t ld_u8_sc1(const uint8_t *p) {
+  uint32_t v;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_load_ubyte %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+#else
+  v = *p;
+#endif
+  return v;
+}
+__device__ __forceinline__ void ld_wait6(uint32_t (&v)[6]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : : "memory");
+#endif
+}
 struct TileNb {
   const uint8_t *t;
   int by, bx;
@@ -590,7 +606,7 @@ __device__ __forceinline__ void run_block(uint8_t *tile, int by, int bx, int n, 
 } // namespace
 
 extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs A, const uint32_t *items, int n_items) {
-  __shared__ uint32_t lds[WAVES][136 + 72 + 72 + 384 + 384];
+  __shared__ uint32_t lds[WAVES][136 + 72 + 72 + 384 + 384 + MOBI_SCALE_STRIDE];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int it = blockIdx.x * WAVES + wave;
   if (it >= n_items) return;
@@ -599,7 +615,7 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   const MbDesc *desc = A.desc + (long)clip * A.n_mbs + mb;
   const uint32_t w1 = desc->w1, w3 = desc->w3;
   const uint32_t *rec = A.payload + desc->payload_off;
-  const int32_t *sc = A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE;
+  const int32_t *sc_g = A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE;
   const int t8 = (w1 >> 14) & 0x3F, ncoef = desc->w2 & 0x3FF;
   const int S = A.stride;
   const Geo g{A.width, A.height, S, A.mbw, 31 - __builtin_clz((unsigned)S)};
@@ -607,6 +623,14 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   uint8_t *uv0 = y0 + (size_t)S * A.height;
   const long off = (long)(mb / A.mbw) * 16 * S + (mb % A.mbw) * 16;
 
+  // block records and the first 64 residual level words: in flight while the wave waits for its dependencies (a record fetched
+  // inside the block loop would be one exposed round trip per block)
+  const uint32_t myrec = lane < MOBI_INTRA_RECORDS ? rec[lane] : 0u;
+  const uint32_t mycw = lane < ncoef ? rec[MOBI_INTRA_RECORDS + lane] : 0u;
+  auto rec_at = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)myrec, i); };
+  const int32_t sc_lo = sc_g[lane], sc_hi = lane < MOBI_SCALE_STRIDE - 64 ? sc_g[64 + lane] : 0; // dequant scales -> LDS
+
+  const unsigned long long pt0 = A.prof ? __builtin_readcyclecounter() : 0;
   // All dependency levels of a frame step run in ONE launch (A.done != null): items are sorted by level, workgroups are
   // dispatched in order, and a wave waits here until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this
   // step's tag.  Hand-off across CUs: producer stores pixels write-through (sc1), drains them, then publishes its
@@ -627,27 +651,40 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  const unsigned long long pt1 = A.prof ? __builtin_readcyclecounter() : 0;
 
   uint32_t *L = lds[wave];
   uint8_t *ty = (uint8_t *)L;                 // 17 rows x TP
   uint8_t *tcu = (uint8_t *)(L + 136);        // 9 rows x TP
   uint8_t *tcv = (uint8_t *)(L + 136 + 72);
   int *coef = (int *)(L + 136 + 144), *tmp = coef + 384;
+  int32_t *sc = (int32_t *)(tmp + 384);
   for (int i = lane; i < 136 + 144; i += 64) L[i] = 0;
   zero_coefs(coef, lane);
+  sc[lane] = sc_lo;
+  if (lane < MOBI_SCALE_STRIDE - 64) sc[64 + lane] = sc_hi;
   wave_sync();
 
   // ---- halo: real pixels only from raster-earlier macroblocks; the rest is the reference's fresh 0 ----
-  for (int i = lane; i < 25 + 16 + 128; i += 64) {
+  // (all loads are issued before the first one is consumed: six dependent round trips otherwise)
+  int hpos[6];
+  uint32_t hval[6];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int i = lane + 64 * k;
     int r, c;
     if (i < 25) { r = -1; c = i - 1; }
     else if (i < 41) { r = i - 25; c = -1; }
     else { r = (i - 41) >> 3; c = 16 + ((i - 41) & 7); }
     const long a = off + (long)r * S + c;
     const int o = g.owner_luma(a);
-    if (o >= 0 && o < mb) ty[(r + 1) * TP + 4 + c] = __hip_atomic_load(y0 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool take = i < 25 + 16 + 128 && o >= 0 && o < mb;
+    hpos[k] = take ? (r + 1) * TP + 4 + c : -1;
+    hval[k] = ld_u8_sc1(y0 + (take ? a : off)); // not ours to read: load our own first pixel instead, and drop it
   }
-  for (int i = lane; i < 2 * (17 + 8 + 64); i += 64) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int i = lane + 64 * k;
     const int v = i >= 89, j = v ? i - 89 : i;
     int r, c;
     if (j < 17) { r = -1; c = j - 1; }
@@ -655,11 +692,20 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     else { r = (j - 25) >> 3; c = 8 + ((j - 25) & 7); }
     const long a = off / 2 + v * (S >> 1) + (long)r * S + c;
     const int o = g.owner_chroma(a);
-    if (o >= 0 && o < mb) (v ? tcv : tcu)[(r + 1) * TP + 4 + c] = __hip_atomic_load(uv0 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool take = i < 2 * (17 + 8 + 64) && o >= 0 && o < mb;
+    hpos[3 + k] = take ? (136 + v * 72) * 4 + (r + 1) * TP + 4 + c : -1; // tcu / tcv follow the luma tile
+    hval[3 + k] = ld_u8_sc1(uv0 + (take ? a : off / 2));
   }
-  scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 0, ncoef, t8, coef, lane);
+  ld_wait6(hval);
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+    if (hpos[k] >= 0) ty[hpos[k]] = (uint8_t)hval[k];
+  if (lane < ncoef) scatter_one(sc, mycw, t8, coef);
+  scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 64, ncoef, t8, coef, lane);
   wave_sync();
 
+  unsigned long long pt2 = 0;
+  if (A.prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt2 = __builtin_readcyclecounter(); }
   // ---- block records, in decode order ----
   int fault = 0;
   if (w3 & 1) run_block(ty, 0, 0, 16, 2, (int16_t)(w3 >> 16), false, coef, tmp, false, 0, off, false, S, lane, &fault);
@@ -667,14 +713,14 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     uint8_t *tile = a < 4 ? ty : (a == 4 ? tcu : tcv);
     const int ay = a < 4 ? (a >> 1) * 8 : 0, ax = a < 4 ? (a & 1) * 8 : 0;
     const long aoff = a < 4 ? off + (long)ay * S + ax : off / 2 + (a - 4) * (S >> 1);
-    const uint32_t r0 = rec[a * 4];
+    const uint32_t r0 = rec_at(a * 4);
     const bool pre = (r0 >> 6) & 1;
     if (pre) run_block(tile, ay, ax, 8, 2, (int16_t)(r0 >> 16), false, coef, tmp, false, 0, aoff, a >= 4, S, lane, &fault);
     if (!((r0 >> 5) & 1)) {
       run_block(tile, ay, ax, 8, r0 & 15, pre ? 0 : (int16_t)(r0 >> 16), (r0 >> 4) & 1, coef + 64 * a, tmp, true, 0, aoff, a >= 4, S, lane, &fault);
     } else {
       for (int s = 0; s < 4; s++) {
-        const uint32_t rr = rec[a * 4 + s];
+        const uint32_t rr = rec_at(a * 4 + s);
         const int sy = (s >> 1) * 4, sx = (s & 1) * 4;
         const int param = (s == 0 && pre) ? 0 : (int16_t)(rr >> 16);
         run_block(tile, ay + sy, ax + sx, 4, rr & 15, param, (rr >> 4) & 1, coef + 64 * a, tmp, false, s, aoff + (long)sy * S + sx, a >= 4, S, lane, &fault);
@@ -683,6 +729,8 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   }
   if (fault) atomicOr(&A.fault[clip], 1);
 
+  unsigned long long pt3 = 0;
+  if (A.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt3 = __builtin_readcyclecounter(); }
   // ---- store interiors ----
   {
     const int row = lane >> 2, c4 = (lane & 3) * 4;
@@ -695,6 +743,10 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   if (A.done) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pixels have left this CU before the tag does
     if (lane == 0) __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + mb, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (A.prof && lane == 0 && it < A.n_clips * A.n_mbs / 2) { // MOBI_DEBUG=9: dependency wait, loads, blocks, store+publish (shader clock)
+    const unsigned long long pt4 = __builtin_readcyclecounter();
+    ((uint4 *)A.prof)[(size_t)A.n_clips * A.n_mbs / 4 + it] = uint4{(uint32_t)(pt1 - pt0), (uint32_t)(pt2 - pt1), (uint32_t)(pt3 - pt2), (uint32_t)(pt4 - pt3)};
   }
 }
 

@@ -22,6 +22,13 @@ def run(tag, **kw):
     live = r.sum(1) > 0
     print(f"{tag}: quads {live.sum()}; mean cycles: issue {r[live,0].mean():.0f}  dma-wait {r[live,1].mean():.0f}  MC(4 MBs) {r[live,2].mean():.0f}  IDCT {r[live,3].mean():.0f}  total {r[live].sum(1).mean():.0f}; coded areas/quad {nent[live].mean():.1f} (>8: {(nent[live]>8).mean()*100:.0f}%)")
     print(f"    p50/p90: issue {np.median(r[live,0]):.0f}/{np.percentile(r[live,0],90):.0f} dma {np.median(r[live,1]):.0f}/{np.percentile(r[live,1],90):.0f} MC {np.median(r[live,2]):.0f}/{np.percentile(r[live,2],90):.0f} IDCT {np.median(r[live,3]):.0f}/{np.percentile(r[live,3],90):.0f}", flush=True)
+    ir = np.zeros((clips * 1200 // 4, 4), np.uint32)
+    full = np.zeros((clips * 1200, 4), np.uint32)
+    lib.mobi_debug_read_prof(b._h, full.ctypes.data, full.size)
+    ir = full[clips * 300:clips * 300 + clips * 150]
+    li = ir.sum(1) > 0
+    if li.any():
+        print(f"    intra items {li.sum()}: mean cycles: dep-wait {ir[li,0].mean():.0f}  loads {ir[li,1].mean():.0f}  blocks {ir[li,2].mean():.0f}  store+publish {ir[li,3].mean():.0f}; p90 {np.percentile(ir[li,0],90):.0f}/{np.percentile(ir[li,1],90):.0f}/{np.percentile(ir[li,2],90):.0f}/{np.percentile(ir[li,3],90):.0f}", flush=True)
     b.close()
 run('default')
 run('pure copy', pm_split1=0, pm_deep=0, cbp_prob=0, pm_intra=0)
