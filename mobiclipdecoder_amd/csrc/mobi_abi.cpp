@@ -97,10 +97,26 @@ struct LevelPlan { // launch plan of one frame step: items of level L are items[
   std::vector<uint32_t> start; // size n_levels + 2, index 0 unused
   bool any_inter = false;
   uint64_t cmd_bytes = 0;
-  void build(const std::vector<const ParsedFrame *> &frames) {
+  uint32_t K = 0; // one-launch layout: items = [clip][K] macroblock indices sorted by level, 0xFFFFFFFF padding
+  void build(const std::vector<const ParsedFrame *> &frames, bool one_launch) {
     uint32_t maxl = 0;
     any_inter = false;
     cmd_bytes = 0;
+    K = 0;
+    if (one_launch) {
+      for (auto *f : frames)
+        if (f) {
+          K = std::max(K, f->hdr.n_intra);
+          maxl = std::max(maxl, f->hdr.n_levels);
+          if (f->hdr.n_intra < f->hdr.n_mbs) any_inter = true;
+          cmd_bytes += f->hdr.cmd_bytes;
+        }
+      items.assign(frames.size() * (size_t)K, 0xFFFFFFFFu);
+      for (size_t c = 0; c < frames.size(); c++)
+        if (frames[c]) std::copy(frames[c]->intra_mbs.begin(), frames[c]->intra_mbs.end(), items.begin() + c * (size_t)K);
+      start.assign(maxl + 2, 0);
+      return;
+    }
     for (auto *f : frames)
       if (f) {
         maxl = std::max(maxl, f->hdr.n_levels);
@@ -144,7 +160,8 @@ struct mobi_batch {
   unsigned long long *d_prof = nullptr; // MOBI_DEBUG=9: in-kernel cycle accumulators
   uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
   uint32_t step_tag = 0;                // bumped once per frame step, never 0
-  bool merged_intra = true;             // all intra levels of a step in ONE launch (MOBI_INTRA_LEVELS=1: one launch per level)
+  int step_mode = 1;                    // 1: inter launch + ONE intra launch for all dependency levels (default, fastest measured);
+                                        // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
   // preloaded replay
   // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
   std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
@@ -182,7 +199,7 @@ struct mobi_batch {
     a.magic_n_mbs = magic((uint32_t)a.n_mbs);
     a.magic_mbw = magic((uint32_t)a.mbw);
     a.step_tag = step_tag;
-    a.done = merged_intra ? d_done : nullptr;
+    a.done = step_mode ? d_done : nullptr;
     a.prof = d_prof;
     a.qpr = (uint32_t)(a.mbw + 3) / 4;
     a.qpc = a.qpr * (uint32_t)g.mbh;
@@ -197,13 +214,22 @@ struct mobi_batch {
     return e;
   }
   int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev) {
-    if (plan.any_inter) {
+    if (step_mode == 2) { // the whole step -- inter quads and intra macroblocks of every clip -- is one launch
       EvPair ep{nullptr, nullptr, 0};
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
-      if (mobi_launch_inter(&a, stream) != 0) return MOBI_E_DEVICE;
+      if (mobi_launch_step(&a, items_dev, (int)plan.K, stream) != 0) return MOBI_E_DEVICE;
+      if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
+      return MOBI_OK;
+    }
+    if (plan.any_inter) {
+      MobiReconArgs ai = a;
+      ai.done = nullptr; // a separate inter launch is complete before any intra wave starts: plain stores, nothing to publish
+      EvPair ep{nullptr, nullptr, 0};
+      if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
+      if (mobi_launch_inter(&ai, stream) != 0) return MOBI_E_DEVICE;
       if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
-    if (merged_intra && plan.n_levels() >= 1) { // every level in one launch: items are sorted by level, waves wait on their own dependencies
+    if (step_mode == 1 && plan.n_levels() >= 1) { // every level in one launch: items are sorted by level, waves wait on their own dependencies
       const int cnt = (int)(plan.start[plan.n_levels() + 1] - plan.start[1]);
       if (cnt > 0) {
         EvPair ep{nullptr, nullptr, 1};
@@ -257,6 +283,7 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
   if (!b || !b->d_prof) return MOBI_E_ARG;
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(out, b->d_prof, n_words * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(b->d_prof, 0, n_words * 4)); // read and clear: the next read sees only the steps in between
   return MOBI_OK;
 }
 
@@ -315,7 +342,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     const size_t dbytes = (size_t)n_clips * b->g.mbw * b->g.mbh * 4;
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
-    if (const char *lv = getenv("MOBI_INTRA_LEVELS")) b->merged_intra = atoi(lv) == 0;
+    if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
   }
   if (b->debug == 9) {
     const size_t pbytes = (size_t)n_clips * (b->g.mbw * b->g.mbh) * 16;
@@ -349,7 +376,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->frames_started++;
   LevelPlan plan;
-  plan.build(ok);
+  plan.build(ok, b->step_mode == 2);
   // 2. stage [desc table][payload arena][items] and upload
   const int n_mbs = b->g.mbw * b->g.mbh;
   const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 4 * sizeof(MbDesc), kAlign); // slack: a quad reads 4 descriptors at once
@@ -444,7 +471,7 @@ int mobi_batch_commit(mobi_batch *b) {
     b->r_desc_off[f] = cmd_bytes;
     b->r_payload_off[f] = cmd_bytes + desc_bytes;
     cmd_bytes += desc_bytes + align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
-    b->r_plan[f].build(ok);
+    b->r_plan[f].build(ok, b->step_mode == 2);
     b->r_items_off[f] = n_items;
     n_items += b->r_plan[f].items.size();
   }

@@ -38,9 +38,9 @@ enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 //     8 / 9 at the 16x16 level with two plain leaves, MD.cs:585-600 -- by far the most common split), leaf 0 =
 //     top / left, leaf 1 = bottom / right; no cell map is emitted for it
 // w6, w7 reserved (0) for inter macroblocks
-// intra: w4..w7 hold up to 8 uint16 macroblock indices (MOBI_DEP_NONE = unused): the INTRA macroblocks of the same
-//        frame whose pixels this one's prediction halo reads.  The intra kernel runs all dependency levels of a
-//        frame step in one launch and waits on exactly these (mobi_kernels.hip).
+// intra: w4..w7 hold up to 8 uint16 macroblock indices (MOBI_DEP_NONE = unused): the raster-earlier macroblocks of the
+//        same frame, inter or intra, whose pixels this one's prediction halo reads.  When a frame step runs as one
+//        launch the macroblock waits for exactly these (mobi_recon_step in mobi_kernels.hip).
 struct MbDesc {
   uint32_t payload_off;
   uint32_t w1;
@@ -52,6 +52,7 @@ struct MbDesc {
   uint32_t w7;
 };
 #define MOBI_DEP_NONE 0xFFFFu
+#define MOBI_DEP_INTER 0x8000u /* flag on a dependency index: that macroblock is an inter one (index = low 13 bits) */
 #define MOBI_INTRA_DEPS 8
 enum { MOBI_DUAL_NONE = 0, MOBI_DUAL_TB = 1, MOBI_DUAL_LR = 2 }; // two 16x8 (top, bottom) / two 8x16 (left, right)
 

@@ -34,6 +34,9 @@ static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");
 
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
+// whole frame step in one launch: items_dev = [clip][K] macroblock indices of the intra macroblocks of each clip sorted by
+// dependency level, padded with 0xFFFFFFFF; needs a->done
+extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int K, hipStream_t s);
 // intra launch item: (clip << 13) | mb
 #define MOBI_ITEM(clip, mb) (((uint32_t)(clip) << 13) | (uint32_t)(mb))
 #endif

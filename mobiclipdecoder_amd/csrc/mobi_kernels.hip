@@ -522,14 +522,34 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t4 = __builtin_readcyclecounter(); }
 
   // ---- stage D: the quad leaves as whole rows: 64 B of luma, 8 B per macroblock of chroma ----
+  // One-launch steps (A.done): intra macroblocks of the same launch read these pixels from other CUs, so the stores are
+  // write-through (sc1), drained, and then the four macroblocks' completion tags are published (see mobi_recon_step).
   uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
   {
     const int gq = lane & 3, yrow = lane >> 2;
     if ((f32 >> (8 * gq)) & 1) {
-      *(uint4 *)(y0 + (off0 + (yrow << lgS) + gq * 16)) = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + gq * 16);
       const int pl = lane >> 5, row = (lane >> 2) & 7;
-      *(uint2 *)(y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + gq * 8);
+      uint8_t *py = y0 + (off0 + (yrow << lgS) + gq * 16), *pc = y0 + ysz + ((off0 >> 1) + pl * (S >> 1) + (row << lgS) + gq * 8);
+      const uint4 vy = *(const uint4 *)(L + Q_OUT_Y + yrow * 64 + gq * 16);
+      const uint2 vc = *(const uint2 *)(L + Q_OUT_C + pl * 256 + row * 32 + gq * 8);
+      if (A.done) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x4 ay = {vy.x, vy.y, vy.z, vy.w};
+        const u32x2 ac = {vc.x, vc.y};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_nop 1" : : "v"(py), "v"(ay), "v"(pc), "v"(ac) : "memory");
+#endif
+      } else {
+        *(uint4 *)py = vy;
+        *(uint2 *)pc = vc;
+      }
     }
+  }
+  if (A.done) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pixels have left this CU before the tags do
+    if (lane < 4 && ((f32 >> (8 * lane)) & 1))
+      __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + (mby * mbw + mbx0) + lane, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (PROF && lane == 0) // MOBI_DEBUG=9: where does a wave's life go (shader clock): issue, DMA wait, MC, IDCT
     ((uint4 *)A.prof)[qi] = uint4{(uint32_t)(t1 - t0), (uint32_t)(t2 - t1), (uint32_t)(t3 - t2) | ((uint32_t)__builtin_popcount(m32) << 24), (uint32_t)(t4 - t3)};
@@ -605,13 +625,9 @@ __device__ __forceinline__ void run_block(uint8_t *tile, int by, int bx, int n, 
 }
 } // namespace
 
-extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs A, const uint32_t *items, int n_items) {
-  __shared__ uint32_t lds[WAVES][136 + 72 + 72 + 384 + 384 + MOBI_SCALE_STRIDE];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int it = blockIdx.x * WAVES + wave;
-  if (it >= n_items) return;
-  const uint32_t item = items[it];
-  const int clip = (int)(item >> 13), mb = (int)(item & 0x1FFF);
+enum { INTRA_LDS_WORDS = 136 + 72 + 72 + 384 + 384 + MOBI_SCALE_STRIDE };
+// one intra macroblock by one wave; L = INTRA_LDS_WORDS words of LDS private to the wave; `it` only labels the profiling record
+__device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_t *L, int clip, int mb, int lane, int it, bool wait_inter) {
   const MbDesc *desc = A.desc + (long)clip * A.n_mbs + mb;
   const uint32_t w1 = desc->w1, w3 = desc->w3;
   const uint32_t *rec = A.payload + desc->payload_off;
@@ -640,8 +656,9 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
     if (lane < MOBI_INTRA_DEPS) {
       const uint32_t wv = (&desc->w4)[lane >> 1];
       const uint32_t dep = (wv >> (16 * (lane & 1))) & 0xFFFFu;
-      if (dep != MOBI_DEP_NONE) {
-        const uint32_t *f = A.done + (size_t)clip * A.n_mbs + dep;
+      // inter macroblocks only count when they run in this same launch (mobi_recon_step); a separate inter launch is complete
+      if (dep != MOBI_DEP_NONE && (wait_inter || !(dep & MOBI_DEP_INTER))) {
+        const uint32_t *f = A.done + (size_t)clip * A.n_mbs + (dep & 0x1FFFu);
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.step_tag) {
           __builtin_amdgcn_s_sleep(4);
@@ -653,7 +670,6 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   }
   const unsigned long long pt1 = A.prof ? __builtin_readcyclecounter() : 0;
 
-  uint32_t *L = lds[wave];
   uint8_t *ty = (uint8_t *)L;                 // 17 rows x TP
   uint8_t *tcu = (uint8_t *)(L + 136);        // 9 rows x TP
   uint8_t *tcv = (uint8_t *)(L + 136 + 72);
@@ -750,6 +766,56 @@ extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs
   }
 }
 
+extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs A, const uint32_t *items, int n_items) {
+  __shared__ uint32_t lds[WAVES][INTRA_LDS_WORDS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int it = blockIdx.x * WAVES + wave;
+  if (it >= n_items) return;
+  const uint32_t item = items[it];
+  recon_intra_item(A, lds[wave], (int)(item >> 13), (int)(item & 0x1FFF), lane, it, false);
+}
+
+// =====================================================================================================
+// mobi_recon_step: a whole frame step -- every inter quad and every intra macroblock of every clip -- in ONE launch
+// =====================================================================================================
+// One wave per workgroup.  Workgroup b runs on XCD b & 7 (observed dispatch order, used for speed and for the
+// order of arrival only -- correctness rests on the completion tags).  Each XCD owns a contiguous range of clips
+// and walks it in segments: segment s = the quads of its clip s, then the intra macroblocks (sorted by dependency
+// level, padded to K per clip) of its clip s - STEP_LAG, whose inter neighbours have been dispatched a while ago.
+// An intra wave waits until every raster-earlier macroblock its halo reads carries this step's tag (done[]); quads
+// publish theirs after write-through stores.  Workgroups are dispatched in index order, so whatever a wave waits for
+// was dispatched before it: waiting cannot deadlock (and a bounded spin reports instead of hanging if that ever fails).
+enum { STEP_LAG = 2 };
+struct MobiStepArgs {
+  const uint32_t *items; // [clip][K] macroblock index or 0xFFFFFFFF
+  uint32_t K, seg, magic_seg, clips_per_xcd;
+};
+template <bool PROF>
+__device__ __forceinline__ void recon_step_entry(const MobiReconArgs &A, const MobiStepArgs &T) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[Q_BYTES > INTRA_LDS_WORDS * 4 ? Q_BYTES : INTRA_LDS_WORDS * 4];
+  const int lane = threadIdx.x;
+  const uint32_t x = blockIdx.x & 7, v = blockIdx.x >> 3;
+  uint32_t pos;
+  const uint32_t sgm = fastdiv(v, T.seg, T.magic_seg, pos);
+  if (pos < A.qpc) {
+    if (sgm >= T.clips_per_xcd) return;
+    const uint32_t clip = x * T.clips_per_xcd + sgm;
+    if (clip >= (uint32_t)A.n_clips) return;
+    recon_inter_quad<PROF>(A, lds, clip * A.qpc + pos, lane);
+  } else {
+    if (sgm < STEP_LAG || sgm - STEP_LAG >= T.clips_per_xcd) return;
+    const uint32_t clip = x * T.clips_per_xcd + (sgm - STEP_LAG);
+    if (clip >= (uint32_t)A.n_clips) return;
+    const uint32_t slot = pos - A.qpc;
+    const uint32_t mb = T.items[(size_t)clip * T.K + slot];
+    if (mb == 0xFFFFFFFFu) return;
+    __builtin_amdgcn_s_setprio(3); // few, long and latency-bound: let them through ahead of the VALU-bound quads
+    recon_intra_item(A, (uint32_t *)lds, (int)clip, (int)mb, lane, (int)(clip * T.K + slot), true);
+  }
+}
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_step(MobiReconArgs A, MobiStepArgs T) { recon_step_entry<false>(A, T); }
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_step_prof(MobiReconArgs A, MobiStepArgs T) { recon_step_entry<true>(A, T); }
+
 // =====================================================================================================
 // launch wrappers (called from mobi_abi.cpp)
 // =====================================================================================================
@@ -768,5 +834,19 @@ extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_d
   if (n_items <= 0) return 0;
   const unsigned grid = (unsigned)((n_items + WAVES - 1) / WAVES);
   hipLaunchKernelGGL(mobi_recon_intra, dim3(grid), dim3(64 * WAVES), 0, s, *a, items_dev, n_items);
+  return (int)hipGetLastError();
+}
+extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int K, hipStream_t s) {
+  if (a->slot_bytes >= (1u << 24) || !a->done || a->n_clips <= 0) return (int)hipErrorInvalidValue;
+  MobiStepArgs t;
+  t.items = items_dev;
+  t.K = (uint32_t)K;
+  t.seg = a->qpc + (uint32_t)K;
+  const uint64_t m = ((uint64_t)1 << 32) / t.seg;
+  t.magic_seg = (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m);
+  t.clips_per_xcd = ((uint32_t)a->n_clips + 7) / 8;
+  const unsigned grid = 8u * (t.clips_per_xcd + STEP_LAG) * t.seg;
+  if (a->prof) hipLaunchKernelGGL(mobi_recon_step_prof, dim3(grid), dim3(64), 0, s, *a, t);
+  else hipLaunchKernelGGL(mobi_recon_step, dim3(grid), dim3(64), 0, s, *a, t);
   return (int)hipGetLastError();
 }

@@ -522,12 +522,13 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     uint16_t deps[MOBI_INTRA_DEPS];
     int n_deps = 0;
     auto dep = [&](int o) {
-      if (o < 0 || o >= mb || level[o] == 0) return; // only raster-earlier INTRA macroblocks of this frame matter
-      if (level[o] > lv) lv = level[o];
+      if (o < 0 || o >= mb) return; // raster-later owners read as the fresh plane's zeros (the kernel masks them)
+      if (level[o] > lv) lv = level[o]; // levels order intra macroblocks only (inter ones are level 0) ...
+      // ... but the dependency list names every raster-earlier owner: in a one-launch step the inter quads run alongside
       for (int k = 0; k < n_deps; k++)
-        if (deps[k] == o) return;
+        if ((deps[k] & 0x1FFF) == o) return;
       if (n_deps == MOBI_INTRA_DEPS) fail(MOBI_E_UNSUPPORTED); // cannot happen: the halo touches at most 7 macroblocks
-      deps[n_deps++] = (uint16_t)o;
+      deps[n_deps++] = (uint16_t)(o | (level[o] == 0 ? MOBI_DEP_INTER : 0));
     };
     for (int c = -1; c <= MOBI_HALO_Y_RIGHT; c++) dep(g_.owner_luma(off - S + c));
     for (int r = 0; r < 16; r++) {

@@ -15,6 +15,9 @@ def run(tag, **kw):
     b.commit(); b.replay(0)
     for f in range(1, 6): b.replay(f)
     b.sync()
+    junk = np.zeros((clips * 1200, 4), np.uint32)
+    lib.mobi_debug_read_prof(b._h, junk.ctypes.data, junk.size)  # read-and-clear: drop the I-frame's records
+    b.replay(6); b.sync()
     rec = np.zeros((clips * 300, 4), np.uint32)
     lib.mobi_debug_read_prof(b._h, rec.ctypes.data, rec.size)
     nent = rec[:, 2] >> 24
