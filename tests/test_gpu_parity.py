@@ -179,3 +179,27 @@ def test_clamp_domain_fault_is_reported():
         assert gpu.last_error in (-1, -6)
         gpu.close()
     pytest.skip("no clamp-only fault found in the random search")
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_every_step_mode_is_bit_exact(mode, monkeypatch):
+    """The frame step can run as inter + one intra launch per dependency level (0), inter + ONE intra launch whose
+    waves wait on per-macroblock completion tags (1, default), or one launch for everything (2).  All three must
+    reproduce the oracle, I-frames (deep dependency chains) and intra-heavy P-frames included, also in a batch."""
+    monkeypatch.setenv("MOBI_STEP_MODE", mode)  # read when the decoder / batch is created
+    _run_stream(default_params("B", BASE_SEED + 31, n_frames=8, pm_intra=300, iframe_interval=4))
+    _run_stream(default_params("A", BASE_SEED + 32, n_frames=8, pm_intra=200, edge_mode=1, mv_range=40))
+    nclips, nfr = 11, 6  # more clips than XCDs: the one-launch layout walks several clips per XCD
+    ps = [default_params("A", BASE_SEED + 300 + i, n_frames=nfr, pm_intra=250) for i in range(nclips)]
+    clips = [generate_clip(p) for p in ps]
+    b = MobiclipBatch(nclips, ps[0].width, ps[0].height, ps[0].version)
+    oras = [OracleDecoder(p.width, p.height, p.version) for p in ps]
+    for f in range(nfr):
+        rcs, offs = b.decode([c[0] for c in clips], [int(c[1][f]) for c in clips])
+        for c in range(nclips):
+            oras[c].Data, oras[c].Offset = clips[c][0], int(clips[c][1][f])
+            o = oras[c].DecodeFrame()
+            assert rcs[c] == 0 and offs[c] == oras[c].Offset
+            y, uv = b.planes(c)
+            assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (mode, f, c)
+    b.close()
