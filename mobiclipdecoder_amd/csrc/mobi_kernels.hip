@@ -232,11 +232,12 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
     for (int m = 0; m < 8; m++) in[m] = t[8 * r + m];
     mobi_bfly8(in, out);
     uint8_t *row = px + r * pitch;
+    const uint2 pred = *(const uint2 *)row; // px is 8-byte aligned
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int v = (int)row[j] + (out[j] >> 6);
+      const int v = (int)(((j < 4 ? pred.x : pred.y) >> (8 * (j & 3))) & 0xFF) + (out[j] >> 6);
       lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-      row[j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      ((volatile uint8_t *)row)[j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); // byte stores: LDS has issue slots to spare, the VALU has not
     }
   } else {
     const int s = r >> 1;
@@ -499,7 +500,9 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       for (int k = 0; k < 4; k++) {
         const bool mine = (uint32_t)(16 * k + j) < ncoef;
         if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
-        if (mine) scatter(cwr[k]);
+        uint32_t e = cwr[k];
+        asm volatile("" : "+v"(e)); // keeps the decode of words 16.. behind the branch (the compiler hoists it out of the pass loop otherwise)
+        if (mine) scatter(e);
       }
       for (uint32_t i = 64u + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 16)
         if (i < ncoef) scatter(cw[i]);
