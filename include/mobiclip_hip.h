@@ -60,6 +60,12 @@ int mobi_decode(mobi_dec *d, const uint8_t *data, size_t len, int32_t *offset_in
  * [Stride/2,Stride) of each row (MD.cs:414-415).  Either pointer may be NULL.
  * Returns MOBI_E_NULLREF when that ring slot has never been produced. */
 int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
+/* The Bitmap that DecodeFrame() returns (MD.cs:260-323) for the frame just decoded: width*height 0xAARRGGBB
+ * words, row pitch = width (Format32bppArgb as LockBits hands it out: bytes B,G,R,A).  Chroma is averaged from up
+ * to four neighbours by pixel parity, then the float matrix with range stretch (Moflex3DS) or the integer form
+ * (ModsDS); float arithmetic is IEEE single, one rounding per operator of the source, no FMA.
+ * MOBI_E_NULLREF before the first frame. */
+int mobi_get_argb(mobi_dec *d, uint32_t *out);
 int mobi_stride(const mobi_dec *d);            /* d.Stride     (MD.cs:30,50-52) */
 uint32_t mobi_quantizer(const mobi_dec *d);    /* d.Quantizer  (MD.cs:26) */
 uint32_t mobi_yuv_format(const mobi_dec *d);   /* d.YuvFormat  (MD.cs:27) */
@@ -75,6 +81,11 @@ void mobi_batch_destroy(mobi_batch *b);
  * MOBI_E_DEVICE/ARG failure of the call itself (per-clip stream errors go to rc[]). */
 int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
+/* Bitmaps (MD.cs:260-323): mobi_batch_convert_argb converts ring slot 0 of EVERY clip into a device-resident buffer
+ * (asynchronously, on the batch's stream); mobi_batch_get_argb copies one clip's width*height words out, converting
+ * just that clip first if the whole-batch conversion has not been run for the current frame. */
+int mobi_batch_convert_argb(mobi_batch *b);
+int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out);
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip);
 int mobi_batch_stride(const mobi_batch *b);
 int mobi_batch_n_clips(const mobi_batch *b);

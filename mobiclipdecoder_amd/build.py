@@ -42,7 +42,7 @@ def _hdrs(d):
 
 
 def build_hip(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_kernels.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_kernels.hip", "mobi_rgb.hip")]
     deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h")]
     if not force and not _newer(LIB_HIP, deps):
         return LIB_HIP
@@ -54,9 +54,10 @@ def build_hip(force=False):
         o = os.path.join(obj, os.path.basename(s) + ".o")
         _run(["g++"] + host_flags + ["-c", s, "-o", o])
         objs.append(o)
-    ko = os.path.join(obj, "mobi_kernels.o")
-    _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", srcs[2], "-o", ko])
-    objs.append(ko)
+    for s in srcs[2:]:
+        ko = os.path.join(obj, os.path.basename(s) + ".o")
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", ko])
+        objs.append(ko)
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_HIP])
     return LIB_HIP
 
@@ -73,7 +74,7 @@ def build_oracle(force=False):
     src = os.path.join(odir, "mobi_oracle.c")
     if force or _newer(LIB_ORACLE, [src] + _hdrs(odir)):
         os.makedirs(os.path.dirname(LIB_ORACLE), exist_ok=True)
-        _run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-fwrapv", "-Wall", src, "-o", LIB_ORACLE])
+        _run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-fwrapv", "-ffp-contract=off", "-Wall", src, "-o", LIB_ORACLE])
     return LIB_ORACLE
 
 

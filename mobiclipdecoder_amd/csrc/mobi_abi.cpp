@@ -158,6 +158,9 @@ struct mobi_batch {
   DevBuf d_cmd, d_items;
   int32_t *d_scale = nullptr; // [MOBI_SCALE_QMAX][MOBI_SCALE_STRIDE]
   unsigned long long *d_prof = nullptr; // MOBI_DEBUG=9: in-kernel cycle accumulators
+  uint32_t *d_argb = nullptr;           // Bitmap output of mobi_batch_convert_argb / mobi_batch_get_argb (lazily allocated)
+  size_t argb_bytes = 0;
+  bool argb_all_valid = false;          // d_argb holds every clip's Bitmap of the current frame
   uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
   uint32_t step_tag = 0;                // bumped once per frame step, never 0
   int step_mode = 1;                    // 1: inter launch + ONE intra launch for all dependency levels (default, fastest measured);
@@ -269,6 +272,7 @@ struct mobi_batch {
     if (d_scale) (void)hipFree(d_scale);
     if (d_prof) (void)hipFree(d_prof);
     if (d_done) (void)hipFree(d_done);
+    if (d_argb) (void)hipFree(d_argb);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -374,6 +378,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (any_version_error) return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
+  b->argb_all_valid = false;
   b->frames_started++;
   LevelPlan plan;
   plan.build(ok, b->step_mode == 2);
@@ -412,6 +417,43 @@ int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out,
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (y_out) HIP_TRY(hipMemcpy(y_out, slot, ysz, hipMemcpyDeviceToHost));
   if (uv_out) HIP_TRY(hipMemcpy(uv_out, slot + ysz, ysz / 2, hipMemcpyDeviceToHost));
+  return MOBI_OK;
+}
+// ---- the Bitmap of DecodeFrame(), MD.cs:260-323 ---------------------------------------------------------
+static int ensure_argb(mobi_batch *b, int n_clips) {
+  const size_t need = (size_t)n_clips * b->g.width * b->g.height * 4;
+  if (b->d_argb && b->argb_bytes >= need) return MOBI_OK;
+  if (b->d_argb) (void)hipFree(b->d_argb);
+  b->d_argb = nullptr;
+  b->argb_bytes = 0;
+  HIP_TRY(hipMalloc((void **)&b->d_argb, need));
+  b->argb_bytes = need;
+  return MOBI_OK;
+}
+int mobi_batch_convert_argb(mobi_batch *b) {
+  if (!b) return MOBI_E_ARG;
+  if (b->frames_started < 1) return MOBI_E_NULLREF;
+  HIP_TRY(hipSetDevice(b->device));
+  if (int e = ensure_argb(b, b->n)) return e;
+  MobiReconArgs a = b->args(nullptr, nullptr);
+  if (mobi_launch_argb(&a, b->version, 0, b->n, b->d_argb, b->stream) != 0) return MOBI_E_DEVICE;
+  b->argb_all_valid = true;
+  return MOBI_OK;
+}
+int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out) {
+  if (!b || clip < 0 || clip >= b->n || !out) return MOBI_E_ARG;
+  if (b->frames_started < 1) return MOBI_E_NULLREF;
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t words = (size_t)b->g.width * b->g.height;
+  size_t src_clip = (size_t)clip;
+  if (!b->argb_all_valid) { // convert just this clip into the front of the buffer
+    if (int e = ensure_argb(b, 1)) return e;
+    MobiReconArgs a = b->args(nullptr, nullptr);
+    if (mobi_launch_argb(&a, b->version, clip, 1, b->d_argb, b->stream) != 0) return MOBI_E_DEVICE;
+    src_clip = 0;
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->d_argb + src_clip * words, words * 4, hipMemcpyDeviceToHost));
   return MOBI_OK;
 }
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) { return (b && clip >= 0 && clip < b->n) ? b->parsers[clip]->quantizer() : 0; }
@@ -506,6 +548,7 @@ int mobi_batch_replay(mobi_batch *b, int frame_idx) {
   if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
   b->ring_base = (b->ring_base + 1) % 6;
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
+  b->argb_all_valid = false;
   b->frames_started++;
   MobiReconArgs a = b->args(b->r_cmd.p + b->r_desc_off[frame_idx], b->r_cmd.p + b->r_payload_off[frame_idx]);
   return b->launch_plan(a, b->r_plan[frame_idx], (const uint32_t *)b->r_items.p + b->r_items_off[frame_idx]);
@@ -575,6 +618,7 @@ int mobi_decode(mobi_dec *d, const uint8_t *data, size_t len, int32_t *offset_in
   int e = mobi_batch_decode(d->b, dp, lp, offset_inout, &rc);
   return e != MOBI_OK ? e : rc;
 }
+int mobi_get_argb(mobi_dec *d, uint32_t *out) { return d ? mobi_batch_get_argb(d->b, 0, out) : MOBI_E_ARG; }
 int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out) { return d ? mobi_batch_get_planes(d->b, 0, ring_idx, y_out, uv_out) : MOBI_E_ARG; }
 int mobi_stride(const mobi_dec *d) { return d ? d->b->g.stride : 0; }
 uint32_t mobi_quantizer(const mobi_dec *d) { return d ? d->b->parsers[0]->quantizer() : 0; }

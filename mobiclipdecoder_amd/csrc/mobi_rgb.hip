@@ -1,0 +1,89 @@
+// mobi_rgb.hip -- the Bitmap that MobiclipDecoder.DecodeFrame() returns (MD.cs:260-323), on the GPU.
+//
+// Per pixel: Y, plus U and V averaged from up to four chroma neighbours chosen by the pixel's parity (not on the
+// last column / last row, MD.cs:269), then either the float BT.601-like matrix with the 16..255 range stretch
+// (Moflex3DS, :297-305) or the integer Y+U-V / Y+V / Y-U-V form on truncated values (ModsDS, :306-311), clamp,
+// truncate, pack as 0xAARRGGBB (:313-319).  HBM-bound: 1.5 bytes read, 4 written per pixel.
+//
+// Float semantics are the reference's: IEEE single, one rounding per C# operator in source order.  Hence the
+// __f*_rn intrinsics throughout: hipcc contracts a*b+c into an FMA by default, which rounds once instead of twice.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mobi_kernels.h"
+
+namespace {
+__device__ __forceinline__ uint32_t pack_argb(float R, float G, float B) {
+  R = R < 0.f ? 0.f : R; R = R > 255.f ? 255.f : R; // :313-318
+  G = G < 0.f ? 0.f : G; G = G > 255.f ? 255.f : G;
+  B = B < 0.f ? 0.f : B; B = B > 255.f ? 255.f : B;
+  return 0xFF000000u | ((uint32_t)(int)R << 16) | ((uint32_t)(int)G << 8) | (uint32_t)(int)B; // Color.FromArgb(r, g, b).ToArgb()
+}
+__device__ __forceinline__ uint32_t convert_px(int version, float Y2, float U, float V) {
+  if (version == 2) { // Moflex3DS
+    float R = __fadd_rn(Y2, __fmul_rn(1.420f, V));
+    float G = __fsub_rn(__fsub_rn(Y2, __fmul_rn(0.344f, U)), __fmul_rn(0.714f, V));
+    float B = __fadd_rn(Y2, __fmul_rn(1.772f, U));
+    R = __fdiv_rn(__fmul_rn(__fsub_rn(R, 16.f), 255.f), 239.f); // (255f - 16f) is a constant
+    G = __fdiv_rn(__fmul_rn(__fsub_rn(G, 16.f), 255.f), 239.f);
+    B = __fdiv_rn(__fmul_rn(__fsub_rn(B, 16.f), 255.f), 239.f);
+    return pack_argb(R, G, B);
+  }
+  const int y = (int)Y2, u = (int)U, v = (int)V; // ModsDS: casts truncate toward zero
+  return pack_argb((float)(y + u - v), (float)(y + v), (float)(y - u - v));
+}
+} // namespace
+
+// one lane = 4 horizontally adjacent pixels (one 16-byte store); block = 256 lanes = 1024 pixels of one row
+extern "C" __global__ __launch_bounds__(256) void mobi_yuv_to_argb(const uint8_t *planes, uint64_t clip_bytes, uint32_t slot_bytes, int ring_base,
+                                                                  int width, int height, int stride, int version, int clip0, uint32_t *out) {
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, clip = blockIdx.z;
+  if (x0 >= width) return;
+  const uint8_t *Y = planes + (size_t)(clip0 + clip) * clip_bytes + (size_t)ring_base * slot_bytes;
+  const uint8_t *UV = Y + (size_t)stride * height;
+  const int S = stride, hS = stride >> 1;
+  const uint32_t yw = *(const uint32_t *)(Y + (size_t)y * S + x0); // width is a multiple of 16: all four pixels exist
+  const int c = (y >> 1) * S + (x0 >> 1);
+  const bool lastrow = y == height - 1, odd = (y & 1) != 0, vert = odd && !lastrow;
+  // chroma samples this lane may touch: columns c .. c+2 of this chroma row and, for odd luma rows, of the next one
+  float u[2][3], v[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const bool need = (r == 0 || vert) && (k < 2 || x0 + 3 != width - 1); // column c+2 only serves pixel 3's interpolation
+      u[r][k] = need ? __fsub_rn((float)UV[c + r * S + k], 128.f) : 0.f;
+      v[r][k] = need ? __fsub_rn((float)UV[c + r * S + k + hS], 128.f) : 0.f;
+    }
+  uint32_t px[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x0 + i, k = i >> 1;
+    float U = u[0][k], V = v[0][k];
+    if (x != width - 1 && !lastrow) { // MD.cs:269
+      const bool h = (x & 1) != 0;
+      if (h && !odd) { // case 1
+        U = __fadd_rn(U, u[0][k + 1]); V = __fadd_rn(V, v[0][k + 1]);
+        U = __fdiv_rn(U, 2.f); V = __fdiv_rn(V, 2.f);
+      } else if (!h && odd) { // case 2
+        U = __fadd_rn(U, u[1][k]); V = __fadd_rn(V, v[1][k]);
+        U = __fdiv_rn(U, 2.f); V = __fdiv_rn(V, 2.f);
+      } else if (h && odd) { // case 3: +1, +Stride, +1+Stride in this order
+        U = __fadd_rn(U, u[0][k + 1]); V = __fadd_rn(V, v[0][k + 1]);
+        U = __fadd_rn(U, u[1][k]); V = __fadd_rn(V, v[1][k]);
+        U = __fadd_rn(U, u[1][k + 1]); V = __fadd_rn(V, v[1][k + 1]);
+        U = __fdiv_rn(U, 4.f); V = __fdiv_rn(V, 4.f);
+      }
+    }
+    px[i] = convert_px(version, (float)((yw >> (8 * i)) & 0xFF), U, V);
+  }
+  *(uint4 *)(out + ((size_t)clip * height + y) * width + x0) = uint4{px[0], px[1], px[2], px[3]};
+}
+
+extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, int n_clips, uint32_t *out_dev, hipStream_t s) {
+  if (n_clips <= 0) return 0;
+  const dim3 grid((unsigned)((a->width / 4 + 255) / 256), (unsigned)a->height, (unsigned)n_clips);
+  hipLaunchKernelGGL(mobi_yuv_to_argb, grid, dim3(256), 0, s, (const uint8_t *)a->planes, (uint64_t)a->clip_bytes, a->slot_bytes, a->ring_base,
+                     a->width, a->height, a->stride, version, clip0, out_dev);
+  return (int)hipGetLastError();
+}

@@ -38,6 +38,7 @@ _SIGS = {
     "mobi_destroy": (None, [C.c_void_p]),
     "mobi_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)]),
     "mobi_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mobi_get_argb": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mobi_stride": (C.c_int, [C.c_void_p]),
     "mobi_quantizer": (C.c_uint32, [C.c_void_p]),
     "mobi_yuv_format": (C.c_uint32, [C.c_void_p]),
@@ -47,6 +48,8 @@ _SIGS = {
     "mobi_batch_destroy": (None, [C.c_void_p]),
     "mobi_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
+    "mobi_batch_get_argb": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mobi_batch_quantizer": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_stride": (C.c_int, [C.c_void_p]),
     "mobi_batch_n_clips": (C.c_int, [C.c_void_p]),
@@ -162,6 +165,17 @@ class MobiclipDecoder:
             raise MobiclipError(error_string(rc))
         return (y.reshape(H, S) if which == 0 else uv.reshape(H // 2, S))
 
+    def Bitmap(self):
+        """The Bitmap DecodeFrame() returns in the reference (MD.cs:260-323), for the frame just decoded:
+        (Height, Width) uint32 array of 0xAARRGGBB; None before the first frame."""
+        out = np.empty((self.Height, self.Width), np.uint32)
+        rc = self._lib.mobi_get_argb(self._h, out.ctypes.data)
+        if rc == -2:  # MOBI_E_NULLREF
+            return None
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.mobi_destroy(self._h)
@@ -210,6 +224,19 @@ class MobiclipBatch:
         if rc != 0:
             raise MobiclipError(error_string(rc))
         return y.reshape(H, S), uv.reshape(H // 2, S)
+
+    def convert_argb(self):
+        """Bitmaps of every clip's current frame into a device-resident buffer (asynchronous)."""
+        rc = self._lib.mobi_batch_convert_argb(self._h)
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+
+    def bitmap(self, clip):
+        out = np.empty((self.Height, self.Width), np.uint32)
+        rc = self._lib.mobi_batch_get_argb(self._h, clip, out.ctypes.data)
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return out
 
     def quantizer(self, clip):
         return self._lib.mobi_batch_quantizer(self._h, clip)

@@ -1166,6 +1166,62 @@ const uint8_t *mobi_oracle_y(const mobi_oracle *d, int idx) { return (idx >= 0 &
 const uint8_t *mobi_oracle_uv(const mobi_oracle *d, int idx) { return (idx >= 0 && idx < 6) ? d->UV[idx].p : NULL; }
 uint32_t *mobi_oracle_internal(mobi_oracle *d) { return d->Internal; }
 
+/* ---- YUV -> ARGB, MD.cs:260-323 (compile with -ffp-contract=off: every operator rounds once, as in the CLR) ---- */
+int mobi_oracle_argb(const mobi_oracle *d, uint32_t *out) {
+  const uint8_t *Y = d->Y[0].p, *UV = d->UV[0].p;
+  if (!Y || !UV) return ORA_E_NULLREF;
+  const int S = d->Stride, W = (int)d->Width, H = (int)d->Height;
+  for (int y = 0; y < H; y++) {
+    for (int x = 0; x < W; x++) {
+      volatile float Y2 = (float)Y[y * S + x];                    /* :266 */
+      const int c = y / 2 * S + x / 2;
+      volatile float U = (float)UV[c] - 128.0f;                   /* :267 */
+      volatile float V = (float)UV[c + S / 2] - 128.0f;           /* :268 */
+      if (x != W - 1 && y != H - 1) {                             /* :269 */
+        switch ((x & 1) | ((y & 1) << 1)) {                       /* :271 */
+          case 1: /* :273-278 */
+            U += (float)UV[c + 1] - 128.0f; V += (float)UV[c + 1 + S / 2] - 128.0f;
+            U /= 2.0f; V /= 2.0f;
+            break;
+          case 2: /* :279-284 */
+            U += (float)UV[c + S] - 128.0f; V += (float)UV[c + S + S / 2] - 128.0f;
+            U /= 2.0f; V /= 2.0f;
+            break;
+          case 3: /* :285-294 */
+            U += (float)UV[c + 1] - 128.0f; V += (float)UV[c + 1 + S / 2] - 128.0f;
+            U += (float)UV[c + S] - 128.0f; V += (float)UV[c + S + S / 2] - 128.0f;
+            U += (float)UV[c + 1 + S] - 128.0f; V += (float)UV[c + 1 + S + S / 2] - 128.0f;
+            U /= 4.0f; V /= 4.0f;
+            break;
+        }
+      }
+      volatile float R, G, B, t;
+      if (d->Version == MOBI_VER_MOFLEX3DS) {                     /* :297-305 */
+        t = 1.420f * V; R = Y2 + t;
+        t = 0.344f * U; G = Y2 - t; t = 0.714f * V; G = G - t;
+        t = 1.772f * U; B = Y2 + t;
+        t = R - 16.0f; t = t * 255.0f; R = t / 239.0f;            /* (255f - 16f) folds to 239f */
+        t = G - 16.0f; t = t * 255.0f; G = t / 239.0f;
+        t = B - 16.0f; t = t * 255.0f; B = t / 239.0f;
+      } else if (d->Version == MOBI_VER_MODSDS) {                 /* :306-311: integer arithmetic on truncated values */
+        R = (float)((int)Y2 + (int)U - (int)V);
+        G = (float)((int)Y2 + (int)V);
+        B = (float)((int)Y2 - (int)U - (int)V);
+      } else {
+        R = G = B = 0.0f;
+      }
+      if (R < 0) R = 0;                                           /* :313-318 */
+      if (R > 255) R = 255;
+      if (G < 0) G = 0;
+      if (G > 255) G = 255;
+      if (B < 0) B = 0;
+      if (B > 255) B = 255;
+      out[y * W + x] = 0xFF000000u | ((uint32_t)(int)R << 16) | ((uint32_t)(int)G << 8) | (uint32_t)(int)B; /* Color.FromArgb(r,g,b).ToArgb(), :319 */
+    }
+  }
+  return ORA_OK;
+}
+
 /* ---- unit-level hooks: run one primitive on caller memory through a scratch decoder ---- */
 static D *scratch(int stride) {
   D *d = (D *)calloc(1, sizeof(D));

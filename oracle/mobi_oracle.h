@@ -3,7 +3,7 @@
  *
  * This is a plain-C restatement of the reference decoder
  *   /root/reference/LibMobiclip/Codec/Mobiclip/MobiclipDecoder.cs  (DecodeVXS2 and callees,
- *   :97-259 and :400-3937; the Bitmap/RGB block :260-323 is NOT part of the graded path)
+ *   :97-259 and :400-3937; the Bitmap/RGB block :260-323 is restated separately in mobi_oracle_argb)
  * used as the checker for the HIP path.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py may load it.  The product library (libmobiclip_hip.so)
  * never links, loads or calls anything in oracle/.
@@ -52,6 +52,12 @@ uint32_t mobi_oracle_yuvformat(const mobi_oracle *d);
  * UV: Stride*H/2 bytes (U in columns [0,Stride/2), V in [Stride/2,Stride)). */
 const uint8_t *mobi_oracle_y(const mobi_oracle *d, int idx);
 const uint8_t *mobi_oracle_uv(const mobi_oracle *d, int idx);
+/* The Bitmap DecodeFrame() returns (MD.cs:260-323), as width*height 0xAARRGGBB words, row pitch = width:
+ * chroma averaged from up to four neighbours by pixel parity (not on the last column / last row), then float
+ * BT.601-like conversion with 16..255 range stretch (Moflex3DS) or the integer Y+U-V / Y+V / Y-U-V form (ModsDS).
+ * Float arithmetic: IEEE single, one rounding per C# operator in source order, no fused multiply-add (what the
+ * x64 CLR's scalar SSE code does); casts truncate toward zero.  Returns ORA_E_NULLREF before the first frame. */
+int mobi_oracle_argb(const mobi_oracle *d, uint32_t *out);
 /* testing hooks: direct access to the Internal[392] word array (MD.cs:28) */
 uint32_t *mobi_oracle_internal(mobi_oracle *d);
 

@@ -30,6 +30,7 @@ def lib():
         L.mobi_oracle_quantizer.restype = C.c_uint32
         L.mobi_oracle_yuvformat.argtypes = [C.c_void_p]
         L.mobi_oracle_yuvformat.restype = C.c_uint32
+        L.mobi_oracle_argb.argtypes = [C.c_void_p, C.c_void_p]
         L.mobi_oracle_internal.argtypes = [C.c_void_p]
         L.mobi_oracle_internal.restype = C.POINTER(C.c_uint32)
         L.mobi_oracle_idct8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -72,6 +73,11 @@ class OracleDecoder:
         if not p:
             return None
         return np.ctypeslib.as_array(p, (self.Height // 2, self.Stride)).copy()
+
+    def argb(self):
+        """Bitmap of ring slot 0 (MD.cs:260-323) as (Height, Width) uint32 0xAARRGGBB; None before the first frame."""
+        out = np.empty((self.Height, self.Width), np.uint32)
+        return out if self.L.mobi_oracle_argb(self.h, out.ctypes.data) == 0 else None
 
     @property
     def Quantizer(self):
