@@ -64,15 +64,15 @@ extern "C" __global__ __launch_bounds__(256) void mobi_yuv_to_argb(const uint8_t
       const bool h = (x & 1) != 0;
       if (h && !odd) { // case 1
         U = __fadd_rn(U, u[0][k + 1]); V = __fadd_rn(V, v[0][k + 1]);
-        U = __fdiv_rn(U, 2.f); V = __fdiv_rn(V, 2.f);
+        U = __fmul_rn(U, 0.5f); V = __fmul_rn(V, 0.5f); // == U / 2f exactly (power of two)
       } else if (!h && odd) { // case 2
         U = __fadd_rn(U, u[1][k]); V = __fadd_rn(V, v[1][k]);
-        U = __fdiv_rn(U, 2.f); V = __fdiv_rn(V, 2.f);
+        U = __fmul_rn(U, 0.5f); V = __fmul_rn(V, 0.5f);
       } else if (h && odd) { // case 3: +1, +Stride, +1+Stride in this order
         U = __fadd_rn(U, u[0][k + 1]); V = __fadd_rn(V, v[0][k + 1]);
         U = __fadd_rn(U, u[1][k]); V = __fadd_rn(V, v[1][k]);
         U = __fadd_rn(U, u[1][k + 1]); V = __fadd_rn(V, v[1][k + 1]);
-        U = __fdiv_rn(U, 4.f); V = __fdiv_rn(V, 4.f);
+        U = __fmul_rn(U, 0.25f); V = __fmul_rn(V, 0.25f);
       }
     }
     px[i] = convert_px(version, (float)((yw >> (8 * i)) & 0xFF), U, V);
