@@ -9,6 +9,11 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/mobiclip_hip.h"
@@ -140,6 +145,52 @@ struct LevelPlan { // launch plan of one frame step: items of level L are items[
 
 } // namespace
 
+// Host-side parse pool: the VLC parse is serial inside a clip but clips are independent (MD.cs:15-39), so the clips of a
+// batch are parsed by a few persistent threads (the reference runs one decode thread per open file, Form1.cs:199-215).
+class ParsePool {
+ public:
+  explicit ParsePool(int n_threads) {
+    for (int i = 0; i < n_threads; i++) th_.emplace_back([this] { worker(); });
+  }
+  ~ParsePool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  int size() const { return (int)th_.size(); }
+  // runs f(0..n-1), the caller's thread included; returns when all are done
+  void run(int n, const std::function<void(int)> &f) {
+    if (th_.empty() || n < 2) { for (int i = 0; i < n; i++) f(i); return; }
+    { std::lock_guard<std::mutex> l(m_); job_ = &f; n_ = n; next_.store(0); busy_ = (int)th_.size(); gen_++; }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [this] { return busy_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void drain() {
+    for (int i; (i = next_.fetch_add(1)) < n_;) (*job_)(i);
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+      drain();
+      { std::lock_guard<std::mutex> l(m_); if (--busy_ == 0) done_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *job_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, busy_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
 struct mobi_batch {
   int n = 0, device = 0, version = 0;
   MobiGeom g{};
@@ -158,6 +209,7 @@ struct mobi_batch {
   DevBuf d_cmd, d_items;
   int32_t *d_scale = nullptr; // [MOBI_SCALE_QMAX][MOBI_SCALE_STRIDE]
   unsigned long long *d_prof = nullptr; // MOBI_DEBUG=9: in-kernel cycle accumulators
+  std::unique_ptr<ParsePool> pool;      // host parse threads (MOBI_PARSE_THREADS, default min(clips, cores, 32) - 1 helpers)
   uint32_t *d_argb = nullptr;           // Bitmap output of mobi_batch_convert_argb / mobi_batch_get_argb (lazily allocated)
   size_t argb_bytes = 0;
   bool argb_all_valid = false;          // d_argb holds every clip's Bitmap of the current frame
@@ -347,6 +399,9 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
+    int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
+    if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
+    b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
   }
   if (b->debug == 9) {
     const size_t pbytes = (size_t)n_clips * (b->g.mbw * b->g.mbh) * 16;
@@ -370,8 +425,8 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // 1. host: serial VLC parse of one frame per clip -> command lists
   std::vector<const ParsedFrame *> ok(n, nullptr);
   bool any_version_error = false;
+  b->pool->run(n, [&](int i) { rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]); });
   for (int i = 0; i < n; i++) {
-    rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]);
     if (rc[i] == MOBI_OK) ok[i] = &b->cur[i];
     if (rc[i] == MOBI_E_VERSION) any_version_error = true;
   }
