@@ -26,18 +26,23 @@ enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 //      so a wave's first load already tells it everything it needs to start fetching pixels ------------
 // w0  payload word offset (host: inside the clip's payload; device: inside the frame step's payload arena)
 // w1  [0]      type (MOBI_MB_*)
-//     [7:1]    n_leaves   (inter: 1 = the single 16x16 leaf INLINE in w2/w3; 2 with a DUAL kind in w5 = both
-//                          leaves inline; otherwise the payload starts with the 64-word MV cell map)
+//     [7:1]    n_leaves   (inter: 1 = the single 16x16 leaf; 2 with a DUAL kind = both halves; both kinds ride in the
+//                          descriptor as LEAF RECORDS, see below; otherwise the payload starts with the 64-word MV cell map)
 //     [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
 //     [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
 //     [25:20]  quantizer  of the frame (selects the dequant scale table, MD.cs:3884-3912)
-// w2  [9:0]    n_coefs (<= 384)      [24:10] inter: leaf 0 word 0 (mobi_leaf_w0)
-// w3  inter: leaf 0 word 1 (MV) ;  intra: [0] plane16 present, [31:16] plane16 parameter
-// w4  DUAL: leaf 1 word 1 (MV)
-// w5  [2:0] DUAL: ref slot of leaf 1   [4:3] MOBI_DUAL_* : the macroblock is exactly two halves (partition codes
-//     8 / 9 at the 16x16 level with two plain leaves, MD.cs:585-600 -- by far the most common split), leaf 0 =
-//     top / left, leaf 1 = bottom / right; no cell map is emitted for it
-// w6, w7 reserved (0) for inter macroblocks
+//     [27:26]  MOBI_DUAL_*: the macroblock is exactly two halves (partition codes 8 / 9 at the 16x16 level with two
+//              plain leaves, MD.cs:585-600 -- by far the most common split), leaf A = top / left, B = bottom / right
+// w2  [9:0]    n_coefs (<= 384)
+//     inter leaf records, decoded by the host so that the kernel does no motion-vector arithmetic (MD.cs:400-416):
+//     [12:10] ref slot 1..5 of leaf A   [15:13] of leaf B
+//     [17:16] luma CopyBlock phase (dx&1)|((dy&1)<<1) of A   [19:18] chroma phase of A   [21:20], [23:22] the same for B
+// w3  inter: luma source position of leaf A = MB offset + (dy>>1)*Stride + (dx>>1), linear inside the reference's Y plane
+//            (signed: a bottom/right half may point above/left of its macroblock's origin; its own rows/columns add back)
+//     intra: [0] plane16 present, [31:16] plane16 parameter
+// w4  inter: chroma source position of leaf A = MB offset/2 + ((dy>>1)>>1)*Stride + ((dx>>1)>>1), inside the UV plane (U half)
+// w5, w6  inter DUAL: the same two positions for leaf B
+// w7  reserved (0) for inter macroblocks
 // intra: w4..w7 hold up to 8 uint16 macroblock indices (MOBI_DEP_NONE = unused): the raster-earlier macroblocks of the
 //        same frame, inter or intra, whose pixels this one's prediction halo reads.  When a frame step runs as one
 //        launch the macroblock waits for exactly these (mobi_recon_step in mobi_kernels.hip).
@@ -56,7 +61,7 @@ struct MbDesc {
 #define MOBI_INTRA_DEPS 8
 enum { MOBI_DUAL_NONE = 0, MOBI_DUAL_TB = 1, MOBI_DUAL_LR = 2 }; // two 16x8 (top, bottom) / two 8x16 (left, right)
 
-// ---- MC leaf (single-leaf macroblocks: inline in the descriptor) ------------------------------
+// ---- MC leaf as the parser records it while walking the partition tree (host only) ----------------
 //  w0: [3:0] x/2  [7:4] y/2  [9:8] log2(16/w)  [11:10] log2(16/h)  [14:12] ref slot 1..5
 //  w1: [15:0] dx (int16, half-pel, absolute)  [31:16] dy                         (MD.cs:400-416)
 static inline uint32_t mobi_leaf_w0(int x, int y, int wi, int hi, int ref) {

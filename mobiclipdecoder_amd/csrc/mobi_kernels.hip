@@ -278,47 +278,41 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last quad
   const uint4 d = dp[0], d2 = dp[1];
   const bool valid = g < nmb && (d.y & 1) == MOBI_MB_INTER;
-  const int nl = (d.y >> 1) & 0x7F, kind2 = (d2.y >> 3) & 3;
+  const int nl = (d.y >> 1) & 0x7F, kind2 = (d.y >> 26) & 3;
   const bool single = valid && nl == 1, dual = valid && kind2 != 0, multi = valid && nl > 1 && kind2 == 0;
   const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
   L[Q_META + g] = (uint8_t)cbp6;
   L[Q_META + 4 + g] = (uint8_t)((d.y >> 14) & 0x3F);
   L[Q_META + 8 + g] = (uint8_t)((valid ? 1 : 0) | (multi ? 2 : 0));
   const bool any_dual = __builtin_amdgcn_ballot_w64(dual) != 0;
-  // Leaf parameters as this lane needs them: one set for its luma rows 0..7 (iterations t = 0,1), one for rows
-  // 8..15 (t = 2,3), one for its chroma samples.  Single-leaf: all three are the inline leaf.  DUAL (two halves,
-  // both inline): top/bottom switches between t = 1 and 2, left/right by the lane's column.
-  struct Leaf { int dx, dy; uint32_t refoff; };
-  auto leaf_of = [&](uint32_t mv, uint32_t ref, bool ok) {
+  // Leaf records (mobi_cmd.h): the host already turned motion vectors into source positions and CopyBlock phases.
+  // What a lane needs: one record for its luma rows 0..7 (iterations t = 0,1), one for rows 8..15 (t = 2,3), one for
+  // its chroma samples.  Single-leaf: all three are leaf A.  DUAL (two halves): top/bottom switches between t = 1
+  // and 2, left/right by the lane's column.
+  auto slot_off = [&](uint32_t ref) {
     int sl = A.ring_base - (int)ref;
     sl = sl < 0 ? sl + 6 : sl;
-    Leaf r;
-    r.dx = ok ? (int)(mv << 16) >> 16 : 0; // lanes without a motion vector keep to their own macroblock position
-    r.dy = ok ? (int)mv >> 16 : 0;
-    r.refoff = ok ? __umul24((uint32_t)sl, A.slot_bytes) : 0u; // slot_bytes < 2^24: checked by mobi_launch_inter
-    return r;
+    return __umul24((uint32_t)sl, A.slot_bytes); // slot_bytes < 2^24: checked by mobi_launch_inter
   };
-  const Leaf PA = leaf_of(d.w, (d.z >> 22) & 7, single || dual);
-  Leaf P01 = PA, P23 = PA, PC = PA;
+  const uint32_t refA = slot_off((d.z >> 10) & 7);
+  uint32_t ref01 = refA, ref23 = refA, refC = refA;
+  int ypos = (int)d.w, ypos23 = (int)d.w, cpos = (int)d2.x;
+  int yph01 = (d.z >> 16) & 3, yph23 = yph01, cph = (d.z >> 18) & 3;
   if (any_dual) {
-    const Leaf PB = leaf_of(d2.x, d2.y & 7, dual);
+    const uint32_t refB = slot_off((d.z >> 13) & 7);
     const bool lr = kind2 == MOBI_DUAL_LR, tb = kind2 == MOBI_DUAL_TB;
     const bool b01 = dual && lr && (j & 2), b23 = dual && (tb || (lr && (j & 2))), bc = dual && (lr ? (j & 1) != 0 : j >= 8);
-    auto pick = [](bool b, const Leaf &x, const Leaf &y) { return Leaf{b ? x.dx : y.dx, b ? x.dy : y.dy, b ? x.refoff : y.refoff}; };
-    P01 = pick(b01, PB, PA);
-    P23 = pick(b23, PB, PA);
-    PC = pick(bc, PB, PA);
+    const int yphB = (d.z >> 20) & 3, cphB = (d.z >> 22) & 3;
+    ref01 = b01 ? refB : refA; ypos = b01 ? (int)d2.y : ypos; yph01 = b01 ? yphB : yph01;
+    ref23 = b23 ? refB : refA; ypos23 = b23 ? (int)d2.y : ypos23; yph23 = b23 ? yphB : yph23;
+    refC = bc ? refB : refA; cpos = bc ? (int)d2.z : cpos; cph = bc ? cphB : cph;
   }
-  const int off = off0 + g * 16;
-  const int ypos = off + ((P01.dy >> 1) << lgS) + (P01.dx >> 1), ypos23 = off + ((P23.dy >> 1) << lgS) + (P23.dx >> 1);
-  const int cdx = PC.dx >> 1, cdy = PC.dy >> 1;
-  const int cpos = (off >> 1) + ((cdy >> 1) << lgS) + (cdx >> 1);
   // a lane without a window keeps re-reading the start of its clip.  (Row offsets by shifts: the pitch is a power of
   // two, and a 32-bit integer multiply costs four VALU slots.)
   const int hS = single ? S >> 1 : 0;
   auto rowoff = [&](int rows) { return single ? (uint32_t)rows << lgS : 0u; };
-  const uint32_t ywin = single ? P01.refoff + (uint32_t)(ypos & ~15) : 0u;
-  const uint32_t cwin = single ? PC.refoff + ysz + (uint32_t)(cpos & ~15) : 0u;
+  const uint32_t ywin = single ? ref01 + (uint32_t)(ypos & ~15) : 0u;
+  const uint32_t cwin = single ? refC + ysz + (uint32_t)(cpos & ~15) : 0u;
   const uint8_t *lbase = clip_base;
   {
     const uint8_t *p0 = lbase + (ywin + rowoff(j));
@@ -351,13 +345,13 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
     const int rr = j >> 2, q = j & 3;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const uint32_t o = (t < 2 ? P01.refoff : P23.refoff) + (uint32_t)(((t < 2 ? ypos : ypos23) + ((4 * t + rr) << lgS) + 4 * q) & ~3);
+      const uint32_t o = (t < 2 ? ref01 : ref23) + (uint32_t)(((t < 2 ? ypos : ypos23) + ((4 * t + rr) << lgS) + 4 * q) & ~3);
       fx[t] = *(const uint2_a4 *)(clip_base + o);
       fy[t] = *(const uint2_a4 *)(clip_base + o + S);
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      const uint32_t o = PC.refoff + ysz + (uint32_t)((cpos + u * (S >> 1) + ((j >> 1) << lgS) + 4 * (j & 1)) & ~3);
+      const uint32_t o = refC + ysz + (uint32_t)((cpos + u * (S >> 1) + ((j >> 1) << lgS) + 4 * (j & 1)) & ~3);
       fx[4 + u] = *(const uint2_a4 *)(clip_base + o);
       fy[4 + u] = *(const uint2_a4 *)(clip_base + o + S);
     }
@@ -383,7 +377,7 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       const int rr = j >> 2, q = j & 3, w0 = (ys + 4 * q) >> 2, w1 = w0 + 1;
       const int a0 = Q_R0 + (w0 >> 2) * 1024 + g * 256 + rr * 16 + (w0 & 3) * 4, a1 = Q_R0 + (w1 >> 2) * 1024 + g * 256 + rr * 16 + (w1 & 3) * 4;
       const int b0 = Q_R4 + g * 256 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + (w1 >> 2) * 16 + (w1 & 3) * 4;
-      const int ph01 = (P01.dx & 1) | ((P01.dy & 1) << 1), ph23 = (P23.dx & 1) | ((P23.dy & 1) << 1);
+      const int ph01 = yph01, ph23 = yph23;
       const uint32_t sh01 = ypos & 3, sh23 = ypos23 & 3;
       const bool p0a = ph01 == 0, p1a = ph01 == 1, p2a = ph01 == 2, p0b = ph23 == 0, p1b = ph23 == 1, p2b = ph23 == 2;
 #pragma unroll
@@ -398,7 +392,7 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       }
     }
     {
-      const int cs = cpos & 15, cph = (cdx & 1) | ((cdy & 1) << 1);
+      const int cs = cpos & 15;
       const int row = j >> 1, q = j & 1, w0 = (cs + 4 * q) >> 2, w1 = w0 + 1;
       const int a0 = Q_R2 + g * 256 + row * 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, a1 = Q_R2 + g * 256 + row * 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
       const int b0 = Q_R4 + g * 256 + 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;

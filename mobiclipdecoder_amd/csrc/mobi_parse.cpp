@@ -107,29 +107,37 @@ void MobiStreamParser::end_mb() {
   MbDesc d{};
   d.payload_off = (uint32_t)out_->payload.size();
   uint32_t nl = 0;
+  int dual = MOBI_DUAL_NONE;
   d.w2 = (uint32_t)coefs_.size();
   d.w3 = w3_;
   if (mb_type_ == MOBI_MB_INTER) {
     nl = (uint32_t)(leaves_.size() / 2);
-    d.w2 |= leaves_[0] << 10; // the leaf of a single-leaf MB rides in the descriptor
-    d.w3 = leaves_[1];
-    int dual = MOBI_DUAL_NONE;
-    if (nl == 2) { // two halves: both leaves ride in the descriptor (leaf word 0: x/2 | y/2<<4 | wi<<8 | hi<<10 | ref<<12)
+    if (nl == 2) { // two halves (leaf word 0: x/2 | y/2<<4 | wi<<8 | hi<<10 | ref<<12)
       const uint32_t a = leaves_[0] & 0xFFF, b = leaves_[2] & 0xFFF;
       if (a == (0u | (1u << 10)) && b == ((4u << 4) | (1u << 10))) dual = MOBI_DUAL_TB;
       if (a == (0u | (1u << 8)) && b == (4u | (1u << 8))) dual = MOBI_DUAL_LR;
     }
-    if (dual) {
-      d.w4 = leaves_[3];
-      d.w5 = ((leaves_[2] >> 12) & 7) | ((uint32_t)dual << 3);
-    } else if (nl > 1) {
+    if (nl == 1 || dual) { // leaf records: positions and phases instead of motion vectors (MD.cs:400-416)
+      const long S = g_.stride;
+      uint32_t pos[4] = {0, 0, 0, 0};
+      for (uint32_t i = 0; i < nl; i++) {
+        const int ref = (leaves_[2 * i] >> 12) & 7;
+        const int dx = (int16_t)(leaves_[2 * i + 1] & 0xFFFF), dy = (int16_t)(leaves_[2 * i + 1] >> 16), cdx = dx >> 1, cdy = dy >> 1;
+        pos[2 * i] = (uint32_t)(int32_t)(cur_off_ + (long)(dy >> 1) * S + (dx >> 1));
+        pos[2 * i + 1] = (uint32_t)(int32_t)(cur_off_ / 2 + (long)(cdy >> 1) * S + (cdx >> 1));
+        d.w2 |= (uint32_t)ref << (10 + 3 * i);
+        d.w2 |= (uint32_t)((dx & 1) | ((dy & 1) << 1)) << (16 + 4 * i);
+        d.w2 |= (uint32_t)((cdx & 1) | ((cdy & 1) << 1)) << (18 + 4 * i);
+      }
+      d.w3 = pos[0]; d.w4 = pos[1]; d.w5 = pos[2]; d.w6 = pos[3];
+    } else {
       out_->payload.insert(out_->payload.end(), cells_, cells_ + MOBI_MV_CELLS);
     }
   } else {
     out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
   }
   out_->payload.insert(out_->payload.end(), coefs_.begin(), coefs_.end());
-  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14) | ((quant_ & 63) << 20);
+  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14) | ((quant_ & 63) << 20) | ((uint32_t)dual << 26);
   out_->desc.push_back(d);
 }
 long MobiStreamParser::area_offset(int area, int sub) const {

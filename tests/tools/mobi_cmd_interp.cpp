@@ -93,18 +93,29 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
   const int nl = (d.w1 >> 1) & 0x7F, cbp6 = (d.w1 >> 8) & 0x3F, t8 = (d.w1 >> 14) & 0x3F, ncoef = d.w2 & 0x3FF;
   const long off = (long)(mb / g.mbw) * 16 * S + (mb % g.mbw) * 16;
   uint8_t ty[16 * TP], tc[2][8 * TP]; // prediction tiles (interior only; pitch TP, origin at byte 0)
-  // per-lane MV: the inline leaf (nl == 1) or the cell under each pixel (nl > 1)
-  const int dual = (d.w5 >> 3) & 3; // two inline halves: no cell map in the payload
-  auto mv_at = [&](int cellx, int celly, int &dx, int &dy, int &ref) {
-    if (dual && (dual == MOBI_DUAL_TB ? celly >= 4 : cellx >= 4)) {
-      ref = d.w5 & 7; dx = (int16_t)(d.w4 & 0xFFFF); dy = (int16_t)(d.w4 >> 16);
-    } else if (nl == 1 || dual) {
-      uint32_t w0 = (d.w2 >> 10) & 0x7FFF;
-      ref = (w0 >> 12) & 7; dx = (int16_t)(d.w3 & 0xFFFF); dy = (int16_t)(d.w3 >> 16);
+  // per pixel group: the leaf record of the descriptor (single / two halves) or the MV cell under it (deeper trees).
+  // A source = (reference slot, position of the macroblock origin's image, CopyBlock phase), for luma and chroma.
+  const int dual = (d.w1 >> 26) & 3; // two inline halves: no cell map in the payload
+  struct Src { int ref; long ypos, cpos; int yph, cph; };
+  auto src_at = [&](int cellx, int celly) {
+    Src s;
+    if (nl == 1 || dual) {
+      const int i = dual && (dual == MOBI_DUAL_TB ? celly >= 4 : cellx >= 4) ? 1 : 0;
+      s.ref = (d.w2 >> (10 + 3 * i)) & 7;
+      s.ypos = (int32_t)(i ? d.w5 : d.w3);
+      s.cpos = (int32_t)(i ? d.w6 : d.w4);
+      s.yph = (d.w2 >> (16 + 4 * i)) & 3;
+      s.cph = (d.w2 >> (18 + 4 * i)) & 3;
     } else {
-      uint32_t c = pl[celly * 8 + cellx];
-      dx = mobi_cell_dx(c); dy = mobi_cell_dy(c); ref = mobi_cell_ref(c);
+      const uint32_t c = pl[celly * 8 + cellx];
+      const int dx = mobi_cell_dx(c), dy = mobi_cell_dy(c), cdx = dx >> 1, cdy = dy >> 1;
+      s.ref = mobi_cell_ref(c);
+      s.ypos = off + (long)(dy >> 1) * S + (dx >> 1);
+      s.cpos = off / 2 + (long)(cdy >> 1) * S + (cdx >> 1);
+      s.yph = (dx & 1) | ((dy & 1) << 1);
+      s.cph = (cdx & 1) | ((cdy & 1) << 1);
     }
+    return s;
   };
   auto fetch5 = [&](const uint8_t *plane, long len, long pos, uint8_t *a, uint8_t *b) {
     for (int k = 0; k < 5; k++) { // the 4-px word may stick out of a leaf's validated window: guard like the HBM slack
@@ -116,23 +127,20 @@ void exec_inter(Interp &I, int mb, const MbDesc &d) {
   for (int lane = 0; lane < 64; lane++) { // luma: lane -> row lane>>2, 4 px at (lane&3)*4 = two cells
     int row = lane >> 2, c4 = (lane & 3) * 4;
     for (int half = 0; half < 2; half++) {
-      int dx, dy, ref;
-      mv_at(c4 / 2 + half, row >> 1, dx, dy, ref);
+      const Src s = src_at(c4 / 2 + half, row >> 1);
       uint8_t a[8] = {0}, b[8] = {0};
-      fetch5(I.Y(ref), S * g.height, off + (long)(row + (dy >> 1)) * S + c4 + (dx >> 1), a, b);
-      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), (dx & 1) | ((dy & 1) << 1));
+      fetch5(I.Y(s.ref), S * g.height, s.ypos + (long)row * S + c4, a, b);
+      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), s.yph);
       for (int k = 2 * half; k < 2 * half + 2; k++) ty[row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
     }
   }
   for (int lane = 0; lane < 32; lane++) { // chroma: lanes 0..15 U, 16..31 V; one cell per chroma sample
     int v01 = lane >> 4, row = (lane & 15) >> 1, c4 = (lane & 1) * 4;
     for (int k = 0; k < 4; k++) {
-      int dx, dy, ref;
-      mv_at(c4 + k, row, dx, dy, ref);
-      int cdx = dx >> 1, cdy = dy >> 1;
+      const Src s = src_at(c4 + k, row);
       uint8_t a[8] = {0}, b[8] = {0};
-      fetch5(I.UV(ref), S * g.height / 2, off / 2 + v01 * (S / 2) + (long)(row + (cdy >> 1)) * S + c4 + (cdx >> 1), a, b);
-      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), (cdx & 1) | ((cdy & 1) << 1));
+      fetch5(I.UV(s.ref), S * g.height / 2, s.cpos + v01 * (S / 2) + (long)row * S + c4, a, b);
+      uint32_t v = mobi_mc4(ld4(a), ld4(a + 1), ld4(b), ld4(b + 1), s.cph);
       tc[v01][row * TP + c4 + k] = (uint8_t)(v >> (8 * k));
     }
   }
