@@ -224,37 +224,34 @@ __device__ __forceinline__ uint32_t mc4_lane(uint32_t x0, uint32_t x1, uint32_t 
   const uint32_t p1 = ha + hb, p2 = ha + hc, p3 = ((p1 >> 1) & M) + (((hc + hd) >> 1) & M);
   return ph0 ? a : ph1 ? p1 : ph2 ? p2 : p3;
 }
-// pass 2 of one area by lane r, tracking the range of pred+residual instead of testing every sample
+// pass 2 of one area by lane r, tracking the range of pred+residual instead of testing every sample.  Only the
+// butterflies differ between one 8x8 transform (lane r = pixel row r) and four 4x4s (lane r = rows (r&1)*2, +1 of
+// sub-block r>>1): both leave 8 residuals for two 4-pixel words, so the pixel update is one shared instruction stream
+// (the 8 lanes of an area agree on the kind, the lanes of a wave do not).
 __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint8_t *px, int pitch, int &lo, int &hi) {
   int in[8], out[8];
+  uint8_t *wa, *wb; // the two 4-pixel words (4-byte aligned)
   if (is8) {
 #pragma unroll
     for (int m = 0; m < 8; m++) in[m] = t[8 * r + m];
     mobi_bfly8(in, out);
-    uint8_t *row = px + r * pitch;
-    const uint2 pred = *(const uint2 *)row; // px is 8-byte aligned
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int v = (int)(((j < 4 ? pred.x : pred.y) >> (8 * (j & 3))) & 0xFF) + (out[j] >> 6);
-      lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-      ((volatile uint8_t *)row)[j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); // byte stores: LDS has issue slots to spare, the VALU has not
-    }
+    wa = px + r * pitch;
+    wb = wa + 4;
   } else {
-    const int s = r >> 1;
+    const int s = r >> 1, i0 = (r & 1) * 2;
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-      const int i = (r & 1) * 2 + g;
+    for (int m = 0; m < 8; m++) in[m] = t[16 * s + 4 * i0 + m]; // groups i0 and i0 + 1
+    mobi_bfly4(in, out);
+    mobi_bfly4(in + 4, out + 4);
+    wa = px + ((s >> 1) * 4 + i0) * pitch + (s & 1) * 4;
+    wb = wa + pitch;
+  }
+  const uint32_t pa = *(const uint32_t *)wa, pb = *(const uint32_t *)wb;
 #pragma unroll
-      for (int m = 0; m < 4; m++) in[m] = t[16 * s + 4 * i + m];
-      mobi_bfly4(in, out);
-      uint8_t *row = px + ((s >> 1) * 4 + i) * pitch + (s & 1) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int v = (int)row[j] + (out[j] >> 6);
-        lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-        row[j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-      }
-    }
+  for (int j = 0; j < 8; j++) {
+    const int v = (int)(((j < 4 ? pa : pb) >> (8 * (j & 3))) & 0xFF) + (out[j] >> 6);
+    lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+    ((volatile uint8_t *)(j < 4 ? wa : wb))[j & 3] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); // byte stores: LDS has issue slots to spare, the VALU has not
   }
 }
 } // namespace
