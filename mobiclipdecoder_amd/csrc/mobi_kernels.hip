@@ -247,12 +247,26 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
     wb = wa + pitch;
   }
   const uint32_t pa = *(const uint32_t *)wa, pb = *(const uint32_t *)wb;
+  int pix[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int v = (int)(((j < 4 ? pa : pb) >> (8 * (j & 3))) & 0xFF) + (out[j] >> 6);
     lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-    ((volatile uint8_t *)(j < 4 ? wa : wb))[j & 3] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); // byte stores: LDS has issue slots to spare, the VALU has not
+    pix[j] = v < 0 ? 0 : (v > 255 ? 255 : v);
   }
+  // byte stores, spelled out: LDS has issue slots to spare and the VALU has not, but left to itself the compiler packs the
+  // eight results into two words with a dozen VALU instructions (and a volatile store through a generic pointer becomes a
+  // flat_store with system scope)
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint8_t __attribute__((address_space(3))) *lds_u8p;
+  const uint32_t aa = (uint32_t)(uintptr_t)(lds_u8p)wa, ab = (uint32_t)(uintptr_t)(lds_u8p)wb;
+  asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8 %0, %3 offset:2\n\tds_write_b8 %0, %4 offset:3"
+               : : "v"(aa), "v"(pix[0]), "v"(pix[1]), "v"(pix[2]), "v"(pix[3]) : "memory");
+  asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8 %0, %3 offset:2\n\tds_write_b8 %0, %4 offset:3"
+               : : "v"(ab), "v"(pix[4]), "v"(pix[5]), "v"(pix[6]), "v"(pix[7]) : "memory");
+#else
+  for (int j = 0; j < 4; j++) { wa[j] = (uint8_t)pix[j]; wb[j] = (uint8_t)pix[4 + j]; }
+#endif
 }
 } // namespace
 
