@@ -15,6 +15,7 @@
 // (a pure compiler barrier -- LDS is FIFO per wave) is all that separates producer and consumer lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -774,10 +775,13 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   }
 }
 
-extern "C" __global__ __launch_bounds__(256) void mobi_recon_intra(MobiReconArgs A, const uint32_t *items, int n_items) {
-  __shared__ uint32_t lds[WAVES][INTRA_LDS_WORDS];
+#ifndef IWAVES
+#define IWAVES 1
+#endif
+extern "C" __global__ __launch_bounds__(64 * IWAVES) void mobi_recon_intra(MobiReconArgs A, const uint32_t *items, int n_items) {
+  __shared__ uint32_t lds[IWAVES][INTRA_LDS_WORDS];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int it = blockIdx.x * WAVES + wave;
+  const int it = blockIdx.x * IWAVES + wave;
   if (it >= n_items) return;
   const uint32_t item = items[it];
   recon_intra_item(A, lds[wave], (int)(item >> 13), (int)(item & 0x1FFF), lane, it, false);
@@ -834,14 +838,15 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const unsigned grid = (unsigned)(((quads + INTER_WAVES - 1) / INTER_WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
-  if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * INTER_WAVES), 0, s, b);
-  else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * INTER_WAVES), 0, s, b);
+  static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
+  if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
+  else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
   if (n_items <= 0) return 0;
-  const unsigned grid = (unsigned)((n_items + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL(mobi_recon_intra, dim3(grid), dim3(64 * WAVES), 0, s, *a, items_dev, n_items);
+  const unsigned grid = (unsigned)((n_items + IWAVES - 1) / IWAVES);
+  hipLaunchKernelGGL(mobi_recon_intra, dim3(grid), dim3(64 * IWAVES), 0, s, *a, items_dev, n_items);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int K, hipStream_t s) {
