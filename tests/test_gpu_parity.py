@@ -203,3 +203,41 @@ def test_every_step_mode_is_bit_exact(mode, monkeypatch):
             y, uv = b.planes(c)
             assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (mode, f, c)
     b.close()
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_loaded_gpu_hand_offs_are_exact(mode, monkeypatch):
+    """The completion-tag hand-off between waves (intra macroblocks waiting on other macroblocks of the same launch)
+    must hold on a LOADED chip, not just for a handful of clips: 320 clips of 640x480 (every CU busy, waves of many
+    clips interleaved), intra-heavy, 7 frames incl. the I-frame's ~100-level wavefront, replayed twice.  Every clip
+    is a private copy of one of 8 streams, so every copy must equal the oracle's frame, word for word, every frame."""
+    monkeypatch.setenv("MOBI_STEP_MODE", mode)
+    nclips, distinct, nfr = 320, 8, 7
+    ps = [default_params("B", BASE_SEED + 700 + i, n_frames=nfr, pm_intra=200, pm_deep=100) for i in range(distinct)]
+    clips = [generate_clip(p) for p in ps]
+    oras = [OracleDecoder(640, 480, MobiclipVersion.Moflex3DS) for _ in range(distinct)]
+    b = MobiclipBatch(nclips, 640, 480, MobiclipVersion.Moflex3DS)
+    for i in range(distinct):
+        assert all(r == 0 for r in b.preload(i, clips[i][0], clips[i][1]))
+    for c in range(distinct, nclips):
+        b.preload_clone(c, c % distinct)
+    b.commit()
+    for rep in range(2):
+        for f in range(nfr):
+            b.replay(f)
+            if rep == 0:
+                for i in range(distinct):
+                    oras[i].Data, oras[i].Offset = clips[i][0], int(clips[i][1][f])
+                    assert oras[i].DecodeFrame() is not None
+            if f in (0, 3, nfr - 1):
+                assert b.sync() == 0
+                want = None
+                for c in range(nclips):
+                    if rep == 0:
+                        want = (oras[c % distinct].y(0), oras[c % distinct].uv(0))
+                    y, uv = b.planes(c)
+                    if rep == 0:
+                        assert np.array_equal(y, want[0]) and np.array_equal(uv, want[1]), (mode, f, c)
+                    elif f == nfr - 1:  # second pass: same command lists on a different ring history -> only P-chain end state is comparable
+                        assert np.array_equal(y, oras[c % distinct].y(0)) and np.array_equal(uv, oras[c % distinct].uv(0)), (mode, "rep", c)
+    b.close()
