@@ -1,18 +1,18 @@
-// mobi_kernels.hip -- gfx950 (MI355X / CDNA4) reconstruction kernels: one wavefront per macroblock.
+// mobi_kernels.hip -- gfx950 (MI355X / CDNA4) reconstruction kernels for the command lists of mobi_cmd.h.
 //
-//   mobi_recon_inter : P-frame inter macroblocks.  Per MB: half-pel truncating motion compensation
-//                      of every partition leaf from the reference planes (CopyBlock, MD.cs:418-456),
+//   mobi_recon_inter : the inter macroblocks of a frame step, one wavefront per quad of four adjacent macroblocks:
+//                      half-pel truncating motion compensation from the reference planes (CopyBlock, MD.cs:418-456),
 //                      dequant + 8x8/4x4 integer inverse transforms + clamp-add of the residual
-//                      (MD.cs:3424-3429, :3435-3798), coalesced dword stores of Y/U/V.
-//   mobi_recon_intra : intra macroblocks of one dependency level (I-frames and codes 6/7 inside
-//                      P-frames): halo load with raster-order availability masking, predictors
-//                      (MD.cs:1883-2774, :3017-3327) and residuals in decode order inside LDS.
+//                      (MD.cs:3424-3429, :3435-3798), whole-row stores of Y/U/V.
+//   mobi_recon_intra : intra macroblocks (I-frames and codes 6/7 inside P-frames), one wavefront each: halo load
+//                      with raster-order availability masking, predictors (MD.cs:1883-2774, :3017-3327) and
+//                      residuals in decode order inside LDS; all dependency levels of a step in one launch, ordered by
+//                      per-macroblock completion tags.
+//   mobi_recon_step  : both of the above as ONE launch (alternative step mode).
 //
-// 8-bit pel work is HBM-bound: no MFMA.  64-wide wavefronts: a 16x16 luma block is 64 lanes x 4 px
-// (one dword per lane per row segment); an 8x8 block is 64 lanes x 1 px for prediction and 8 lanes x
-// 8-point butterflies for the transform, with the transpose staged through LDS.
-// LDS use is per wave (no workgroup barriers): waves never share data, so a wavefront-scope fence
-// (a pure compiler barrier -- LDS is FIFO per wave) is all that separates producer and consumer lanes.
+// 8-bit pel work is HBM-bound by nature: no MFMA.  LDS use is per wave (no workgroup barriers): waves never share
+// LDS data, so a wavefront-scope fence (a pure compiler barrier -- LDS executes a wave's instructions in order) is
+// all that separates producer and consumer lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -27,11 +27,8 @@ namespace {
 
 enum { TP = 32 };                     // intra tile pitch: interior col c at byte 4+c, halo col -1 at byte 3
 enum { HALO_Y_RIGHT = 23, HALO_C_RIGHT = 15 }; // must match MOBI_HALO_* in mobi_parse.h
-enum { WAVES = 4 };
-#ifndef QWAVES
-#define QWAVES 1
-#endif
-enum { INTER_WAVES = QWAVES }; // waves per workgroup of the inter kernel
+enum { INTER_WAVES = 1, IWAVES = 1 }; // waves per workgroup: one (a workgroup's LDS and wave slots are released only when its last wave
+                                      // ends, and quads / intra macroblocks differ widely in how long they take)
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
@@ -77,22 +74,6 @@ __device__ __forceinline__ uint32_t mc4_select(const Win &w, int phase) {
   const uint32_t p1 = ha + hb, p2 = ha + hc, p3 = ((p1 >> 1) & M) + (((hc + hd) >> 1) & M);
   return phase == 0 ? a : phase == 1 ? p1 : phase == 2 ? p2 : p3;
 }
-// the same with a wave-uniform phase (single-leaf macroblocks): scalar branch, only the needed terms
-__device__ __forceinline__ uint32_t mc4_uniform(const Win &w, int phase) {
-  const uint32_t a = cut(w.r0, w.sh);
-  if (phase == 0) return a;
-  const uint32_t b = (phase & 1) ? cut1(w.r0, w.sh) : 0, c = (phase & 2) ? cut(w.r1, w.sh) : 0, d = phase == 3 ? cut1(w.r1, w.sh) : 0;
-  return mobi_mc4(a, b, c, d, phase);
-}
-// byte mask of the pixels [c4, c4+4) that fall inside [lo, lo+len)
-__device__ __forceinline__ uint32_t seg_mask(int c4, int lo, int len) {
-  uint32_t m = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (c4 + k >= lo && c4 + k < lo + len) m |= 0xFFu << (8 * k);
-  return m;
-}
-
 // ---- residual helpers (LDS: coef[6*64] ints, tmp[6*64] ints) --------------------------------------
 __device__ __forceinline__ void zero_coefs(int *coef, int lane) {
 #pragma unroll
@@ -775,9 +756,6 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   }
 }
 
-#ifndef IWAVES
-#define IWAVES 1
-#endif
 extern "C" __global__ __launch_bounds__(64 * IWAVES) void mobi_recon_intra(MobiReconArgs A, const uint32_t *items, int n_items) {
   __shared__ uint32_t lds[IWAVES][INTRA_LDS_WORDS];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
