@@ -34,15 +34,15 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 
 struct Geo { // stride is 256/512/1024 (MD.cs:50-52): divide/modulo by shifts
   int width, height, stride, mbw, lg;
-  __device__ __forceinline__ int owner_luma(long a) const {
+  __device__ __forceinline__ int owner_luma(int a) const {
     if (a < 0) return -1;
-    const int row = (int)(a >> lg), col = (int)(a & (stride - 1));
+    const int row = a >> lg, col = a & (stride - 1);
     if (col >= width || row >= height) return -1;
     return (row >> 4) * mbw + (col >> 4);
   }
-  __device__ __forceinline__ int owner_chroma(long a) const {
+  __device__ __forceinline__ int owner_chroma(int a) const {
     if (a < 0) return -1;
-    const int row = (int)(a >> lg), col = (int)(a & (stride - 1));
+    const int row = a >> lg, col = a & (stride - 1);
     const int x = col >= (stride >> 1) ? col - (stride >> 1) : col;
     if (x >= (width >> 1) || row >= (height >> 1)) return -1;
     return (row >> 3) * mbw + (x >> 3);
@@ -562,12 +562,14 @@ extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter_
 namespace {
 // byte load that bypasses this CU's L1 (sc1): issued now, valid only after ld_wait6() -- the compiler puts a full wait
 // behind every __hip_atomic_load, which serialises the halo into six round trips
-__device__ __forceinline__ uint32_t ld_u8_sc1(const uint8_t *p) {
+__device__ __forceinline__ uint32_t ld_u8_sc1(const uint8_t *base, uint32_t off) { // base: wave-uniform
   uint32_t v;
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("global_load_ubyte %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  // s_nop 4: when the compiler has to make `base` scalar with v_readfirstlane, a VMEM instruction may not read that
+  // SGPR for 5 wait states, and nothing inside an asm string is padded for us (cdna_hip_programming.md 5.7)
+  asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory");
 #else
-  v = *p;
+  v = base[off];
 #endif
   return v;
 }
@@ -583,7 +585,7 @@ struct TileNb {
 };
 // predict one block on the tile (all lanes call; lanes >= n*n idle), then its residual when coded
 __device__ __forceinline__ void run_block(uint8_t *tile, int by, int bx, int n, int mode, int param, bool coded,
-                                          const int *coef, int *tmp, bool is8, int sub, long block_off, bool is_uv,
+                                          const int *coef, int *tmp, bool is8, int sub, int block_off, bool is_uv,
                                           int S, int lane, int *fault) {
   TileNb nb{tile, by, bx};
   if (mode == 2) {
@@ -627,7 +629,7 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   const Geo g{A.width, A.height, S, A.mbw, 31 - __builtin_clz((unsigned)S)};
   uint8_t *y0 = A.planes + (size_t)clip * A.clip_bytes + (size_t)(A.ring_base % 6) * A.slot_bytes;
   uint8_t *uv0 = y0 + (size_t)S * A.height;
-  const long off = (long)(mb / A.mbw) * 16 * S + (mb % A.mbw) * 16;
+  const int off = (mb / A.mbw) * 16 * S + (mb % A.mbw) * 16; // < 2^20
 
   // block records and the first 64 residual level words: in flight while the wave waits for its dependencies (a record fetched
   // inside the block loop would be one exposed round trip per block)
@@ -682,11 +684,11 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
     if (i < 25) { r = -1; c = i - 1; }
     else if (i < 41) { r = i - 25; c = -1; }
     else { r = (i - 41) >> 3; c = 16 + ((i - 41) & 7); }
-    const long a = off + (long)r * S + c;
+    const int a = off + (r << g.lg) + c;
     const int o = g.owner_luma(a);
     const bool take = i < 25 + 16 + 128 && o >= 0 && o < mb;
     hpos[k] = take ? (r + 1) * TP + 4 + c : -1;
-    hval[k] = ld_u8_sc1(y0 + (take ? a : off)); // not ours to read: load our own first pixel instead, and drop it
+    hval[k] = ld_u8_sc1(y0, (uint32_t)(take ? a : off)); // not ours to read: load our own first pixel instead, and drop it
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -696,11 +698,11 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
     if (j < 17) { r = -1; c = j - 1; }
     else if (j < 25) { r = j - 17; c = -1; }
     else { r = (j - 25) >> 3; c = 8 + ((j - 25) & 7); }
-    const long a = off / 2 + v * (S >> 1) + (long)r * S + c;
+    const int a = off / 2 + v * (S >> 1) + (r << g.lg) + c;
     const int o = g.owner_chroma(a);
     const bool take = i < 2 * (17 + 8 + 64) && o >= 0 && o < mb;
     hpos[3 + k] = take ? (136 + v * 72) * 4 + (r + 1) * TP + 4 + c : -1; // tcu / tcv follow the luma tile
-    hval[3 + k] = ld_u8_sc1(uv0 + (take ? a : off / 2));
+    hval[3 + k] = ld_u8_sc1(uv0, (uint32_t)(take ? a : off / 2));
   }
   ld_wait6(hval);
 #pragma unroll
@@ -718,7 +720,7 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   for (int a = 0; a < 6; a++) {
     uint8_t *tile = a < 4 ? ty : (a == 4 ? tcu : tcv);
     const int ay = a < 4 ? (a >> 1) * 8 : 0, ax = a < 4 ? (a & 1) * 8 : 0;
-    const long aoff = a < 4 ? off + (long)ay * S + ax : off / 2 + (a - 4) * (S >> 1);
+    const int aoff = a < 4 ? off + ay * S + ax : off / 2 + (a - 4) * (S >> 1);
     const uint32_t r0 = rec_at(a * 4);
     const bool pre = (r0 >> 6) & 1;
     if (pre) run_block(tile, ay, ax, 8, 2, (int16_t)(r0 >> 16), false, coef, tmp, false, 0, aoff, a >= 4, S, lane, &fault);
@@ -729,7 +731,7 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
         const uint32_t rr = rec_at(a * 4 + s);
         const int sy = (s >> 1) * 4, sx = (s & 1) * 4;
         const int param = (s == 0 && pre) ? 0 : (int16_t)(rr >> 16);
-        run_block(tile, ay + sy, ax + sx, 4, rr & 15, param, (rr >> 4) & 1, coef + 64 * a, tmp, false, s, aoff + (long)sy * S + sx, a >= 4, S, lane, &fault);
+        run_block(tile, ay + sy, ax + sx, 4, rr & 15, param, (rr >> 4) & 1, coef + 64 * a, tmp, false, s, aoff + sy * S + sx, a >= 4, S, lane, &fault);
       }
     }
   }
@@ -740,10 +742,10 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   // ---- store interiors ----
   {
     const int row = lane >> 2, c4 = (lane & 3) * 4;
-    __hip_atomic_store((uint32_t *)(y0 + off + (long)row * S + c4), *(const uint32_t *)(ty + (row + 1) * TP + 4 + c4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((uint32_t *)(y0 + off + row * S + c4), *(const uint32_t *)(ty + (row + 1) * TP + 4 + c4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < 32) {
       const int v = lane >> 4, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-      __hip_atomic_store((uint32_t *)(uv0 + off / 2 + v * (S >> 1) + (long)crow * S + cc4), *(const uint32_t *)((v ? tcv : tcu) + (crow + 1) * TP + 4 + cc4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((uint32_t *)(uv0 + off / 2 + v * (S >> 1) + crow * S + cc4), *(const uint32_t *)((v ? tcv : tcu) + (crow + 1) * TP + 4 + cc4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (A.done) {

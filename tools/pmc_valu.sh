@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'inter' not in k: continue
+        if "mobi" not in k: continue
         acc[k][r['Counter_Name']] += float(r['Counter_Value']); 
         if r['Counter_Name'] == 'SQ_WAVES': n[k] += 1
 for k in acc:
