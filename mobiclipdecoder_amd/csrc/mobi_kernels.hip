@@ -667,13 +667,40 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   uint8_t *tcv = (uint8_t *)(L + 136 + 72);
   int *coef = (int *)(L + 136 + 144), *tmp = coef + 384;
   int32_t *sc = (int32_t *)(tmp + 384);
-  for (int i = lane; i < 136 + 144; i += 64) L[i] = 0;
-  zero_coefs(coef, lane);
+  { // tiles (280 words) and coefficients (384 words): 664 words = 2656 B, as 16-byte stores
+    const uint4 z = uint4{0, 0, 0, 0};
+    uint4 *L4 = (uint4 *)L;
+    L4[lane] = z;
+    L4[64 + lane] = z;
+    if (lane < 166 - 128) L4[128 + lane] = z;
+  }
   sc[lane] = sc_lo;
   if (lane < MOBI_SCALE_STRIDE - 64) sc[64 + lane] = sc_hi;
   wave_sync();
 
   // ---- halo: real pixels only from raster-earlier macroblocks; the rest is the reference's fresh 0 ----
+  const int mbx = mb % A.mbw, mby = mb / A.mbw;
+  if (mbx >= 1 && mbx + 1 < A.mbw && mby >= 1) {
+    // away from the picture's left, right and top edges ownership is known without arithmetic: the row above (left,
+    // above, above-right macroblocks) and the column to the left are raster-earlier, everything to the right in the
+    // macroblock's own rows is raster-later (reads the fresh plane's 0).  Two loads per lane instead of six.
+    int p0 = -1, p1 = -1;
+    uint32_t v[6] = {0, 0, 0, 0, 0, 0};
+    int a0 = off, a1 = off / 2;
+    if (lane < 25) { a0 = off - S + lane - 1; p0 = 4 + lane - 1; }                          // luma row -1, columns -1..23
+    else if (lane < 41) { a0 = off + ((lane - 25) << g.lg) - 1; p0 = (lane - 25 + 1) * TP + 3; } // luma column -1
+    {
+      const int vv = lane >> 5, jl = lane & 31; // lanes 0..24 U, 32..56 V
+      const int cb = off / 2 + vv * (S >> 1), tb = (136 + vv * 72) * 4;
+      if (jl < 17) { a1 = cb - S + jl - 1; p1 = tb + 4 + jl - 1; }
+      else if (jl < 25) { a1 = cb + ((jl - 17) << g.lg) - 1; p1 = tb + (jl - 17 + 1) * TP + 3; }
+    }
+    v[0] = ld_u8_sc1(y0, (uint32_t)a0);
+    v[1] = ld_u8_sc1(uv0, (uint32_t)a1);
+    ld_wait6(v);
+    if (p0 >= 0) ty[p0] = (uint8_t)v[0];
+    if (p1 >= 0) ty[p1] = (uint8_t)v[1];
+  } else {
   // (all loads are issued before the first one is consumed: six dependent round trips otherwise)
   int hpos[6];
   uint32_t hval[6];
@@ -708,6 +735,7 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
 #pragma unroll
   for (int k = 0; k < 6; k++)
     if (hpos[k] >= 0) ty[hpos[k]] = (uint8_t)hval[k];
+  }
   if (lane < ncoef) scatter_one(sc, mycw, t8, coef);
   scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 64, ncoef, t8, coef, lane);
   wave_sync();
