@@ -66,6 +66,10 @@ int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
  * (ModsDS); float arithmetic is IEEE single, one rounding per operator of the source, no FMA.
  * MOBI_E_NULLREF before the first frame. */
 int mobi_get_argb(mobi_dec *d, uint32_t *out);
+/* Self-test of the Bitmap kernel's arithmetic: its three-instruction x / 239f against the correctly rounded IEEE
+ * division for every float bit pattern with 1e-30 <= |x| <= 1e30 (about 20 ms on the device).  Returns the number of
+ * mismatches (0 is the only acceptable answer) or -1 when the device cannot be used. */
+long long mobi_selftest_div239(int device);
 int mobi_stride(const mobi_dec *d);            /* d.Stride     (MD.cs:30,50-52) */
 uint32_t mobi_quantizer(const mobi_dec *d);    /* d.Quantizer  (MD.cs:26) */
 uint32_t mobi_yuv_format(const mobi_dec *d);   /* d.YuvFormat  (MD.cs:27) */

@@ -673,6 +673,10 @@ int mobi_decode(mobi_dec *d, const uint8_t *data, size_t len, int32_t *offset_in
   int e = mobi_batch_decode(d->b, dp, lp, offset_inout, &rc);
   return e != MOBI_OK ? e : rc;
 }
+long long mobi_selftest_div239(int device) {
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  return mobi_launch_div239_check(nullptr);
+}
 int mobi_get_argb(mobi_dec *d, uint32_t *out) { return d ? mobi_batch_get_argb(d->b, 0, out) : MOBI_E_ARG; }
 int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out) { return d ? mobi_batch_get_planes(d->b, 0, ring_idx, y_out, uv_out) : MOBI_E_ARG; }
 int mobi_stride(const mobi_dec *d) { return d ? d->b->g.stride : 0; }

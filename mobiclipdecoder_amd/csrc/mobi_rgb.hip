@@ -13,6 +13,16 @@
 #include "mobi_kernels.h"
 
 namespace {
+// x / 239f, correctly rounded, in three instructions instead of the ~10 of a generic IEEE division: q0 = x*r,
+// q = fma(fma(-239, q0, x), r, q0) with r = RN(1/239).  Not a theorem for every divisor: it is CHECKED for this one,
+// exhaustively over all 2^32 bit patterns (mobi_selftest_div239, tests/test_rgb.py): identical to __fdiv_rn for every
+// float with 1e-30 <= |x| <= 1e30, and for x = 0 up to the sign of zero, which the clamp and the int cast discard.
+// (The stretch's numerator is (c - 16) * 255 with |c| < 1000: zero, or at least 1e-4 in magnitude.)
+__device__ __forceinline__ float div239(float x) {
+  const float r = 1.0f / 239.0f;
+  const float q0 = __fmul_rn(x, r);
+  return __fmaf_rn(__fmaf_rn(-239.0f, q0, x), r, q0);
+}
 __device__ __forceinline__ uint32_t pack_argb(float R, float G, float B) {
   R = R < 0.f ? 0.f : R; R = R > 255.f ? 255.f : R; // :313-318
   G = G < 0.f ? 0.f : G; G = G > 255.f ? 255.f : G;
@@ -24,9 +34,9 @@ __device__ __forceinline__ uint32_t convert_px(int version, float Y2, float U, f
     float R = __fadd_rn(Y2, __fmul_rn(1.420f, V));
     float G = __fsub_rn(__fsub_rn(Y2, __fmul_rn(0.344f, U)), __fmul_rn(0.714f, V));
     float B = __fadd_rn(Y2, __fmul_rn(1.772f, U));
-    R = __fdiv_rn(__fmul_rn(__fsub_rn(R, 16.f), 255.f), 239.f); // (255f - 16f) is a constant
-    G = __fdiv_rn(__fmul_rn(__fsub_rn(G, 16.f), 255.f), 239.f);
-    B = __fdiv_rn(__fmul_rn(__fsub_rn(B, 16.f), 255.f), 239.f);
+    R = div239(__fmul_rn(__fsub_rn(R, 16.f), 255.f)); // (255f - 16f) is a constant
+    G = div239(__fmul_rn(__fsub_rn(G, 16.f), 255.f));
+    B = div239(__fmul_rn(__fsub_rn(B, 16.f), 255.f));
     return pack_argb(R, G, B);
   }
   const int y = (int)Y2, u = (int)U, v = (int)V; // ModsDS: casts truncate toward zero
@@ -45,16 +55,20 @@ extern "C" __global__ __launch_bounds__(256) void mobi_yuv_to_argb(const uint8_t
   const uint32_t yw = *(const uint32_t *)(Y + (size_t)y * S + x0); // width is a multiple of 16: all four pixels exist
   const int c = (y >> 1) * S + (x0 >> 1);
   const bool lastrow = y == height - 1, odd = (y & 1) != 0, vert = odd && !lastrow;
-  // chroma samples this lane may touch: columns c .. c+2 of this chroma row and, for odd luma rows, of the next one
+  // chroma samples this lane may touch: columns c .. c+2 of this chroma row and, for odd luma rows, of the next one.
+  // c is even, so the four bytes c .. c+3 are one 2-byte-aligned dword (it stays inside the row: c + 3 < Stride/2).
+  typedef uint32_t __attribute__((aligned(2))) u32_a2;
   float u[2][3], v[2][3];
 #pragma unroll
-  for (int r = 0; r < 2; r++)
+  for (int r = 0; r < 2; r++) {
+    const bool need = r == 0 || vert;
+    const uint32_t uw = need ? *(const u32_a2 *)(UV + c + r * S) : 0u, vw = need ? *(const u32_a2 *)(UV + c + r * S + hS) : 0u;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const bool need = (r == 0 || vert) && (k < 2 || x0 + 3 != width - 1); // column c+2 only serves pixel 3's interpolation
-      u[r][k] = need ? __fsub_rn((float)UV[c + r * S + k], 128.f) : 0.f;
-      v[r][k] = need ? __fsub_rn((float)UV[c + r * S + k + hS], 128.f) : 0.f;
+      u[r][k] = __fsub_rn((float)((uw >> (8 * k)) & 0xFF), 128.f);
+      v[r][k] = __fsub_rn((float)((vw >> (8 * k)) & 0xFF), 128.f);
     }
+  }
   uint32_t px[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -86,4 +100,25 @@ extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, 
   hipLaunchKernelGGL(mobi_yuv_to_argb, grid, dim3(256), 0, s, (const uint8_t *)a->planes, (uint64_t)a->clip_bytes, a->slot_bytes, a->ring_base,
                      a->width, a->height, a->stride, version, clip0, out_dev);
   return (int)hipGetLastError();
+}
+
+// ---- self-test: div239 against the correctly rounded division for every float bit pattern ------------------
+extern "C" __global__ void mobi_div239_check(unsigned long long *bad) {
+  const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * 256u;
+  unsigned long long n = 0;
+  for (uint32_t k = 0; k < 256; k++) {
+    const float x = __uint_as_float(base + k);
+    if (!(fabsf(x) >= 1e-30f && fabsf(x) <= 1e30f)) continue; // also drops NaN
+    if (__float_as_uint(div239(x)) != __float_as_uint(__fdiv_rn(x, 239.0f))) n++;
+  }
+  if (n) atomicAdd(bad, n);
+}
+extern "C" long long mobi_launch_div239_check(hipStream_t s) {
+  unsigned long long *bad = nullptr, h = 0;
+  if (hipMalloc((void **)&bad, 8) != hipSuccess) return -1;
+  (void)hipMemsetAsync(bad, 0, 8, s);
+  hipLaunchKernelGGL(mobi_div239_check, dim3(65536), dim3(256), 0, s, bad);
+  const bool ok = hipMemcpyAsync(&h, bad, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  (void)hipFree(bad);
+  return ok ? (long long)h : -1;
 }

@@ -39,6 +39,7 @@ _SIGS = {
     "mobi_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)]),
     "mobi_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_get_argb": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mobi_selftest_div239": (C.c_longlong, [C.c_int]),
     "mobi_stride": (C.c_int, [C.c_void_p]),
     "mobi_quantizer": (C.c_uint32, [C.c_void_p]),
     "mobi_yuv_format": (C.c_uint32, [C.c_void_p]),
