@@ -587,6 +587,7 @@ struct TileNb {
 __device__ __forceinline__ void run_block(uint8_t *tile, int by, int bx, int n, int mode, int param, bool coded,
                                           const int *coef, int *tmp, bool is8, int sub, int block_off, bool is_uv,
                                           int S, int lane, int *fault) {
+  asm volatile("" : "+v"(lane)); // per-lane predicates are recomputed here: hoisted out of the block loops they end up as ~50 spilled SGPR pairs
   TileNb nb{tile, by, bx};
   if (mode == 2) {
     const int wpr = n >> 2, nw = n * wpr; // words per row, words in block
