@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
+    ap.add_argument("--intra-events", action="store_true", help="HIP events around the intra launches too (adds a few us per step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +106,7 @@ def main():
         b.replay(f)
     assert b.sync() == 0, "clamp-domain fault during warm-up"
 
-    b.set_kernel_timing(not args.no_kernel_events)
+    b.set_kernel_timing(0 if args.no_kernel_events else (2 if args.intra_events else 1))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -136,8 +137,8 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_ms, 5),
                     "launches": km["inter_launches"],
-                    "intra_kernel_ms_per_step": round(km["intra_ms"] / steps, 5),
-                    "intra_launches_per_step": round(km["intra_launches"] / steps, 2)}
+                    "intra_kernel_ms_per_step": round(km["intra_ms"] / steps, 5) if km["intra_launches"] else None,
+                    "intra_launches_per_step": round(km["intra_launches"] / steps, 2) if km["intra_launches"] else None}
             prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(prof):  # HBM bytes per launch from a separate rocprofv3 --pmc run (see profiles/README.md)
                 try:

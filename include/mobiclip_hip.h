@@ -117,8 +117,10 @@ uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx);
 int mobi_batch_time_begin(mobi_batch *b);
 int mobi_batch_time_end(mobi_batch *b, float *ms_out);
 /* per-kernel-class device time (ms) accumulated since the last time_begin: [0] inter MC+IDCT kernel,
- * [1] intra kernel launches; measured with HIP events around each launch when profiling is enabled */
-int mobi_batch_set_kernel_timing(mobi_batch *b, int enable);
+ * [1] intra kernel launches; measured with HIP events around launches on the batch's stream.
+ * level 0: off; 1: the inter launches only (the dominant kernel -- what a roofline needs; the events themselves cost a
+ * few microseconds per launch); 2: every launch */
+int mobi_batch_set_kernel_timing(mobi_batch *b, int level);
 int mobi_batch_kernel_ms(mobi_batch *b, float *inter_ms, float *intra_ms, int *inter_launches, int *intra_launches);
 
 const char *mobi_error_string(int rc);

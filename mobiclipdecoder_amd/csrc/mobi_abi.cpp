@@ -229,7 +229,7 @@ struct mobi_batch {
   bool committed = false;
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  bool ktiming = false;
+  int ktiming = 0; // HIP events around launches: 0 none, 1 the inter launches (the dominant kernel: roofline), 2 every launch
   struct EvPair { hipEvent_t a, b; int kind; };
   std::vector<EvPair> evs;
   std::vector<hipEvent_t> ev_pool;
@@ -288,9 +288,9 @@ struct mobi_batch {
       const int cnt = (int)(plan.start[plan.n_levels() + 1] - plan.start[1]);
       if (cnt > 0) {
         EvPair ep{nullptr, nullptr, 1};
-        if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
+        if (ktiming >= 2) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
         if (mobi_launch_intra(&a, items_dev + plan.start[1], cnt, stream) != 0) return MOBI_E_DEVICE;
-        if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
+        if (ktiming >= 2) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
       }
       return MOBI_OK;
     }
@@ -298,9 +298,9 @@ struct mobi_batch {
       int cnt = (int)(plan.start[L + 1] - plan.start[L]);
       if (cnt <= 0) continue;
       EvPair ep{nullptr, nullptr, 1};
-      if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
+      if (ktiming >= 2) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
       if (mobi_launch_intra(&a, items_dev + plan.start[L], cnt, stream) != 0) return MOBI_E_DEVICE;
-      if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
+      if (ktiming >= 2) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
     return MOBI_OK;
   }
@@ -640,7 +640,7 @@ int mobi_batch_time_end(mobi_batch *b, float *ms_out) {
 }
 int mobi_batch_set_kernel_timing(mobi_batch *b, int enable) {
   if (!b) return MOBI_E_ARG;
-  b->ktiming = enable != 0;
+  b->ktiming = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   return MOBI_OK;
 }
 int mobi_batch_kernel_ms(mobi_batch *b, float *inter_ms, float *intra_ms, int *inter_launches, int *intra_launches) {

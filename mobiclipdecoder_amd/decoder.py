@@ -282,8 +282,9 @@ class MobiclipBatch:
             raise MobiclipError(error_string(rc))
         return ms.value
 
-    def set_kernel_timing(self, on):
-        self._lib.mobi_batch_set_kernel_timing(self._h, 1 if on else 0)
+    def set_kernel_timing(self, level):
+        """0 / False: off; 1 / True: HIP events around the inter launches; 2: around every launch."""
+        self._lib.mobi_batch_set_kernel_timing(self._h, int(level))
 
     def kernel_ms(self):
         a, b, na, nb = C.c_float(), C.c_float(), C.c_int(), C.c_int()

@@ -10,7 +10,7 @@ def run(tag, **kw):
     for c in range(distinct,clips): b.preload_clone(c,c%distinct)
     b.commit(); b.replay(0)
     for f in range(1,9): b.replay(f)
-    b.sync(); b.set_kernel_timing(True); b.time_begin()
+    b.sync(); b.set_kernel_timing(2); b.time_begin()
     for i in range(32): b.replay(1+(i%32))
     ms=b.time_end(); km=b.kernel_ms()
     print(tag, 'step %.3f ms  inter %.3f ms  intra %.3f ms/step (%d launches)'%(ms/32, km['inter_ms']/max(1,km['inter_launches']), km['intra_ms']/32, km['intra_launches']/32), flush=True)
