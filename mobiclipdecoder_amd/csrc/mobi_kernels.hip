@@ -175,9 +175,9 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
 // deals consecutive workgroups round-robin to the 8 XCDs, so XCD x gets one contiguous run of quads.
 namespace {
 enum {                           // per-wave LDS map.  A DMA round r puts lane i's 16 bytes at R_r + 16 * i, i = g*16 + j
-  Q_R0 = 0,                      // luma window rows 0..15, bytes 0..15 of the row  (j = row)
-  Q_R1 = 1024,                   // luma window rows 0..15, bytes 16..31
-  Q_R2 = 2048,                   // U window rows 0..7 (j = row*2 + 16-byte half)
+  Q_R0 = 0,                      // luma window rows 0..7: j = row*2 + 16-byte half, so a row's 32 bytes are contiguous
+  Q_R1 = 1024,                   // luma window rows 8..15
+  Q_R2 = 2048,                   // U window rows 0..7
   Q_R3 = 3072,                   // V window rows 0..7
   Q_R4 = 4096,                   // j 0,1: luma row 16; 2,3: U row 8; 4,5: V row 8; j 6..15 of g 0,1: dequant scales (20 chunks)
   // after motion compensation the windows are dead and the same bytes are reused:
@@ -196,7 +196,8 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 
 __device__ __forceinline__ uint32_t lds32(const uint8_t *L, int byte_off) { return *(const uint32_t *)(L + byte_off); }
 // CopyBlock on four packed pixels (MD.cs:424-452): x0,x1 = aligned dwords holding the row, y0,y1 the row below,
-// sh = byte shift 0..3, sh8 = 8*sh; the phase arrives as three lane masks
+// sh = byte shift 0..3, sh8 = 8*sh; the phase arrives as three lane masks.  (Unaligned LDS dword reads would make the
+// byte-align arithmetic unnecessary -- they work on gfx950, but at a quarter of the aligned rate: 0.39 vs 0.25 ms.)
 __device__ __forceinline__ uint32_t mc4_lane(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t sh, uint32_t sh8,
                                              bool ph0, bool ph1, bool ph2) {
   const uint32_t M = 0x7F7F7F7Fu;
@@ -308,9 +309,9 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   const uint32_t cwin = single ? refC + ysz + (uint32_t)(cpos & ~15) : 0u;
   const uint8_t *lbase = clip_base;
   {
-    const uint8_t *p0 = lbase + (ywin + rowoff(j));
+    const uint8_t *p0 = lbase + (ywin + rowoff(j >> 1) + (uint32_t)(j & 1) * 16u);
     MOBI_DMA16(p0, L + Q_R0, 0);
-    MOBI_DMA16(p0, L + Q_R1 - 16, 16); // the instruction offset moves the LDS side as well as the global side
+    MOBI_DMA16(p0 + rowoff(8), L + Q_R1, 0);
     const uint8_t *p2 = lbase + (cwin + rowoff(j >> 1) + (uint32_t)(j & 1) * 16u);
     MOBI_DMA16(p2, L + Q_R2, 0);
     MOBI_DMA16(p2 + hS, L + Q_R3, 0);
@@ -366,18 +367,19 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
   auto stage_b = [&](auto with_dual) {
     constexpr bool DUAL = decltype(with_dual)::value;
     {
-      const int ys = ypos & 15;
-      const int rr = j >> 2, q = j & 3, w0 = (ys + 4 * q) >> 2, w1 = w0 + 1;
-      const int a0 = Q_R0 + (w0 >> 2) * 1024 + g * 256 + rr * 16 + (w0 & 3) * 4, a1 = Q_R0 + (w1 >> 2) * 1024 + g * 256 + rr * 16 + (w1 & 3) * 4;
-      const int b0 = Q_R4 + g * 256 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + (w1 >> 2) * 16 + (w1 & 3) * 4;
-      const int ph01 = yph01, ph23 = yph23;
+      // lane (g, rr = j>>2, q = j&3) takes row 4t + rr, pixels 4q..4q+3 (+1 for the half-pel neighbour): two aligned dwords of
+      // the row and of the row below.  Row y of the window: (y>>3)*1024 + g*256 + (y&7)*32, row 16 in Q_R4; rows 7 -> 8
+      // and 15 -> 16 are the only non-contiguous steps (lanes rr == 3 at t = 1, 3).
+      const int rr = j >> 2, q = j & 3, ys = ypos & 15, wq = (ys + 4 * q) & ~3;
+      const int A0 = Q_R0 + g * 256 + rr * 32 + wq;
+      const int c1 = rr == 3 ? Q_R1 + g * 256 + wq : A0 + 128 + 32;        // row below at t = 1 (row 8 for rr == 3)
+      const int c3 = rr == 3 ? Q_R4 + g * 256 + wq : A0 + 1024 + 128 + 32; // row below at t = 3 (row 16 for rr == 3)
       const uint32_t sh01 = ypos & 3, sh23 = ypos23 & 3;
-      const bool p0a = ph01 == 0, p1a = ph01 == 1, p2a = ph01 == 2, p0b = ph23 == 0, p1b = ph23 == 1, p2b = ph23 == 2;
+      const bool p0a = yph01 == 0, p1a = yph01 == 1, p2a = yph01 == 2, p0b = yph23 == 0, p1b = yph23 == 1, p2b = yph23 == 2;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        uint32_t x0 = lds32(L, a0 + 64 * t), x1 = lds32(L, a1 + 64 * t), y0, y1;
-        if (t < 3) { y0 = lds32(L, a0 + 64 * t + 16); y1 = lds32(L, a1 + 64 * t + 16); }
-        else { y0 = lds32(L, rr == 3 ? b0 : a0 + 64 * 3 + 16); y1 = lds32(L, rr == 3 ? b1 : a1 + 64 * 3 + 16); }
+        const int at = A0 + (t >> 1) * 1024 + (t & 1) * 128, ct = t == 1 ? c1 : t == 3 ? c3 : at + 32;
+        uint32_t x0 = lds32(L, at), x1 = lds32(L, at + 4), y0 = lds32(L, ct), y1 = lds32(L, ct + 4);
         if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
         const bool second = DUAL && t >= 2;
         const uint32_t sh = second ? sh23 : sh01;
@@ -385,17 +387,16 @@ __device__ __forceinline__ void recon_inter_quad(const MobiReconArgs &A, uint8_t
       }
     }
     {
-      const int cs = cpos & 15;
-      const int row = j >> 1, q = j & 1, w0 = (cs + 4 * q) >> 2, w1 = w0 + 1;
-      const int a0 = Q_R2 + g * 256 + row * 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, a1 = Q_R2 + g * 256 + row * 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
-      const int b0 = Q_R4 + g * 256 + 32 + (w0 >> 2) * 16 + (w0 & 3) * 4, b1 = Q_R4 + g * 256 + 32 + (w1 >> 2) * 16 + (w1 & 3) * 4;
-      const int n0 = row == 7 ? b0 : a0 + 32, n1 = row == 7 ? b1 : a1 + 32;
+      // chroma: plane u, lane (g, row = j>>1, q = j&1); row r of the window: Q_R2 + u*1024 + g*256 + r*32, row 8 in Q_R4
+      const int row = j >> 1, q = j & 1, cs = cpos & 15, wq = (cs + 4 * q) & ~3;
+      const int A0 = Q_R2 + g * 256 + row * 32 + wq;
+      const int C0 = row == 7 ? Q_R4 + g * 256 + 32 + wq : A0 + 32, cstep = row == 7 ? 32 : 1024; // U row 8 at +32, V row 8 at +64
       const uint32_t sh = cs & 3, sh8 = sh * 8;
       const bool ph0 = cph == 0, ph1 = cph == 1, ph2 = cph == 2;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        uint32_t x0 = lds32(L, a0 + 1024 * u), x1 = lds32(L, a1 + 1024 * u);
-        uint32_t y0 = lds32(L, row == 7 ? n0 + 32 * u : n0 + 1024 * u), y1 = lds32(L, row == 7 ? n1 + 32 * u : n1 + 1024 * u);
+        const int at = A0 + 1024 * u, ct = C0 + u * cstep;
+        uint32_t x0 = lds32(L, at), x1 = lds32(L, at + 4), y0 = lds32(L, ct), y1 = lds32(L, ct + 4);
         if (DUAL) { x0 = dual ? fx[4 + u].x : x0; x1 = dual ? fx[4 + u].y : x1; y0 = dual ? fy[4 + u].x : y0; y1 = dual ? fy[4 + u].y : y1; }
         mcv[4 + u] = mc4_lane(x0, x1, y0, y1, sh, sh8, ph0, ph1, ph2);
       }
