@@ -1,0 +1,74 @@
+/*
+ * mobiclip_demux.h -- C ABI of the host-side container readers that hand frames to the decoder.
+ *
+ *   Mods (.mods, Nintendo DS)   mirrors LibMobiclip.Containers.Mods.ModsDemuxer (ModsDemuxer.cs:16-117)
+ *   MOC5 (Wii)                  mirrors the inline parser of the reference GUI (MobiclipDecoder/Form1.cs:282-320)
+ *
+ * Pure byte parsing on the host: no GPU, no copies -- every pointer handed out points into the caller's file buffer,
+ * which must outlive the handle.  Where the reference would throw (reads past the end of the stream) these return
+ * an error instead.
+ */
+#ifndef MOBICLIP_DEMUX_H
+#define MOBICLIP_DEMUX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Mods --------------------------------------------------------------------------------------- */
+typedef struct mobi_mods mobi_mods;
+
+/* ModsDemuxer.ModsHeader (ModsDemuxer.cs:44-79): the first 0x30 bytes of the file, little endian */
+typedef struct {
+  char mods_string[4];          /* 0x00 */
+  uint16_t tag_id;              /* 0x04 */
+  uint16_t tag_id_size_dword;   /* 0x06 */
+  uint32_t frame_count;         /* 0x08 */
+  uint32_t width, height;       /* 0x0C, 0x10 */
+  uint32_t fps;                 /* 0x14  (raw field, as the reference keeps it) */
+  uint16_t audio_codec;         /* 0x18 */
+  uint16_t nb_channel;          /* 0x1A */
+  uint32_t frequency;           /* 0x1C */
+  uint32_t biggest_frame;       /* 0x20 */
+  uint32_t audio_offset;        /* 0x24 */
+  uint32_t keyframe_index_offset; /* 0x28 */
+  uint32_t keyframe_count;      /* 0x2C */
+} mobi_mods_header;
+
+#define MOBI_MODS_CODEBOOK_BYTES 0xC34 /* ModsDemuxer.cs:26 */
+
+/* new ModsDemuxer(stream) (:16-42): header, audio codebooks, key frame index, JumpToKeyFrame(0).
+ * NULL when the file is shorter than what the header points at. */
+mobi_mods *mobi_mods_open(const uint8_t *file, size_t len);
+void mobi_mods_close(mobi_mods *m);
+int mobi_mods_get_header(const mobi_mods *m, mobi_mods_header *out);
+/* KeyFrames[k] (:81-86); returns 0, or -1 when k is out of range */
+int mobi_mods_keyframe(const mobi_mods *m, int k, uint32_t *frame_number, uint32_t *data_offset);
+/* AudioCodebooks[channel] (:21-29): MOBI_MODS_CODEBOOK_BYTES bytes, or NULL (no audio / bad channel) */
+const uint8_t *mobi_mods_audio_codebook(const mobi_mods *m, int channel);
+/* JumpToKeyFrame(k) (:88-95): silently ignored when k >= KeyframeCount, like the reference */
+void mobi_mods_jump_to_keyframe(mobi_mods *m, int k);
+/* ReadFrame(out NrAudioPackets, out IsKeyFrame) (:97-116).  Returns 1 and the packet (video bits first, then the audio
+ * packets; feed it to mobi_decode with offset 0), 0 when CurFrame >= FrameCount (the reference returns null),
+ * -1 when the file ends inside the packet. */
+int mobi_mods_read_frame(mobi_mods *m, const uint8_t **packet, uint32_t *packet_size, uint32_t *nr_audio_packets, int *is_key_frame);
+
+/* ---- MOC5 --------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t width, height;   /* u32 at 0x1C, 0x20 (Form1.cs:286-287) */
+  uint32_t fps_x128;        /* u32 at 0x0C; frames per second = fps_x128 / 128 (:289) */
+  uint32_t first_block;     /* u32 at 0x04, + 8 (:285) */
+} mobi_moc5_info;
+/* returns 0, or -1 when the file is too short */
+int mobi_moc5_open(const uint8_t *file, size_t len, mobi_moc5_info *info);
+/* One iteration of the frame loop (:293-318): the block at *offs.  Returns 1 and decode_offset = *offs + 8 (the
+ * decoder gets the WHOLE file as Data and this Offset), then advances *offs by 4 + (blocksize & ~1), rounded up to a
+ * multiple of 4; returns 0 when *offs >= len (the reference exits). */
+int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_t *decode_offset, uint32_t *block_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

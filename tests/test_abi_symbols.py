@@ -27,6 +27,17 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert set(decoder._SIGS) <= set(names)
 
 
+def test_demux_header_symbols_are_exported_and_bound():
+    from mobiclipdecoder_amd import decoder, demux
+    lib = decoder.load_library()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mobiclip_demux.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mobi_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) == 9
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mobiclip_demux.h but not exported"
+    assert set(demux._SIGS) == set(names)
+
+
 def test_library_contains_gfx950_code_object_and_no_oracle():
     path = os.path.join(ROOT, "mobiclipdecoder_amd", "libmobiclip_hip.so")
     blob = open(path, "rb").read()
