@@ -439,7 +439,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   plan.build(ok, b->step_mode == 2);
   // 2. stage [desc table][payload arena][items] and upload
   const int n_mbs = b->g.mbw * b->g.mbh;
-  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 4 * sizeof(MbDesc), kAlign); // slack: a quad reads 4 descriptors at once
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign); // slack: a wave reads up to 8 descriptors at once
   const size_t pay_bytes = align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
   const size_t item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
   if (int e = b->h_stage.reserve(desc_bytes + pay_bytes + item_bytes)) return e;
@@ -554,7 +554,7 @@ int mobi_batch_commit(mobi_batch *b) {
     if ((int)b->staged[c]->size() != nf) return MOBI_E_ARG;
   }
   const int n_mbs = b->g.mbw * b->g.mbh;
-  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 4 * sizeof(MbDesc), kAlign); // slack: a quad reads 4 descriptors at once
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign); // slack: a wave reads up to 8 descriptors at once
   size_t cmd_bytes = 0, n_items = 0;
   b->r_plan.assign(nf, LevelPlan());
   b->r_items_off.assign(nf, 0);

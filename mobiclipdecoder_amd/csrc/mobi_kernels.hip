@@ -557,6 +557,302 @@ __device__ __forceinline__ void recon_inter_entry(const MobiReconArgs &A) {
 extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter(MobiReconArgs A) { recon_inter_entry<false>(A); }
 extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter_prof(MobiReconArgs A) { recon_inter_entry<true>(A); }
 
+
+// =====================================================================================================
+// mobi_recon_inter8: the same work, one wavefront per OCTET of eight horizontally adjacent macroblocks
+// =====================================================================================================
+// The quad kernel is bound by instruction issue of every kind, and a good part of its instructions do not scale with
+// the pixels: the per-wave prologue, and the decode / address stage in which every lane works for "its" macroblock.
+// With 8 lanes per macroblock instead of 16, one pass through that code serves eight macroblocks.  Lane (g, j):
+// g = lane >> 3 the macroblock, j = lane & 7.  DMA rounds hold 8 chunks per macroblock: 4 rows x 2 halves.
+namespace {
+enum {
+  O_L = 0,       // 4 rounds: luma window rows 4t..4t+3  (slot g*8 + (row&3)*2 + half: a row's 32 bytes are contiguous)
+  O_U = 4096,    // 2 rounds: U rows 0..3, 4..7
+  O_V = 6144,    // 2 rounds: V rows 0..3, 4..7
+  O_X = 8192,    // leftovers, per macroblock: j 0,1 luma row 16; 2,3 U row 8; 4,5 V row 8
+  O_SC = 9216,   // dequant scales (320 B)
+  O_META = 9536, // cbp6[8], t8mask[8], flags[8]
+  O_BYTES = 9568,
+  // after motion compensation:
+  O_OUT_Y = 0,     // 16 rows x 128 B
+  O_OUT_C = 2048,  // 2 planes x 8 rows x 64 B
+  O_COEF = 3072,   // 8 areas x 64 ints, transposed in place
+  O_TAB = O_X      // entry -> g*8 + area (<= 48 bytes)
+};
+} // namespace
+
+__device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
+  uint32_t rem, ox;
+  const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); // qpr / qpc: OCTETS per row / per clip for this kernel
+  const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);
+  const uint32_t mbx0 = ox * 8, mbw = (uint32_t)A.mbw;
+  const int nmb = (int)(mbw - mbx0 < 8 ? mbw - mbx0 : 8);
+  const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S);
+  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height, slot_w = A.slot_bytes >> 2, ysz_w = ysz >> 2;
+  uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
+  const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16);
+  const int g = lane >> 3, j = lane & 7;
+
+  // ---- stage A ----
+  const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last octet
+  const uint4 d = dp[0], d2 = dp[1];
+  const bool valid = g < nmb && (d.y & 1) == MOBI_MB_INTER;
+  const int nl = (d.y >> 1) & 0x7F, kind2 = (d.y >> 26) & 3;
+  const bool single = valid && nl == 1, dual = valid && kind2 != 0, multi = valid && nl > 1 && kind2 == 0;
+  const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
+  L[O_META + g] = (uint8_t)cbp6;
+  L[O_META + 8 + g] = (uint8_t)((d.y >> 14) & 0x3F);
+  L[O_META + 16 + g] = (uint8_t)((valid ? 1 : 0) | (multi ? 2 : 0));
+  const bool any_dual = __builtin_amdgcn_ballot_w64(dual) != 0;
+  auto slot_off = [&](uint32_t ref) {
+    int sl = A.ring_base - (int)ref;
+    sl = sl < 0 ? sl + 6 : sl;
+    return __umul24((uint32_t)sl, A.slot_bytes);
+  };
+  // leaf records as this lane needs them: luma rows 0..7 (iterations t < 4) / rows 8..15 (t >= 4); chroma rows 0..3 (u even) /
+  // rows 4..7 (u odd).  DUAL top/bottom switches with the iteration, left/right with the lane's column.
+  const uint32_t refA = slot_off((d.z >> 10) & 7);
+  uint32_t refY0 = refA, refY1 = refA, refC0 = refA, refC1 = refA;
+  int ypos0 = (int)d.w, ypos1 = (int)d.w, cpos0 = (int)d2.x, cpos1 = (int)d2.x;
+  int yph0 = (d.z >> 16) & 3, yph1 = yph0, cph0 = (d.z >> 18) & 3, cph1 = cph0;
+  if (any_dual) {
+    const uint32_t refB = slot_off((d.z >> 13) & 7);
+    const bool lr = kind2 == MOBI_DUAL_LR, tb = kind2 == MOBI_DUAL_TB;
+    const bool by0 = dual && lr && (j & 2), by1 = dual && (tb || (lr && (j & 2)));
+    const bool bc0 = dual && lr && (j & 1), bc1 = dual && (tb || (lr && (j & 1)));
+    const int yphB = (d.z >> 20) & 3, cphB = (d.z >> 22) & 3;
+    refY0 = by0 ? refB : refA; ypos0 = by0 ? (int)d2.y : ypos0; yph0 = by0 ? yphB : yph0;
+    refY1 = by1 ? refB : refA; ypos1 = by1 ? (int)d2.y : ypos1; yph1 = by1 ? yphB : yph1;
+    refC0 = bc0 ? refB : refA; cpos0 = bc0 ? (int)d2.z : cpos0; cph0 = bc0 ? cphB : cph0;
+    refC1 = bc1 ? refB : refA; cpos1 = bc1 ? (int)d2.z : cpos1; cph1 = bc1 ? cphB : cph1;
+  }
+  const int hS = single ? S >> 1 : 0;
+  auto rowoff = [&](int rows) { return single ? (uint32_t)rows << lgS : 0u; };
+  const uint32_t ywin = single ? refA + (uint32_t)((int)d.w & ~15) : 0u;
+  const uint32_t cwin = single ? refA + ysz + (uint32_t)((int)d2.x & ~15) : 0u;
+  {
+    const uint8_t *p0 = clip_base + (ywin + rowoff(j >> 1) + (uint32_t)(j & 1) * 16u);
+    MOBI_DMA16(p0, L + O_L, 0);
+    MOBI_DMA16(p0 + rowoff(4), L + O_L + 1024, 0);
+    MOBI_DMA16(p0 + rowoff(8), L + O_L + 2048, 0);
+    MOBI_DMA16(p0 + rowoff(12), L + O_L + 3072, 0);
+    const uint8_t *p2 = clip_base + (cwin + rowoff(j >> 1) + (uint32_t)(j & 1) * 16u);
+    MOBI_DMA16(p2, L + O_U, 0);
+    MOBI_DMA16(p2 + rowoff(4), L + O_U + 1024, 0);
+    MOBI_DMA16(p2 + hS, L + O_V, 0);
+    MOBI_DMA16(p2 + hS + rowoff(4), L + O_V + 1024, 0);
+    const int h = j >> 1;
+    const uint32_t o4 = (h == 0 ? ywin + rowoff(16) : h == 1 ? cwin + rowoff(8) : h == 2 ? cwin + hS + rowoff(8) : 0u) + (uint32_t)(j & 1) * 16u;
+    MOBI_DMA16(clip_base + o4, L + O_X, 0);
+    const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
+    if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + O_SC, 0);
+  }
+  const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
+  uint32_t cwr[4] = {0, 0, 0, 0}; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g
+  if ((uint32_t)j < ncoef) cwr[0] = cw[j];
+  if (__builtin_amdgcn_ballot_w64(ncoef > 8) != 0) {
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+  }
+  uint2 fx[12], fy[12]; // DUAL lanes: their own 2 x 8 bytes per iteration, straight into registers
+  if (dual) {
+    const int rr = j >> 2, q = j & 3;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const uint32_t o = (t < 4 ? refY0 : refY1) + (uint32_t)(((t < 4 ? ypos0 : ypos1) + ((2 * t + rr) << lgS) + 4 * q) & ~3);
+      fx[t] = *(const uint2_a4 *)(clip_base + o);
+      fy[t] = *(const uint2_a4 *)(clip_base + o + S);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int row = (u & 1) * 4 + (j >> 1);
+      const uint32_t o = ((u & 1) ? refC1 : refC0) + ysz + (uint32_t)((((u & 1) ? cpos1 : cpos0) + (u >> 1) * (S >> 1) + (row << lgS) + 4 * (j & 1)) & ~3);
+      fx[8 + u] = *(const uint2_a4 *)(clip_base + o);
+      fy[8 + u] = *(const uint2_a4 *)(clip_base + o + S);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wave_sync();
+  const uint2 mm2 = *(const uint2 *)(L + O_META), tt2 = *(const uint2 *)(L + O_META + 8), ff2 = *(const uint2 *)(L + O_META + 16);
+  const uint32_t m_lo = __builtin_amdgcn_readfirstlane(mm2.x), m_hi = __builtin_amdgcn_readfirstlane(mm2.y); // coded areas: bit g*8 + area
+  const uint32_t t_lo = __builtin_amdgcn_readfirstlane(tt2.x), t_hi = __builtin_amdgcn_readfirstlane(tt2.y);
+  const uint32_t f_lo = __builtin_amdgcn_readfirstlane(ff2.x), f_hi = __builtin_amdgcn_readfirstlane(ff2.y); // byte g: bit 0 inter, bit 1 cell map
+  if (((f_lo | f_hi) & 0x01010101u) == 0) return;
+
+  // ---- stage B ----
+  uint32_t mcv[12];
+  auto stage_b = [&](auto with_dual) {
+    constexpr bool DUAL = decltype(with_dual)::value;
+    {
+      // lane (g, rr = j>>2, q = j&3): row 2t + rr.  Row y of the window: O_L + (y>>2)*1024 + g*128 + (y&3)*32, row 16 in O_X.
+      const int rr = j >> 2, q = j & 3, wq = (((int)d.w & 15) + 4 * q) & ~3;
+      const int A0 = O_L + g * 128 + rr * 32 + wq;
+      const int cdo = rr ? 928 : 32;                                           // odd t: row 3 of a group -> row 0 of the next round
+      const int c7 = rr ? O_X + g * 128 + wq : A0 + 3 * 1024 + 64 + 32;      // t = 7: row 15 -> row 16
+      const uint32_t sh0 = ypos0 & 3, sh1 = ypos1 & 3;
+      const bool p0a = yph0 == 0, p1a = yph0 == 1, p2a = yph0 == 2, p0b = yph1 == 0, p1b = yph1 == 1, p2b = yph1 == 2;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int at = A0 + (t >> 1) * 1024 + (t & 1) * 64, ct = t == 7 ? c7 : (t & 1) ? at + cdo : at + 32;
+        uint32_t x0 = lds32(L, at), x1 = lds32(L, at + 4), y0 = lds32(L, ct), y1 = lds32(L, ct + 4);
+        if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
+        const bool second = DUAL && t >= 4;
+        const uint32_t sh = second ? sh1 : sh0;
+        mcv[t] = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
+      }
+    }
+    {
+      // chroma: iteration u: plane u>>1, rows (u&1)*4 + (j>>1), q = j&1.  Row r: O_U/O_V + (r>>2)*1024 + g*128 + (r&3)*32, row 8 in O_X
+      const int r4 = j >> 1, q = j & 1, wq = (((int)d2.x & 15) + 4 * q) & ~3;
+      const int A0 = g * 128 + r4 * 32 + wq;
+      const int cdo = r4 == 3 ? 928 : 32;
+      const uint32_t sh0 = cpos0 & 3, sh1 = cpos1 & 3;
+      const bool p0a = cph0 == 0, p1a = cph0 == 1, p2a = cph0 == 2, p0b = cph1 == 0, p1b = cph1 == 1, p2b = cph1 == 2;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int pl = u >> 1, half = u & 1;
+        const int at = (pl ? O_V : O_U) + half * 1024 + A0;
+        const int ct = half == 0 ? at + cdo : (r4 == 3 ? O_X + g * 128 + 32 + pl * 32 + wq : at + 32);
+        uint32_t x0 = lds32(L, at), x1 = lds32(L, at + 4), y0 = lds32(L, ct), y1 = lds32(L, ct + 4);
+        if (DUAL) { x0 = dual ? fx[8 + u].x : x0; x1 = dual ? fx[8 + u].y : x1; y0 = dual ? fy[8 + u].x : y0; y1 = dual ? fy[8 + u].y : y1; }
+        const bool second = DUAL && half;
+        const uint32_t sh = second ? sh1 : sh0;
+        mcv[8 + u] = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
+      }
+    }
+  };
+  if (any_dual) stage_b(std::true_type{});
+  else stage_b(std::false_type{});
+  wave_sync();
+  {
+    const int oy = O_OUT_Y + (j >> 2) * 128 + g * 16 + (j & 3) * 4, oc = O_OUT_C + (j >> 1) * 64 + g * 8 + (j & 1) * 4;
+#pragma unroll
+    for (int t = 0; t < 8; t++) *(uint32_t *)(L + oy + 256 * t) = mcv[t];
+#pragma unroll
+    for (int u = 0; u < 4; u++) *(uint32_t *)(L + oc + (u >> 1) * 512 + (u & 1) * 256) = mcv[8 + u];
+  }
+  // B2: macroblocks with deeper partition trees, one at a time by the whole wave (as in the quad kernel)
+  {
+    const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
+    const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
+#pragma unroll 1
+    for (int hsel = 0; hsel < 2; hsel++) {
+      uint32_t mm = ((hsel ? f_hi : f_lo) >> 1) & 0x01010101u;
+      while (mm) {
+        const int gm = hsel * 4 + ((__builtin_ctz(mm)) >> 3);
+        mm &= mm - 1;
+        const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm * 8);
+        const uint32_t *clip32 = (const uint32_t *)clip_base;
+        const int offm = off0 + gm * 16;
+        const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
+        const uint2 yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
+        const uint4_a4 c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+        const uint32_t cell[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+        auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return __umul24((uint32_t)(s2 < 0 ? s2 + 6 : s2), slot_w); };
+        const bool ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
+        const bool csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
+        const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
+        const Win wa = fetch_win(clip32 + slot_of(yc.x), ybase + ((dya >> 1) << lgS) + (dxa >> 1), S);
+        Win wb;
+        if (ysplit) wb = fetch_win(clip32 + slot_of(yc.y), ybase + ((dyb >> 1) << lgS) + (dxb >> 1), S);
+        int qx[4], qy[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { qx[k] = mobi_cell_dx(cell[k]) >> 1; qy[k] = mobi_cell_dy(cell[k]) >> 1; }
+        Win wq[4];
+        wq[0] = fetch_win(clip32 + slot_of(cell[0]) + ysz_w, cbase + ((qy[0] >> 1) << lgS) + (qx[0] >> 1), S);
+        if (csplit) {
+#pragma unroll
+          for (int k = 1; k < 4; k++) wq[k] = fetch_win(clip32 + slot_of(cell[k]) + ysz_w, cbase + ((qy[k] >> 1) << lgS) + (qx[k] >> 1), S);
+        }
+        asm volatile("" ::: "memory");
+        const uint32_t va = mc4_select(wa, (dxa & 1) | ((dya & 1) << 1));
+        const uint32_t vb = ysplit ? mc4_select(wb, (dxb & 1) | ((dyb & 1) << 1)) : va;
+        uint32_t cpred = mc4_select(wq[0], (qx[0] & 1) | ((qy[0] & 1) << 1));
+        if (csplit) {
+          cpred &= 0xFFu;
+#pragma unroll
+          for (int k = 1; k < 4; k++) cpred |= mc4_select(wq[k], (qx[k] & 1) | ((qy[k] & 1) << 1)) & (0xFFu << (8 * k));
+        }
+        *(uint32_t *)(L + O_OUT_Y + yrow * 128 + gm * 16 + yc4) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
+        if (lane < 32) *(uint32_t *)(L + O_OUT_C + cv * 512 + crow * 64 + gm * 8 + cc4) = cpred;
+      }
+    }
+  }
+
+  // ---- stage C ----
+  wave_sync();
+  if (m_lo | m_hi) {
+    const int n_lo = __builtin_popcount(m_lo), n_ent = n_lo + __builtin_popcount(m_hi);
+    int *coef = (int *)(L + O_COEF);
+    {
+      const uint32_t w = lane < 32 ? m_lo : m_hi, sh = lane & 31;
+      if ((w >> sh) & 1) L[O_TAB + (lane < 32 ? 0 : n_lo) + __builtin_popcount(w & ((1u << sh) - 1))] = (uint8_t)lane;
+    }
+    const uint32_t mg = g < 4 ? m_lo : m_hi, tg = g < 4 ? t_lo : t_hi; // this lane's macroblock lives in one half of the masks
+    const int gbase = g < 4 ? 0 : n_lo;
+    int lo = 0, hi = 0;
+    for (int pass = 0; pass * 8 < n_ent; pass++) {
+      {
+        const uint4 z = uint4{0, 0, 0, 0};
+        *(uint4 *)(L + O_COEF + lane * 16) = z;
+        *(uint4 *)(L + O_COEF + 1024 + lane * 16) = z;
+      }
+      wave_sync();
+      auto scatter = [&](uint32_t e) {
+        const int t = e & 0x1FF, level = (int32_t)e >> 16, kk = (g & 3) * 8 + (t >> 6), p = t & 63;
+        const int slot = gbase + __builtin_popcount(mg & ((1u << kk) - 1)) - pass * 8;
+        const int si = ((tg >> kk) & 1) ? p : 64 + (p & 15);
+        const int scale = (int)lds32(L, O_SC + si * 4);
+        if ((unsigned)slot < 8u) coef[slot * 64 + p] = __mul24(scale, level);
+      };
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool mine = (uint32_t)(8 * k + j) < ncoef;
+        if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
+        uint32_t e = cwr[k];
+        asm volatile("" : "+v"(e));
+        if (mine) scatter(e);
+      }
+      for (uint32_t i = 32u + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 8)
+        if (i < ncoef) scatter(cw[i]);
+      wave_sync();
+      const int e = lane >> 3, r = lane & 7, idx = pass * 8 + e;
+      const bool act = idx < n_ent;
+      const int k = act ? L[O_TAB + idx] : 0;
+      const int ge = k >> 3, a = k & 7;
+      const bool is8 = ((k < 32 ? t_lo : t_hi) >> (k & 31)) & 1;
+      if (act) idct_pass1(coef + 64 * e, coef + 64 * e, is8, r);
+      wave_sync();
+      if (act) {
+        uint8_t *px = a < 4 ? L + O_OUT_Y + (a >> 1) * 8 * 128 + ge * 16 + (a & 1) * 8 : L + O_OUT_C + (a - 4) * 512 + ge * 8;
+        idct_pass2_q(coef + 64 * e, is8, r, px, a < 4 ? 128 : 64, lo, hi);
+      }
+      wave_sync();
+    }
+    if (lo < -64 || hi > 319) atomicOr(&A.fault[clip], 1);
+  }
+
+  // ---- stage D: whole rows, 128 B of luma and 8 B per macroblock of chroma ----
+  uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int i = lane + 64 * it, gq = i & 7, yrow = i >> 3;
+    if (((gq < 4 ? f_lo : f_hi) >> (8 * (gq & 3))) & 1) {
+      *(uint4 *)(y0 + (off0 + (yrow << lgS) + gq * 16)) = *(const uint4 *)(L + O_OUT_Y + yrow * 128 + gq * 16);
+      const int row = yrow & 7; // chroma: plane = it, row = (i >> 3) & 7
+      *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + O_OUT_C + it * 512 + row * 64 + gq * 8);
+    }
+  }
+}
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_inter8(MobiReconArgs A) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[O_BYTES];
+  const uint32_t oi = (blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3);
+  if (oi >= A.qpc * (uint32_t)A.n_clips) return;
+  recon_inter_oct(A, lds, oi, (int)threadIdx.x);
+}
+
 // =====================================================================================================
 // intra macroblocks of one dependency level
 // =====================================================================================================
@@ -848,6 +1144,18 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const unsigned grid = (unsigned)(((quads + INTER_WAVES - 1) / INTER_WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
+  static const int oct = getenv("MOBI_INTER_OCT") ? atoi(getenv("MOBI_INTER_OCT")) : 0;
+  if (oct && !b.prof && !b.done) { // eight macroblocks per wave: the q* fields count octets for this kernel
+    b.qpr = ((uint32_t)b.mbw + 7) / 8;
+    b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);
+    auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };
+    b.magic_qpr = magic(b.qpr);
+    b.magic_qpc = magic(b.qpc);
+    const unsigned g8 = (unsigned)(((long)b.qpc * b.n_clips + 7) / 8 * 8);
+    b.inter_per_xcd = g8 / 8;
+    hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), 0, s, b);
+    return (int)hipGetLastError();
+  }
   static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
   if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
   else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
