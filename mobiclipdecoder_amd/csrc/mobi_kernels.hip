@@ -577,7 +577,7 @@ enum {
   // after motion compensation:
   O_OUT_Y = 0,     // 16 rows x 128 B
   O_OUT_C = 2048,  // 2 planes x 8 rows x 64 B
-  O_COEF = 3072,   // 8 areas x 64 ints, transposed in place
+  O_COEF = 3072,   // 16 areas x 64 ints, transposed in place (up to 7168)
   O_TAB = O_X      // entry -> g*8 + area (<= 48 bytes)
 };
 } // namespace
@@ -793,19 +793,20 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     const uint32_t mg = g < 4 ? m_lo : m_hi, tg = g < 4 ? t_lo : t_hi; // this lane's macroblock lives in one half of the masks
     const int gbase = g < 4 ? 0 : n_lo;
     int lo = 0, hi = 0;
-    for (int pass = 0; pass * 8 < n_ent; pass++) {
+    // 16 areas per round (two tiles of 8): half as many LDS round trips between the stages as with 8
+    for (int base = 0; base < n_ent; base += 16) {
       {
         const uint4 z = uint4{0, 0, 0, 0};
-        *(uint4 *)(L + O_COEF + lane * 16) = z;
-        *(uint4 *)(L + O_COEF + 1024 + lane * 16) = z;
+#pragma unroll
+        for (int k = 0; k < 4; k++) *(uint4 *)(L + O_COEF + k * 1024 + lane * 16) = z;
       }
       wave_sync();
       auto scatter = [&](uint32_t e) {
         const int t = e & 0x1FF, level = (int32_t)e >> 16, kk = (g & 3) * 8 + (t >> 6), p = t & 63;
-        const int slot = gbase + __builtin_popcount(mg & ((1u << kk) - 1)) - pass * 8;
+        const int slot = gbase + __builtin_popcount(mg & ((1u << kk) - 1)) - base;
         const int si = ((tg >> kk) & 1) ? p : 64 + (p & 15);
         const int scale = (int)lds32(L, O_SC + si * 4);
-        if ((unsigned)slot < 8u) coef[slot * 64 + p] = __mul24(scale, level);
+        if ((unsigned)slot < 16u) coef[slot * 64 + p] = __mul24(scale, level);
       };
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -818,16 +819,29 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       for (uint32_t i = 32u + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 8)
         if (i < ncoef) scatter(cw[i]);
       wave_sync();
-      const int e = lane >> 3, r = lane & 7, idx = pass * 8 + e;
-      const bool act = idx < n_ent;
-      const int k = act ? L[O_TAB + idx] : 0;
-      const int ge = k >> 3, a = k & 7;
-      const bool is8 = ((k < 32 ? t_lo : t_hi) >> (k & 31)) & 1;
-      if (act) idct_pass1(coef + 64 * e, coef + 64 * e, is8, r);
+      const int r = lane & 7;
+      int kx[2];
+      bool actx[2], is8x[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int idx = base + 8 * h + (lane >> 3);
+        actx[h] = idx < n_ent;
+        kx[h] = actx[h] ? L[O_TAB + idx] : 0;
+        is8x[h] = ((kx[h] < 32 ? t_lo : t_hi) >> (kx[h] & 31)) & 1;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int *tile = coef + 64 * (8 * h + (lane >> 3));
+        if (actx[h]) idct_pass1(tile, tile, is8x[h], r);
+      }
       wave_sync();
-      if (act) {
-        uint8_t *px = a < 4 ? L + O_OUT_Y + (a >> 1) * 8 * 128 + ge * 16 + (a & 1) * 8 : L + O_OUT_C + (a - 4) * 512 + ge * 8;
-        idct_pass2_q(coef + 64 * e, is8, r, px, a < 4 ? 128 : 64, lo, hi);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (actx[h]) {
+          const int ge = kx[h] >> 3, a = kx[h] & 7;
+          uint8_t *px = a < 4 ? L + O_OUT_Y + (a >> 1) * 8 * 128 + ge * 16 + (a & 1) * 8 : L + O_OUT_C + (a - 4) * 512 + ge * 8;
+          idct_pass2_q(coef + 64 * (8 * h + (lane >> 3)), is8x[h], r, px, a < 4 ? 128 : 64, lo, hi);
+        }
       }
       wave_sync();
     }
