@@ -567,10 +567,10 @@ extern "C" __global__ __launch_bounds__(64 * INTER_WAVES) void mobi_recon_inter_
 // g = lane >> 3 the macroblock, j = lane & 7.  DMA rounds hold 8 chunks per macroblock: 4 rows x 2 halves.
 namespace {
 enum {
-  O_L = 0,       // 4 rounds: luma window rows 4t..4t+3  (slot g*8 + (row&3)*2 + half: a row's 32 bytes are contiguous)
+  O_L = 0,       // 4 rounds: luma window rows 4t..4t+3  (slot ((row&3)*2 + half)*8 + g: 256 B per row, the rounds are contiguous)
   O_U = 4096,    // 2 rounds: U rows 0..3, 4..7
   O_V = 6144,    // 2 rounds: V rows 0..3, 4..7
-  O_X = 8192,    // leftovers, per macroblock: j 0,1 luma row 16; 2,3 U row 8; 4,5 V row 8
+  O_X = 8192,    // leftovers: j 0,1 luma row 16; 2,3 U row 8; 4,5 V row 8 (same 256 B row shape)
   O_SC = 9216,   // dequant scales (320 B)
   O_META = 9536, // cbp6[8], t8mask[8], flags[8]
   O_BYTES = 9568,
@@ -592,7 +592,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const uint32_t ysz = (uint32_t)S * (uint32_t)A.height, slot_w = A.slot_bytes >> 2, ysz_w = ysz >> 2;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
   const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16);
-  const int g = lane >> 3, j = lane & 7;
+  const int g = lane & 7, j = lane >> 3; // adjacent lanes = adjacent macroblocks: a DMA round lays chunk j of the 8 macroblocks side by
+                                         // side (slot j*8 + g), so the eight macroblocks of an LDS access fall on different banks
 
   // ---- stage A ----
   const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last octet
@@ -686,17 +687,18 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   auto stage_b = [&](auto with_dual) {
     constexpr bool DUAL = decltype(with_dual)::value;
     {
-      // lane (g, rr = j>>2, q = j&3): row 2t + rr.  Row y of the window: O_L + (y>>2)*1024 + g*128 + (y&3)*32, row 16 in O_X.
-      const int rr = j >> 2, q = j & 3, wq = (((int)d.w & 15) + 4 * q) & ~3;
-      const int A0 = O_L + g * 128 + rr * 32 + wq;
-      const int cdo = rr ? 928 : 32;                                           // odd t: row 3 of a group -> row 0 of the next round
-      const int c7 = rr ? O_X + g * 128 + wq : A0 + 3 * 1024 + 64 + 32;      // t = 7: row 15 -> row 16
+      // lane (g, rr = j>>2, q = j&3): row 2t + rr.  Dword w (0..7) of window row y: O_L + y*256 + (w>>2)*128 + g*16 + (w&3)*4
+      // (rows 0..15; the four rounds are contiguous), row 16 at O_X.
+      const int rr = j >> 2, q = j & 3, w0 = (((int)d.w & 15) + 4 * q) >> 2, w1 = w0 + 1;
+      const int c0 = g * 16 + (w0 >> 2) * 128 + (w0 & 3) * 4, c1 = g * 16 + (w1 >> 2) * 128 + (w1 & 3) * 4;
+      const int A0 = O_L + rr * 256 + c0, A1 = O_L + rr * 256 + c1;
       const uint32_t sh0 = ypos0 & 3, sh1 = ypos1 & 3;
       const bool p0a = yph0 == 0, p1a = yph0 == 1, p2a = yph0 == 2, p0b = yph1 == 0, p1b = yph1 == 1, p2b = yph1 == 2;
 #pragma unroll
       for (int t = 0; t < 8; t++) {
-        const int at = A0 + (t >> 1) * 1024 + (t & 1) * 64, ct = t == 7 ? c7 : (t & 1) ? at + cdo : at + 32;
-        uint32_t x0 = lds32(L, at), x1 = lds32(L, at + 4), y0 = lds32(L, ct), y1 = lds32(L, ct + 4);
+        const int at0 = A0 + 512 * t, at1 = A1 + 512 * t;
+        const int ct0 = t == 7 ? (rr ? O_X + c0 : at0 + 256) : at0 + 256, ct1 = t == 7 ? (rr ? O_X + c1 : at1 + 256) : at1 + 256;
+        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0 = lds32(L, ct0), y1 = lds32(L, ct1);
         if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
         const bool second = DUAL && t >= 4;
         const uint32_t sh = second ? sh1 : sh0;
@@ -704,18 +706,19 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       }
     }
     {
-      // chroma: iteration u: plane u>>1, rows (u&1)*4 + (j>>1), q = j&1.  Row r: O_U/O_V + (r>>2)*1024 + g*128 + (r&3)*32, row 8 in O_X
-      const int r4 = j >> 1, q = j & 1, wq = (((int)d2.x & 15) + 4 * q) & ~3;
-      const int A0 = g * 128 + r4 * 32 + wq;
-      const int cdo = r4 == 3 ? 928 : 32;
+      // chroma: iteration u: plane u>>1, rows (u&1)*4 + (j>>1), q = j&1.  Dword w of row r: O_U/O_V + r*256 + (w>>2)*128 + g*16 + (w&3)*4,
+      // row 8 at O_X + 256 (U) / 512 (V)
+      const int r4 = j >> 1, q = j & 1, w0 = (((int)d2.x & 15) + 4 * q) >> 2, w1 = w0 + 1;
+      const int c0 = g * 16 + (w0 >> 2) * 128 + (w0 & 3) * 4, c1 = g * 16 + (w1 >> 2) * 128 + (w1 & 3) * 4;
       const uint32_t sh0 = cpos0 & 3, sh1 = cpos1 & 3;
       const bool p0a = cph0 == 0, p1a = cph0 == 1, p2a = cph0 == 2, p0b = cph1 == 0, p1b = cph1 == 1, p2b = cph1 == 2;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pl = u >> 1, half = u & 1;
-        const int at = (pl ? O_V : O_U) + half * 1024 + A0;
-        const int ct = half == 0 ? at + cdo : (r4 == 3 ? O_X + g * 128 + 32 + pl * 32 + wq : at + 32);
-        uint32_t x0 = lds32(L, at), x1 = lds32(L, at + 4), y0 = lds32(L, ct), y1 = lds32(L, ct + 4);
+        const int pl = u >> 1, half = u & 1, rb = (pl ? O_V : O_U) + (half * 4 + r4) * 256;
+        const int at0 = rb + c0, at1 = rb + c1;
+        const bool last = half == 1 && r4 == 3; // row 7 -> row 8
+        const int ct0 = last ? O_X + 256 + pl * 256 + c0 : at0 + 256, ct1 = last ? O_X + 256 + pl * 256 + c1 : at1 + 256;
+        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0 = lds32(L, ct0), y1 = lds32(L, ct1);
         if (DUAL) { x0 = dual ? fx[8 + u].x : x0; x1 = dual ? fx[8 + u].y : x1; y0 = dual ? fy[8 + u].x : y0; y1 = dual ? fy[8 + u].y : y1; }
         const bool second = DUAL && half;
         const uint32_t sh = second ? sh1 : sh0;
@@ -743,7 +746,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       while (mm) {
         const int gm = hsel * 4 + ((__builtin_ctz(mm)) >> 3);
         mm &= mm - 1;
-        const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm * 8);
+        const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
         const uint32_t *clip32 = (const uint32_t *)clip_base;
         const int offm = off0 + gm * 16;
         const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
@@ -1158,7 +1161,7 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   const unsigned grid = (unsigned)(((quads + INTER_WAVES - 1) / INTER_WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
-  static const int oct = getenv("MOBI_INTER_OCT") ? atoi(getenv("MOBI_INTER_OCT")) : 0;
+  static const int oct = getenv("MOBI_INTER_OCT") ? atoi(getenv("MOBI_INTER_OCT")) : 1; // default: eight macroblocks per wave (5 % faster than four)
   if (oct && !b.prof && !b.done) { // eight macroblocks per wave: the q* fields count octets for this kernel
     b.qpr = ((uint32_t)b.mbw + 7) / 8;
     b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);
