@@ -343,7 +343,7 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
   return MOBI_OK;
 }
 
-const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter, mobi_recon_intra, mobi_recon_step, mobi_yuv_to_argb; no CPU reconstruction path)"; }
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_inter, mobi_recon_intra, mobi_recon_step, mobi_yuv_to_argb; no CPU reconstruction path)"; }
 
 const char *mobi_error_string(int rc) {
   switch (rc) {
