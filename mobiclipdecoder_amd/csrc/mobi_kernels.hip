@@ -570,15 +570,14 @@ enum {
   O_L = 0,       // 4 rounds: luma window rows 4t..4t+3  (slot ((row&3)*2 + half)*8 + g: 256 B per row, the rounds are contiguous)
   O_U = 4096,    // 2 rounds: U rows 0..3, 4..7
   O_V = 6144,    // 2 rounds: V rows 0..3, 4..7
-  O_X = 8192,    // leftovers: j 0,1 luma row 16; 2,3 U row 8; 4,5 V row 8 (same 256 B row shape)
-  O_SC = 9216,   // dequant scales (320 B)
-  O_META = 9536, // cbp6[8], t8mask[8], flags[8]
-  O_BYTES = 9568,
+  O_SC = 8192,   // dequant scales (320 B)
+  O_META = 8512, // cbp6[8], t8mask[8], flags[8]
+  O_BYTES = 8544,
   // after motion compensation:
   O_OUT_Y = 0,     // 16 rows x 128 B
   O_OUT_C = 2048,  // 2 planes x 8 rows x 64 B
   O_COEF = 3072,   // 16 areas x 64 ints, transposed in place (up to 7168)
-  O_TAB = O_X      // entry -> g*8 + area (<= 48 bytes)
+  O_TAB = 7168     // entry -> g*8 + area (<= 48 bytes)
 };
 } // namespace
 
@@ -643,9 +642,6 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     MOBI_DMA16(p2 + rowoff(4), L + O_U + 1024, 0);
     MOBI_DMA16(p2 + hS, L + O_V, 0);
     MOBI_DMA16(p2 + hS + rowoff(4), L + O_V + 1024, 0);
-    const int h = j >> 1;
-    const uint32_t o4 = (h == 0 ? ywin + rowoff(16) : h == 1 ? cwin + rowoff(8) : h == 2 ? cwin + hS + rowoff(8) : 0u) + (uint32_t)(j & 1) * 16u;
-    MOBI_DMA16(clip_base + o4, L + O_X, 0);
     const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
     if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + O_SC, 0);
   }
@@ -656,6 +652,17 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
     for (int k = 1; k < 4; k++)
       if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+  }
+  // The 17th luma row and the 9th chroma rows of the windows (needed by the last row's vertical half-pel only) go
+  // straight into the registers of the lanes that use them: a tenth DMA round would cost 1 KB of LDS, i.e. two waves per CU
+  uint2 r16, r8u, r8v;
+  {
+    const int q = j & 3, qc = j & 1;
+    const uint32_t oy = single ? refA + (uint32_t)(((int)d.w + (16 << lgS) + 4 * q) & ~3) : 0u;
+    const uint32_t oc = single ? refA + ysz + (uint32_t)(((int)d2.x + (8 << lgS) + 4 * qc) & ~3) : 0u;
+    r16 = *(const uint2_a4 *)(clip_base + oy);
+    r8u = *(const uint2_a4 *)(clip_base + oc);
+    r8v = *(const uint2_a4 *)(clip_base + oc + (S >> 1));
   }
   uint2 fx[12], fy[12]; // DUAL lanes: their own 2 x 8 bytes per iteration, straight into registers
   if (dual) {
@@ -688,7 +695,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     constexpr bool DUAL = decltype(with_dual)::value;
     {
       // lane (g, rr = j>>2, q = j&3): row 2t + rr.  Dword w (0..7) of window row y: O_L + y*256 + (w>>2)*128 + g*16 + (w&3)*4
-      // (rows 0..15; the four rounds are contiguous), row 16 at O_X.
+      // (rows 0..15; the four rounds are contiguous); row 16 sits in the registers of the lanes that need it.
       const int rr = j >> 2, q = j & 3, w0 = (((int)d.w & 15) + 4 * q) >> 2, w1 = w0 + 1;
       const int c0 = g * 16 + (w0 >> 2) * 128 + (w0 & 3) * 4, c1 = g * 16 + (w1 >> 2) * 128 + (w1 & 3) * 4;
       const int A0 = O_L + rr * 256 + c0, A1 = O_L + rr * 256 + c1;
@@ -697,8 +704,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
       for (int t = 0; t < 8; t++) {
         const int at0 = A0 + 512 * t, at1 = A1 + 512 * t;
-        const int ct0 = t == 7 ? (rr ? O_X + c0 : at0 + 256) : at0 + 256, ct1 = t == 7 ? (rr ? O_X + c1 : at1 + 256) : at1 + 256;
-        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0 = lds32(L, ct0), y1 = lds32(L, ct1);
+        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0, y1;
+        if (t < 7) { y0 = lds32(L, at0 + 256); y1 = lds32(L, at1 + 256); }
+        else { y0 = lds32(L, rr ? at0 : at0 + 256); y1 = lds32(L, rr ? at1 : at1 + 256); y0 = rr ? r16.x : y0; y1 = rr ? r16.y : y1; } // row 15 -> row 16
         if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
         const bool second = DUAL && t >= 4;
         const uint32_t sh = second ? sh1 : sh0;
@@ -707,7 +715,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     }
     {
       // chroma: iteration u: plane u>>1, rows (u&1)*4 + (j>>1), q = j&1.  Dword w of row r: O_U/O_V + r*256 + (w>>2)*128 + g*16 + (w&3)*4,
-      // row 8 at O_X + 256 (U) / 512 (V)
+      // row 8 sits in registers
       const int r4 = j >> 1, q = j & 1, w0 = (((int)d2.x & 15) + 4 * q) >> 2, w1 = w0 + 1;
       const int c0 = g * 16 + (w0 >> 2) * 128 + (w0 & 3) * 4, c1 = g * 16 + (w1 >> 2) * 128 + (w1 & 3) * 4;
       const uint32_t sh0 = cpos0 & 3, sh1 = cpos1 & 3;
@@ -716,9 +724,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       for (int u = 0; u < 4; u++) {
         const int pl = u >> 1, half = u & 1, rb = (pl ? O_V : O_U) + (half * 4 + r4) * 256;
         const int at0 = rb + c0, at1 = rb + c1;
-        const bool last = half == 1 && r4 == 3; // row 7 -> row 8
-        const int ct0 = last ? O_X + 256 + pl * 256 + c0 : at0 + 256, ct1 = last ? O_X + 256 + pl * 256 + c1 : at1 + 256;
-        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0 = lds32(L, ct0), y1 = lds32(L, ct1);
+        const bool last = half == 1 && r4 == 3; // row 7 -> row 8 (in registers)
+        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0 = lds32(L, last ? at0 : at0 + 256), y1 = lds32(L, last ? at1 : at1 + 256);
+        if (half) { y0 = last ? (pl ? r8v.x : r8u.x) : y0; y1 = last ? (pl ? r8v.y : r8u.y) : y1; }
         if (DUAL) { x0 = dual ? fx[8 + u].x : x0; x1 = dual ? fx[8 + u].y : x1; y0 = dual ? fy[8 + u].x : y0; y1 = dual ? fy[8 + u].y : y1; }
         const bool second = DUAL && half;
         const uint32_t sh = second ? sh1 : sh0;
