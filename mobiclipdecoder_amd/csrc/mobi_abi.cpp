@@ -215,6 +215,7 @@ struct mobi_batch {
   bool argb_all_valid = false;          // d_argb holds every clip's Bitmap of the current frame
   uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
   uint32_t step_tag = 0;                // bumped once per frame step, never 0
+  int inter_oct = 1;                    // inter kernel: eight macroblocks per wave (env MOBI_INTER_OCT=0: four)
   int step_mode = 1;                    // 1: inter launch + ONE intra launch for all dependency levels (default, fastest measured);
                                         // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
   // preloaded replay
@@ -281,7 +282,7 @@ struct mobi_batch {
       ai.done = nullptr; // a separate inter launch is complete before any intra wave starts: plain stores, nothing to publish
       EvPair ep{nullptr, nullptr, 0};
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
-      if (mobi_launch_inter(&ai, stream) != 0) return MOBI_E_DEVICE;
+      if (mobi_launch_inter(&ai, inter_oct, stream) != 0) return MOBI_E_DEVICE;
       if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
     if (step_mode == 1 && plan.n_levels() >= 1) { // every level in one launch: items are sorted by level, waves wait on their own dependencies
@@ -399,6 +400,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
+    if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = atoi(io) != 0;
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
     b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));

@@ -1162,14 +1162,13 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_step_prof(MobiReconA
 // =====================================================================================================
 // launch wrappers (called from mobi_abi.cpp)
 // =====================================================================================================
-extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
+extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s) {
   const long quads = (long)a->qpc * a->n_clips;
   if (quads <= 0) return 0;
   if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue; // 24-bit multiply in the kernel
   const unsigned grid = (unsigned)(((quads + INTER_WAVES - 1) / INTER_WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
-  static const int oct = getenv("MOBI_INTER_OCT") ? atoi(getenv("MOBI_INTER_OCT")) : 1; // default: eight macroblocks per wave (5 % faster than four)
   if (oct && !b.prof && !b.done) { // eight macroblocks per wave: the q* fields count octets for this kernel
     b.qpr = ((uint32_t)b.mbw + 7) / 8;
     b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);

@@ -241,3 +241,14 @@ def test_loaded_gpu_hand_offs_are_exact(mode, monkeypatch):
                     elif f == nfr - 1:  # second pass: same command lists on a different ring history -> only P-chain end state is comparable
                         assert np.array_equal(y, oras[c % distinct].y(0)) and np.array_equal(uv, oras[c % distinct].uv(0)), (mode, "rep", c)
     b.close()
+
+
+def test_quad_and_octet_inter_kernels_agree_with_the_oracle(monkeypatch):
+    """The default inter kernel takes eight macroblocks per wave (mobi_recon_inter8); the four-per-wave kernel
+    (mobi_recon_inter) stays in use for the one-launch step mode.  Both must be bit-exact on a mix with every kind of
+    inter macroblock (single, two halves, deep trees, multi-reference, residual 8x8 and 4x4) and odd widths in
+    macroblocks (848 = 53: the last octet / quad of a row is partial)."""
+    for oct in ("0", "1"):
+        monkeypatch.setenv("MOBI_INTER_OCT", oct)  # read at the first launch of a process: set before any decoder exists in this test
+        _run_stream(default_params("C", BASE_SEED + 61, n_frames=6, pm_deep=150, pm_multiref=200))
+        _run_stream(default_params("A", BASE_SEED + 62, n_frames=6, pm_split1=400, t8_prob=500))
