@@ -3,6 +3,7 @@
  *
  *   Mods (.mods, Nintendo DS)   mirrors LibMobiclip.Containers.Mods.ModsDemuxer (ModsDemuxer.cs:16-117)
  *   MOC5 (Wii)                  mirrors the inline parser of the reference GUI (MobiclipDecoder/Form1.cs:282-320)
+ *   Moflex (.moflex, 3DS)       mirrors LibMobiclip.Containers.Moflex.MoLiveDemux (MoLiveDemux.cs)
  *
  * Pure byte parsing on the host: no GPU, no copies -- every pointer handed out points into the caller's file buffer,
  * which must outlive the handle.  Where the reference would throw (reads past the end of the stream) these return
@@ -67,6 +68,35 @@ int mobi_moc5_open(const uint8_t *file, size_t len, mobi_moc5_info *info);
  * decoder gets the WHOLE file as Data and this Offset), then advances *offs by 4 + (blocksize & ~1), rounded up to a
  * multiple of 4; returns 0 when *offs >= len (the reference exits). */
 int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_t *decode_offset, uint32_t *block_size);
+
+/* ---- Moflex (3DS) ------------------------------------------------------------------------------ */
+/* mirrors LibMobiclip.Containers.Moflex.MoLiveDemux (MoLiveDemux.cs:11-416) with the file held in memory as its Stream:
+ * ReadPacket() is restated step for step (synchronisation search, synchro header + stream chunks, data block flags,
+ * bit-packed EP headers, per-stream frame assembly) and keeps the reference's return codes; completed frames -- what
+ * the reference hands to OnCompleteFrameReceived, two zero bytes appended (:353) -- are queued. */
+typedef struct mobi_moflex mobi_moflex;
+
+/* MoLiveStream chunk of a frame (MoLiveStreamVideo.cs / ...WithLayout.cs / ...Audio.cs / ...Timeline.cs) */
+typedef struct {
+  uint32_t chunk_id;       /* 1 video, 2 audio, 3 video with layout, 4 timeline (MoLiveDemux.cs:181-199) */
+  int32_t stream_index;
+  uint32_t codec_id;
+  uint32_t fps_rate, fps_scale, width, height, pel_ratio_rate, pel_ratio_scale; /* video */
+  uint32_t image_layout, image_rotation;                                         /* video with layout */
+  uint32_t frequency, channel;                                                   /* audio */
+  uint32_t associated_stream_index;                                              /* timeline */
+} mobi_moflex_stream;
+
+mobi_moflex *mobi_moflex_open(const uint8_t *file, size_t len);
+void mobi_moflex_close(mobi_moflex *m);
+/* MoLiveDemux.ReadPacket() (:67-160): returns the reference's code (0 ok; 73 = end of stream / packet size mismatch, the
+ * value the callers stop on, Program.cs:164-166; 1, 0x43.., 0x80 as in the source); -1 where the reference would throw. */
+int mobi_moflex_read_packet(mobi_moflex *m);
+/* Pops the oldest completed frame; the data pointer stays valid until the next call on this handle.  1 = a frame, 0 = none. */
+int mobi_moflex_pop_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len);
+/* Convenience: ReadPacket() until a frame is available.  1 = a frame, 0 = the stream ended (code 73), <0 = demux error
+ * (the negated ReadPacket code, or -1). */
+int mobi_moflex_next_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len);
 
 #ifdef __cplusplus
 }

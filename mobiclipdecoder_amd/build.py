@@ -42,7 +42,7 @@ def _hdrs(d):
 
 
 def build_hip(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_kernels.hip", "mobi_rgb.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip")]
     deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h"), os.path.join(ROOT, "include", "mobiclip_demux.h")]
     if not force and not _newer(LIB_HIP, deps):
         return LIB_HIP
@@ -50,11 +50,11 @@ def build_hip(force=False):
     os.makedirs(obj, exist_ok=True)
     host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
     objs = []
-    for s in srcs[:3]:
+    for s in srcs[:4]:
         o = os.path.join(obj, os.path.basename(s) + ".o")
         _run(["g++"] + host_flags + ["-c", s, "-o", o])
         objs.append(o)
-    for s in srcs[3:]:
+    for s in srcs[4:]:
         ko = os.path.join(obj, os.path.basename(s) + ".o")
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", ko])
         objs.append(ko)

@@ -15,6 +15,15 @@ class _ModsHeader(C.Structure):
                 ("keyframe_count", C.c_uint32)]
 
 
+class MoflexStream(C.Structure):
+    """MoLiveStream chunk of a frame: video (chunk_id 1), audio (2), video with layout (3), timeline (4)."""
+    _fields_ = [("chunk_id", C.c_uint32), ("stream_index", C.c_int32), ("codec_id", C.c_uint32),
+                ("fps_rate", C.c_uint32), ("fps_scale", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("pel_ratio_rate", C.c_uint32), ("pel_ratio_scale", C.c_uint32),
+                ("image_layout", C.c_uint32), ("image_rotation", C.c_uint32),
+                ("frequency", C.c_uint32), ("channel", C.c_uint32), ("associated_stream_index", C.c_uint32)]
+
+
 class _Moc5Info(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("fps_x128", C.c_uint32), ("first_block", C.c_uint32)]
 
@@ -28,6 +37,11 @@ _SIGS = {
     "mobi_mods_audio_codebook": (C.c_void_p, [C.c_void_p, C.c_int]),
     "mobi_mods_jump_to_keyframe": (None, [C.c_void_p, C.c_int]),
     "mobi_mods_read_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "mobi_moflex_open": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "mobi_moflex_close": (None, [C.c_void_p]),
+    "mobi_moflex_read_packet": (C.c_int, [C.c_void_p]),
+    "mobi_moflex_pop_frame": (C.c_int, [C.c_void_p, C.POINTER(MoflexStream), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "mobi_moflex_next_frame": (C.c_int, [C.c_void_p, C.POINTER(MoflexStream), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "mobi_moc5_open": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_Moc5Info)]),
     "mobi_moc5_next_block": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
 }
@@ -109,3 +123,50 @@ def moc5_blocks(data):
         if rc < 0:
             raise EOFError("file ends inside a block header")
         yield dec.value, bs.value
+
+
+class MoLiveDemux:
+    """MoLiveDemux over a file held in memory (MoLiveDemux.cs): ReadPacket() with the reference's return codes, completed
+    frames via frames() / next_frame() instead of the OnCompleteFrameReceived event."""
+
+    def __init__(self, data):
+        self._buf = np.ascontiguousarray(np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data)
+        self._lib = _lib()
+        self._h = self._lib.mobi_moflex_open(self._buf.ctypes.data, self._buf.size)
+        if not self._h:
+            raise MemoryError("mobi_moflex_open")
+
+    def ReadPacket(self):
+        return self._lib.mobi_moflex_read_packet(self._h)
+
+    def _take(self, fn):
+        st, p, n = MoflexStream(), C.c_void_p(), C.c_size_t()
+        rc = fn(self._h, C.byref(st), C.byref(p), C.byref(n))
+        if rc <= 0:
+            return rc, None
+        return rc, (st, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy())
+
+    def pop_frame(self):
+        return self._take(self._lib.mobi_moflex_pop_frame)[1]
+
+    def next_frame(self):
+        """-> (MoflexStream, frame bytes incl. the two appended zero bytes), or None at the end of the stream."""
+        rc, fr = self._take(self._lib.mobi_moflex_next_frame)
+        if rc < 0:
+            raise ValueError(f"Moflex demux error {-rc:#x}")
+        return fr
+
+    def frames(self):
+        while (fr := self.next_frame()) is not None:
+            yield fr
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mobi_moflex_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

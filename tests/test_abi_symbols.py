@@ -32,7 +32,7 @@ def test_demux_header_symbols_are_exported_and_bound():
     lib = decoder.load_library()
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mobiclip_demux.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(mobi_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 9
+    assert len(names) == 14
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mobiclip_demux.h but not exported"
     assert set(demux._SIGS) == set(names)
