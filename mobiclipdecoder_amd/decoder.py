@@ -68,7 +68,7 @@ _SIGS = {
     "mobi_build_info": (C.c_char_p, []),
 }
 
-LIB_PATH = os.path.join(_HERE, "libmobiclip_hip.so")
+LIB_PATH = os.environ.get("MOBI_LIB") or os.path.join(_HERE, "libmobiclip_hip.so")  # MOBI_LIB: A/B-test another build of the library
 
 
 def load_library():
