@@ -27,6 +27,7 @@ MobiStreamParser::MobiStreamParser(uint32_t width, uint32_t height, int version)
   g_.stride = (width <= 256) ? 256 : (width <= 512) ? 512 : 1024; // MD.cs:50-52
   g_.mbw = (int)width / 16;
   g_.mbh = (int)height / 16;
+  g_.lg = g_.stride == 256 ? 8 : g_.stride == 512 ? 9 : 10;
   ver_ = (version == MOBI_VERSION_MOFLEX3DS) ? 0 : 1;
   memset(dq8_, 0, sizeof(dq8_));
   memset(dq4_, 0, sizeof(dq4_));
@@ -131,6 +132,7 @@ void MobiStreamParser::end_mb() {
       }
       d.w3 = pos[0]; d.w4 = pos[1]; d.w5 = pos[2]; d.w6 = pos[3];
     } else {
+      build_cells();
       out_->payload.insert(out_->payload.end(), cells_, cells_ + MOBI_MV_CELLS);
     }
   } else {
@@ -176,9 +178,16 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
   if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) fail(MOBI_E_UNSUPPORTED);
   leaves_.push_back(mobi_leaf_w0(x, y, wi, hi, ref));
   leaves_.push_back(mobi_leaf_w1(dx, dy));
-  const uint32_t cell = mobi_cell(dx, dy, ref);
-  for (int cy = y >> 1; cy < (y + h) >> 1; cy++)
-    for (int cx = x >> 1; cx < (x + w) >> 1; cx++) cells_[cy * 8 + cx] = cell;
+}
+// the 64-entry MV cell map of a macroblock with a deeper partition tree, from its leaves (only those need it)
+void MobiStreamParser::build_cells() {
+  for (size_t i = 0; i + 1 < leaves_.size(); i += 2) {
+    const uint32_t w0 = leaves_[i], mv = leaves_[i + 1];
+    const int x = (int)(w0 & 15) * 2, y = (int)((w0 >> 4) & 15) * 2, w = 16 >> ((w0 >> 8) & 3), h = 16 >> ((w0 >> 10) & 3);
+    const uint32_t cell = mobi_cell((int16_t)(mv & 0xFFFF), (int16_t)(mv >> 16), (int)((w0 >> 12) & 7));
+    for (int cy = y >> 1; cy < (y + h) >> 1; cy++)
+      for (int cx = x >> 1; cx < (x + w) >> 1; cx++) cells_[cy * 8 + cx] = cell;
+  }
 }
 // ReadPBlock*/SwitchPBlock* (MD.cs:469-1746) as one table-driven routine; x,y are MB-relative.
 void MobiStreamParser::pblock(int wi, int hi, int x, int y, int mv_slot) {

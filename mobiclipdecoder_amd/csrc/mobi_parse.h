@@ -27,16 +27,17 @@ struct ParsedFrame {
 // which macroblock owns the pixel at linear address `a` of the Y / UV plane; -1 = padding / outside.
 struct MobiGeom {
   int width, height, stride, mbw, mbh;
+  int lg; // log2(stride): the stride is 256 / 512 / 1024 (MD.cs:50-52), so rows and columns come by shift and mask
   int owner_luma(long a) const {
     if (a < 0) return -1;
-    long row = a / stride, col = a % stride;
+    const long row = a >> lg, col = a & (stride - 1);
     if (col >= width || row >= height) return -1;
     return (int)((row >> 4) * mbw + (col >> 4));
   }
   int owner_chroma(long a) const {
     if (a < 0) return -1;
-    long row = a / stride, col = a % stride;
-    long x = col >= stride / 2 ? col - stride / 2 : col;
+    const long row = a >> lg, col = a & (stride - 1);
+    const long x = col >= stride / 2 ? col - stride / 2 : col;
     if (x >= width / 2 || row >= height / 2) return -1;
     return (int)((row >> 3) * mbw + (x >> 3));
   }
@@ -74,6 +75,7 @@ class MobiStreamParser {
   void parse_i(ParsedFrame &out);
   void pblock(int wi, int hi, int x, int y, int mv_slot);
   void mc_leaf(int wi, int hi, int x, int y, int ref, int dx, int dy, int mv_slot);
+  void build_cells();
   void check_window(long pos, int w, int h, int phase, long plane_len) const;
   void p_residual();
   void resid_area(int area);
