@@ -84,6 +84,12 @@ void mobi_batch_destroy(mobi_batch *b);
  * Parses on the host, uploads the command lists, launches, synchronises.  Returns MOBI_OK or a
  * MOBI_E_DEVICE/ARG failure of the call itself (per-clip stream errors go to rc[]). */
 int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
+/* Where mobi_batch_decode parses the bitstreams.  0 (default): host threads, command lists uploaded per call.
+ * 1: on the GPU, one wavefront per clip (mobi_dparse.hip): Data[Offset..) of every clip is uploaded instead and the command
+ * lists never leave HBM; same rc / Offset / planes.  Worth it from about a thousand resident clips per GPU upward (the parse of
+ * one clip is serial and a GPU lane is slow at it; the GPU wins by running thousands of clips at once).  Only before the
+ * first frame: the decoder state lives on one side.  Default can be preset with MOBI_DEVICE_PARSE=1. */
+int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
 /* Bitmaps (MD.cs:260-323): mobi_batch_convert_argb converts ring slot 0 of EVERY clip into a device-resident buffer
  * (asynchronously, on the batch's stream); mobi_batch_get_argb copies one clip's width*height words out, converting
@@ -91,6 +97,7 @@ int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out,
 int mobi_batch_convert_argb(mobi_batch *b);
 int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out);
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip);
+uint32_t mobi_batch_yuv_format(const mobi_batch *b, int clip);
 int mobi_batch_stride(const mobi_batch *b);
 int mobi_batch_n_clips(const mobi_batch *b);
 

@@ -18,6 +18,7 @@
 
 #include "../../include/mobiclip_hip.h"
 #include "mobi_cmd.h"
+#include "mobi_dparse.h"
 #include "mobi_kernels.h"
 #include "mobi_parse.h"
 
@@ -218,6 +219,16 @@ struct mobi_batch {
   int inter_oct = 1;                    // inter kernel: eight macroblocks per wave (env MOBI_INTER_OCT=0: four)
   int step_mode = 1;                    // 1: inter launch + ONE intra launch for all dependency levels (default, fastest measured);
                                         // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
+  // device-side parse (mobi_dparse.hip): parse_mode 1 = mobi_batch_decode parses on the GPU (env MOBI_DEVICE_PARSE=1 or
+  // mobi_batch_set_parse_mode); the per-clip decoder state then lives in d_pstate and the host parsers stay untouched
+  int parse_mode = 0;
+  size_t last_pay_cap = 0;
+  DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
+  MobiDevState *d_pstate = nullptr;
+  MobiDevResult *d_pres = nullptr;
+  uint8_t *d_ptables = nullptr;
+  PinnedBuf h_pres;
+  std::vector<uint32_t> dev_quant, dev_yuvfmt;
   // preloaded replay
   // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
   std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
@@ -326,6 +337,9 @@ struct mobi_batch {
     if (d_prof) (void)hipFree(d_prof);
     if (d_done) (void)hipFree(d_done);
     if (d_argb) (void)hipFree(d_argb);
+    if (d_pstate) (void)hipFree(d_pstate);
+    if (d_pres) (void)hipFree(d_pres);
+    if (d_ptables) (void)hipFree(d_ptables);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -342,6 +356,19 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
   HIP_TRY(hipMemcpy(out, b->d_prof, n_words * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(b->d_prof, 0, n_words * 4)); // read and clear: the next read sees only the steps in between
   return MOBI_OK;
+}
+
+// test aid, not part of the public header: what the last device-side parse left in HBM.  desc_out: n_clips*n_mbs*8 words,
+// items_out: n_clips*n_mbs words, res_out: n_clips*8 words, payload_out: n_clips*pay_cap words (any may be null); returns pay_cap
+long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *items_out, uint32_t *res_out, uint32_t *payload_out, size_t payload_words) {
+  if (!b || !b->d_pres) return MOBI_E_ARG;
+  const size_t n = (size_t)b->n, n_mbs = (size_t)b->g.mbw * b->g.mbh;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (desc_out) HIP_TRY(hipMemcpy(desc_out, b->d_pdesc.p, n * n_mbs * sizeof(MbDesc), hipMemcpyDeviceToHost));
+  if (items_out) HIP_TRY(hipMemcpy(items_out, b->d_pitems.p, n * n_mbs * 4, hipMemcpyDeviceToHost));
+  if (res_out) HIP_TRY(hipMemcpy(res_out, b->d_pres, n * sizeof(MobiDevResult), hipMemcpyDeviceToHost));
+  if (payload_out) HIP_TRY(hipMemcpy(payload_out, b->d_ppay.p, std::min(payload_words * 4, b->d_ppay.cap), hipMemcpyDeviceToHost));
+  return (long long)b->last_pay_cap;
 }
 
 const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_inter, mobi_recon_intra, mobi_recon_step, mobi_yuv_to_argb; no CPU reconstruction path)"; }
@@ -401,6 +428,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
     if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = atoi(io) != 0;
+    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) b->parse_mode = atoi(dp) != 0;
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
     b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
@@ -420,9 +448,119 @@ void mobi_batch_destroy(mobi_batch *b) {
   delete b;
 }
 
+// DecodeFrame() of every clip with the bitstream parse on the GPU: upload Data[Offset..) of every clip, one parse launch
+// (one wave per clip) that leaves descriptors, payload and intra lists in HBM, then the usual reconstruction launches.
+static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
+  const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
+  if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) {
+    for (int i = 0; i < n; i++) rc[i] = MOBI_E_VERSION;
+    return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
+  }
+  if (b->g.mbw > 64) return MOBI_E_ARG;
+  if (!b->d_pstate) { // first use: zeroed decoder state (a new MobiclipDecoder), result array, tables
+    HIP_TRY(hipMalloc((void **)&b->d_pstate, sizeof(MobiDevState) * n));
+    HIP_TRY(hipMemset(b->d_pstate, 0, sizeof(MobiDevState) * n));
+    HIP_TRY(hipMalloc((void **)&b->d_pres, sizeof(MobiDevResult) * n));
+    HIP_TRY(hipMemset(b->d_pres, 0, sizeof(MobiDevResult) * n));
+    std::vector<uint8_t> blob(MOBI_DT_BYTES);
+    mobi_dparse_build_tables(b->version, blob.data());
+    HIP_TRY(hipMalloc((void **)&b->d_ptables, MOBI_DT_BYTES));
+    HIP_TRY(hipMemcpy(b->d_ptables, blob.data(), MOBI_DT_BYTES, hipMemcpyHostToDevice));
+    b->dev_quant.assign(n, 0);
+    b->dev_yuvfmt.assign(n, 0);
+    if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
+  }
+  // 1. stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded]
+  constexpr size_t kBitPad = 32; // the reader runs two 8-byte registers ahead
+  std::vector<uint64_t> boff(n);
+  std::vector<uint32_t> blen(n);
+  size_t pos = 0, max_len = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t o = offsets[i];
+    const size_t l = (data[i] && o >= 0 && (uint64_t)o < len[i]) ? len[i] - (size_t)o : 0; // nothing readable: the first ReadU16LE throws
+    if (l >= ((size_t)1 << 31)) return MOBI_E_ARG;
+    boff[i] = pos;
+    blen[i] = (uint32_t)l;
+    pos += align_up(l + kBitPad, 8);
+    max_len = std::max(max_len, l);
+  }
+  const size_t hdr_bytes = align_up((size_t)n * 12, 16);
+  if (int e = b->h_stage.reserve(hdr_bytes + pos)) return e;
+  if (int e = b->d_bits.reserve(hdr_bytes + pos)) return e;
+  uint8_t *hs = b->h_stage.p;
+  memcpy(hs, boff.data(), (size_t)n * 8);
+  memcpy(hs + (size_t)n * 8, blen.data(), (size_t)n * 4);
+  b->pool->run(n, [&](int i) {
+    uint8_t *dst = hs + hdr_bytes + boff[i];
+    if (blen[i]) memcpy(dst, data[i] + offsets[i], blen[i]);
+    memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
+  });
+  HIP_TRY(hipMemcpyAsync(b->d_bits.p, hs, hdr_bytes + pos, hipMemcpyHostToDevice, b->stream));
+  // 2. output buffers: a clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level per bit read
+  const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * max_len) + 448 + 64;
+  if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // payload offsets are 32-bit words
+  if (int e = b->d_pdesc.reserve(align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign))) return e;
+  if (int e = b->d_ppay.reserve(align_up((size_t)n * cap_words * 4 + kPaySlack, kAlign))) return e;
+  if (int e = b->d_pitems.reserve((size_t)n * n_mbs * 4)) return e;
+  MobiDevParseArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.bits = b->d_bits.p + hdr_bytes;
+  pa.bit_off = (const uint64_t *)b->d_bits.p;
+  pa.bit_len = (const uint32_t *)(b->d_bits.p + (size_t)n * 8);
+  pa.tables = b->d_ptables;
+  pa.state = b->d_pstate;
+  pa.desc = (MbDesc *)b->d_pdesc.p;
+  pa.payload = (uint32_t *)b->d_ppay.p;
+  pa.items = (uint32_t *)b->d_pitems.p;
+  pa.res = b->d_pres;
+  pa.pay_cap = (uint32_t)cap_words;
+  b->last_pay_cap = cap_words;
+  pa.n_clips = n; pa.version = b->version;
+  pa.width = b->g.width; pa.height = b->g.height; pa.stride = b->g.stride; pa.lg = b->g.lg; pa.mbw = b->g.mbw; pa.mbh = b->g.mbh;
+  if (mobi_launch_parse(&pa, b->stream) != 0) return MOBI_E_DEVICE;
+  MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
+  HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream)); // the launch sizes below depend on what the parse found
+  uint32_t K = 0;
+  for (int i = 0; i < n; i++) {
+    rc[i] = res[i].rc;
+    offsets[i] += res[i].consumed;
+    b->dev_quant[i] = res[i].quant;
+    b->dev_yuvfmt[i] = res[i].yuvfmt;
+    if (rc[i] == MOBI_OK) K = std::max(K, res[i].n_intra);
+  }
+  // 3. reconstruction straight from what the parse left in HBM
+  b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
+  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
+  b->argb_all_valid = false;
+  b->frames_started++;
+  MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
+  a.done = b->d_done;
+  {
+    MobiReconArgs ai = a;
+    ai.done = nullptr;
+    if (mobi_launch_inter(&ai, b->inter_oct, b->stream) != 0) return MOBI_E_DEVICE;
+  }
+  if (K && mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), (int)K, b->stream) != 0)
+    return MOBI_E_DEVICE;
+  HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  for (int i = 0; i < n; i++)
+    if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+  return MOBI_OK;
+}
+
+int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
+  if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
+  b->parse_mode = device_parse != 0;
+  return MOBI_OK;
+}
+
 int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
   if (!b || !data || !len || !offsets || !rc) return MOBI_E_ARG;
   HIP_TRY(hipSetDevice(b->device));
+  if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;
   // 1. host: serial VLC parse of one frame per clip -> command lists
   std::vector<const ParsedFrame *> ok(n, nullptr);
@@ -513,7 +651,16 @@ int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out) {
   HIP_TRY(hipMemcpy(out, b->d_argb + src_clip * words, words * 4, hipMemcpyDeviceToHost));
   return MOBI_OK;
 }
-uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) { return (b && clip >= 0 && clip < b->n) ? b->parsers[clip]->quantizer() : 0; }
+uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) {
+  if (!b || clip < 0 || clip >= b->n) return 0;
+  if (b->parse_mode) return b->dev_quant.empty() ? 0 : b->dev_quant[clip];
+  return b->parsers[clip]->quantizer();
+}
+uint32_t mobi_batch_yuv_format(const mobi_batch *b, int clip) {
+  if (!b || clip < 0 || clip >= b->n) return 0;
+  if (b->parse_mode) return b->dev_yuvfmt.empty() ? 0 : b->dev_yuvfmt[clip];
+  return b->parsers[clip]->yuv_format();
+}
 int mobi_batch_stride(const mobi_batch *b) { return b ? b->g.stride : 0; }
 int mobi_batch_n_clips(const mobi_batch *b) { return b ? b->n : 0; }
 
@@ -682,8 +829,8 @@ long long mobi_selftest_div239(int device) {
 int mobi_get_argb(mobi_dec *d, uint32_t *out) { return d ? mobi_batch_get_argb(d->b, 0, out) : MOBI_E_ARG; }
 int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out) { return d ? mobi_batch_get_planes(d->b, 0, ring_idx, y_out, uv_out) : MOBI_E_ARG; }
 int mobi_stride(const mobi_dec *d) { return d ? d->b->g.stride : 0; }
-uint32_t mobi_quantizer(const mobi_dec *d) { return d ? d->b->parsers[0]->quantizer() : 0; }
-uint32_t mobi_yuv_format(const mobi_dec *d) { return d ? d->b->parsers[0]->yuv_format() : 0; }
+uint32_t mobi_quantizer(const mobi_dec *d) { return d ? mobi_batch_quantizer(d->b, 0) : 0; }
+uint32_t mobi_yuv_format(const mobi_dec *d) { return d ? mobi_batch_yuv_format(d->b, 0) : 0; }
 uint32_t mobi_width(const mobi_dec *d) { return d ? (uint32_t)d->b->g.width : 0; }
 uint32_t mobi_height(const mobi_dec *d) { return d ? (uint32_t)d->b->g.height : 0; }
 

@@ -64,10 +64,10 @@ enum { MOBI_DUAL_NONE = 0, MOBI_DUAL_TB = 1, MOBI_DUAL_LR = 2 }; // two 16x8 (to
 // ---- MC leaf as the parser records it while walking the partition tree (host only) ----------------
 //  w0: [3:0] x/2  [7:4] y/2  [9:8] log2(16/w)  [11:10] log2(16/h)  [14:12] ref slot 1..5
 //  w1: [15:0] dx (int16, half-pel, absolute)  [31:16] dy                         (MD.cs:400-416)
-static inline uint32_t mobi_leaf_w0(int x, int y, int wi, int hi, int ref) {
+MOBI_CMD_FN uint32_t mobi_leaf_w0(int x, int y, int wi, int hi, int ref) {
   return (uint32_t)((x >> 1) | ((y >> 1) << 4) | (wi << 8) | (hi << 10) | (ref << 12));
 }
-static inline uint32_t mobi_leaf_w1(int dx, int dy) { return ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16); }
+MOBI_CMD_FN uint32_t mobi_leaf_w1(int dx, int dy) { return ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16); }
 
 // ---- MV cell map (macroblocks with more than one leaf that are not DUAL): 64 words, first thing in the payload ---
 // The partition tree bottoms out at 2x2 luma (MD.cs:1683-1746), so an 8x8 grid of 2x2-pixel cells
@@ -89,7 +89,7 @@ MOBI_CMD_FN int mobi_cell_ref(uint32_t c) { return (int)(c >> 28) & 7; }
 //            8x8 transform:  p = natural-order coefficient index (MD.cs:3426 zigzag target)
 //            4x4 transforms: p = sub*16 + natural index inside that 4x4 (sub = 0..3: TL,TR,BL,BR)
 //  [31:16] level (int16); the GPU multiplies by the dequant scale (MD.cs:3427-3429)
-static inline uint32_t mobi_coef(int area, int p, int level) {
+MOBI_CMD_FN uint32_t mobi_coef(int area, int p, int level) {
   return (uint32_t)(area * 64 + p) | ((uint32_t)level << 16);
 }
 
@@ -103,7 +103,7 @@ static inline uint32_t mobi_coef(int area, int p, int level) {
 //            [31:16] plane16 param; chroma plane params live in the U/V slot-0 records with mode 9:
 //            record bit [6] = "run plane8 with param before this area" (keeps decode order).
 #define MOBI_INTRA_RECORDS 24
-static inline uint32_t mobi_intra_rec(int mode, int coded, int split, int pre_plane, int param) {
+MOBI_CMD_FN uint32_t mobi_intra_rec(int mode, int coded, int split, int pre_plane, int param) {
   return (uint32_t)(mode | (coded << 4) | (split << 5) | (pre_plane << 6)) | ((uint32_t)param << 16);
 }
 

@@ -1,0 +1,48 @@
+// mobi_dparse.h -- interface of the device-side bitstream parser (mobi_dparse.hip), SURVEY.md 8(f) row 3.
+//
+// The serial VLC / Elias-gamma parse of one frame cannot be split inside a clip (every code's position depends on the
+// previous one), but clips share nothing (MD.cs:15-39).  mobi_parse_frames runs the same parser as mobi_parse.cpp with one
+// wave per clip -- thousands of clips in flight on one GPU -- and writes the same command list (mobi_cmd.h) straight into
+// HBM, so the reconstruction kernels start without a host parse or a command upload in between.
+#ifndef MOBI_DPARSE_H
+#define MOBI_DPARSE_H
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "mobi_cmd.h"
+
+#include "mobi_dparse_tables.h"
+
+// decoder state that survives from frame to frame (the rest of MobiclipDecoder's fields are per frame)
+struct MobiDevState {
+  uint32_t quant;         // Quantizer (MD.cs:26)
+  uint32_t yuvfmt;        // YuvFormat (MD.cs:27)
+  int32_t frames_started; // how many ring slots hold a frame
+  uint32_t tables_set;    // SetupQuantTables ran at least once (MD.cs:3884): the zigzag bytes of Internal[10..89] are valid
+  uint8_t mcache[40];     // bytes of Internal[0..9]: intra-mode neighbour cache (MD.cs:1840-1859)
+  uint32_t pad[2];
+};
+struct MobiDevResult { // per clip, read back by the host after the parse launch
+  int32_t rc;          // MOBI_OK / MOBI_E_*
+  int32_t consumed;    // bytes the bit reader advanced from the start offset (Offset out = Offset in + consumed)
+  uint32_t n_intra;    // intra macroblocks = items written
+  uint32_t payload_words;
+  uint32_t quant, yuvfmt;
+  uint32_t frame_type; // 1 = I
+  uint32_t pad;
+};
+struct MobiDevParseArgs {
+  const uint8_t *bits;      // frame bytes of every clip; clip c starts at bits + bit_off[c] (8-byte aligned, >= 32 zero bytes follow)
+  const uint64_t *bit_off;
+  const uint32_t *bit_len;  // Data.Length - Offset of clip c (0: nothing readable)
+  const uint8_t *tables;    // MOBI_DT_BYTES blob
+  MobiDevState *state;      // [clip]
+  MbDesc *desc;             // [clip][n_mbs]  out
+  uint32_t *payload;        // out: clip c owns words [c * pay_cap, (c + 1) * pay_cap)
+  uint32_t *items;          // [clip][n_mbs] out: MOBI_ITEM(clip, mb) of the intra macroblocks in raster order, rest untouched
+  MobiDevResult *res;       // [clip] out
+  uint32_t pay_cap;
+  int n_clips, version, width, height, stride, lg, mbw, mbh;
+};
+extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s);
+#endif

@@ -35,6 +35,8 @@ static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");
 // oct != 0: mobi_recon_inter8 (eight macroblocks per wave, the default: 5 % faster); 0: mobi_recon_inter (four per wave)
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s);
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
+// device-parsed frames: items_dev = [clip][n_mbs] in raster order, n_intra_dev[clip * stride_words] of them valid; K = the largest count
+extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s);
 // whole frame step in one launch: items_dev = [clip][K] macroblock indices of the intra macroblocks of each clip sorted by
 // dependency level, padded with 0xFFFFFFFF; needs a->done
 extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int K, hipStream_t s);

@@ -1118,6 +1118,21 @@ extern "C" __global__ __launch_bounds__(64 * IWAVES) void mobi_recon_intra(MobiR
   recon_intra_item(A, lds[wave], (int)(item >> 13), (int)(item & 0x1FFF), lane, it, false);
 }
 
+// Items as the device-side parser leaves them (mobi_dparse.hip): per clip, raster order, n_intra[clip] of them at a stride
+// of n_mbs.  Workgroup it = slot * n_clips + clip: neighbours in the dispatch order belong to different clips, so every
+// clip advances along its own dependency chain at the same time, and what a wave waits for (raster-earlier, same clip)
+// always sits in an earlier slot, i.e. was dispatched before it.
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconArgs A, const uint32_t *items, const uint32_t *n_intra, uint32_t n_intra_stride,
+                                                                      uint32_t magic_n_clips) {
+  __shared__ uint32_t lds[INTRA_LDS_WORDS];
+  const int lane = threadIdx.x;
+  uint32_t clip;
+  const uint32_t slot = fastdiv(blockIdx.x, (uint32_t)A.n_clips, magic_n_clips, clip);
+  if (slot >= n_intra[(size_t)clip * n_intra_stride]) return;
+  const uint32_t item = items[(size_t)clip * A.n_mbs + slot];
+  recon_intra_item(A, lds, (int)clip, (int)(item & 0x1FFF), lane, (int)blockIdx.x, false);
+}
+
 // =====================================================================================================
 // mobi_recon_step: a whole frame step -- every inter quad and every intra macroblock of every clip -- in ONE launch
 // =====================================================================================================
@@ -1189,6 +1204,13 @@ extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_d
   if (n_items <= 0) return 0;
   const unsigned grid = (unsigned)((n_items + IWAVES - 1) / IWAVES);
   hipLaunchKernelGGL(mobi_recon_intra, dim3(grid), dim3(64 * IWAVES), 0, s, *a, items_dev, n_items);
+  return (int)hipGetLastError();
+}
+extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s) {
+  if (K <= 0 || a->n_clips <= 0) return 0;
+  const uint64_t m = ((uint64_t)1 << 32) / (uint32_t)a->n_clips;
+  hipLaunchKernelGGL(mobi_recon_intra_cl, dim3((unsigned)K * (unsigned)a->n_clips), dim3(64), 0, s, *a, items_dev, n_intra_dev, (uint32_t)n_intra_stride_words,
+                     (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m));
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int K, hipStream_t s) {

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "../../include/mobiclip_hip.h"
+#include "mobi_dparse_tables.h"
 #include "mobi_tables.h"
 
 namespace {
@@ -618,4 +619,25 @@ void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]) {
   const int sh = mobi_qdiv6[q] + 8, m = mobi_qmod6[q];
   for (int i = 0; i < 64; i++) out[mobi_zz8[i]] = (int32_t)((((uint32_t)mobi_dq8[m * 64 + i]) << (sh - 2)) >> 8);
   for (int i = 0; i < 16; i++) out[64 + mobi_zz4[i]] = (int32_t)((((uint32_t)mobi_dq4[m * 16 + i]) << sh) >> 8);
+}
+
+// The tables the device-side parser (mobi_dparse.hip) keeps in LDS, as one blob (layout: MOBI_DT_* in mobi_dparse.h).
+void mobi_dparse_build_tables(int version, uint8_t out[MOBI_DT_BYTES]) {
+  const int v = (version == MOBI_VERSION_MOFLEX3DS) ? 0 : 1;
+  memset(out, 0, MOBI_DT_BYTES);
+  memcpy(out + MOBI_DT_A0, mobi_vx2table0_a, sizeof(mobi_vx2table0_a));
+  memcpy(out + MOBI_DT_A1, mobi_vx2table1_a, sizeof(mobi_vx2table1_a));
+  memcpy(out + MOBI_DT_B0, mobi_vx2table0_b, sizeof(mobi_vx2table0_b));
+  memcpy(out + MOBI_DT_B1, mobi_vx2table1_b, sizeof(mobi_vx2table1_b));
+  memcpy(out + MOBI_DT_PLUT, mobi_part_lut[v], sizeof(mobi_part_lut[v]));
+  memcpy(out + MOBI_DT_PBITS, mobi_part_bits[v], sizeof(mobi_part_bits[v]));
+  memcpy(out + MOBI_DT_PSHIFT, mobi_part_shift[v], sizeof(mobi_part_shift[v]));
+  memcpy(out + MOBI_DT_PNB, mobi_part_nbits_len[v], sizeof(mobi_part_nbits_len[v]));
+  memcpy(out + MOBI_DT_CBP_I, mobi_cbp_intra, sizeof(mobi_cbp_intra));
+  memcpy(out + MOBI_DT_CBP_P, mobi_cbp_inter, sizeof(mobi_cbp_inter));
+  memcpy(out + MOBI_DT_CBP4_I, mobi_cbp4_intra, sizeof(mobi_cbp4_intra));
+  memcpy(out + MOBI_DT_CBP4_P, mobi_cbp4_inter, sizeof(mobi_cbp4_inter));
+  memcpy(out + MOBI_DT_ZZ8, mobi_zz8, sizeof(mobi_zz8));
+  memcpy(out + MOBI_DT_ZZ4, mobi_zz4, sizeof(mobi_zz4));
+  static_assert(sizeof(mobi_vx2table0_a) == 8192 && sizeof(mobi_part_lut[0]) == 1024 && sizeof(mobi_part_bits[0]) == 192, "blob layout");
 }

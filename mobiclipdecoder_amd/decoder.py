@@ -52,6 +52,8 @@ _SIGS = {
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
     "mobi_batch_get_argb": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mobi_batch_quantizer": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "mobi_batch_yuv_format": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "mobi_batch_set_parse_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mobi_batch_stride": (C.c_int, [C.c_void_p]),
     "mobi_batch_n_clips": (C.c_int, [C.c_void_p]),
     "mobi_batch_preload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
@@ -194,13 +196,19 @@ class MobiclipBatch:
     (decoder instances share nothing: MD.cs:15-39).  Also the pre-parsed replay path used for
     throughput measurement."""
 
-    def __init__(self, n_clips, Width, Height, Version, device=0):
+    def __init__(self, n_clips, Width, Height, Version, device=0, device_parse=None):
+        """device_parse: True = decode() parses the bitstreams on the GPU (one wavefront per clip, mobi_dparse.hip),
+        False = on host threads, None = library default (env MOBI_DEVICE_PARSE)."""
         self._lib = load_library()
         self.n, self.Width, self.Height, self.Version = int(n_clips), int(Width), int(Height), MobiclipVersion(Version)
         self._h = self._lib.mobi_batch_create(self.n, self.Width, self.Height, int(self.Version), device)
         if not self._h:
             raise MobiclipError(f"mobi_batch_create failed: {error_string(-8)}")
         self.Stride = self._lib.mobi_batch_stride(self._h)
+        if device_parse is not None:
+            rc = self._lib.mobi_batch_set_parse_mode(self._h, int(bool(device_parse)))
+            if rc != 0:
+                raise MobiclipError(error_string(rc))
 
     def decode(self, datas, offsets):
         """One DecodeFrame() per clip.  datas: list of byte buffers; offsets: list of ints.
@@ -241,6 +249,9 @@ class MobiclipBatch:
 
     def quantizer(self, clip):
         return self._lib.mobi_batch_quantizer(self._h, clip)
+
+    def yuv_format(self, clip):
+        return self._lib.mobi_batch_yuv_format(self._h, clip)
 
     # -- replay ---------------------------------------------------------------------------------
     def preload(self, clip, data, frame_off):

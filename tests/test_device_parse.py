@@ -1,0 +1,158 @@
+"""GPU parity of the device-side bitstream parser (mobi_dparse.hip): mobi_batch_decode with the
+parse on the GPU must give the oracle's planes, return codes, post-call Offset, Quantizer and YuvFormat -- on good
+streams of every frame type and partition depth, whole-file (MOC5 style) and per-packet buffers, and on the streams the
+reference throws on (truncated, corrupted, P-frame into an empty ring)."""
+import numpy as np
+import pytest
+
+from mobiclipdecoder_amd import MobiclipBatch, MobiclipVersion, default_params, generate_clip
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+from tests.oracle_binding import OracleDecoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _lockstep(params_list, whole_file=False, mutate=None):
+    """Decode the clips frame by frame on the GPU (device parse) and with the oracle; compare everything."""
+    clips = [generate_clip(p) for p in params_list]
+    if mutate:
+        clips = [(mutate(i, np.array(d, copy=True)), fo) for i, (d, fo) in enumerate(clips)]
+    p0 = params_list[0]
+    n = len(clips)
+    b = MobiclipBatch(n, p0.width, p0.height, p0.version, device_parse=True)
+    oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(n)]
+    n_err = 0
+    for f in range(p0.n_frames):
+        if whole_file:
+            datas, offs = [c[0] for c in clips], [int(c[1][f]) for c in clips]
+        else:
+            datas, offs = [c[0][c[1][f]:c[1][f + 1]] for c in clips], [0] * n
+        rcs, new_offs = b.decode(datas, offs)
+        for i in range(n):
+            oras[i].Data, oras[i].Offset = datas[i], offs[i]
+            o = oras[i].DecodeFrame()
+            assert rcs[i] == oras[i].last_error, (f, i, rcs[i], oras[i].last_error)
+            assert new_offs[i] == oras[i].Offset, (f, i, new_offs[i], oras[i].Offset)
+            assert b.quantizer(i) == oras[i].Quantizer, (f, i)
+            if rcs[i] != 0:
+                n_err += 1
+                continue
+            assert b.yuv_format(i) == oras[i].YuvFormat, (f, i)
+            y, uv = b.planes(i)
+            assert np.array_equal(y, o[0]), f"Y mismatch frame {f} clip {i}: {np.argwhere(y != o[0])[:4].tolist()}"
+            assert np.array_equal(uv, o[1]), f"UV mismatch frame {f} clip {i}: {np.argwhere(uv != o[1])[:4].tolist()}"
+    b.close()
+    for o in oras:
+        o.close()
+    return n_err
+
+
+@pytest.mark.parametrize("cfg", ["A", "B", "C"])
+def test_default_streams(cfg):
+    ps = [default_params(cfg, BASE_SEED + 300 + i, n_frames=7) for i in range(5 if cfg != "B" else 3)]
+    assert _lockstep(ps) == 0
+
+
+@pytest.mark.parametrize("cfg", ["A", "B"])
+def test_rich_streams_whole_file(cfg):
+    """Every syntax element: intra macroblocks inside P-frames, deep partition trees, several references, quantiser
+    deltas, VLC table 1, escapes, I-frames in between; Data = the whole file, Offset = frame start (Form1.cs:292-302)."""
+    ps = [default_params(cfg, BASE_SEED + 320 + i, n_frames=9, pm_intra=150, pm_deep=150, pm_multiref=300,
+                         qdelta_prob=300, table1_prob=500, escape_prob=100, iframe_interval=4) for i in range(4)]
+    assert _lockstep(ps, whole_file=True) == 0
+
+
+def test_edge_motion_vectors():
+    ps = [default_params("A", BASE_SEED + 340 + i, n_frames=6, edge_mode=1, mv_range=40) for i in range(4)]
+    assert _lockstep(ps) == 0
+
+
+def test_uneven_clip_count_and_wide_picture():
+    """9 clips (the parse kernel packs 4 per workgroup) of a 1024-wide picture: width == stride, so the dependency probes
+    of the intra macroblocks wrap across rows like the reference's linear addressing does."""
+    ps = [default_params("A", BASE_SEED + 360 + i, n_frames=4, pm_intra=200) for i in range(9)]
+    for p in ps:
+        p.width, p.height = 1024, 64
+    assert _lockstep(ps) == 0
+
+
+def test_streams_the_reference_throws_on():
+    """Truncated packets, flipped bits, and a P-frame first: same rc, same Offset at the throw, and the clips next to a
+    failing one are untouched."""
+    ps = [default_params("A", BASE_SEED + 380 + i, n_frames=6, pm_intra=100, iframe_interval=3) for i in range(8)]
+
+    def mutate(i, d):
+        rng = np.random.default_rng(1234 + i)
+        if i % 4 == 1:    # flip a handful of bits somewhere after the first frame's header
+            for pos in rng.integers(64, d.size, 6):
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+        elif i % 4 == 2:  # cut the tail off (the per-packet slices below then end early)
+            d = d[: d.size * 2 // 3]
+        return d
+
+    clips = [generate_clip(p) for p in ps]
+    clips = [(mutate(i, np.array(d, copy=True)), fo) for i, (d, fo) in enumerate(clips)]
+    n = len(clips)
+    b = MobiclipBatch(n, 256, 192, MobiclipVersion.ModsDS, device_parse=True)
+    hb = MobiclipBatch(n, 256, 192, MobiclipVersion.ModsDS, device_parse=False)
+    oras = [OracleDecoder(256, 192, MobiclipVersion.ModsDS) for _ in range(n)]
+    refused = [False] * n  # MOBI_E_UNSUPPORTED: the library refuses what the reference decodes through Internal[] aliasing
+    order = [1, 0, 1, 2, 3, 4, 5]  # a P-frame into an empty ring first
+    seen = set()
+    for f in order:
+        datas = [c[0][min(int(c[1][f]), c[0].size):min(int(c[1][f + 1]), c[0].size)] for c in clips]
+        rcs, offs = b.decode(datas, [0] * n)
+        hrcs, hoffs = hb.decode(datas, [0] * n)
+        assert rcs == hrcs and offs == hoffs, (f, rcs, hrcs, offs, hoffs)  # device parse == host parse, always
+        for i in range(n):
+            seen.add(rcs[i])
+            if rcs[i] == 0:
+                y, uv = b.planes(i)
+                hy, huv = hb.planes(i)
+                assert np.array_equal(y, hy) and np.array_equal(uv, huv), (f, i)
+            oras[i].Data, oras[i].Offset = datas[i], 0
+            o = oras[i].DecodeFrame()
+            refused[i] = refused[i] or rcs[i] == -6
+            if refused[i]:
+                continue  # from here on the oracle's decoder state differs by design (error codes)
+            assert rcs[i] == oras[i].last_error, (f, i, rcs[i], oras[i].last_error)
+            assert offs[i] == oras[i].Offset, (f, i)
+            if rcs[i] == 0:
+                assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (f, i)
+    assert 0 in seen and -2 in seen and len(seen) >= 3, seen
+    assert not all(refused)
+    b.close()
+    hb.close()
+
+
+def test_host_and_device_parse_agree_on_a_larger_batch():
+    """64 clips of the BASELINE 640x480 configuration, 4 frames: device parse against the default host parse."""
+    nclips, nfr = 64, 4
+    ps = [default_params("B", BASE_SEED + 400 + (i % 8), n_frames=nfr) for i in range(nclips)]
+    clips = {}
+    for p in ps:
+        if p.seed not in clips:
+            clips[p.seed] = generate_clip(p)
+    hb = MobiclipBatch(nclips, 640, 480, MobiclipVersion.Moflex3DS, device_parse=False)
+    db = MobiclipBatch(nclips, 640, 480, MobiclipVersion.Moflex3DS, device_parse=True)
+    for f in range(nfr):
+        datas = [clips[p.seed][0][clips[p.seed][1][f]:clips[p.seed][1][f + 1]] for p in ps]
+        r1, o1 = hb.decode(datas, [0] * nclips)
+        r2, o2 = db.decode(datas, [0] * nclips)
+        assert r1 == r2 == [0] * nclips and o1 == o2
+        for i in (0, 7, 31, 63):
+            y1, uv1 = hb.planes(i)
+            y2, uv2 = db.planes(i)
+            assert np.array_equal(y1, y2) and np.array_equal(uv1, uv2), (f, i)
+    hb.close()
+    db.close()
+
+
+def test_parse_mode_cannot_change_after_the_first_frame():
+    from mobiclipdecoder_amd.decoder import load_library
+    p = default_params("A", BASE_SEED + 1, n_frames=2)
+    data, fo = generate_clip(p)
+    b = MobiclipBatch(1, 256, 192, MobiclipVersion.ModsDS, device_parse=True)
+    b.decode([data[fo[0]:fo[1]]], [0])
+    assert load_library().mobi_batch_set_parse_mode(b._h, 0) != 0
+    b.close()
