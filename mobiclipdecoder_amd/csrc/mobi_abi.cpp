@@ -10,6 +10,7 @@
 #include <memory>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -223,6 +224,8 @@ struct mobi_batch {
   // mobi_batch_set_parse_mode); the per-clip decoder state then lives in d_pstate and the host parsers stay untouched
   int parse_mode = 0;
   size_t last_pay_cap = 0;
+  float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
+  float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
   MobiDevState *d_pstate = nullptr;
   MobiDevResult *d_pres = nullptr;
@@ -241,6 +244,7 @@ struct mobi_batch {
   bool committed = false;
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr; // around the parse launch (kernel timing on)
   int ktiming = 0; // HIP events around launches: 0 none, 1 the inter launches (the dominant kernel: roofline), 2 every launch
   struct EvPair { hipEvent_t a, b; int kind; };
   std::vector<EvPair> evs;
@@ -329,6 +333,8 @@ struct mobi_batch {
     if (stream) (void)hipStreamSynchronize(stream);
     drain_events();
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (ev_p0) (void)hipEventDestroy(ev_p0);
+    if (ev_p1) (void)hipEventDestroy(ev_p1);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (arena) (void)hipFree(arena);
@@ -360,6 +366,9 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
 
 // test aid, not part of the public header: what the last device-side parse left in HBM.  desc_out: n_clips*n_mbs*8 words,
 // items_out: n_clips*n_mbs words, res_out: n_clips*8 words, payload_out: n_clips*pay_cap words (any may be null); returns pay_cap
+float mobi_debug_parse_ms(const mobi_batch *b) { return b ? b->last_parse_ms : 0.f; }
+float mobi_debug_decode_ms(const mobi_batch *b) { return b ? b->last_decode_ms : 0.f; }
+float mobi_debug_stage_ms(const mobi_batch *b) { return b ? b->last_stage_ms : 0.f; }
 long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *items_out, uint32_t *res_out, uint32_t *payload_out, size_t payload_words) {
   if (!b || !b->d_pres) return MOBI_E_ARG;
   const size_t n = (size_t)b->n, n_mbs = (size_t)b->g.mbw * b->g.mbh;
@@ -471,14 +480,19 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
   }
   // 1. stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded]
+  const auto t_stage0 = std::chrono::steady_clock::now();
   constexpr size_t kBitPad = 32; // the reader runs two 8-byte registers ahead
   std::vector<uint64_t> boff(n);
   std::vector<uint32_t> blen(n);
   size_t pos = 0, max_len = 0;
+  const size_t frame_bound = (size_t)n_mbs * 4096 + 64;
   for (int i = 0; i < n; i++) {
     const int64_t o = offsets[i];
-    const size_t l = (data[i] && o >= 0 && (uint64_t)o < len[i]) ? len[i] - (size_t)o : 0; // nothing readable: the first ReadU16LE throws
-    if (l >= ((size_t)1 << 31)) return MOBI_E_ARG;
+    size_t l = (data[i] && o >= 0 && (uint64_t)o < len[i]) ? len[i] - (size_t)o : 0; // nothing readable: the first ReadU16LE throws
+    // MOC5 callers pass the whole file as Data (Form1.cs:292-302).  The reader advances two bytes per refill and refills at most
+    // once per syntax element: <= ~1450 refills per macroblock (127 partition nodes, 384 levels of up to three reads each), so
+    // bytes beyond 4 KB per macroblock cannot influence the parse of this frame
+    l = std::min(l, frame_bound);
     boff[i] = pos;
     blen[i] = (uint32_t)l;
     pos += align_up(l + kBitPad, 8);
@@ -495,6 +509,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     if (blen[i]) memcpy(dst, data[i] + offsets[i], blen[i]);
     memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
   });
+  b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
   HIP_TRY(hipMemcpyAsync(b->d_bits.p, hs, hdr_bytes + pos, hipMemcpyHostToDevice, b->stream));
   // 2. output buffers: a clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level per bit read
   const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * max_len) + 448 + 64;
@@ -517,10 +532,15 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   b->last_pay_cap = cap_words;
   pa.n_clips = n; pa.version = b->version;
   pa.width = b->g.width; pa.height = b->g.height; pa.stride = b->g.stride; pa.lg = b->g.lg; pa.mbw = b->g.mbw; pa.mbh = b->g.mbh;
+  if (b->ktiming && !b->ev_p0) { (void)hipEventCreate(&b->ev_p0); (void)hipEventCreate(&b->ev_p1); }
+  const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
+  if (ptime) (void)hipEventRecord(b->ev_p0, b->stream);
   if (mobi_launch_parse(&pa, b->stream) != 0) return MOBI_E_DEVICE;
+  if (ptime) (void)hipEventRecord(b->ev_p1, b->stream);
   MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
   HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream)); // the launch sizes below depend on what the parse found
+  if (ptime) { float ms = 0; if (hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
   uint32_t K = 0;
   for (int i = 0; i < n; i++) {
     rc[i] = res[i].rc;
@@ -560,6 +580,11 @@ int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
 int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
   if (!b || !data || !len || !offsets || !rc) return MOBI_E_ARG;
   HIP_TRY(hipSetDevice(b->device));
+  struct CallTimer { // wall time of this call, for the end-to-end measurements (tools/exp_dparse.py)
+    mobi_batch *b;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~CallTimer() { b->last_decode_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  } call_timer{b};
   if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;
   // 1. host: serial VLC parse of one frame per clip -> command lists

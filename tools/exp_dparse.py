@@ -12,22 +12,34 @@ def run(n_clips, device_parse, n_frames=9, distinct=16):
         p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=n_frames)
         streams.append(m.generate_clip(p))
     b = m.MobiclipBatch(n_clips, 640, 480, 2, device_parse=device_parse)
-    t_frames = []
+    b.set_kernel_timing(1)
+    import ctypes as C
+    from mobiclipdecoder_amd.decoder import load_library
+    lib = load_library(); lib.mobi_debug_parse_ms.restype = C.c_float; lib.mobi_debug_parse_ms.argtypes = [C.c_void_p]
+    lib.mobi_debug_decode_ms.restype = C.c_float; lib.mobi_debug_decode_ms.argtypes = [C.c_void_p]
+    lib.mobi_debug_stage_ms.restype = C.c_float; lib.mobi_debug_stage_ms.argtypes = [C.c_void_p]
+    c_ms, s_ms = [], []
+    t_frames, k_ms = [], []
     for f in range(n_frames):
         datas = [streams[c % distinct][0][streams[c % distinct][1][f]:streams[c % distinct][1][f + 1]] for c in range(n_clips)]
         offs = [0] * n_clips
         t0 = time.perf_counter()
         rcs, _ = b.decode(datas, offs)
         t_frames.append(time.perf_counter() - t0)
+        k_ms.append(lib.mobi_debug_parse_ms(b._h)); c_ms.append(lib.mobi_debug_decode_ms(b._h)); s_ms.append(lib.mobi_debug_stage_ms(b._h))
         assert all(r == 0 for r in rcs), rcs[:8]
     b.close()
     p_ms = np.array(t_frames[2:]) * 1e3   # skip the I-frame and the first P-frame (allocations)
     px = n_clips * 640 * 480
     print(f"clips={n_clips:5d} device_parse={int(device_parse)}  I-frame {t_frames[0]*1e3:8.2f} ms   P-frame median {np.median(p_ms):8.2f} ms  "
-          f"min {p_ms.min():8.2f} ms  -> {px / np.median(p_ms) / 1e3:9.1f} Mpix/s end to end", flush=True)
+          f"min {p_ms.min():8.2f} ms  -> {px / np.median(p_ms) / 1e3:9.1f} Mpix/s end to end"
+          + f" | inside the C call: P median {np.median(c_ms[2:]):.2f} ms = {px / np.median(c_ms[2:]) / 1e3:.0f} Mpix/s"
+          + (f" | parse kernel: I {k_ms[0]:.2f} ms, P median {np.median(k_ms[2:]):.2f} ms, staging {np.median(s_ms[2:]):.2f} ms" if device_parse else ""), flush=True)
 
 if __name__ == "__main__":
-    sizes = [int(a) for a in sys.argv[1:]] or [512, 2048]
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    modes = (True,) if "--device-only" in sys.argv else (False, True)
+    sizes = [int(a) for a in args] or [512, 2048]
     for n in sizes:
-        for dp in (False, True):
+        for dp in modes:
             run(n, dp)
