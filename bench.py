@@ -53,6 +53,24 @@ def cpu_baseline(params, data, fo, budget_s):
                       f"VLC parse + reconstruction, planes only, {t_used:.1f} s on 1 thread of {os.cpu_count()} host cpus"}
 
 
+def end_to_end(m, streams, W, H, version, device, n_clips, n_steps):
+    """Bitstreams in host memory -> planes in HBM: mobi_batch_decode with the parse on the GPU (row f3).  Reported next to
+    the headline value, never as it: the timed region of `value` starts with the command lists already in HBM."""
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=True)
+    ms = []
+    for f in range(2 + n_steps):  # the I-frame, one untimed P-frame (allocations), then n_steps P-frames
+        datas = [streams[c % len(streams)][1][streams[c % len(streams)][2][f]:streams[c % len(streams)][2][f + 1]] for c in range(n_clips)]
+        rcs, _ = b.decode(datas, [0] * n_clips)
+        assert all(r == 0 for r in rcs), "stream error in the end-to-end leg"
+        if f >= 2:
+            ms.append(b.last_decode_ms())
+    b.close()
+    t = float(np.median(ms))
+    return {"value": round(n_clips * W * H / t / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(t, 3), "clips": n_clips, "steps": n_steps,
+            "parse": "device: mobi_parse_frames, one wavefront per clip",
+            "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +80,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated streams per GPU (others are private HBM copies)")
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
+    ap.add_argument("--e2e-steps", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
     ap.add_argument("--intra-events", action="store_true", help="HIP events around the intra launches too (adds a few us per step)")
     args = ap.parse_args()
@@ -123,11 +143,15 @@ def main():
     km = b.kernel_ms()
 
     elapsed = sharding.max_over_ranks(dist, elapsed, device=f"cuda:{local}")
+    cmd_bytes_per_step = sum(b.cmd_bytes(f) for f in step_frames[args.warmup:]) / args.steps
+    b.close()
+    e2e = None
+    if world == 1 and args.e2e_clips > 0 and args.config == "B":
+        e2e = end_to_end(m, streams, W, H, p0.version, local, args.e2e_clips, args.e2e_steps)
 
     if rank == 0:
         steps = args.steps
-        timed = step_frames[args.warmup:]
-        cmd_bytes = sum(b.cmd_bytes(f) for f in timed) / steps          # per launch, all clips of this GPU
+        cmd_bytes = cmd_bytes_per_step                                   # per launch, all clips of this GPU
         algo_bytes = args.clips * 3.0 * W * H + cmd_bytes                # ref read 1.5WH + write 1.5WH + commands
         roof = None
         if km["inter_launches"]:
@@ -162,10 +186,9 @@ def main():
                                    f"{distinct} distinct streams, command lists resident in HBM",
                        "generator_overrides": gen_over or None, "clips_per_gpu": args.clips, "parallelism": f"clips sharded over {world} GPU(s), no collective",
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
-            "roofline": roof, "cpu_baseline": base,
+            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e,
         }
         print(json.dumps(out), flush=True)
-    b.close()
     if dist is not None:
         dist.destroy_process_group()
 

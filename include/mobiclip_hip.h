@@ -90,6 +90,8 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * one clip is serial and a GPU lane is slow at it; the GPU wins by running thousands of clips at once).  Only before the
  * first frame: the decoder state lives on one side.  Default can be preset with MOBI_DEVICE_PARSE=1. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
+/* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
+float mobi_batch_last_decode_ms(const mobi_batch *b);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
 /* Bitmaps (MD.cs:260-323): mobi_batch_convert_argb converts ring slot 0 of EVERY clip into a device-resident buffer
  * (asynchronously, on the batch's stream); mobi_batch_get_argb copies one clip's width*height words out, converting

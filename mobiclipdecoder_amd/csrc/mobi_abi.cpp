@@ -367,7 +367,6 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
 // test aid, not part of the public header: what the last device-side parse left in HBM.  desc_out: n_clips*n_mbs*8 words,
 // items_out: n_clips*n_mbs words, res_out: n_clips*8 words, payload_out: n_clips*pay_cap words (any may be null); returns pay_cap
 float mobi_debug_parse_ms(const mobi_batch *b) { return b ? b->last_parse_ms : 0.f; }
-float mobi_debug_decode_ms(const mobi_batch *b) { return b ? b->last_decode_ms : 0.f; }
 float mobi_debug_stage_ms(const mobi_batch *b) { return b ? b->last_stage_ms : 0.f; }
 long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *items_out, uint32_t *res_out, uint32_t *payload_out, size_t payload_words) {
   if (!b || !b->d_pres) return MOBI_E_ARG;
@@ -686,6 +685,7 @@ uint32_t mobi_batch_yuv_format(const mobi_batch *b, int clip) {
   if (b->parse_mode) return b->dev_yuvfmt.empty() ? 0 : b->dev_yuvfmt[clip];
   return b->parsers[clip]->yuv_format();
 }
+float mobi_batch_last_decode_ms(const mobi_batch *b) { return b ? b->last_decode_ms : 0.f; }
 int mobi_batch_stride(const mobi_batch *b) { return b ? b->g.stride : 0; }
 int mobi_batch_n_clips(const mobi_batch *b) { return b ? b->n : 0; }
 

@@ -54,6 +54,7 @@ _SIGS = {
     "mobi_batch_quantizer": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_yuv_format": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_set_parse_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "mobi_batch_last_decode_ms": (C.c_float, [C.c_void_p]),
     "mobi_batch_stride": (C.c_int, [C.c_void_p]),
     "mobi_batch_n_clips": (C.c_int, [C.c_void_p]),
     "mobi_batch_preload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
@@ -252,6 +253,10 @@ class MobiclipBatch:
 
     def yuv_format(self, clip):
         return self._lib.mobi_batch_yuv_format(self._h, clip)
+
+    def last_decode_ms(self):
+        """Wall time the last decode() spent inside the library."""
+        return float(self._lib.mobi_batch_last_decode_ms(self._h))
 
     # -- replay ---------------------------------------------------------------------------------
     def preload(self, clip, data, frame_off):

@@ -16,7 +16,6 @@ def run(n_clips, device_parse, n_frames=9, distinct=16):
     import ctypes as C
     from mobiclipdecoder_amd.decoder import load_library
     lib = load_library(); lib.mobi_debug_parse_ms.restype = C.c_float; lib.mobi_debug_parse_ms.argtypes = [C.c_void_p]
-    lib.mobi_debug_decode_ms.restype = C.c_float; lib.mobi_debug_decode_ms.argtypes = [C.c_void_p]
     lib.mobi_debug_stage_ms.restype = C.c_float; lib.mobi_debug_stage_ms.argtypes = [C.c_void_p]
     c_ms, s_ms = [], []
     t_frames, k_ms = [], []
@@ -26,7 +25,7 @@ def run(n_clips, device_parse, n_frames=9, distinct=16):
         t0 = time.perf_counter()
         rcs, _ = b.decode(datas, offs)
         t_frames.append(time.perf_counter() - t0)
-        k_ms.append(lib.mobi_debug_parse_ms(b._h)); c_ms.append(lib.mobi_debug_decode_ms(b._h)); s_ms.append(lib.mobi_debug_stage_ms(b._h))
+        k_ms.append(lib.mobi_debug_parse_ms(b._h)); c_ms.append(b.last_decode_ms()); s_ms.append(lib.mobi_debug_stage_ms(b._h))
         assert all(r == 0 for r in rcs), rcs[:8]
     b.close()
     p_ms = np.array(t_frames[2:]) * 1e3   # skip the I-frame and the first P-frame (allocations)
