@@ -3,9 +3,11 @@
 
 A "step" = one P-frame of every resident clip: the reconstruction kernels (MC + dequant/IDCT +
 intra) run over pre-parsed command lists that already sit in HBM (the serial VLC
-parse and PCIe cannot feed a TB/s kernel, so they are outside the timed region; end-to-end numbers
-are in DESIGN.md).  Workload = BASELINE config "640x480 3DS Moflex stream" at a batch large enough to
-leave the Infinity Cache: `--clips` independent clips per GPU (weak scaling: per-GPU work fixed).
+parse and PCIe cannot feed a TB/s kernel, so they are outside the timed region; the `end_to_end`
+object of the output line times the whole DecodeFrame path, bitstream in).  Workload = BASELINE config
+"640x480 3DS Moflex stream" at a batch sized for this part's HBM: `--clips` independent clips per GPU
+(default 4096 = 31 GB of 288 GB; weak scaling: per-GPU work fixed).  Launches this long (1.7 ms) no longer
+pay for their ramp-up and tail: DESIGN.md has the same measurement at 512 / 1024 / 2048 clips.
 
   python bench.py                      # 1 GPU, defaults finish in well under a minute
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
@@ -76,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--clips", type=int, default=512, help="independent clips resident per GPU")
+    ap.add_argument("--clips", type=int, default=4096, help="independent clips resident per GPU (4096 x 640x480 = 19 GB of rings + 12 GB of command lists)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated streams per GPU (others are private HBM copies)")
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

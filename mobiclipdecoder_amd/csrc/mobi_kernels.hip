@@ -1184,6 +1184,7 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s)
   const unsigned grid = (unsigned)(((quads + INTER_WAVES - 1) / INTER_WAVES + 7) / 8 * 8); // whole number of workgroups per XCD
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
+  static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
   if (oct && !b.prof && !b.done) { // eight macroblocks per wave: the q* fields count octets for this kernel
     b.qpr = ((uint32_t)b.mbw + 7) / 8;
     b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);
@@ -1192,10 +1193,9 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s)
     b.magic_qpc = magic(b.qpc);
     const unsigned g8 = (unsigned)(((long)b.qpc * b.n_clips + 7) / 8 * 8);
     b.inter_per_xcd = g8 / 8;
-    hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), lds_pad, s, b);
     return (int)hipGetLastError();
   }
-  static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
   if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
   else hipLaunchKernelGGL(mobi_recon_inter, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
   return (int)hipGetLastError();

@@ -3,8 +3,9 @@
 # usage: tools/profile_round.sh <tag> ; outputs under gpurun_out/<tag>/ (copy the summaries into profiles/)
 TAG=${1:-round}; REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --cpu-seconds 0 --no-kernel-events"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.log" 2>&1
+# kernel trace: the default command (its end-to-end leg included); counter passes: the timed loop only
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python $REPO/bench.py --cpu-seconds 0 > "$OUT/trace.log" 2>&1
+BENCH="python $REPO/bench.py --cpu-seconds 0 --no-kernel-events --e2e-clips 0"
 i=0
 while read -r PMC; do
   [ -z "$PMC" ] && continue
