@@ -570,14 +570,14 @@ enum {
   O_L = 0,       // 4 rounds: luma window rows 4t..4t+3  (slot ((row&3)*2 + half)*8 + g: 256 B per row, the rounds are contiguous)
   O_U = 4096,    // 2 rounds: U rows 0..3, 4..7
   O_V = 6144,    // 2 rounds: V rows 0..3, 4..7
-  O_SC = 8192,   // dequant scales (320 B)
-  O_META = 8512, // cbp6[8], t8mask[8], flags[8]
-  O_BYTES = 8544,
+  O_BYTES = 8192, // exactly 8 KB per wave: 20 waves per CU fit in the 160 KB of LDS (5 per SIMD)
+  // once the chroma windows have been consumed (the V rows lie under them):
+  O_TAB = 7168,    // entry -> area*8 + g (<= 48 bytes)
+  O_SC = 7232,     // dequant scales (320 B), fetched while the luma is interpolated
   // after motion compensation:
   O_OUT_Y = 0,     // 16 rows x 128 B
   O_OUT_C = 2048,  // 2 planes x 8 rows x 64 B
-  O_COEF = 3072,   // 16 areas x 64 ints, transposed in place (up to 7168)
-  O_TAB = 7168     // entry -> g*8 + area (<= 48 bytes)
+  O_COEF = 3072    // 16 areas x 64 ints, transposed in place (up to 7168)
 };
 } // namespace
 
@@ -601,9 +601,13 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const int nl = (d.y >> 1) & 0x7F, kind2 = (d.y >> 26) & 3;
   const bool single = valid && nl == 1, dual = valid && kind2 != 0, multi = valid && nl > 1 && kind2 == 0;
   const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
-  L[O_META + g] = (uint8_t)cbp6;
-  L[O_META + 8 + g] = (uint8_t)((d.y >> 14) & 0x3F);
-  L[O_META + 16 + g] = (uint8_t)((valid ? 1 : 0) | (multi ? 2 : 0));
+  // What the whole wave needs to know about the eight macroblocks travels by ballot (lane index = j*8 + g): coded areas and
+  // transform kinds as bit area*8 + g (areas 0..3 in the low word, 4..5 in the high one), inter / cell-map flags as bit g.
+  const unsigned long long mb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((cbp6 >> j) & 1));
+  const unsigned long long tb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((d.y >> (14 + j)) & 1));
+  const uint32_t m_lo = (uint32_t)mb64, m_hi = (uint32_t)(mb64 >> 32), t_lo = (uint32_t)tb64, t_hi = (uint32_t)(tb64 >> 32);
+  const uint32_t inter_mask = (uint32_t)__builtin_amdgcn_ballot_w64(valid) & 0xFFu, multi_mask = (uint32_t)__builtin_amdgcn_ballot_w64(multi) & 0xFFu;
+  if (inter_mask == 0) return; // nothing but intra macroblocks here
   const bool any_dual = __builtin_amdgcn_ballot_w64(dual) != 0;
   auto slot_off = [&](uint32_t ref) {
     int sl = A.ring_base - (int)ref;
@@ -642,9 +646,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     MOBI_DMA16(p2 + rowoff(4), L + O_U + 1024, 0);
     MOBI_DMA16(p2 + hS, L + O_V, 0);
     MOBI_DMA16(p2 + hS + rowoff(4), L + O_V + 1024, 0);
-    const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
-    if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + O_SC, 0);
   }
+  const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
   const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
   uint32_t cwr[4] = {0, 0, 0, 0}; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g
   if ((uint32_t)j < ncoef) cwr[0] = cw[j];
@@ -683,36 +686,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
-  const uint2 mm2 = *(const uint2 *)(L + O_META), tt2 = *(const uint2 *)(L + O_META + 8), ff2 = *(const uint2 *)(L + O_META + 16);
-  const uint32_t m_lo = __builtin_amdgcn_readfirstlane(mm2.x), m_hi = __builtin_amdgcn_readfirstlane(mm2.y); // coded areas: bit g*8 + area
-  const uint32_t t_lo = __builtin_amdgcn_readfirstlane(tt2.x), t_hi = __builtin_amdgcn_readfirstlane(tt2.y);
-  const uint32_t f_lo = __builtin_amdgcn_readfirstlane(ff2.x), f_hi = __builtin_amdgcn_readfirstlane(ff2.y); // byte g: bit 0 inter, bit 1 cell map
-  if (((f_lo | f_hi) & 0x01010101u) == 0) return;
 
   // ---- stage B ----
   uint32_t mcv[12];
   auto stage_b = [&](auto with_dual) {
     constexpr bool DUAL = decltype(with_dual)::value;
-    {
-      // lane (g, rr = j>>2, q = j&3): row 2t + rr.  Dword w (0..7) of window row y: O_L + y*256 + (w>>2)*128 + g*16 + (w&3)*4
-      // (rows 0..15; the four rounds are contiguous); row 16 sits in the registers of the lanes that need it.
-      const int rr = j >> 2, q = j & 3, w0 = (((int)d.w & 15) + 4 * q) >> 2, w1 = w0 + 1;
-      const int c0 = g * 16 + (w0 >> 2) * 128 + (w0 & 3) * 4, c1 = g * 16 + (w1 >> 2) * 128 + (w1 & 3) * 4;
-      const int A0 = O_L + rr * 256 + c0, A1 = O_L + rr * 256 + c1;
-      const uint32_t sh0 = ypos0 & 3, sh1 = ypos1 & 3;
-      const bool p0a = yph0 == 0, p1a = yph0 == 1, p2a = yph0 == 2, p0b = yph1 == 0, p1b = yph1 == 1, p2b = yph1 == 2;
-#pragma unroll
-      for (int t = 0; t < 8; t++) {
-        const int at0 = A0 + 512 * t, at1 = A1 + 512 * t;
-        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0, y1;
-        if (t < 7) { y0 = lds32(L, at0 + 256); y1 = lds32(L, at1 + 256); }
-        else { y0 = lds32(L, rr ? at0 : at0 + 256); y1 = lds32(L, rr ? at1 : at1 + 256); y0 = rr ? r16.x : y0; y1 = rr ? r16.y : y1; } // row 15 -> row 16
-        if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
-        const bool second = DUAL && t >= 4;
-        const uint32_t sh = second ? sh1 : sh0;
-        mcv[t] = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
-      }
-    }
     {
       // chroma: iteration u: plane u>>1, rows (u&1)*4 + (j>>1), q = j&1.  Dword w of row r: O_U/O_V + r*256 + (w>>2)*128 + g*16 + (w&3)*4,
       // row 8 sits in registers
@@ -733,6 +711,29 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         mcv[8 + u] = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
       }
     }
+    // the chroma windows are consumed: the dequant scales of this frame's quantizer land on the V rows while the luma is interpolated
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + O_SC, 0);
+    {
+      // lane (g, rr = j>>2, q = j&3): row 2t + rr.  Dword w (0..7) of window row y: O_L + y*256 + (w>>2)*128 + g*16 + (w&3)*4
+      // (rows 0..15; the four rounds are contiguous); row 16 sits in the registers of the lanes that need it.
+      const int rr = j >> 2, q = j & 3, w0 = (((int)d.w & 15) + 4 * q) >> 2, w1 = w0 + 1;
+      const int c0 = g * 16 + (w0 >> 2) * 128 + (w0 & 3) * 4, c1 = g * 16 + (w1 >> 2) * 128 + (w1 & 3) * 4;
+      const int A0 = O_L + rr * 256 + c0, A1 = O_L + rr * 256 + c1;
+      const uint32_t sh0 = ypos0 & 3, sh1 = ypos1 & 3;
+      const bool p0a = yph0 == 0, p1a = yph0 == 1, p2a = yph0 == 2, p0b = yph1 == 0, p1b = yph1 == 1, p2b = yph1 == 2;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int at0 = A0 + 512 * t, at1 = A1 + 512 * t;
+        uint32_t x0 = lds32(L, at0), x1 = lds32(L, at1), y0, y1;
+        if (t < 7) { y0 = lds32(L, at0 + 256); y1 = lds32(L, at1 + 256); }
+        else { y0 = lds32(L, rr ? at0 : at0 + 256); y1 = lds32(L, rr ? at1 : at1 + 256); y0 = rr ? r16.x : y0; y1 = rr ? r16.y : y1; } // row 15 -> row 16
+        if (DUAL) { x0 = dual ? fx[t].x : x0; x1 = dual ? fx[t].y : x1; y0 = dual ? fy[t].x : y0; y1 = dual ? fy[t].y : y1; }
+        const bool second = DUAL && t >= 4;
+        const uint32_t sh = second ? sh1 : sh0;
+        mcv[t] = mc4_lane(x0, x1, y0, y1, sh, sh * 8, second ? p0b : p0a, second ? p1b : p1a, second ? p2b : p2a);
+      }
+    }
   };
   if (any_dual) stage_b(std::true_type{});
   else stage_b(std::false_type{});
@@ -748,11 +749,10 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   {
     const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
     const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-#pragma unroll 1
-    for (int hsel = 0; hsel < 2; hsel++) {
-      uint32_t mm = ((hsel ? f_hi : f_lo) >> 1) & 0x01010101u;
+    {
+      uint32_t mm = multi_mask;
       while (mm) {
-        const int gm = hsel * 4 + ((__builtin_ctz(mm)) >> 3);
+        const int gm = __builtin_ctz(mm);
         mm &= mm - 1;
         const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
         const uint32_t *clip32 = (const uint32_t *)clip_base;
@@ -793,6 +793,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
 
   // ---- stage C ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the scales
   wave_sync();
   if (m_lo | m_hi) {
     const int n_lo = __builtin_popcount(m_lo), n_ent = n_lo + __builtin_popcount(m_hi);
@@ -801,8 +802,6 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       const uint32_t w = lane < 32 ? m_lo : m_hi, sh = lane & 31;
       if ((w >> sh) & 1) L[O_TAB + (lane < 32 ? 0 : n_lo) + __builtin_popcount(w & ((1u << sh) - 1))] = (uint8_t)lane;
     }
-    const uint32_t mg = g < 4 ? m_lo : m_hi, tg = g < 4 ? t_lo : t_hi; // this lane's macroblock lives in one half of the masks
-    const int gbase = g < 4 ? 0 : n_lo;
     int lo = 0, hi = 0;
     // 16 areas per round (two tiles of 8): half as many LDS round trips between the stages as with 8
     for (int base = 0; base < n_ent; base += 16) {
@@ -813,9 +812,10 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       }
       wave_sync();
       auto scatter = [&](uint32_t e) {
-        const int t = e & 0x1FF, level = (int32_t)e >> 16, kk = (g & 3) * 8 + (t >> 6), p = t & 63;
-        const int slot = gbase + __builtin_popcount(mg & ((1u << kk) - 1)) - base;
-        const int si = ((tg >> kk) & 1) ? p : 64 + (p & 15);
+        const int t = e & 0x1FF, level = (int32_t)e >> 16, ar = t >> 6, kk = (ar & 3) * 8 + g, p = t & 63;
+        const bool chroma = ar >= 4; // entries are ordered by area, then macroblock: luma areas in the low mask word
+        const int slot = (chroma ? n_lo : 0) + __builtin_popcount((chroma ? m_hi : m_lo) & ((1u << kk) - 1)) - base;
+        const int si = (((chroma ? t_hi : t_lo) >> kk) & 1) ? p : 64 + (p & 15);
         const int scale = (int)lds32(L, O_SC + si * 4);
         if ((unsigned)slot < 16u) coef[slot * 64 + p] = __mul24(scale, level);
       };
@@ -849,7 +849,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         if (actx[h]) {
-          const int ge = kx[h] >> 3, a = kx[h] & 7;
+          const int ge = kx[h] & 7, a = kx[h] >> 3;
           uint8_t *px = a < 4 ? L + O_OUT_Y + (a >> 1) * 8 * 128 + ge * 16 + (a & 1) * 8 : L + O_OUT_C + (a - 4) * 512 + ge * 8;
           idct_pass2_q(coef + 64 * (8 * h + (lane >> 3)), is8x[h], r, px, a < 4 ? 128 : 64, lo, hi);
         }
@@ -864,7 +864,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int i = lane + 64 * it, gq = i & 7, yrow = i >> 3;
-    if (((gq < 4 ? f_lo : f_hi) >> (8 * (gq & 3))) & 1) {
+    if ((inter_mask >> gq) & 1) {
       *(uint4 *)(y0 + (off0 + (yrow << lgS) + gq * 16)) = *(const uint4 *)(L + O_OUT_Y + yrow * 128 + gq * 16);
       const int row = yrow & 7; // chroma: plane = it, row = (i >> 3) & 7
       *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + O_OUT_C + it * 512 + row * 64 + gq * 8);
