@@ -98,6 +98,13 @@ int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out,
  * just that clip first if the whole-batch conversion has not been run for the current frame. */
 int mobi_batch_convert_argb(mobi_batch *b);
 int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out);
+/* Encoder-side analysis: Analyzer.InterPredict2x2 (Analyzer.cs:608-681) for every 2x2 luma block of
+ * every macroblock of every clip, as SolveInterPredictionPuzzle calls it (:683-693): three-step search (6, 3, 1 pels) in up
+ * to five past frames = ring slots 0..4 of this batch (the encoder's PastFramesY, MobiEncoder.cs:138-144).
+ * src_y[clip]: the picture to analyse, width*height luma bytes, pitch = width.  out[((clip * n_mbs + mb) * 64) + Y*8 + X] =
+ * (Delta.X & 0xFF) | (Delta.Y & 0xFF) << 8 | Frame << 16 | score << 20 (Delta in half pels, as the reference stores it;
+ * score = 0xFFF when the ring is empty). */
+int mobi_batch_motion_search(mobi_batch *b, const uint8_t *const *src_y, uint32_t *out);
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip);
 uint32_t mobi_batch_yuv_format(const mobi_batch *b, int clip);
 int mobi_batch_stride(const mobi_batch *b);

@@ -10,5 +10,6 @@ from .decoder import (  # noqa: F401
     MobiclipVersion,
     MobiclipError,
     load_library,
+    unpack_motion_search,
 )
 from .streamgen import GenParams, generate_clip, default_params  # noqa: F401

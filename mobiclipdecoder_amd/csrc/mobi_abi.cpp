@@ -227,6 +227,7 @@ struct mobi_batch {
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
+  DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
   MobiDevState *d_pstate = nullptr;
   MobiDevResult *d_pres = nullptr;
   uint8_t *d_ptables = nullptr;
@@ -675,6 +676,26 @@ int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out) {
   HIP_TRY(hipMemcpy(out, b->d_argb + src_clip * words, words * 4, hipMemcpyDeviceToHost));
   return MOBI_OK;
 }
+// ---- encoder-side analysis: Analyzer.InterPredict2x2 over the ring this batch keeps in HBM (Analyzer.cs:608-693) ----
+int mobi_batch_motion_search(mobi_batch *b, const uint8_t *const *src_y, uint32_t *out) {
+  if (!b || !src_y || !out) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t n = (size_t)b->n, px = (size_t)b->g.width * b->g.height, n_mbs = (size_t)b->g.mbw * b->g.mbh;
+  if (int e = b->h_stage.reserve(n * px)) return e;
+  if (int e = b->d_src.reserve(n * px)) return e;
+  if (int e = b->d_search.reserve(n * n_mbs * 64 * 4)) return e;
+  for (size_t i = 0; i < n; i++)
+    if (!src_y[i]) return MOBI_E_ARG;
+  b->pool->run((int)n, [&](int i) { memcpy(b->h_stage.p + (size_t)i * px, src_y[i], px); });
+  HIP_TRY(hipMemcpyAsync(b->d_src.p, b->h_stage.p, n * px, hipMemcpyHostToDevice, b->stream));
+  MobiReconArgs a = b->args(nullptr, nullptr);
+  const int n_past = std::min(5, b->frames_started); // PastFramesY[i] == null ends the loop (:618)
+  if (mobi_launch_motion_search(&a, b->d_src.p, (uint32_t *)b->d_search.p, n_past, b->stream) != 0) return MOBI_E_DEVICE;
+  HIP_TRY(hipMemcpyAsync(out, b->d_search.p, n * n_mbs * 64 * 4, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return MOBI_OK;
+}
+
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) {
   if (!b || clip < 0 || clip >= b->n) return 0;
   if (b->parse_mode) return b->dev_quant.empty() ? 0 : b->dev_quant[clip];

@@ -43,6 +43,8 @@ extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_de
 // MD.cs:260-323: ring slot 0 of clips [clip0, clip0 + n_clips) -> out_dev[clip][height][width] 0xAARRGGBB words (mobi_rgb.hip)
 extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, int n_clips, uint32_t *out_dev, hipStream_t s);
 extern "C" long long mobi_launch_div239_check(hipStream_t s); // mismatches of the RGB kernel's x/239 over all floats, or -1
+// Analyzer.cs:608-693: three-step 2x2 motion search of src_dev[clip][height][width] against ring slots 0..n_past-1 (mobi_analysis.hip)
+extern "C" int mobi_launch_motion_search(const MobiReconArgs *a, const uint8_t *src_dev, uint32_t *out_dev, int n_past, hipStream_t s);
 // intra launch item: (clip << 13) | mb
 #define MOBI_ITEM(clip, mb) (((uint32_t)(clip) << 13) | (uint32_t)(mb))
 #endif

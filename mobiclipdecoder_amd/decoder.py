@@ -55,6 +55,7 @@ _SIGS = {
     "mobi_batch_yuv_format": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_set_parse_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mobi_batch_last_decode_ms": (C.c_float, [C.c_void_p]),
+    "mobi_batch_motion_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_stride": (C.c_int, [C.c_void_p]),
     "mobi_batch_n_clips": (C.c_int, [C.c_void_p]),
     "mobi_batch_preload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
@@ -192,6 +193,13 @@ class MobiclipDecoder:
             pass
 
 
+def unpack_motion_search(words):
+    """Packed results of mobi_batch_motion_search / the oracle -> dict(dx, dy, frame, score)."""
+    w = np.asarray(words, dtype=np.uint32)
+    return {"dx": (w & 0xFF).astype(np.int8).astype(np.int32), "dy": ((w >> 8) & 0xFF).astype(np.int8).astype(np.int32),
+            "frame": ((w >> 16) & 7).astype(np.int32), "score": (w >> 20).astype(np.int32), "packed": w}
+
+
 class MobiclipBatch:
     """N independent decoder instances of equal geometry decoded in lock step on one GPU
     (decoder instances share nothing: MD.cs:15-39).  Also the pre-parsed replay path used for
@@ -253,6 +261,18 @@ class MobiclipBatch:
 
     def yuv_format(self, clip):
         return self._lib.mobi_batch_yuv_format(self._h, clip)
+
+    def motion_search(self, pictures):
+        """Analyzer.InterPredict2x2 for every 2x2 luma block (Analyzer.cs:608-693) of `pictures` (one (Height, Width) uint8 luma
+        picture per clip) against this batch's ring.  -> dict of (n, mbh, mbw, 8, 8) arrays: dx, dy (half pels), frame, score."""
+        pics = [np.ascontiguousarray(p, dtype=np.uint8) for p in pictures]
+        assert len(pics) == self.n and all(p.shape == (self.Height, self.Width) for p in pics)
+        ptrs = (C.c_void_p * self.n)(*[p.ctypes.data for p in pics])
+        out = np.empty((self.n, self.Height // 16, self.Width // 16, 8, 8), np.uint32)
+        rc = self._lib.mobi_batch_motion_search(self._h, ptrs, out.ctypes.data)
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return unpack_motion_search(out)
 
     def last_decode_ms(self):
         """Wall time the last decode() spent inside the library."""

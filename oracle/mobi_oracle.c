@@ -1166,6 +1166,62 @@ const uint8_t *mobi_oracle_y(const mobi_oracle *d, int idx) { return (idx >= 0 &
 const uint8_t *mobi_oracle_uv(const mobi_oracle *d, int idx) { return (idx >= 0 && idx < 6) ? d->UV[idx].p : NULL; }
 uint32_t *mobi_oracle_internal(mobi_oracle *d) { return d->Internal; }
 
+/* ---- Analyzer.InterPredict2x2, Analyzer.cs:608-681, over every 2x2 block of every macroblock (:683-693) ---- */
+void mobi_oracle_motion_search(const mobi_oracle *d, const uint8_t *src, uint32_t *out) {
+  const int W = (int)d->Width, H = (int)d->Height, S = d->Stride;
+  for (int mby = 0; mby < H / 16; mby++)
+    for (int mbx = 0; mbx < W / 16; mbx++)
+      for (int Y = 0; Y < 8; Y++)
+        for (int X = 0; X < 8; X++) {
+          const int BX = mbx * 16, BY = mby * 16;                 /* Block.X, Block.Y */
+          const uint8_t *c0 = src + (BY + Y * 2) * W + BX + X * 2; /* cmp[0..3], Encoder/MacroBlock.cs:80-83 */
+          const int cmp[4] = {c0[0], c0[1], c0[W], c0[W + 1]};
+          int rdx = 0, rdy = 0, rframe = 0, resultscore = INT32_MAX; /* InterPredict2x2Result defaults, :613-615 */
+          for (int i = 0; i < 5; i++) {                            /* :616 */
+            const uint8_t *past = d->Y[i].p;
+            if (!past) break;                                      /* :618 */
+            int St = 6, centerx = 0, centery = 0, centerscore = 0; /* :619-622 */
+            while (St >= 1) {                                      /* :623 */
+              int bestscore = INT32_MAX, bestx = 0, besty = 0;
+              for (int y = -St; y <= St; y += St) {                /* :628 */
+                if (BY + y + centery + Y * 2 < 0 || BY + 2 + y + centery + Y * 2 > H) continue; /* :630 */
+                for (int x = -St; x <= St; x += St) {
+                  if (BX + x + centerx + X * 2 < 0 || BX + 2 + x + centerx + X * 2 > W) continue; /* :633 */
+                  const uint8_t *ps = past + (BY + Y * 2) * S + (BX + X * 2) + x + centerx + (y + centery) * S; /* :635 */
+                  int a = cmp[0] - ps[0], b = cmp[1] - ps[1], c = cmp[2] - ps[S], e = cmp[3] - ps[S + 1];
+                  if (a < 0) a = -a;
+                  if (b < 0) b = -b;
+                  if (c < 0) c = -c;
+                  if (e < 0) e = -e;
+                  const int score = a + b + c + e;                 /* :645 */
+                  const int nx = x + centerx, ny = y + centery;
+                  if (score < bestscore ||
+                      (score == bestscore && (nx < 0 ? -nx : nx) + (ny < 0 ? -ny : ny) < (bestx < 0 ? -bestx : bestx) + (besty < 0 ? -besty : besty))) { /* :646-651 */
+                    bestx = nx;
+                    besty = ny;
+                    bestscore = score;
+                  }
+                }
+              }
+              St /= 2;                                             /* :661-664 */
+              centerx = bestx;
+              centery = besty;
+              centerscore = bestscore;
+            }
+            const int cx2 = centerx * 2, cy2 = centery * 2;
+            if (centerscore < resultscore ||
+                (centerscore == resultscore && (cx2 < 0 ? -cx2 : cx2) + (cy2 < 0 ? -cy2 : cy2) < (rdx < 0 ? -rdx : rdx) + (rdy < 0 ? -rdy : rdy))) { /* :666-671 */
+              rdx = cx2;
+              rdy = cy2;
+              rframe = i;
+              resultscore = centerscore;
+            }
+          }
+          const uint32_t sc = resultscore == INT32_MAX ? 0xFFFu : (uint32_t)resultscore;
+          out[((size_t)(mby * (W / 16) + mbx) * 64) + Y * 8 + X] = ((uint32_t)rdx & 0xFFu) | (((uint32_t)rdy & 0xFFu) << 8) | ((uint32_t)rframe << 16) | (sc << 20);
+        }
+}
+
 /* ---- YUV -> ARGB, MD.cs:260-323 (compile with -ffp-contract=off: every operator rounds once, as in the CLR) ---- */
 int mobi_oracle_argb(const mobi_oracle *d, uint32_t *out) {
   const uint8_t *Y = d->Y[0].p, *UV = d->UV[0].p;

@@ -58,6 +58,13 @@ const uint8_t *mobi_oracle_uv(const mobi_oracle *d, int idx);
  * Float arithmetic: IEEE single, one rounding per C# operator in source order, no fused multiply-add (what the
  * x64 CLR's scalar SSE code does); casts truncate toward zero.  Returns ORA_E_NULLREF before the first frame. */
 int mobi_oracle_argb(const mobi_oracle *d, uint32_t *out);
+/* Encoder-side analysis, Analyzer.InterPredict2x2 (Analyzer.cs:608-681) for all 64 2x2 luma blocks of every macroblock
+ * (SolveInterPredictionPuzzle's loop, :683-693): three-step search (steps 6, 3, 1 full pels) over up to five past frames,
+ * ties broken towards the shorter vector; the encoder's PastFramesY[i] (MobiEncoder.cs:138-144) are this decoder's ring
+ * slots Y[i].  src: the picture being analysed, width*height luma bytes, pitch = width (MacroBlock.YData2x2,
+ * Encoder/MacroBlock.cs:76-85).  out[(mb * 64) + Y*8 + X] = (Delta.X & 0xFF) | (Delta.Y & 0xFF) << 8 | Frame << 16 |
+ * score << 20, Delta in half pels as the reference stores it; score = 0xFFF when there is no past frame at all. */
+void mobi_oracle_motion_search(const mobi_oracle *d, const uint8_t *src, uint32_t *out);
 /* testing hooks: direct access to the Internal[392] word array (MD.cs:28) */
 uint32_t *mobi_oracle_internal(mobi_oracle *d);
 

@@ -31,6 +31,8 @@ def lib():
         L.mobi_oracle_yuvformat.argtypes = [C.c_void_p]
         L.mobi_oracle_yuvformat.restype = C.c_uint32
         L.mobi_oracle_argb.argtypes = [C.c_void_p, C.c_void_p]
+        L.mobi_oracle_motion_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mobi_oracle_motion_search.restype = None
         L.mobi_oracle_internal.argtypes = [C.c_void_p]
         L.mobi_oracle_internal.restype = C.POINTER(C.c_uint32)
         L.mobi_oracle_idct8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -78,6 +80,14 @@ class OracleDecoder:
         """Bitmap of ring slot 0 (MD.cs:260-323) as (Height, Width) uint32 0xAARRGGBB; None before the first frame."""
         out = np.empty((self.Height, self.Width), np.uint32)
         return out if self.L.mobi_oracle_argb(self.h, out.ctypes.data) == 0 else None
+
+    def motion_search(self, picture):
+        """Analyzer.InterPredict2x2 over every 2x2 block (Analyzer.cs:608-693) -> packed (mbh, mbw, 8, 8) uint32."""
+        pic = np.ascontiguousarray(picture, dtype=np.uint8)
+        assert pic.shape == (self.Height, self.Width)
+        out = np.empty((self.Height // 16, self.Width // 16, 8, 8), np.uint32)
+        self.L.mobi_oracle_motion_search(self.h, pic.ctypes.data, out.ctypes.data)
+        return out
 
     @property
     def Quantizer(self):
