@@ -6,8 +6,8 @@ intra) run over pre-parsed command lists that already sit in HBM (SURVEY.md 8(d)
 parse and PCIe cannot feed a TB/s kernel, so they are outside the timed region; the `end_to_end`
 object of the output line times the whole DecodeFrame path, bitstream in).  Workload = BASELINE config
 "640x480 3DS Moflex stream" at a batch sized for this part's HBM: `--clips` independent clips per GPU
-(default 4096 = 31 GB of 288 GB; weak scaling: per-GPU work fixed).  Launches this long (1.7 ms) no longer
-pay for their ramp-up and tail: DESIGN.md has the same measurement at 512 / 1024 / 2048 clips.
+(default 24576 = 189 GB of the 288 GB; weak scaling: per-GPU work fixed).  Few, long launches (9 ms) are measurably
+more efficient on this part than many short ones: DESIGN.md has the same measurement from 512 to 24576 clips.
 
   python bench.py                      # 1 GPU, defaults finish in well under a minute
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--clips", type=int, default=4096, help="independent clips resident per GPU (4096 x 640x480 = 19 GB of rings + 12 GB of command lists)")
+    ap.add_argument("--clips", type=int, default=24576, help="independent clips resident per GPU (24576 x 640x480 = 116 GB of rings + 73 GB of command lists; halved if it does not fit)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated streams per GPU (others are private HBM copies)")
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -113,16 +113,31 @@ def main():
     p0 = streams[0][0]
     W, H = p0.width, p0.height
 
-    b = m.MobiclipBatch(args.clips, W, H, p0.version, device=local)
-    for i, (p, data, fo) in enumerate(streams):
-        rcs = b.preload(i, data, fo)
-        assert all(r == 0 for r in rcs), rcs
-    for c in range(distinct, args.clips):
-        b.preload_clone(c, c % distinct)
-    b.commit()
+    # the batch: as many clips as asked for; if this GPU cannot hold them (rings + command lists), halve until it can
+    clips = args.clips
+    while True:
+        b = None
+        try:
+            b = m.MobiclipBatch(clips, W, H, p0.version, device=local)
+            for i, (p, data, fo) in enumerate(streams):
+                rcs = b.preload(i, data, fo)
+                assert all(r == 0 for r in rcs), rcs
+            for c in range(distinct, clips):
+                b.preload_clone(c, c % distinct)
+            b.commit()
+            b.replay(0)  # the I-frame: the first replay allocates what is still missing, so it belongs to the "does it fit" test
+            assert b.sync() == 0
+            break
+        except m.MobiclipError as e:
+            if b is not None:
+                b.close()
+            if clips <= 512:
+                raise
+            print(f"bench.py: {clips} clips do not fit ({e}); retrying with {clips // 2}", file=sys.stderr, flush=True)
+            clips //= 2
+    args.clips = clips
 
-    # warm-up: the I-frame (frame 0) then W P-frames, in stream order
-    b.replay(0)
+    # warm-up: (the I-frame, frame 0, ran above) W P-frames, in stream order
     step_frames = [1 + (i % N_PFRAMES) for i in range(args.warmup + args.steps)]
     for f in step_frames[: args.warmup]:
         b.replay(f)

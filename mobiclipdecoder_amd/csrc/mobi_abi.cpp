@@ -418,7 +418,9 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   b->clip_bytes = 6 * b->slot_bytes;
   b->cur.resize(n_clips);
   b->h_fault.assign(n_clips, 0);
-  size_t total = kGuard * 2 + b->clip_bytes * (size_t)n_clips;
+  size_t arena_clips = (size_t)n_clips;
+  if (const char *ac = getenv("MOBI_ARENA_CLIPS")) arena_clips = std::max(arena_clips, (size_t)atoll(ac)); // experiment: allocation size vs speed
+  size_t total = kGuard * 2 + b->clip_bytes * arena_clips;
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipMalloc((void **)&b->arena, total) != hipSuccess) return nullptr;
   if (hipMemsetAsync(b->arena, 0, total, b->stream) != hipSuccess) return nullptr; // padding must read 0 forever (MD.cs:107)

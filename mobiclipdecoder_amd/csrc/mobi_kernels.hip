@@ -138,6 +138,30 @@ __device__ __forceinline__ void idct_pass2(const int *t, bool is8, int r, uint8_
   }
 }
 
+// pass 2 that keeps the residual instead of adding it: res[y * 8 + x] for the 8x8 pixel area (all four 4x4 blocks of a split area)
+__device__ __forceinline__ void idct_pass2_res(const int *t, bool is8, int r, int *res) {
+  int in[8], out[8];
+  if (is8) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) in[m] = t[8 * r + m];
+    mobi_bfly8(in, out);
+#pragma unroll
+    for (int j = 0; j < 8; j++) res[8 * r + j] = out[j] >> 6;
+  } else {
+    const int s = r >> 1;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const int i = (r & 1) * 2 + g;
+#pragma unroll
+      for (int m = 0; m < 4; m++) in[m] = t[16 * s + 4 * i + m];
+      mobi_bfly4(in, out);
+      int *row = res + ((s >> 1) * 4 + i) * 8 + (s & 1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; j++) row[j] = out[j] >> 6;
+    }
+  }
+}
+
 } // namespace
 
 // =====================================================================================================
@@ -905,36 +929,40 @@ struct TileNb {
   int by, bx;
   __device__ __forceinline__ int operator()(int dy, int dx) const { return t[(by + dy + 1) * TP + 4 + bx + dx]; }
 };
-// predict one block on the tile (all lanes call; lanes >= n*n idle), then its residual when coded
+// predict one block on the tile (all lanes call; lanes >= n*n idle) and add its residual when coded.  The residuals of the whole
+// macroblock were computed beforehand (they do not depend on the prediction): res = the area's 8x8 residual tile.
 __device__ __forceinline__ void run_block(uint8_t *tile, int by, int bx, int n, int mode, int param, bool coded,
-                                          const int *coef, int *tmp, bool is8, int sub, int block_off, bool is_uv,
+                                          const int *res, int sub, int block_off, bool is_uv,
                                           int S, int lane, int *fault) {
   asm volatile("" : "+v"(lane)); // per-lane predicates are recomputed here: hoisted out of the block loops they end up as ~50 spilled SGPR pairs
   TileNb nb{tile, by, bx};
+  const int y = (n == 8) ? lane >> 3 : lane >> 2, x = (n == 8) ? lane & 7 : lane & 3; // this lane's pixel of an 8x8 / 4x4 block
+  const int ri = (n == 8) ? lane : ((sub >> 1) * 4 + y) * 8 + (sub & 1) * 4 + x;        // ... and its place in the area's residual tile
+  bool add_pending = coded;
   if (mode == 2) {
     const int wpr = n >> 2, nw = n * wpr; // words per row, words in block
     if (lane < nw) {
-      const int y = lane / wpr, x0 = (lane % wpr) * 4;
-      const uint32_t w = mobi_plane_word(n, param, y, x0, nb);
-      *(uint32_t *)(tile + (by + y + 1) * TP + 4 + bx + x0) = w;
+      const int yy = lane / wpr, x0 = (lane % wpr) * 4;
+      const uint32_t w = mobi_plane_word(n, param, yy, x0, nb);
+      *(uint32_t *)(tile + (by + yy + 1) * TP + 4 + bx + x0) = w;
     }
     wave_sync();
   } else if (mode != 9) {
     const int vfix = is_uv && (block_off & (S - 1)) >= (S >> 1);                                      // MD.cs:1886
     const int left_avail = ((block_off - (vfix ? (S >> 1) : 0)) & (S - 1)) != 0, top_avail = block_off >= S; // :1923-1924
     if (lane < n * n) {
-      const int y = (n == 8) ? lane >> 3 : lane >> 2, x = (n == 8) ? lane & 7 : lane & 3;
-      const int v = mobi_pred_px(mode, n, y, x, top_avail, left_avail, nb);
+      int v = mobi_pred_px(mode, n, y, x, top_avail, left_avail, nb);
+      if (coded) v = mobi_add_clamp(v, res[ri], fault);
       tile[(by + y + 1) * TP + 4 + bx + x] = (uint8_t)v;
     }
+    add_pending = false;
     wave_sync();
   }
-  if (coded) {
-    uint8_t *area_px = tile + (by + 1) * TP + 4 + bx - (is8 ? 0 : ((sub >> 1) * 4 * TP + (sub & 1) * 4));
-    const int r0 = is8 ? 0 : sub * 2, r1 = is8 ? 8 : sub * 2 + 2; // lanes (as pass rows r) that take part
-    if (lane >= r0 && lane < r1) idct_pass1(coef, tmp, is8, lane);
-    wave_sync();
-    if (lane >= r0 && lane < r1) idct_pass2(tmp, is8, lane, area_px, TP, 1 << sub, fault);
+  if (add_pending) { // the block was predicted by a plane (mode 2) or by an earlier plane pass (mode 9): add on top of what is there
+    if (lane < n * n) {
+      uint8_t *px = tile + (by + y + 1) * TP + 4 + bx + x;
+      *px = (uint8_t)mobi_add_clamp(*px, res[ri], fault);
+    }
     wave_sync();
   }
 }
@@ -1062,27 +1090,36 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   if (lane < ncoef) scatter_one(sc, mycw, t8, coef);
   scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 64, ncoef, t8, coef, lane);
   wave_sync();
+  // residuals of all coded areas at once, eight lanes per area (the block loop below only predicts and adds): coef -> tmp -> coef
+  {
+    const int a = lane >> 3, r = lane & 7;
+    const bool act = a < 6 && ((w1 >> (8 + a)) & 1), is8a = (t8 >> a) & 1;
+    if (act) idct_pass1(coef + 64 * a, tmp + 64 * a, is8a, r);
+    wave_sync();
+    if (act) idct_pass2_res(tmp + 64 * a, is8a, r, coef + 64 * a);
+    wave_sync();
+  }
 
   unsigned long long pt2 = 0;
   if (A.prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt2 = __builtin_readcyclecounter(); }
   // ---- block records, in decode order ----
   int fault = 0;
-  if (w3 & 1) run_block(ty, 0, 0, 16, 2, (int16_t)(w3 >> 16), false, coef, tmp, false, 0, off, false, S, lane, &fault);
+  if (w3 & 1) run_block(ty, 0, 0, 16, 2, (int16_t)(w3 >> 16), false, coef, 0, off, false, S, lane, &fault);
   for (int a = 0; a < 6; a++) {
     uint8_t *tile = a < 4 ? ty : (a == 4 ? tcu : tcv);
     const int ay = a < 4 ? (a >> 1) * 8 : 0, ax = a < 4 ? (a & 1) * 8 : 0;
     const int aoff = a < 4 ? off + ay * S + ax : off / 2 + (a - 4) * (S >> 1);
     const uint32_t r0 = rec_at(a * 4);
     const bool pre = (r0 >> 6) & 1;
-    if (pre) run_block(tile, ay, ax, 8, 2, (int16_t)(r0 >> 16), false, coef, tmp, false, 0, aoff, a >= 4, S, lane, &fault);
+    if (pre) run_block(tile, ay, ax, 8, 2, (int16_t)(r0 >> 16), false, coef, 0, aoff, a >= 4, S, lane, &fault);
     if (!((r0 >> 5) & 1)) {
-      run_block(tile, ay, ax, 8, r0 & 15, pre ? 0 : (int16_t)(r0 >> 16), (r0 >> 4) & 1, coef + 64 * a, tmp, true, 0, aoff, a >= 4, S, lane, &fault);
+      run_block(tile, ay, ax, 8, r0 & 15, pre ? 0 : (int16_t)(r0 >> 16), (r0 >> 4) & 1, coef + 64 * a, 0, aoff, a >= 4, S, lane, &fault);
     } else {
       for (int s = 0; s < 4; s++) {
         const uint32_t rr = rec_at(a * 4 + s);
         const int sy = (s >> 1) * 4, sx = (s & 1) * 4;
         const int param = (s == 0 && pre) ? 0 : (int16_t)(rr >> 16);
-        run_block(tile, ay + sy, ax + sx, 4, rr & 15, param, (rr >> 4) & 1, coef + 64 * a, tmp, false, s, aoff + sy * S + sx, a >= 4, S, lane, &fault);
+        run_block(tile, ay + sy, ax + sx, 4, rr & 15, param, (rr >> 4) & 1, coef + 64 * a, s, aoff + sy * S + sx, a >= 4, S, lane, &fault);
       }
     }
   }
