@@ -694,7 +694,10 @@ struct DP {
 };
 } // namespace
 
-extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void mobi_parse_frames(MobiDevParseArgs A) {
+#ifndef MOBI_PARSE_WAVES
+#define MOBI_PARSE_WAVES 4 // waves per SIMD the register budget is cut for: 128 VGPRs; 5, 6 and 8 spill and are slower
+#endif
+extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves_per_eu(MOBI_PARSE_WAVES, MOBI_PARSE_WAVES))) void mobi_parse_frames(MobiDevParseArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t tab[MOBI_DT_BYTES];
   __shared__ WaveLds wl[PWAVES];
   for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += 64 * PWAVES) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
