@@ -113,12 +113,11 @@ def main():
     p0 = streams[0][0]
     W, H = p0.width, p0.height
 
-    # the batch: as many clips as asked for; if this GPU cannot hold them (rings + command lists), halve until it can
-    clips = args.clips
-    while True:
-        b = None
+    # the batch: as many clips as asked for; if a GPU cannot hold them (rings + command lists), halve until it can -- and every
+    # rank settles on the same size (weak scaling: per-GPU work is fixed and equal)
+    def build_batch(clips):
+        b = m.MobiclipBatch(clips, W, H, p0.version, device=local)
         try:
-            b = m.MobiclipBatch(clips, W, H, p0.version, device=local)
             for i, (p, data, fo) in enumerate(streams):
                 rcs = b.preload(i, data, fo)
                 assert all(r == 0 for r in rcs), rcs
@@ -127,14 +126,25 @@ def main():
             b.commit()
             b.replay(0)  # the I-frame: the first replay allocates what is still missing, so it belongs to the "does it fit" test
             assert b.sync() == 0
-            break
+        except m.MobiclipError:
+            b.close()
+            raise
+        return b
+
+    clips, b = args.clips, None
+    while b is None:
+        try:
+            b = build_batch(clips)
         except m.MobiclipError as e:
-            if b is not None:
-                b.close()
             if clips <= 512:
                 raise
-            print(f"bench.py: {clips} clips do not fit ({e}); retrying with {clips // 2}", file=sys.stderr, flush=True)
+            print(f"bench.py: rank {rank}: {clips} clips do not fit ({e}); retrying with {clips // 2}", file=sys.stderr, flush=True)
             clips //= 2
+    agreed = -int(sharding.max_over_ranks(dist, -clips, device=f"cuda:{local}"))  # the smallest size any rank settled on
+    if agreed != clips:
+        b.close()
+        clips = agreed
+        b = build_batch(clips)
     args.clips = clips
 
     # warm-up: (the I-frame, frame 0, ran above) W P-frames, in stream order
