@@ -78,6 +78,30 @@ def test_corrupted_streams_agree_on_error_class():
     assert tally["unsupported"] < tally["err"] + tally["ok"], tally
 
 
+@pytest.mark.parametrize("version,cfg", [(2, "B"), (1, "A")])
+def test_heavier_corruption_both_versions(version, cfg):
+    """The same differential check with the richer syntax mix (deep trees, several references, quantiser deltas, escapes,
+    intra macroblocks in P-frames), both codec versions, byte garbage and many flips per stream."""
+    rng = np.random.default_rng(11 + version)
+    tally = {"ok": 0, "err": 0, "unsupported": 0}
+    for trial in range(50):
+        p = default_params(cfg, BASE_SEED + 700 + trial, n_frames=5, width=96, height=64, version=version, pm_intra=120, pm_deep=150,
+                           pm_multiref=250, qdelta_prob=250, escape_prob=80, table1_prob=400, iframe_interval=3)
+
+        def mangle(d, fo, rng=rng, trial=trial):
+            if trial % 3 == 0:
+                a = int(rng.integers(0, max(1, d.size - 16)))
+                d[a:a + 16] = rng.integers(0, 256, d[a:a + 16].size, dtype=np.uint8)
+            else:
+                for _ in range(int(rng.integers(1, 12))):
+                    d[int(rng.integers(0, d.size))] ^= 1 << int(rng.integers(0, 8))
+            return d
+        s = _compare(p, mutate=mangle)
+        for k in tally:
+            tally[k] += s[k]
+    assert tally["ok"] > 20 and tally["err"] > 5, tally
+
+
 def test_truncated_and_odd_length_data():
     p = default_params("A", BASE_SEED + 1, n_frames=2, width=64, height=48)
     data, fo = generate_clip(p)
