@@ -382,7 +382,7 @@ long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *ite
   return (long long)b->last_pay_cap;
 }
 
-const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_inter, mobi_recon_intra, mobi_recon_step, mobi_yuv_to_argb; no CPU reconstruction path)"; }
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_inter, mobi_recon_intra, mobi_recon_intra_cl, mobi_recon_step, mobi_parse_frames, mobi_yuv_to_argb, mobi_motion_search_2x2; no CPU reconstruction path)"; }
 
 const char *mobi_error_string(int rc) {
   switch (rc) {
