@@ -11,7 +11,11 @@
 //  * levels go straight to their place in the payload (no per-macroblock staging);
 //  * intra macroblocks are listed in raster order (a valid order for the dependency waits of mobi_recon_intra: every
 //    dependency is raster-earlier); the launch interleaves clips so that a clip's chain never fills the machine;
-//  * exceptions become a sticky error code: after the first error nothing else is read or written.
+//  * exceptions become a sticky error code.  The first error freezes the bit reader (Offset stays where the reference threw) and
+//    the decoder state that survives a frame; the walk then runs on to the end of the current macroblock without testing the
+//    code after every read -- every loop of the syntax is bounded by its structure, not by the data (a macroblock holds at
+//    most 127 partition nodes, 6 areas of 4 blocks, 64 tokens per block) -- and the frame loop stops there.  Testing after
+//    every read costs 23 % of the kernel (execution-mask bookkeeping of ~40 extra branches per macroblock).
 #include <hip/hip_runtime.h>
 
 #include "../../include/mobiclip_hip.h"
@@ -337,7 +341,6 @@ struct DP {
         add_dep(owner_chroma(b + S - 1), deps, n_deps);
         add_dep(owner_chroma(b + S + 8), deps, n_deps);
       }
-      if (r.err) return;
       #pragma nounroll
       for (int k = n_deps; k < MOBI_INTRA_DEPS; k++) deps[k] = MOBI_DEP_NONE;
       d.w4 = deps[0] | (deps[1] << 16);
@@ -370,14 +373,11 @@ struct DP {
     if (ref > imin(5, frames_started - 1)) { fail(MOBI_E_NULLREF); return; } // Y[ref] == null
     const long long o = (long long)cur_off + (long long)y * S + x;
     check_window(o + (long long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * height);
-    if (r.err) return;
     const int cdx = dx >> 1, cdy = dy >> 1;
     const long long cpos = o / 2 + (long long)(cdy >> 1) * S + (cdx >> 1);
     const int cph = (cdx & 1) | ((cdy & 1) << 1);
     check_window(cpos, w >> 1, h >> 1, cph, S * height / 2);
-    if (r.err) return;
     check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * height / 2);
-    if (r.err) return;
     if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) { fail(MOBI_E_UNSUPPORTED); return; }
     L->leaves[n_leaf_words] = mobi_leaf_w0(x, y, wi, hi, ref);
     L->leaves[n_leaf_words + 1] = mobi_leaf_w1(dx, dy);
@@ -400,14 +400,12 @@ struct DP {
       resid_block(area, 0, true);
     } else {
       const uint32_t u = ue();
-      if (r.err) return;
       if (u >= 16) { fail(MOBI_E_INDEX); return; }
       const uint32_t m = T[MOBI_DT_CBP4_P + u];
       #pragma nounroll
       for (int sub = 0; sub < 4; sub++)
         if ((m >> sub) & 1) {
           resid_block(area, sub, false);
-          if (r.err) return;
         }
     }
   }
@@ -416,14 +414,12 @@ struct DP {
     const int dual = classify_leaves(nl);
     hdr_words = (nl == 1 || dual) ? 0 : MOBI_MV_CELLS; // end_mb() fills the cell map
     const uint32_t u = ue();
-    if (r.err) return;
     if (u >= 64) { fail(MOBI_E_INDEX); return; }
     cbp6 = T[MOBI_DT_CBP_P + u];
     #pragma nounroll
     for (int area = 0; area < 6; area++)
       if ((cbp6 >> area) & 1) {
         resid_area(area);
-        if (r.err) return;
       }
   }
 
@@ -440,8 +436,10 @@ struct DP {
     int v = (int)(r.win >> 28), nb = 1, mode = pred;
     if (v >= pred) v++;
     if (v < 9) { mode = v; nb = 4; }
-    if (four) L->mcache[ci] = (uint8_t)mode;
-    else L->mcache[ci] = L->mcache[ci + 1] = L->mcache[ci + 8] = L->mcache[ci + 9] = (uint8_t)mode;
+    if (!r.err) { // the cache survives the frame: nothing may touch it after the (sticky) error = the reference's throw
+      if (four) L->mcache[ci] = (uint8_t)mode;
+      else L->mcache[ci] = L->mcache[ci + 1] = L->mcache[ci + 8] = L->mcache[ci + 9] = (uint8_t)mode;
+    }
     take(nb);
     return mode;
   }
@@ -449,7 +447,6 @@ struct DP {
   __device__ __forceinline__ void intra_area_fixed(int area, int mode, bool coded) {
     if (!coded) {
       check_intra_reads(mode, area_offset(area, 0));
-      if (r.err) return;
       L->recs[area * 4] |= mobi_intra_rec(mode, 0, 0, 0, 0);
       return;
     }
@@ -457,26 +454,22 @@ struct DP {
       r.win += r.win;
       r.nbr--;
       check_intra_reads(mode, area_offset(area, 0));
-      if (r.err) return;
       L->recs[area * 4] |= mobi_intra_rec(mode, 1, 0, 0, 0);
       cbp6 |= 1u << area;
       t8mask |= 1u << area;
       resid_block(area, 0, true);
     } else {
       const uint32_t u = ue();
-      if (r.err) return;
       if (u >= 20) { fail(MOBI_E_INDEX); return; }
       const uint32_t m4 = T[MOBI_DT_CBP4_I + u];
       #pragma nounroll
       for (int sub = 0; sub < 4; sub++) {
         check_intra_reads(mode, area_offset(area, sub));
-        if (r.err) return;
         const int c = (m4 >> sub) & 1;
         L->recs[area * 4 + sub] |= mobi_intra_rec(mode, c, 1, 0, 0);
         if (c) {
           cbp6 |= 1u << area;
           resid_block(area, sub, false);
-          if (r.err) return;
         }
       }
     }
@@ -484,15 +477,12 @@ struct DP {
   __device__ __forceinline__ void intra_chroma(uint32_t cbp) { // loc_116290, MD.cs:1864-1880
     int m = (int)(r.win >> 29);
     take(3);
-    if (r.err) return;
     if (m == 2) {
       m = 9;
       #pragma nounroll
       for (int area = 4; area < 6; area++) {
         const int p = se();
-        if (r.err) return;
         check_intra_reads(2, area_offset(area, 0));
-        if (r.err) return;
         if (p < -32768 || p > 32767) { fail(MOBI_E_UNSUPPORTED); return; }
         L->recs[area * 4] |= mobi_intra_rec(0, 0, 0, 1, (int16_t)p);
       }
@@ -500,26 +490,21 @@ struct DP {
     #pragma nounroll
     for (int area = 4; area < 6; area++) {
       intra_area_fixed(area, m, (cbp >> area) & 1);
-      if (r.err) return;
     }
   }
   __device__ __forceinline__ void intra_full_luma(uint32_t cbp) { // DecIntraFullBlockPMode, MD.cs:1759-1786
     int m = (int)(r.win >> 29);
     take(3);
-    if (r.err) return;
     if (m == 2) {
       m = 9;
       const int p = se();
-      if (r.err) return;
       check_intra_reads(2, cur_off);
-      if (r.err) return;
       if (p < -32768 || p > 32767) { fail(MOBI_E_UNSUPPORTED); return; }
       w3 = 1u | ((uint32_t)(uint16_t)(int16_t)p << 16);
     }
     #pragma nounroll
     for (int k = 0; k < 4; k++) {
       intra_area_fixed(k, m, (cbp >> k) & 1);
-      if (r.err) return;
     }
   }
   __device__ __forceinline__ void intra_sub_luma(uint32_t cbp) { // DecIntraSubBlockPMode, MD.cs:1789-1807
@@ -534,45 +519,36 @@ struct DP {
       }
       if (whole) {
         const int m = pmode(cik, false);
-        if (r.err) return;
         int p = 0;
         if (m == 2) { // the predictor itself reads its parameter (MD.cs:1915-1919)
           p = se();
-          if (r.err) return;
           if (p < -32768 || p > 32767) { fail(MOBI_E_UNSUPPORTED); return; }
         }
         check_intra_reads(m, area_offset(k, 0));
-        if (r.err) return;
         L->recs[k * 4] |= mobi_intra_rec(m, coded, 0, 0, (int16_t)p);
         if (coded) {
           cbp6 |= 1u << k;
           t8mask |= 1u << k;
           resid_block(k, 0, true);
-          if (r.err) return;
         }
       } else {
         const uint32_t u4 = ue();
-        if (r.err) return;
         if (u4 >= 20) { fail(MOBI_E_INDEX); return; }
         const uint32_t m4 = T[MOBI_DT_CBP4_I + u4];
         #pragma nounroll
         for (int sub = 0; sub < 4; sub++) {
           const int m = pmode(cik + (sub & 1) + (sub >> 1) * 8, true);
-          if (r.err) return;
           int p = 0;
           if (m == 2) {
             p = se();
-            if (r.err) return;
             if (p < -32768 || p > 32767) { fail(MOBI_E_UNSUPPORTED); return; }
           }
           check_intra_reads(m, area_offset(k, sub));
-          if (r.err) return;
           const int c = (m4 >> sub) & 1;
           L->recs[k * 4 + sub] |= mobi_intra_rec(m, c, 1, 0, (int16_t)p);
           if (c) {
             cbp6 |= 1u << k;
             resid_block(k, sub, false);
-            if (r.err) return;
           }
         }
       }
@@ -582,11 +558,9 @@ struct DP {
   __device__ __forceinline__ void intra_mb(bool sub) {
     begin_intra_payload();
     const uint32_t u = ue();
-    if (r.err) return;
     if (u >= 64) { fail(MOBI_E_INDEX); return; }
     const uint32_t cbp = T[MOBI_DT_CBP_I + u];
     if (sub) intra_sub_luma(cbp); else intra_full_luma(cbp);
-    if (r.err) return;
     intra_chroma(cbp);
   }
 
@@ -604,14 +578,11 @@ struct DP {
       const uint32_t code = plut[s * 64 + (r.win >> T[MOBI_DT_PSHIFT + s])];
       if (code >= T[MOBI_DT_PNB + s]) { fail(MOBI_E_INDEX); return 0; }
       take(pbits[s * 12 + code]);
-      if (r.err) return 0;
       if (code == 0) {
         mc_leaf(wi, hi, x, y, 1, predx, predy, mv_slot);
       } else if (code <= 5) {
         const int dx = se();
-        if (r.err) return 0;
         const int dy = se();
-        if (r.err) return 0;
         mc_leaf(wi, hi, x, y, (int)code, dx + predx, dy + predy, mv_slot);
       } else if (code == 6 || code == 7) {
         if (s != 0) { fail(MOBI_E_PARTCODE); return 0; }
@@ -626,7 +597,6 @@ struct DP {
         L->stk[sp++] = (uint32_t)((wi + 1) | (hi << 2) | (((x + w / 2) >> 1) << 4) | ((y >> 1) << 8));
         L->stk[sp++] = (uint32_t)((wi + 1) | (hi << 2) | ((x >> 1) << 4) | ((y >> 1) << 8));
       }
-      if (r.err) return 0;
     }
     return 0;
   }

@@ -127,19 +127,27 @@ def test_streams_the_reference_throws_on():
 
 @pytest.mark.parametrize("cfg,version,w,h", [("A", MobiclipVersion.ModsDS, 256, 192), ("B", MobiclipVersion.Moflex3DS, 640, 480)])
 def test_fuzzed_streams_device_parse_equals_host_parse(cfg, version, w, h):
-    """Differential fuzz: 48 clips with random bit flips (headers included), byte garbage and truncations, decoded frame
+    """Differential fuzz: 96 clips with random bit flips (headers included), byte garbage, noise frames and truncations, decoded frame
     after frame by two batches that differ only in where the parse runs.  Same rc, same Offset, same Quantizer for every
     clip and frame whatever the stream does; same planes wherever the frame decoded."""
-    n, nfr = 48, 6
-    rng = np.random.default_rng(20240928)
-    base = [generate_clip(default_params(cfg, BASE_SEED + 500 + i, n_frames=nfr, pm_intra=120, pm_deep=120, pm_multiref=200,
+    n, nfr = 96, 8
+    import os
+    fuzz_seed = int(os.environ.get("MOBI_FUZZ_SEED", "0"))  # sweeps: MOBI_FUZZ_SEED=1..N python -m pytest -k fuzzed
+    rng = np.random.default_rng(20240928 + fuzz_seed)
+    base = [generate_clip(default_params(cfg, BASE_SEED + 500 + i + 16 * fuzz_seed, n_frames=nfr, pm_intra=120, pm_deep=120, pm_multiref=200,
                                          qdelta_prob=200, escape_prob=60, iframe_interval=3)) for i in range(6)]
     clips = []
     for i in range(n):
         d, fo = base[i % len(base)]
         d = np.array(d, copy=True)
-        kind = i % 6
-        if kind in (1, 2):      # sparse bit flips anywhere
+        kind = i % 8
+        if kind == 6:           # a whole frame of noise behind a valid first word
+            f = int(rng.integers(0, nfr))
+            d[fo[f] + 2:fo[f + 1]] = rng.integers(0, 256, int(fo[f + 1] - fo[f] - 2), dtype=np.uint8)
+        elif kind == 7:         # dense flips: one in every ~40 bytes
+            for pos in rng.integers(0, d.size, d.size // 40):
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind in (1, 2):    # sparse bit flips anywhere
             for pos in rng.integers(0, d.size, 3 if kind == 1 else 40):
                 d[pos] ^= 1 << int(rng.integers(0, 8))
         elif kind == 3:         # a run of random bytes inside one frame
