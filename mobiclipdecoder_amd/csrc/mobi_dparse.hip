@@ -48,14 +48,20 @@ struct BitR {
   const uint8_t *pf;
   uint64_t cur, nxt;
   int cur_n, len, off;
+  int lim;      // = len while no error is pending, INT_MIN afterwards: one comparison decides whether a refill may happen
   uint32_t win; // r3
   int nbr;      // nrBitsRemaining
   int err;      // sticky: the first MOBI_E_* (the reference's exception); nothing is read after it
 
-  __device__ __forceinline__ void fail(int c) { if (!err) err = c; }
+  __device__ __forceinline__ void fail(int c) {
+    if (!err) err = c;
+    lim = (int)0x80000000;
+  }
   __device__ __forceinline__ void fill_bits() { // FillBits: one 16-bit LE word, no refill at/after Data.Length
-    if (err || off >= len) return;
-    if (off + 1 >= len) { fail(MOBI_E_INDEX); return; } // IOUtil.ReadU16LE past the array
+    if (off + 1 >= lim) { // rare: an error is pending (reader frozen), or the data ends here
+      if (!err && off < len) fail(MOBI_E_INDEX); // off + 1 == len: IOUtil.ReadU16LE past the array; off >= len: FillBits returns silently
+      return;
+    }
     const uint32_t w = (uint32_t)cur & 0xFFFFu;
     cur >>= 16;
     if (--cur_n == 0) {
@@ -170,8 +176,7 @@ __device__ __noinline__ ResidOut resid_block_fn(BitR r, uint32_t n_coefs, lds_u8
       skip = (int)((e >> 9) & 0x3F);
       e >>= 15;
     }
-    if (r.err) break;
-    p += skip;
+    p += skip; // (no test for a pending error here: the reader is frozen, p still advances, the loop ends within N tokens)
     if (p >= N) { r.fail(MOBI_E_UNSUPPORTED); break; } // the reference would walk past the dequant words (Internal[] aliasing)
     const int idx = (flags & 4) ? zz[p] : 0; // low byte of the dequant word = zigzag target (MD.cs:3426); all zero before the first SetupQuantTables
     p++;
@@ -704,6 +709,7 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
     // bit reader: DecodeFrame() reads the first 16-bit word itself (MD.cs:110-112)
     const uint8_t *base = A.bits + A.bit_off[clip];
     p.r.len = (int)A.bit_len[clip];
+    p.r.lim = p.r.len;
     p.r.off = 0;
     p.r.nbr = 0;
     p.r.win = 0;
