@@ -84,11 +84,11 @@ void mobi_batch_destroy(mobi_batch *b);
  * Parses on the host, uploads the command lists, launches, synchronises.  Returns MOBI_OK or a
  * MOBI_E_DEVICE/ARG failure of the call itself (per-clip stream errors go to rc[]). */
 int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
-/* Where mobi_batch_decode parses the bitstreams.  0 (default): host threads, command lists uploaded per call.
- * 1: on the GPU, one wavefront per clip (mobi_dparse.hip): Data[Offset..) of every clip is uploaded instead and the command
- * lists never leave HBM; same rc / Offset / planes.  Worth it from about a thousand resident clips per GPU upward (the parse of
- * one clip is serial and a GPU lane is slow at it; the GPU wins by running thousands of clips at once).  Only before the
- * first frame: the decoder state lives on one side.  Default can be preset with MOBI_DEVICE_PARSE=1. */
+/* Where mobi_batch_decode parses the bitstreams.  0: host threads, command lists uploaded per call.  1: on the GPU, one
+ * wavefront per clip (mobi_dparse.hip): Data[Offset..) of every clip is uploaded instead and the command lists never leave
+ * HBM; same rc / Offset / planes.  The parse of one clip is serial and a GPU lane is slow at it; the GPU wins by running
+ * thousands of clips at once, from about 900 resident clips upward.  Default: by batch size (device parse from 1024 clips),
+ * or MOBI_DEVICE_PARSE=0/1.  Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
 /* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
 float mobi_batch_last_decode_ms(const mobi_batch *b);

@@ -224,7 +224,7 @@ struct mobi_batch {
                                         // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
   // device-side parse (mobi_dparse.hip): parse_mode 1 = mobi_batch_decode parses on the GPU (env MOBI_DEVICE_PARSE=1 or
   // mobi_batch_set_parse_mode); the per-clip decoder state then lives in d_pstate and the host parsers stay untouched
-  int parse_mode = 0;
+  int parse_mode = 0; // resolved at creation: explicit (env / mobi_batch_set_parse_mode) or by batch size
   size_t last_pay_cap = 0;
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
@@ -441,6 +441,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
     if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = atoi(io) != 0;
+    b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) b->parse_mode = atoi(dp) != 0;
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;

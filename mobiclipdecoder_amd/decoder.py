@@ -207,7 +207,7 @@ class MobiclipBatch:
 
     def __init__(self, n_clips, Width, Height, Version, device=0, device_parse=None):
         """device_parse: True = decode() parses the bitstreams on the GPU (one wavefront per clip, mobi_dparse.hip),
-        False = on host threads, None = library default (env MOBI_DEVICE_PARSE)."""
+        False = on host threads, None = library default (device parse from 1024 clips; env MOBI_DEVICE_PARSE=0/1)."""
         self._lib = load_library()
         self.n, self.Width, self.Height, self.Version = int(n_clips), int(Width), int(Height), MobiclipVersion(Version)
         self._h = self._lib.mobi_batch_create(self.n, self.Width, self.Height, int(self.Version), device)
