@@ -6,7 +6,7 @@ intra) run over pre-parsed command lists that already sit in HBM (SURVEY.md 8(d)
 parse and PCIe cannot feed a TB/s kernel, so they are outside the timed region; the `end_to_end`
 object of the output line times the whole DecodeFrame path, bitstream in).  Workload = BASELINE config
 "640x480 3DS Moflex stream" at a batch sized for this part's HBM: `--clips` independent clips per GPU
-(default 24576 = 189 GB of the 288 GB; weak scaling: per-GPU work fixed).  Few, long launches (9 ms) are measurably
+(default 24576 = 183 GB of the 288 GB; weak scaling: per-GPU work fixed).  Few, long launches (9 ms) are measurably
 more efficient on this part than many short ones: DESIGN.md has the same measurement from 512 to 24576 clips.
 
   python bench.py                      # 1 GPU, defaults finish in well under a minute
@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--clips", type=int, default=24576, help="independent clips resident per GPU (24576 x 640x480 = 116 GB of rings + 73 GB of command lists; halved if it does not fit)")
+    ap.add_argument("--clips", type=int, default=24576, help="independent clips resident per GPU (24576 x 640x480 = 109 GB of rings + 74 GB of command lists; halved if it does not fit)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated streams per GPU (others are private HBM copies)")
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
