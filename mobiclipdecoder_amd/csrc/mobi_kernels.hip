@@ -605,6 +605,10 @@ enum {
 };
 } // namespace
 
+#ifndef MOBI_OCT_CWR
+#define MOBI_OCT_CWR 12 // 96 level words per macroblock in registers: no effect on the default mix, -12 % kernel time on dense streams (848x480 config); 123 VGPRs, still 4 waves per SIMD
+#endif
+enum { CWR = MOBI_OCT_CWR };
 __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
   uint32_t rem, ox;
   const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); // qpr / qpc: OCTETS per row / per clip for this kernel
@@ -673,12 +677,17 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
   const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
-  uint32_t cwr[4] = {0, 0, 0, 0}; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g
+  uint32_t cwr[CWR] = {}; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
   if ((uint32_t)j < ncoef) cwr[0] = cw[j];
   if (__builtin_amdgcn_ballot_w64(ncoef > 8) != 0) {
 #pragma unroll
     for (int k = 1; k < 4; k++)
       if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+    if (CWR > 4 && __builtin_amdgcn_ballot_w64(ncoef > 32) != 0) {
+#pragma unroll
+      for (int k = 4; k < CWR; k++)
+        if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+    }
   }
   // The 17th luma row and the 9th chroma rows of the windows (needed by the last row's vertical half-pel only) go
   // straight into the registers of the lanes that use them: a tenth DMA round would cost 1 KB of LDS, i.e. two waves per CU
@@ -844,14 +853,14 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         if ((unsigned)slot < 16u) coef[slot * 64 + p] = __mul24(scale, level);
       };
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < CWR; k++) {
         const bool mine = (uint32_t)(8 * k + j) < ncoef;
         if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
         uint32_t e = cwr[k];
         asm volatile("" : "+v"(e));
         if (mine) scatter(e);
       }
-      for (uint32_t i = 32u + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 8)
+      for (uint32_t i = 8u * CWR + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 8) // beyond the registers: one exposed round trip per 8 words
         if (i < ncoef) scatter(cw[i]);
       wave_sync();
       const int r = lane & 7;
