@@ -224,7 +224,8 @@ struct mobi_batch {
                                         // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
   // device-side parse (mobi_dparse.hip): parse_mode 1 = mobi_batch_decode parses on the GPU (env MOBI_DEVICE_PARSE=1 or
   // mobi_batch_set_parse_mode); the per-clip decoder state then lives in d_pstate and the host parsers stay untouched
-  int parse_mode = 0; // resolved at creation: explicit (env / mobi_batch_set_parse_mode) or by batch size
+  int parse_mode = 0; // explicit (env / mobi_batch_set_parse_mode), or by batch size and settled at the first frame (parse_auto)
+  bool parse_auto = false;
   size_t last_pay_cap = 0;
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
@@ -442,7 +443,8 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
     if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = atoi(io) != 0;
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
-    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) b->parse_mode = atoi(dp) != 0;
+    b->parse_auto = true;
+    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = atoi(dp) != 0; b->parse_auto = false; }
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
     b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
@@ -579,6 +581,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
   if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
   b->parse_mode = device_parse != 0;
+  b->parse_auto = false;
   return MOBI_OK;
 }
 
@@ -590,6 +593,15 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~CallTimer() { b->last_decode_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
   } call_timer{b};
+  if (b->parse_auto && b->parse_mode && b->frames_started == 0) {
+    // Chosen by batch size only: a caller that hands over whole files as Data (MOC5 style, Form1.cs:292-302) would make the
+    // device path upload up to 4 KB per macroblock per clip and frame (the frame length is unknown before the parse).  Packets
+    // of a frame or a few are what the device path is for; anything much larger stays on the host parser.
+    const size_t packet_like = (size_t)b->g.mbw * b->g.mbh * 256 + 65536;
+    for (int i = 0; i < b->n; i++)
+      if (data[i] && offsets[i] >= 0 && (uint64_t)offsets[i] < len[i] && len[i] - (size_t)offsets[i] > packet_like) { b->parse_mode = 0; break; }
+  }
+  b->parse_auto = false; // the decoder state lives on one side from the first frame on
   if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;
   // 1. host: serial VLC parse of one frame per clip -> command lists

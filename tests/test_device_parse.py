@@ -201,6 +201,40 @@ def test_host_and_device_parse_agree_on_a_larger_batch():
     db.close()
 
 
+def test_default_parse_side_follows_batch_size_and_packet_shape():
+    """No explicit choice: 1024 clips and more parse on the GPU when Data looks like packets, on the host when Data is a whole
+    file (MOC5 style; the device path would have to upload megabytes per clip and frame).  Same planes either way."""
+    import ctypes as C
+    from mobiclipdecoder_amd.decoder import load_library
+    lib = load_library()
+    lib.mobi_debug_read_parse.restype = C.c_longlong
+    lib.mobi_debug_read_parse.argtypes = [C.c_void_p] * 5 + [C.c_size_t]
+    p = default_params("A", BASE_SEED + 77, n_frames=3, width=64, height=48)
+    data, fo = generate_clip(p)
+    ora = OracleDecoder(64, 48, p.version)
+    want = []
+    for f in range(3):
+        ora.Data, ora.Offset = data[fo[f]:fo[f + 1]], 0
+        o = ora.DecodeFrame()
+        want.append((o[0].copy(), o[1].copy()))
+    whole = np.concatenate([data, np.zeros(300000, np.uint8)])  # a "file" with a long tail behind the three frames
+    for n, style, expect_device in [(1024, "packets", True), (1024, "file", False), (1023, "packets", False)]:
+        b = MobiclipBatch(n, 64, 48, p.version)
+        for f in range(3):
+            if style == "packets":
+                rcs, offs = b.decode([data[fo[f]:fo[f + 1]]] * n, [0] * n)
+            else:
+                rcs, offs = b.decode([whole] * n, [int(fo[f])] * n)
+                assert offs[0] - int(fo[f]) == offs[-1] - int(fo[f])
+            assert rcs == [0] * n
+            for i in (0, n // 2, n - 1):
+                y, uv = b.planes(i)
+                assert np.array_equal(y, want[f][0]) and np.array_equal(uv, want[f][1]), (n, style, f, i)
+        used_device = lib.mobi_debug_read_parse(b._h, None, None, None, None, 0) >= 0
+        assert used_device == expect_device, (n, style)
+        b.close()
+
+
 def test_parse_mode_cannot_change_after_the_first_frame():
     from mobiclipdecoder_amd.decoder import load_library
     p = default_params("A", BASE_SEED + 1, n_frames=2)

@@ -20,4 +20,6 @@ def run(nb, clips_each, steps=64):
     torch.cuda.synchronize(); dt=time.perf_counter()-t0
     print(f'{nb} batch(es) x {clips_each} clips: {dt*1e3/steps:.3f} ms per step of {nb*clips_each} clips -> {nb*clips_each*steps*640*480/dt/1e9:.1f} Gpix/s', flush=True)
     for b in bs: b.close()
-run(1,512); run(2,256); run(4,128); run(2,512)
+sizes = [int(a) for a in sys.argv[1:]] or [512]
+for n in sizes:
+    run(1, n); run(2, n // 2); run(4, n // 4)
