@@ -548,18 +548,25 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
       if (n_deps == MOBI_INTRA_DEPS) fail(MOBI_E_UNSUPPORTED); // cannot happen: the halo touches at most 7 macroblocks
       deps[n_deps++] = (uint16_t)(o | (level[o] == 0 ? MOBI_DEP_INTER : 0));
     };
-    for (int c = -1; c <= MOBI_HALO_Y_RIGHT; c++) dep(g_.owner_luma(off - S + c));
-    for (int r = 0; r < 16; r++) {
-      dep(g_.owner_luma(off + r * S - 1));
-      dep(g_.owner_luma(off + r * S + 16)); // right halo: one owner per row (an MB is 16 wide, halo is 8)
-    }
+    // The halo is the row above (columns -1 .. +23 luma, -1 .. +15 chroma) and the columns left and right of the macroblock.
+    // Its owners change only at 16-pixel (8 for chroma) boundaries and, in the side columns, between the first row and the
+    // rest (row wrap when width == stride), so these probes meet every distinct owner, in the order a full scan would.
+    dep(g_.owner_luma(off - S - 1));
+    dep(g_.owner_luma(off - S));
+    dep(g_.owner_luma(off - S + 16));
+    dep(g_.owner_luma(off - 1));
+    dep(g_.owner_luma(off + 16));
+    dep(g_.owner_luma(off + S - 1));
+    dep(g_.owner_luma(off + S + 16));
     for (int v = 0; v < 2; v++) {
-      long base = off / 2 + v * (S / 2);
-      for (int c = -1; c <= MOBI_HALO_C_RIGHT; c++) dep(g_.owner_chroma(base - S + c));
-      for (int r = 0; r < 8; r++) {
-        dep(g_.owner_chroma(base + r * S - 1));
-        dep(g_.owner_chroma(base + r * S + 8));
-      }
+      const long base = off / 2 + v * (S / 2);
+      dep(g_.owner_chroma(base - S - 1));
+      dep(g_.owner_chroma(base - S));
+      dep(g_.owner_chroma(base - S + 8));
+      dep(g_.owner_chroma(base - 1));
+      dep(g_.owner_chroma(base + 8));
+      dep(g_.owner_chroma(base + S - 1));
+      dep(g_.owner_chroma(base + S + 8));
     }
     level[mb] = (uint16_t)(lv + 1);
     if (lv + 1 > maxl) maxl = lv + 1;
