@@ -99,8 +99,8 @@ void MobiStreamParser::begin_mb(int mb, int type) {
   cur_x_ = (mb % g_.mbw) * 16;
   cur_y_ = (mb / g_.mbw) * 16;
   cur_off_ = (long)cur_y_ * g_.stride + cur_x_;
-  leaves_.clear();
-  coefs_.clear();
+  n_leaf_words_ = 0;
+  n_coefs_ = 0;
   memset(recs_, 0, sizeof(recs_));
   cbp6_ = t8mask_ = w3_ = 0;
   mb_type_ = type;
@@ -110,10 +110,10 @@ void MobiStreamParser::end_mb() {
   d.payload_off = (uint32_t)out_->payload.size();
   uint32_t nl = 0;
   int dual = MOBI_DUAL_NONE;
-  d.w2 = (uint32_t)coefs_.size();
+  d.w2 = (uint32_t)n_coefs_;
   d.w3 = w3_;
   if (mb_type_ == MOBI_MB_INTER) {
-    nl = (uint32_t)(leaves_.size() / 2);
+    nl = (uint32_t)(n_leaf_words_ / 2);
     if (nl == 2) { // two halves (leaf word 0: x/2 | y/2<<4 | wi<<8 | hi<<10 | ref<<12)
       const uint32_t a = leaves_[0] & 0xFFF, b = leaves_[2] & 0xFFF;
       if (a == (0u | (1u << 10)) && b == ((4u << 4) | (1u << 10))) dual = MOBI_DUAL_TB;
@@ -139,7 +139,7 @@ void MobiStreamParser::end_mb() {
   } else {
     out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
   }
-  out_->payload.insert(out_->payload.end(), coefs_.begin(), coefs_.end());
+  out_->payload.insert(out_->payload.end(), coefs_, coefs_ + n_coefs_);
   d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14) | ((quant_ & 63) << 20) | ((uint32_t)dual << 26);
   out_->desc.push_back(d);
 }
@@ -177,12 +177,12 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
   check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
   check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
   if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) fail(MOBI_E_UNSUPPORTED);
-  leaves_.push_back(mobi_leaf_w0(x, y, wi, hi, ref));
-  leaves_.push_back(mobi_leaf_w1(dx, dy));
+  leaves_[n_leaf_words_++] = mobi_leaf_w0(x, y, wi, hi, ref); // at most 64 leaves: the tree bottoms out at 2x2
+  leaves_[n_leaf_words_++] = mobi_leaf_w1(dx, dy);
 }
 // the 64-entry MV cell map of a macroblock with a deeper partition tree, from its leaves (only those need it)
 void MobiStreamParser::build_cells() {
-  for (size_t i = 0; i + 1 < leaves_.size(); i += 2) {
+  for (int i = 0; i + 1 < n_leaf_words_; i += 2) {
     const uint32_t w0 = leaves_[i], mv = leaves_[i + 1];
     const int x = (int)(w0 & 15) * 2, y = (int)((w0 >> 4) & 15) * 2, w = 16 >> ((w0 >> 8) & 3), h = 16 >> ((w0 >> 10) & 3);
     const uint32_t cell = mobi_cell((int16_t)(mv & 0xFFFF), (int16_t)(mv >> 16), (int)((w0 >> 12) & 7));
@@ -229,8 +229,7 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
   const uint16_t *A = vlc_table_ == 1 ? mobi_vx2table1_a : mobi_vx2table0_a;
   const uint8_t *B = vlc_table_ == 1 ? mobi_vx2table1_b : mobi_vx2table0_b;
   int p = 0;
-  struct { uint8_t idx; int16_t level; } tmp[64];
-  int n = 0;
+  const int tile = is8 ? area * 64 : area * 64 + sub * 16;
   for (;;) {
     int skip, value;
     uint32_t e;
@@ -292,25 +291,11 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
     p += skip;
     if (p >= N) fail(MOBI_E_UNSUPPORTED); // the reference would walk past the dequant words (Internal[] aliasing)
     uint32_t word = dq[p++];
-    if (value != 0) {
-      tmp[n].idx = (uint8_t)(word & 0xFF);
-      tmp[n].level = (int16_t)value;
-      n++;
-    }
+    // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the reduced transforms only
+    // look at part of the block, but for q >= 12 nothing they skip can be nonzero: scan positions 0, 0..2, 0..9 map inside the
+    // respective regions (tests/test_oracle_identities.py pins that property of the zigzag tables), so every level is kept.
+    if (value != 0) coefs_[n_coefs_++] = (uint32_t)(tile + (int)(word & 0xFF)) | ((uint32_t)(int)(int16_t)value << 16); // = mobi_coef()
     if (e & 1) break;
-  }
-  // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the
-  // reduced transforms only look at part of the block, so drop what they would not see.  (For q >= 12
-  // nothing is ever dropped: scan positions 0, 0..2, 0..9 map inside the respective regions.)
-  int vis = 3;
-  if (is8) vis = (p <= 1) ? 0 : (p <= 3) ? 1 : (p <= 10) ? 2 : 3;
-  else vis = (p <= 1) ? 0 : 3;
-  for (int i = 0; i < n; i++) {
-    int idx = tmp[i].idx;
-    bool keep = vis == 3 || (vis == 0 && idx == 0) || (vis == 1 && (idx == 0 || idx == 1 || idx == 8)) ||
-                (vis == 2 && (idx & 7) < 4 && (idx >> 3) < 4);
-    if (!keep) continue;
-    coefs_.push_back(mobi_coef(area, is8 ? idx : sub * 16 + idx, tmp[i].level));
   }
 }
 void MobiStreamParser::resid_area(int area) { // loc_11652C, MD.cs:2909-2929

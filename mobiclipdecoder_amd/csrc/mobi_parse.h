@@ -111,7 +111,8 @@ class MobiStreamParser {
   ParsedFrame *out_ = nullptr;
   int cur_mb_ = 0, cur_x_ = 0, cur_y_ = 0;
   long cur_off_ = 0;
-  std::vector<uint32_t> leaves_, coefs_;
+  uint32_t leaves_[128], coefs_[384]; // MC leaves (two words each) and residual levels (6 areas x 64) of the macroblock being built
+  int n_leaf_words_ = 0, n_coefs_ = 0;
   uint32_t recs_[MOBI_INTRA_RECORDS];
   uint32_t cells_[MOBI_MV_CELLS];
   uint32_t cbp6_ = 0, t8mask_ = 0, w3_ = 0;
