@@ -229,6 +229,7 @@ struct mobi_batch {
   size_t last_pay_cap = 0;
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
+  float last_hostparse_ms = 0;                 // ... / of its host parse part (host parse mode)
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
   DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
   MobiDevState *d_pstate = nullptr;
@@ -372,6 +373,7 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
 // items_out: n_clips*n_mbs words, res_out: n_clips*8 words, payload_out: n_clips*pay_cap words (any may be null); returns pay_cap
 float mobi_debug_parse_ms(const mobi_batch *b) { return b ? b->last_parse_ms : 0.f; }
 float mobi_debug_stage_ms(const mobi_batch *b) { return b ? b->last_stage_ms : 0.f; }
+float mobi_debug_hostparse_ms(const mobi_batch *b) { return b ? b->last_hostparse_ms : 0.f; }
 long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *items_out, uint32_t *res_out, uint32_t *payload_out, size_t payload_words) {
   if (!b || !b->d_pres) return MOBI_E_ARG;
   const size_t n = (size_t)b->n, n_mbs = (size_t)b->g.mbw * b->g.mbh;
@@ -607,7 +609,9 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // 1. host: serial VLC parse of one frame per clip -> command lists
   std::vector<const ParsedFrame *> ok(n, nullptr);
   bool any_version_error = false;
+  const auto t_parse0 = std::chrono::steady_clock::now();
   b->pool->run(n, [&](int i) { rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]); });
+  b->last_hostparse_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
   for (int i = 0; i < n; i++) {
     if (rc[i] == MOBI_OK) ok[i] = &b->cur[i];
     if (rc[i] == MOBI_E_VERSION) any_version_error = true;
@@ -628,6 +632,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (int e = b->d_cmd.reserve(desc_bytes + pay_bytes)) return e;
   if (int e = b->d_items.reserve(item_bytes)) return e;
   uint8_t *hs = b->h_stage.p;
+  const auto t_stage0 = std::chrono::steady_clock::now();
   { // every clip writes its own descriptors and payload (190 MB per step at 2048 clips of 640x480: too much for one thread)
     std::vector<size_t> base(n + 1, 0);
     for (int i = 0; i < n; i++) base[i + 1] = base[i] + (ok[i] ? ok[i]->payload.size() : 0);
@@ -639,6 +644,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
     });
   }
   if (!plan.items.empty()) memcpy(hs + desc_bytes + pay_bytes, plan.items.data(), plan.items.size() * 4);
+  b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
   HIP_TRY(hipMemcpyAsync(b->d_cmd.p, hs, desc_bytes + pay_bytes, hipMemcpyHostToDevice, b->stream));
   if (!plan.items.empty())
     HIP_TRY(hipMemcpyAsync(b->d_items.p, hs + desc_bytes + pay_bytes, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
