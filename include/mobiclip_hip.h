@@ -89,7 +89,9 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * HBM; same rc / Offset / planes.  The parse of one clip is serial and a GPU lane is slow at it; the GPU wins by running
  * thousands of clips at once, from about 900 resident clips upward.  Default: by batch size (device parse from 1024 clips,
  * unless the first call hands over far more than a frame per clip -- whole files as Data, MOC5 style -- which the device path
- * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1.  Can only be changed before the first frame: the decoder state lives on one side. */
+ * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1/2.  2 = hybrid: the GPU parses most clips while the
+ * host pool parses a fixed share of them (a fifth, at most 1024; MOBI_HYBRID_HOST_CLIPS) at the same time; one set of
+ * reconstruction launches serves both.  Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
 /* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
 float mobi_batch_last_decode_ms(const mobi_batch *b);

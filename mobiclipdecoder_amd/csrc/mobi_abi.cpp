@@ -226,6 +226,10 @@ struct mobi_batch {
   // mobi_batch_set_parse_mode); the per-clip decoder state then lives in d_pstate and the host parsers stay untouched
   int parse_mode = 0; // explicit (env / mobi_batch_set_parse_mode), or by batch size and settled at the first frame (parse_auto)
   bool parse_auto = false;
+  int hybrid_host = 0;           // parse mode 2: the last hybrid_host clips are parsed by the host pool while the GPU parses the others
+  hipStream_t stream2 = nullptr; // their command lists go up on this stream, beside the parse kernel
+  hipEvent_t ev_up = nullptr;
+  PinnedBuf h_stage2;
   size_t last_pay_cap = 0;
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
@@ -338,6 +342,8 @@ struct mobi_batch {
     if (stream) (void)hipStreamSynchronize(stream);
     drain_events();
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (ev_up) (void)hipEventDestroy(ev_up);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -446,7 +452,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = atoi(io) != 0;
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     b->parse_auto = true;
-    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = atoi(dp) != 0; b->parse_auto = false; }
+    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = std::max(0, std::min(2, atoi(dp))); b->parse_auto = false; }
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
     b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
@@ -470,6 +476,7 @@ void mobi_batch_destroy(mobi_batch *b) {
 // (one wave per clip) that leaves descriptors, payload and intra lists in HBM, then the usual reconstruction launches.
 static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
+  const int nd = n - b->hybrid_host, nh = b->hybrid_host; // clips [0, nd): parsed on the GPU; [nd, n): by the host pool meanwhile
   if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) {
     for (int i = 0; i < n; i++) rc[i] = MOBI_E_VERSION;
     return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
@@ -491,8 +498,8 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   // 1. stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded]
   const auto t_stage0 = std::chrono::steady_clock::now();
   constexpr size_t kBitPad = 32; // the reader runs two 8-byte registers ahead
-  std::vector<uint64_t> boff(n);
-  std::vector<uint32_t> blen(n);
+  std::vector<uint64_t> boff(nd);
+  std::vector<uint32_t> blen(nd);
   size_t pos = 0, max_len = 0;
   const size_t frame_bound = (size_t)n_mbs * 4096 + 64;
   for (int i = 0; i < n; i++) {
@@ -502,18 +509,19 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     // once per syntax element: <= ~1450 refills per macroblock (127 partition nodes, 384 levels of up to three reads each), so
     // bytes beyond 4 KB per macroblock cannot influence the parse of this frame
     l = std::min(l, frame_bound);
+    max_len = std::max(max_len, l);
+    if (i >= nd) continue; // parsed on the host: only its share of the payload bound counts
     boff[i] = pos;
     blen[i] = (uint32_t)l;
     pos += align_up(l + kBitPad, 8);
-    max_len = std::max(max_len, l);
   }
-  const size_t hdr_bytes = align_up((size_t)n * 12, 16);
+  const size_t hdr_bytes = align_up((size_t)nd * 12, 16);
   if (int e = b->h_stage.reserve(hdr_bytes + pos)) return e;
   if (int e = b->d_bits.reserve(hdr_bytes + pos)) return e;
   uint8_t *hs = b->h_stage.p;
-  memcpy(hs, boff.data(), (size_t)n * 8);
-  memcpy(hs + (size_t)n * 8, blen.data(), (size_t)n * 4);
-  b->pool->run(n, [&](int i) {
+  memcpy(hs, boff.data(), (size_t)nd * 8);
+  memcpy(hs + (size_t)nd * 8, blen.data(), (size_t)nd * 4);
+  b->pool->run(nd, [&](int i) {
     uint8_t *dst = hs + hdr_bytes + boff[i];
     if (blen[i]) memcpy(dst, data[i] + offsets[i], blen[i]);
     memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
@@ -530,7 +538,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   memset(&pa, 0, sizeof(pa));
   pa.bits = b->d_bits.p + hdr_bytes;
   pa.bit_off = (const uint64_t *)b->d_bits.p;
-  pa.bit_len = (const uint32_t *)(b->d_bits.p + (size_t)n * 8);
+  pa.bit_len = (const uint32_t *)(b->d_bits.p + (size_t)nd * 8);
   pa.tables = b->d_ptables;
   pa.state = b->d_pstate;
   pa.desc = (MbDesc *)b->d_pdesc.p;
@@ -539,7 +547,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   pa.res = b->d_pres;
   pa.pay_cap = (uint32_t)cap_words;
   b->last_pay_cap = cap_words;
-  pa.n_clips = n; pa.version = b->version;
+  pa.n_clips = nd; pa.version = b->version;
   pa.width = b->g.width; pa.height = b->g.height; pa.stride = b->g.stride; pa.lg = b->g.lg; pa.mbw = b->g.mbw; pa.mbh = b->g.mbh;
   if (b->ktiming && !b->ev_p0) { (void)hipEventCreate(&b->ev_p0); (void)hipEventCreate(&b->ev_p1); }
   const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
@@ -547,16 +555,65 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   if (mobi_launch_parse(&pa, b->stream) != 0) return MOBI_E_DEVICE;
   if (ptime) (void)hipEventRecord(b->ev_p1, b->stream);
   MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
-  HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * nd, hipMemcpyDeviceToHost, b->stream));
+  if (nh > 0) { // hybrid: while the GPU parses its clips, the host pool parses the others and sends their command lists up beside it
+    if (!b->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+    }
+    b->pool->run(nh, [&](int j) { const int i = nd + j; rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]); });
+    std::vector<size_t> pbase(nh + 1, 0);
+    for (int j = 0; j < nh; j++) pbase[j + 1] = pbase[j] + (rc[nd + j] == MOBI_OK ? b->cur[nd + j].payload.size() : 0);
+    if (pbase[nh] > (size_t)nh * cap_words) return MOBI_E_DEVICE; // cannot happen: cap_words bounds any clip's payload
+    const size_t desc_b = (size_t)nh * n_mbs * sizeof(MbDesc), pay_b = align_up(pbase[nh] * 4 + 16, 16), item_b = (size_t)nh * n_mbs * 4, res_b = (size_t)nh * sizeof(MobiDevResult);
+    if (int e = b->h_stage2.reserve(desc_b + pay_b + item_b + res_b)) return e;
+    uint8_t *h2 = b->h_stage2.p;
+    const int groups = std::min(nh, 32);
+    b->pool->run(groups, [&](int g) {
+      for (int j = (int)((long)nh * g / groups), e = (int)((long)nh * (g + 1) / groups); j < e; j++) {
+        const int i = nd + j;
+        const ParsedFrame *f = rc[i] == MOBI_OK ? &b->cur[i] : nullptr;
+        MbDesc *dd = (MbDesc *)h2 + (size_t)j * n_mbs;
+        uint32_t *it = (uint32_t *)(h2 + desc_b + pay_b) + (size_t)j * n_mbs;
+        MobiDevResult *rr = (MobiDevResult *)(h2 + desc_b + pay_b + item_b) + j;
+        memset(rr, 0, sizeof(*rr));
+        rr->rc = rc[i];
+        if (!f) {
+          for (int k = 0; k < n_mbs; k++) dd[k] = MbDesc{0, MOBI_MB_INTRA, 0, 0, 0, 0, 0, 0};
+          continue;
+        }
+        const uint32_t base = (uint32_t)((size_t)nd * cap_words + pbase[j]); // where this clip's payload lands in the arena
+        for (int k = 0; k < n_mbs; k++) {
+          dd[k] = f->desc[k];
+          dd[k].payload_off += base;
+        }
+        if (!f->payload.empty()) memcpy((uint32_t *)(h2 + desc_b) + pbase[j], f->payload.data(), f->payload.size() * 4);
+        if (!f->intra_mbs.empty()) memcpy(it, f->intra_mbs.data(), f->intra_mbs.size() * 4); // level order: a valid order for the waits
+        rr->n_intra = f->hdr.n_intra;
+      }
+    });
+    HIP_TRY(hipMemcpyAsync(b->d_pdesc.p + (size_t)nd * n_mbs * sizeof(MbDesc), h2, desc_b, hipMemcpyHostToDevice, b->stream2));
+    HIP_TRY(hipMemcpyAsync(b->d_ppay.p + (size_t)nd * cap_words * 4, h2 + desc_b, pbase[nh] * 4 + 4, hipMemcpyHostToDevice, b->stream2));
+    HIP_TRY(hipMemcpyAsync(b->d_pitems.p + (size_t)nd * n_mbs * 4, h2 + desc_b + pay_b, item_b, hipMemcpyHostToDevice, b->stream2));
+    HIP_TRY(hipMemcpyAsync(b->d_pres + nd, h2 + desc_b + pay_b + item_b, res_b, hipMemcpyHostToDevice, b->stream2));
+    HIP_TRY(hipEventRecord(b->ev_up, b->stream2));
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_up, 0));
+    HIP_TRY(hipStreamSynchronize(b->stream2));
+  }
   HIP_TRY(hipStreamSynchronize(b->stream)); // the launch sizes below depend on what the parse found
   if (ptime) { float ms = 0; if (hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
   uint32_t K = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < nd; i++) {
     rc[i] = res[i].rc;
     offsets[i] += res[i].consumed;
     b->dev_quant[i] = res[i].quant;
     b->dev_yuvfmt[i] = res[i].yuvfmt;
     if (rc[i] == MOBI_OK) K = std::max(K, res[i].n_intra);
+  }
+  for (int i = nd; i < n; i++) {
+    b->dev_quant[i] = b->parsers[i]->quantizer();
+    b->dev_yuvfmt[i] = b->parsers[i]->yuv_format();
+    if (rc[i] == MOBI_OK) K = std::max(K, b->cur[i].hdr.n_intra);
   }
   // 3. reconstruction straight from what the parse left in HBM
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
@@ -582,7 +639,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
 
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
   if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
-  b->parse_mode = device_parse != 0;
+  b->parse_mode = device_parse == 2 ? 2 : device_parse != 0;
   b->parse_auto = false;
   return MOBI_OK;
 }
@@ -604,6 +661,10 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
       if (data[i] && offsets[i] >= 0 && (uint64_t)offsets[i] < len[i] && len[i] - (size_t)offsets[i] > packet_like) { b->parse_mode = 0; break; }
   }
   b->parse_auto = false; // the decoder state lives on one side from the first frame on
+  if (b->parse_mode == 2 && b->frames_started == 0) { // hybrid: a fixed share of the clips stays with the host parsers (their state lives there)
+    b->hybrid_host = std::min(1024, b->n / 5);
+    if (const char *hh = getenv("MOBI_HYBRID_HOST_CLIPS")) b->hybrid_host = std::max(0, std::min(b->n - 1, atoi(hh)));
+  }
   if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;
   // 1. host: serial VLC parse of one frame per clip -> command lists

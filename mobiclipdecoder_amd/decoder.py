@@ -207,7 +207,8 @@ class MobiclipBatch:
 
     def __init__(self, n_clips, Width, Height, Version, device=0, device_parse=None):
         """device_parse: True = decode() parses the bitstreams on the GPU (one wavefront per clip, mobi_dparse.hip),
-        False = on host threads, None = library default (device parse from 1024 clips; env MOBI_DEVICE_PARSE=0/1)."""
+        False = on host threads, "hybrid" = most clips on the GPU and a fixed share (a fifth, at most 1024) on the host pool at the same
+        time, None = library default (device parse from 1024 clips; env MOBI_DEVICE_PARSE=0/1/2)."""
         self._lib = load_library()
         self.n, self.Width, self.Height, self.Version = int(n_clips), int(Width), int(Height), MobiclipVersion(Version)
         self._h = self._lib.mobi_batch_create(self.n, self.Width, self.Height, int(self.Version), device)
@@ -215,7 +216,8 @@ class MobiclipBatch:
             raise MobiclipError(f"mobi_batch_create failed: {error_string(-8)}")
         self.Stride = self._lib.mobi_batch_stride(self._h)
         if device_parse is not None:
-            rc = self._lib.mobi_batch_set_parse_mode(self._h, int(bool(device_parse)))
+            mode = 2 if device_parse == "hybrid" else int(bool(device_parse))
+            rc = self._lib.mobi_batch_set_parse_mode(self._h, mode)
             if rc != 0:
                 raise MobiclipError(error_string(rc))
 

@@ -201,6 +201,38 @@ def test_host_and_device_parse_agree_on_a_larger_batch():
     db.close()
 
 
+def test_hybrid_parse_matches_the_oracle(monkeypatch):
+    """Parse mode 2: the GPU parses most clips while the host pool parses the rest; one set of reconstruction launches for all."""
+    monkeypatch.setenv("MOBI_HYBRID_HOST_CLIPS", "3")
+    n, nfr = 8, 7
+    ps = [default_params("A", BASE_SEED + 600 + i, n_frames=nfr, pm_intra=150, pm_deep=120, iframe_interval=4) for i in range(n)]
+    clips = [generate_clip(p) for p in ps]
+    clips[6] = (clips[6][0][: clips[6][0].size // 2], clips[6][1])  # a host-side clip that runs out of data
+    clips[1] = (clips[1][0][: clips[1][0].size // 2], clips[1][1])  # and a device-side one
+    b = MobiclipBatch(n, 256, 192, MobiclipVersion.ModsDS, device_parse="hybrid")
+    oras = [OracleDecoder(256, 192, MobiclipVersion.ModsDS) for _ in range(n)]
+    seen_err, refused = 0, [False] * n
+    for f in range(nfr):
+        datas = [c[0][min(int(c[1][f]), c[0].size):min(int(c[1][f + 1]), c[0].size)] for c in clips]
+        rcs, offs = b.decode(datas, [0] * n)
+        for i in range(n):
+            oras[i].Data, oras[i].Offset = datas[i], 0
+            o = oras[i].DecodeFrame()
+            refused[i] = refused[i] or rcs[i] == -6  # MOBI_E_UNSUPPORTED: the library refuses what the reference decodes by aliasing
+            if refused[i]:
+                seen_err += 1
+                continue
+            assert rcs[i] == oras[i].last_error and offs[i] == oras[i].Offset, (f, i, rcs[i], oras[i].last_error)
+            assert b.quantizer(i) == oras[i].Quantizer, (f, i)
+            if rcs[i] != 0:
+                seen_err += 1
+                continue
+            y, uv = b.planes(i)
+            assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (f, i)
+    assert seen_err >= 2 and not all(refused)
+    b.close()
+
+
 def test_default_parse_side_follows_batch_size_and_packet_shape():
     """No explicit choice: 1024 clips and more parse on the GPU when Data looks like packets, on the host when Data is a whole
     file (MOC5 style; the device path would have to upload megabytes per clip and frame).  Same planes either way."""

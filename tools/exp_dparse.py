@@ -30,14 +30,14 @@ def run(n_clips, device_parse, n_frames=9, distinct=16):
     b.close()
     p_ms = np.array(t_frames[2:]) * 1e3   # skip the I-frame and the first P-frame (allocations)
     px = n_clips * 640 * 480
-    print(f"clips={n_clips:5d} device_parse={int(device_parse)}  I-frame {t_frames[0]*1e3:8.2f} ms   P-frame median {np.median(p_ms):8.2f} ms  "
+    print(f"clips={n_clips:5d} device_parse={device_parse if isinstance(device_parse, str) else int(device_parse)}  I-frame {t_frames[0]*1e3:8.2f} ms   P-frame median {np.median(p_ms):8.2f} ms  "
           f"min {p_ms.min():8.2f} ms  -> {px / np.median(p_ms) / 1e3:9.1f} Mpix/s end to end"
           + f" | inside the C call: P median {np.median(c_ms[2:]):.2f} ms = {px / np.median(c_ms[2:]) / 1e3:.0f} Mpix/s"
           + (f" | parse kernel: I {k_ms[0]:.2f} ms, P median {np.median(k_ms[2:]):.2f} ms, staging {np.median(s_ms[2:]):.2f} ms" if device_parse else ""), flush=True)
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
-    modes = (True,) if "--device-only" in sys.argv else (False, True)
+    modes = (True,) if "--device-only" in sys.argv else ("hybrid",) if "--hybrid" in sys.argv else (False, True)
     sizes = [int(a) for a in args] or [512, 2048]
     for n in sizes:
         for dp in modes:
