@@ -1159,6 +1159,17 @@ int mobi_oracle_decode(mobi_oracle *d, const uint8_t *data, size_t len, int32_t 
   *offset = d->Offset;
   return rc;
 }
+/* timing aid for bench.py's cpu_baseline: DecodeFrame() over a whole clip in one call (Data = the bytes up to the end of the
+ * frame, Offset = its start, as the parity tests do), optionally followed by the Bitmap conversion of every frame */
+int mobi_oracle_decode_clip(mobi_oracle *d, const uint8_t *data, const uint32_t *frame_off, int n_frames, uint32_t *argb_or_null) {
+  for (int f = 0; f < n_frames; f++) {
+    int32_t off = (int32_t)frame_off[f];
+    const int rc = mobi_oracle_decode(d, data, frame_off[f + 1], &off);
+    if (rc != 0) return rc;
+    if (argb_or_null) mobi_oracle_argb(d, argb_or_null);
+  }
+  return n_frames;
+}
 int mobi_oracle_stride(const mobi_oracle *d) { return d->Stride; }
 uint32_t mobi_oracle_quantizer(const mobi_oracle *d) { return d->Quantizer; }
 uint32_t mobi_oracle_yuvformat(const mobi_oracle *d) { return d->YuvFormat; }

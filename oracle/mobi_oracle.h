@@ -45,6 +45,9 @@ void mobi_oracle_destroy(mobi_oracle *d);
  * exactly as MD.cs:102-108 + :325 leave it. */
 int mobi_oracle_decode(mobi_oracle *d, const uint8_t *data, size_t len, int32_t *offset);
 
+/* DecodeFrame() over a whole clip (frame f = data[frame_off[f] .. frame_off[f+1])), optionally with the Bitmap of every frame:
+ * one call per clip, for timing.  Returns n_frames or the first error. */
+int mobi_oracle_decode_clip(mobi_oracle *d, const uint8_t *data, const uint32_t *frame_off, int n_frames, uint32_t *argb_or_null);
 int mobi_oracle_stride(const mobi_oracle *d);
 uint32_t mobi_oracle_quantizer(const mobi_oracle *d);
 uint32_t mobi_oracle_yuvformat(const mobi_oracle *d);

@@ -33,6 +33,7 @@ def lib():
         L.mobi_oracle_argb.argtypes = [C.c_void_p, C.c_void_p]
         L.mobi_oracle_motion_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mobi_oracle_motion_search.restype = None
+        L.mobi_oracle_decode_clip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mobi_oracle_internal.argtypes = [C.c_void_p]
         L.mobi_oracle_internal.restype = C.POINTER(C.c_uint32)
         L.mobi_oracle_idct8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -80,6 +81,13 @@ class OracleDecoder:
         """Bitmap of ring slot 0 (MD.cs:260-323) as (Height, Width) uint32 0xAARRGGBB; None before the first frame."""
         out = np.empty((self.Height, self.Width), np.uint32)
         return out if self.L.mobi_oracle_argb(self.h, out.ctypes.data) == 0 else None
+
+    def decode_clip(self, data, frame_off, with_bitmap=False):
+        """Every frame of a clip in one C call (timing); returns the number of frames decoded or a negative error."""
+        buf = np.ascontiguousarray(data, dtype=np.uint8)
+        fo = np.ascontiguousarray(frame_off, dtype=np.uint32)
+        argb = np.empty((self.Height, self.Width), np.uint32) if with_bitmap else None
+        return self.L.mobi_oracle_decode_clip(self.h, buf.ctypes.data, fo.ctypes.data, fo.size - 1, argb.ctypes.data if with_bitmap else None)
 
     def motion_search(self, picture):
         """Analyzer.InterPredict2x2 over every 2x2 block (Analyzer.cs:608-693) -> packed (mbh, mbw, 8, 8) uint32."""
