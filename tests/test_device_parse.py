@@ -62,6 +62,13 @@ def test_rich_streams_whole_file(cfg):
     assert _lockstep(ps, whole_file=True) == 0
 
 
+def test_long_gop_640x480_uses_every_reference_slot():
+    """33 frames (1 I + 32 P, the bench's clip shape) of the BASELINE 640x480 configuration with references up to five frames
+    back: every frame of every clip bit-exact against the oracle, parse on the GPU."""
+    ps = [default_params("B", BASE_SEED + 330 + i, n_frames=33, pm_multiref=300, pm_intra=60) for i in range(2)]
+    assert _lockstep(ps) == 0
+
+
 def test_edge_motion_vectors():
     ps = [default_params("A", BASE_SEED + 340 + i, n_frames=6, edge_mode=1, mv_range=40) for i in range(4)]
     assert _lockstep(ps) == 0
