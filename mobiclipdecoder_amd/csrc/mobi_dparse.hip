@@ -371,19 +371,31 @@ struct DP {
     if (hi >= plane_len) fail(MOBI_E_INDEX);
   }
   __device__ __forceinline__ void mc_leaf(int wi, int hi, int x, int y, int ref, int dx, int dy, int mv_slot) {
-    const long long S = stride;
     const int w = 16 >> wi, h = 16 >> hi;
     L->mvc[mv_slot] = dx; // every leaf overwrites the macroblock's exported MV (MD.cs:411-412)
     L->mvc[mv_slot + 1] = dy;
     if (ref > imin(5, frames_started - 1)) { fail(MOBI_E_NULLREF); return; } // Y[ref] == null
-    const long long o = (long long)cur_off + (long long)y * S + x;
-    check_window(o + (long long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * height);
-    const int cdx = dx >> 1, cdy = dy >> 1;
-    const long long cpos = o / 2 + (long long)(cdy >> 1) * S + (cdx >> 1);
-    const int cph = (cdx & 1) | ((cdy & 1) << 1);
-    check_window(cpos, w >> 1, h >> 1, cph, S * height / 2);
-    check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * height / 2);
-    if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) { fail(MOBI_E_UNSUPPORTED); return; }
+    const bool in_range = dx >= -MOBI_MV_LIMIT && dx <= MOBI_MV_LIMIT && dy >= -MOBI_MV_LIMIT && dy <= MOBI_MV_LIMIT;
+    if (in_range) { // every position fits 32 bits: would CopyBlock throw?  (rows are visited top to bottom: first row / last row bound the rest)
+      const int S = stride, o = cur_off + y * S + x, ylen = S * height;
+      const int pos = o + (dy >> 1) * S + (dx >> 1);
+      const int hi_y = pos + (h - 1) * S + w - 1 + (dx & 1) + ((dy & 1) ? S : 0); // phase 0: Array.Copy end is exclusive
+      const int cdx = dx >> 1, cdy = dy >> 1;
+      const int cpos = o / 2 + (cdy >> 1) * S + (cdx >> 1);
+      const int hi_c = cpos + S / 2 + ((h >> 1) - 1) * S + (w >> 1) - 1 + (cdx & 1) + ((cdy & 1) ? S : 0); // the V window ends last
+      if (pos < 0 || hi_y >= ylen || cpos < 0 || hi_c >= ylen / 2) { fail(MOBI_E_INDEX); return; }
+    } else {
+      const long long S = stride;
+      const long long o = (long long)cur_off + (long long)y * S + x;
+      check_window(o + (long long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * height);
+      const int cdx = dx >> 1, cdy = dy >> 1;
+      const long long cpos = o / 2 + (long long)(cdy >> 1) * S + (cdx >> 1);
+      const int cph = (cdx & 1) | ((cdy & 1) << 1);
+      check_window(cpos, w >> 1, h >> 1, cph, S * height / 2);
+      check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * height / 2);
+      fail(MOBI_E_UNSUPPORTED); // (an index error above wins: the first error sticks)
+      return;
+    }
     L->leaves[n_leaf_words] = mobi_leaf_w0(x, y, wi, hi, ref);
     L->leaves[n_leaf_words + 1] = mobi_leaf_w1(dx, dy);
     n_leaf_words += 2;

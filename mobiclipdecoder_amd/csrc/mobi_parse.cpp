@@ -169,14 +169,22 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
   mvc_[mv_slot] = dx; // every leaf overwrites the MB's exported MV (MD.cs:411-412)
   mvc_[mv_slot + 1] = dy;
   if (ref > std::min(5, frames_started_ - 1)) fail(MOBI_E_NULLREF); // Y[ref] == null
-  long off = cur_off_ + (long)y * S + x;
-  check_window(off + (long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * g_.height);
-  int cdx = dx >> 1, cdy = dy >> 1;
-  long cpos = off / 2 + (long)(cdy >> 1) * S + (cdx >> 1);
-  int cph = (cdx & 1) | ((cdy & 1) << 1);
-  check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
-  check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
-  if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) fail(MOBI_E_UNSUPPORTED);
+  const long off = cur_off_ + (long)y * S + x;
+  const int cdx = dx >> 1, cdy = dy >> 1;
+  const long cpos = off / 2 + (long)(cdy >> 1) * S + (cdx >> 1);
+  const int cph = (cdx & 1) | ((cdy & 1) << 1);
+  if (dx >= -MOBI_MV_LIMIT && dx <= MOBI_MV_LIMIT && dy >= -MOBI_MV_LIMIT && dy <= MOBI_MV_LIMIT) {
+    // the three windows at once: the luma one, and of the two chroma ones U starts first and V (S/2 further) ends last
+    const long pos = off + (long)(dy >> 1) * S + (dx >> 1), ylen = S * g_.height;
+    const long hi_y = pos + (long)(h - 1) * S + w - 1 + (dx & 1) + ((dy & 1) ? S : 0); // phase 0: Array.Copy end is exclusive
+    const long hi_c = cpos + S / 2 + (long)((h >> 1) - 1) * S + (w >> 1) - 1 + (cdx & 1) + ((cdy & 1) ? S : 0);
+    if (pos < 0 || hi_y >= ylen || cpos < 0 || hi_c >= ylen / 2) fail(MOBI_E_INDEX);
+  } else {
+    check_window(off + (long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * g_.height);
+    check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
+    check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
+    fail(MOBI_E_UNSUPPORTED);
+  }
   leaves_[n_leaf_words_++] = mobi_leaf_w0(x, y, wi, hi, ref); // at most 64 leaves: the tree bottoms out at 2x2
   leaves_[n_leaf_words_++] = mobi_leaf_w1(dx, dy);
 }
