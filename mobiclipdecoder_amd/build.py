@@ -54,9 +54,12 @@ def build_hip(force=False):
         o = os.path.join(obj, os.path.basename(s) + ".o")
         _run(["g++"] + host_flags + ["-c", s, "-o", o])
         objs.append(o)
+    # the reconstruction kernels are bound by instruction issue: LLVM's ILP-first scheduling is worth 1.5 % on mobi_recon_inter8
+    # (same registers, same occupancy; measured A/B on one box); the other kernels keep the default
+    extra = {"mobi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     for s in srcs[4:]:
         ko = os.path.join(obj, os.path.basename(s) + ".o")
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", ko])
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
         objs.append(ko)
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_HIP])
     return LIB_HIP
