@@ -606,7 +606,7 @@ enum {
 } // namespace
 
 #ifndef MOBI_OCT_CWR
-#define MOBI_OCT_CWR 12 // 96 level words per macroblock in registers: no effect on the default mix, -12 % kernel time on dense streams (848x480 config); 123 VGPRs, still 4 waves per SIMD
+#define MOBI_OCT_CWR 16 // 128 level words per macroblock in registers: no effect on the default mix, -15 % kernel time on dense streams (848x480 config) against 32; 127 VGPRs, still 4 waves per SIMD
 #endif
 enum { CWR = MOBI_OCT_CWR };
 __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
