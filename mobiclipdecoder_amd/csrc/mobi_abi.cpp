@@ -219,7 +219,7 @@ struct mobi_batch {
   bool argb_all_valid = false;          // d_argb holds every clip's Bitmap of the current frame
   uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
   uint32_t step_tag = 0;                // bumped once per frame step, never 0
-  int inter_oct = 1;                    // inter kernel: eight macroblocks per wave (env MOBI_INTER_OCT=0: four)
+  int inter_oct = 1;                    // inter kernel: eight macroblocks per wave (env MOBI_INTER_OCT=0: four per wave, 2: r01's octet kernel)
   int step_mode = 1;                    // 1: inter launch + ONE intra launch for all dependency levels (default, fastest measured);
                                         // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
   // device-side parse (mobi_dparse.hip): parse_mode 1 = mobi_batch_decode parses on the GPU (env MOBI_DEVICE_PARSE=1 or
@@ -449,7 +449,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
-    if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = atoi(io) != 0;
+    if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = std::max(0, std::min(2, atoi(io)));
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     b->parse_auto = true;
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = std::max(0, std::min(2, atoi(dp))); b->parse_auto = false; }

@@ -609,7 +609,7 @@ enum {
 #define MOBI_OCT_CWR 16 // 128 level words per macroblock in registers: no effect on the default mix, -15 % kernel time on dense streams (848x480 config) against 32; 127 VGPRs, still 4 waves per SIMD
 #endif
 enum { CWR = MOBI_OCT_CWR };
-__device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
+__device__ __forceinline__ void recon_inter_oct_r1(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
   uint32_t rem, ox;
   const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); // qpr / qpc: OCTETS per row / per clip for this kernel
   const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);
@@ -904,12 +904,405 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     }
   }
 }
-extern "C" __global__ __launch_bounds__(64) void mobi_recon_inter8(MobiReconArgs A) {
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_inter8_r1(MobiReconArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[O_BYTES];
   const uint32_t oi = (blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3);
   if (oi >= A.qpc * (uint32_t)A.n_clips) return;
-  recon_inter_oct(A, lds, oi, (int)threadIdx.x);
+  recon_inter_oct_r1(A, lds, oi, (int)threadIdx.x);
 }
+
+// =====================================================================================================
+// mobi_recon_inter8 (r02): one wavefront per octet, second generation
+// =====================================================================================================
+// What r01's counters said about the kernel above (profiles/r01_pmc_summary.txt): the texture addresser is busy 80 % of
+// the launch (44 vector-memory instructions per wave, 24 of them the 8-byte register fetches of the two-half macroblocks),
+// every wave waits for two memory round trips in series (descriptor, then windows), and the integer VALU is not one
+// machine: two-operand adds / shifts / logic ops issue in ~2.7 cycles per wave, everything with three operands, byte
+// selects, compares, SDWA and 16-bit packed forms in ~4.3 (tools/ubench/oprate.hip).  Hence:
+//   * ONE fetch path for every macroblock with whole leaves (16x16, two 16x8, two 8x16): the DMA rounds take a per-lane
+//     source address, so the rows of a top/bottom pair and the 16-byte halves of a left/right pair simply come from the
+//     other leaf's position.  Windows start at a 4-byte boundary (not 16): 20 bytes of a row always fit the two chunks,
+//     9 + 3 chroma bytes fit ONE chunk, and the dword a lane reads no longer depends on the motion vector.
+//     19 vector-memory instructions per wave instead of 44.
+//   * a lane owns 8 consecutive luma rows x 4 pixels (4 chroma rows x 4): it lies inside one leaf whatever the split, the
+//     row below of one row is the row of the next (masked bytes and the horizontal average are computed once per row),
+//     and the extra row under a lane's rows (9th / 5th) comes straight into its registers.
+//   * CopyBlock (MD.cs:424-452) by v_perm_b32 (byte window out of two dwords) and v_lerp_u8: (a>>1)+(b>>1) per byte is
+//     the byte average of a & 0xFE and b & 0xFE; phase 0 uses the same instructions with mask 0xFF and b = a.
+//   * macroblocks with deeper trees fetch their MV cells beside the DMA rounds and their pixels under the MC of the others.
+//   * coefficient tiles at a pitch of 72 words (the transposing stores of the 8 lanes of 4 areas hit 32 different banks),
+//     8x8 areas sorted in front of 4x4 ones so that a half round usually runs one kind of butterfly.
+namespace {
+enum {
+  P_L = 0,        // luma windows: dword w (0..7) of row y (0..15) of macroblock g at y*256 + (w>>2)*128 + g*16 + (w&3)*4
+  P_C = 4096,     // chroma windows, chunk 0: plane pl, row r at pl*1024 + r*128 + g*16
+  P_C1 = 6144,    //   chunk 1: the right half of a LEFT/RIGHT pair (other macroblocks leave it unused)
+  P_BYTES = 8192,
+  // after motion compensation:
+  P_OUT_Y = 0,    // 16 rows x 128 B
+  P_OUT_C = 2048, // 2 planes x 8 rows x 64 B
+  P_COEF = 3072,  // 16 tiles of P_TILE words
+  P_TILE = 72,
+  P_TAB = 7680,   // entry -> area*8 + g (<= 48 bytes)
+  P_SC = 7744     // dequant scales (320 B): on top of the last V rows of chunk 1, once the chroma has been interpolated
+};
+// N output rows of 4 pixels from N + 1 window rows (x0[i], x1[i] = the two aligned dwords holding row i's 5 bytes)
+template <int N>
+__device__ __forceinline__ void mc_rows(const uint32_t (&x0)[N + 1], const uint32_t (&x1)[N + 1], uint32_t sh, int phase, uint32_t *out) {
+  const uint32_t selA = 0x03020100u + sh * 0x01010101u;
+  const bool ph0 = phase == 0, ph2 = phase == 2, ph3 = phase == 3;
+  const uint32_t selB = ph0 ? selA : selA + 0x01010101u;
+  const uint32_t Em = ph0 ? 0xFFFFFFFFu : 0xFEFEFEFEu, m2 = ph2 ? 0xFFFFFFFFu : 0u;
+  uint32_t ae[N + 1], be[N + 1], s[N + 1];
+#pragma unroll
+  for (int i = 0; i <= N; i++) {
+    ae[i] = __builtin_amdgcn_perm(x1[i], x0[i], selA) & Em;
+    be[i] = __builtin_amdgcn_perm(x1[i], x0[i], selB) & Em;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) s[i] = __builtin_amdgcn_lerp(ae[i], (ae[i + 1] & m2) | (be[i] & ~m2), 0u); // v_bfi_b32 (a select between two
+                                                                                   // array elements would become a select between their addresses)
+  s[N] = __builtin_amdgcn_lerp(ae[N], be[N], 0u); // the horizontal average of the row below: phase 3 only
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const uint32_t p3 = __builtin_amdgcn_lerp(s[i] & 0xFEFEFEFEu, s[i + 1] & 0xFEFEFEFEu, 0u);
+    out[i] = ph3 ? p3 : s[i];
+  }
+}
+} // namespace
+
+__device__ __forceinline__ unsigned long long prof_stamp() { // shader clock, pinned: nothing is scheduled across it
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+  const unsigned long long t = __builtin_readcyclecounter();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+template <int PROF, int CWR>
+__device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
+  unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (PROF) pt[0] = prof_stamp();
+  uint32_t rem, ox;
+  const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); // qpr / qpc: OCTETS per row / per clip for this kernel
+  const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);
+  const uint32_t mbx0 = ox * 8, mbw = (uint32_t)A.mbw;
+  const int nmb = (int)(mbw - mbx0 < 8 ? mbw - mbx0 : 8);
+  const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S);
+  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height, slot_w = A.slot_bytes >> 2, ysz_w = ysz >> 2;
+  uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
+  const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16);
+  const int g = lane & 7, j = lane >> 3; // adjacent lanes = adjacent macroblocks: chunk j of the 8 macroblocks lies side by side in LDS
+  unsigned long long pa = 0, pb = 0;
+  if (PROF) { asm volatile("" : : "s"(off0), "s"(clip)); pa = prof_stamp(); }
+
+  // ---- stage A: descriptor, then every global read of the octet ----
+  const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last octet
+  const uint4 d = dp[0], d2 = dp[1];
+  if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pb = prof_stamp(); }
+  const bool valid = g < nmb && (d.y & 1) == MOBI_MB_INTER;
+  const int nl = (d.y >> 1) & 0x7F, kind2 = (d.y >> 26) & 3;
+  const bool win = valid && (nl == 1 || kind2 != 0);         // whole leaves: fetched through the LDS windows
+  const bool multi = valid && nl > 1 && kind2 == 0;          // deeper tree: MV cell map
+  const bool tb = valid && kind2 == MOBI_DUAL_TB, lr = valid && kind2 == MOBI_DUAL_LR;
+  const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
+  const unsigned long long mb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((cbp6 >> j) & 1));      // bit area*8 + g
+  const unsigned long long tb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((d.y >> (14 + j)) & 1));
+  const uint32_t m_lo = (uint32_t)mb64, m_hi = (uint32_t)(mb64 >> 32), t_lo = (uint32_t)tb64, t_hi = (uint32_t)(tb64 >> 32);
+  const uint32_t inter_mask = (uint32_t)__builtin_amdgcn_ballot_w64(valid) & 0xFFu, multi_mask = (uint32_t)__builtin_amdgcn_ballot_w64(multi) & 0xFFu;
+  if (inter_mask == 0) return; // nothing but intra macroblocks here
+  const bool any_lr = __builtin_amdgcn_ballot_w64(lr) != 0;
+  auto slot_off = [&](uint32_t ref) {
+    int sl = A.ring_base - (int)ref;
+    sl = sl < 0 ? sl + 6 : sl;
+    return __umul24((uint32_t)sl, A.slot_bytes); // slot_bytes < 2^24: checked by mobi_launch_inter
+  };
+  const uint32_t refA = slot_off((d.z >> 10) & 7), refB = slot_off((d.z >> 13) & 7);
+  const int posA = (int)d.w, cposA = (int)d2.x, posB = (int)d2.y, cposB = (int)d2.z;
+  {
+    // luma rounds: lane (g, j) brings chunk (row 4t + (j >> 1), half j & 1).  A row's two chunks start at the leaf's position
+    // rounded down to 4 bytes; the right half of a LEFT/RIGHT pair is the first chunk of leaf B's columns 8..15
+    const int h = j & 1, r4 = win ? j >> 1 : 0;
+    const bool rB = lr && h;
+    const int pT = win ? (rB ? posB + 8 : posA) : 0, xT = (win && !lr) ? h * 16 : 0;
+    const uint32_t fT = win ? (rB ? refB : refA) : 0u;
+    const int pU = tb ? posB : pT;
+    const uint32_t fU = tb ? refB : fT;
+    const uint8_t *sT = clip_base + fT + (uint32_t)(((pT + (r4 << lgS)) & ~3) + xT);
+    const uint8_t *sU = clip_base + fU + (uint32_t)(((pU + ((8 + r4) << lgS)) & ~3) + xT);
+    const int s4 = win ? 4 << lgS : 0;
+    MOBI_DMA16(sT, L + P_L, 0);
+    MOBI_DMA16(sT + s4, L + P_L + 1024, 0);
+    MOBI_DMA16(sU, L + P_L + 2048, 0);
+    MOBI_DMA16(sU + s4, L + P_L + 3072, 0);
+    // chroma rounds: round = plane, lane j = row; one chunk per row
+    const bool cB = tb && j >= 4;
+    const int cp = win ? (cB ? cposB : cposA) : 0;
+    const uint32_t cf = win ? (cB ? refB : refA) + ysz : 0u;
+    const uint8_t *sC = clip_base + cf + (uint32_t)((cp + ((win ? j : 0) << lgS)) & ~3);
+    MOBI_DMA16(sC, L + P_C, 0);
+    MOBI_DMA16(sC + (win ? S >> 1 : 0), L + P_C + 1024, 0);
+    if (any_lr) {
+      if (lr) {
+        const uint8_t *sD = clip_base + refB + ysz + (uint32_t)((cposB + 4 + (j << lgS)) & ~3);
+        MOBI_DMA16(sD, L + P_C1, 0);
+        MOBI_DMA16(sD + (S >> 1), L + P_C1 + 1024, 0);
+      }
+    }
+  }
+  // this lane's leaf for the luma rows it interpolates: lane (g, rr = j >> 2, q = j & 3) = rows 8rr..8rr+7, pixels 4q..4q+3
+  const int rr = j >> 2, q = j & 3;
+  const bool yB = (tb && rr) || (lr && q >= 2);
+  const int ypos = yB ? posB : posA, yph = (d.z >> (yB ? 20 : 16)) & 3;
+  // ... and for its chroma samples: lane (g, pl = j >> 2, ch = (j >> 1) & 1, qc = j & 1) = plane pl, rows 4ch..4ch+3, samples 4qc..4qc+3
+  const int pl = j >> 2, ch = (j >> 1) & 1, qc = j & 1;
+  const bool cBl = (tb && ch) || (lr && qc);
+  const int cpos = cBl ? cposB : cposA, cph = (d.z >> (cBl ? 22 : 18)) & 3;
+  // the row under the lane's rows (luma row 8rr + 8, chroma row 4ch + 4): straight into registers
+  uint2 hy, hc;
+  {
+    // (only a vertical half-pel reads it: the other lanes all point at one line instead -- the kernel is bound by the number of
+    // 64-byte requests a CU's L1 can send to the L2, ~0.15 per clock, and a row costs at least one)
+    const uint32_t oy = (win && (yph & 2)) ? (yB ? refB : refA) + (uint32_t)((ypos + ((8 * rr + 8) << lgS) + 4 * q) & ~3) : 0u;
+    const uint32_t oc = (win && (cph & 2)) ? (cBl ? refB : refA) + ysz + (uint32_t)((cpos + pl * (S >> 1) + ((4 * ch + 4) << lgS) + 4 * qc) & ~3) : 0u;
+    hy = *(const uint2_a4 *)(clip_base + oy);
+    hc = *(const uint2_a4 *)(clip_base + oc);
+  }
+  const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
+  const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
+  uint32_t cwr[CWR] = {}; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
+  if ((uint32_t)j < ncoef) cwr[0] = cw[j];
+  if (__builtin_amdgcn_ballot_w64(ncoef > 8) != 0) {
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+    if (CWR > 4 && __builtin_amdgcn_ballot_w64(ncoef > 32) != 0) {
+#pragma unroll
+      for (int k = 4; k < CWR; k++)
+        if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+    }
+  }
+  // deeper trees: the first such macroblock's MV cells travel with everything else (the whole wave works for it later:
+  // lane = (row lane >> 2, pixels 4 * (lane & 3)) for luma, lanes 0..31 = (plane, row, 4 samples) for chroma)
+  const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
+  const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
+  uint2 yc0 = uint2{0, 0};
+  uint4 c4v0 = uint4{0, 0, 0, 0};
+  if (multi_mask) {
+    const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, __builtin_ctz(multi_mask));
+    yc0 = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
+    c4v0 = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+  }
+  if (PROF) pt[1] = prof_stamp();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wave_sync();
+  if (PROF) pt[2] = prof_stamp();
+
+  // deeper trees: issue the first one's pixel fetches now, consume them after the others' motion compensation
+  const uint32_t *clip32 = (const uint32_t *)clip_base;
+  auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return __umul24((uint32_t)(s2 < 0 ? s2 + 6 : s2), slot_w); };
+  struct Deep { Win wa, wb, wq[4]; uint2 yc; uint32_t cell[4]; bool ysplit, csplit; };
+  auto deep_fetch = [&](Deep &D, int gm, uint2 yc, uint4 c4v) {
+    D.yc = yc;
+    D.cell[0] = c4v.x; D.cell[1] = c4v.y; D.cell[2] = c4v.z; D.cell[3] = c4v.w;
+    const int offm = off0 + gm * 16;
+    const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
+    // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits they are the same cell
+    D.ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
+    D.csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (D.cell[0] != D.cell[1] || D.cell[0] != D.cell[2] || D.cell[0] != D.cell[3])) != 0;
+    const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
+    D.wa = fetch_win(clip32 + slot_of(yc.x), ybase + ((dya >> 1) << lgS) + (dxa >> 1), S);
+    if (D.ysplit) D.wb = fetch_win(clip32 + slot_of(yc.y), ybase + ((dyb >> 1) << lgS) + (dxb >> 1), S);
+    {
+      const int qx = mobi_cell_dx(D.cell[0]) >> 1, qy = mobi_cell_dy(D.cell[0]) >> 1;
+      D.wq[0] = fetch_win(clip32 + slot_of(D.cell[0]) + ysz_w, cbase + ((qy >> 1) << lgS) + (qx >> 1), S);
+    }
+    if (D.csplit) {
+#pragma unroll
+      for (int k = 1; k < 4; k++) {
+        const int qx = mobi_cell_dx(D.cell[k]) >> 1, qy = mobi_cell_dy(D.cell[k]) >> 1;
+        D.wq[k] = fetch_win(clip32 + slot_of(D.cell[k]) + ysz_w, cbase + ((qy >> 1) << lgS) + (qx >> 1), S);
+      }
+    }
+  };
+  auto deep_finish = [&](int gm, const Deep &D) {
+    const int dxa = mobi_cell_dx(D.yc.x), dya = mobi_cell_dy(D.yc.x), dxb = mobi_cell_dx(D.yc.y), dyb = mobi_cell_dy(D.yc.y);
+    const uint32_t va = mc4_select(D.wa, (dxa & 1) | ((dya & 1) << 1));
+    const uint32_t vb = D.ysplit ? mc4_select(D.wb, (dxb & 1) | ((dyb & 1) << 1)) : va;
+    auto cph_of = [&](uint32_t c) { const int qx = mobi_cell_dx(c) >> 1, qy = mobi_cell_dy(c) >> 1; return (qx & 1) | ((qy & 1) << 1); };
+    uint32_t cpred = mc4_select(D.wq[0], cph_of(D.cell[0]));
+    if (D.csplit) {
+      cpred &= 0xFFu;
+#pragma unroll
+      for (int k = 1; k < 4; k++) cpred |= mc4_select(D.wq[k], cph_of(D.cell[k])) & (0xFFu << (8 * k));
+    }
+    *(uint32_t *)(L + P_OUT_Y + yrow * 128 + gm * 16 + yc4) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
+    if (lane < 32) *(uint32_t *)(L + P_OUT_C + cv * 512 + crow * 64 + gm * 8 + cc4) = cpred;
+  };
+  Deep D0;
+  if (multi_mask) deep_fetch(D0, __builtin_ctz(multi_mask), yc0, c4v0);
+
+  // ---- stage B: motion compensation ----
+  uint32_t mcv[12];
+  {
+    // chroma first: its windows make room for the dequant scales
+    const bool c1 = lr && qc; // the right half of a LEFT/RIGHT pair has its own chunk; everybody else reads dwords qc, qc + 1 of chunk 0
+    const int base = (c1 ? P_C1 : P_C + qc * 4) + pl * 1024 + ch * 512 + g * 16;
+    uint32_t x0[5], x1[5];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x0[k] = lds32(L, base + k * 128); x1[k] = lds32(L, base + k * 128 + 4); }
+    x0[4] = hc.x; x1[4] = hc.y;
+    mc_rows<4>(x0, x1, (uint32_t)cpos & 3u, cph, mcv + 8);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + P_SC, 0);
+  {
+    const int w0 = q + ((lr && q >= 2) ? 2 : 0), w1 = w0 + 1; // columns 8..15 of a LEFT/RIGHT pair start their own chunk
+    const int base = P_L + rr * 2048 + g * 16;
+    const int a0 = base + (w0 >> 2) * 128 + (w0 & 3) * 4, a1 = base + (w1 >> 2) * 128 + (w1 & 3) * 4;
+    uint32_t x0[9], x1[9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x0[k] = lds32(L, a0 + k * 256); x1[k] = lds32(L, a1 + k * 256); }
+    x0[8] = hy.x; x1[8] = hy.y;
+    mc_rows<8>(x0, x1, (uint32_t)ypos & 3u, yph, mcv);
+  }
+  wave_sync();
+  {
+    const int oy = P_OUT_Y + rr * 1024 + g * 16 + q * 4, oc = P_OUT_C + pl * 512 + ch * 256 + g * 8 + qc * 4;
+#pragma unroll
+    for (int k = 0; k < 8; k++) *(uint32_t *)(L + oy + 128 * k) = mcv[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) *(uint32_t *)(L + oc + 64 * k) = mcv[8 + k];
+  }
+  if (PROF) pt[3] = prof_stamp();
+  if (multi_mask) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the scales too)
+    deep_finish(__builtin_ctz(multi_mask), D0);
+    uint32_t mm = multi_mask & (multi_mask - 1);
+    while (mm) { // a second, third ... macroblock with a deep tree in the same octet: one exposed round trip each (rare)
+      const int gm = __builtin_ctz(mm);
+      mm &= mm - 1;
+      const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
+      const uint2 yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
+      const uint4 c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+      Deep Dn;
+      deep_fetch(Dn, gm, yc, c4v);
+      asm volatile("" ::: "memory");
+      deep_finish(gm, Dn);
+    }
+  }
+  if (PROF) pt[4] = prof_stamp();
+
+  // ---- stage C: residual ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the scales
+  wave_sync();
+  if (m_lo | m_hi) {
+    // entries: 8x8 areas first, then the areas made of 4x4 blocks; inside a kind by area, then macroblock
+    const uint32_t m8_lo = m_lo & t_lo, m8_hi = m_hi & t_hi, m4_lo = m_lo & ~t_lo, m4_hi = m_hi & ~t_hi;
+    const int n8_lo = __builtin_popcount(m8_lo), n8 = n8_lo + __builtin_popcount(m8_hi);
+    const int n4_lo = __builtin_popcount(m4_lo), n_ent = n8 + n4_lo + __builtin_popcount(m4_hi);
+    auto slot_of_entry = [=](int kk, bool chroma, bool is8) { // kk = (area & 3) * 8 + g.  (By value, and masks by arithmetic: a select between
+      const uint32_t flip = is8 ? 0u : 0xFFFFFFFFu;          // captured variables turns into a select between their addresses, i.e. scratch.)
+      const uint32_t mask = chroma ? m_hi & (t_hi ^ flip) : m_lo & (t_lo ^ flip);
+      const int first = (is8 ? 0 : n8) + (chroma ? (is8 ? n8_lo : n4_lo) : 0);
+      return first + __builtin_popcount(mask & ((1u << kk) - 1u));
+    };
+    int *coef = (int *)(L + P_COEF);
+    {
+      const bool hi = lane >= 32;
+      const int kk = lane & 31;
+      if (((hi ? m_hi : m_lo) >> kk) & 1) L[P_TAB + slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1)] = (uint8_t)lane;
+    }
+    int lo = 0, hi = 0;
+    for (int base = 0; base < n_ent; base += 16) {
+      {
+        const uint4 z = uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) *(uint4 *)(L + P_COEF + k * 1024 + lane * 16) = z;
+        if (lane < (16 * P_TILE * 4 - 4096) / 16) *(uint4 *)(L + P_COEF + 4096 + lane * 16) = z;
+      }
+      wave_sync();
+      auto scatter = [&](uint32_t e) {
+        const int t = e & 0x1FF, level = (int32_t)e >> 16, ar = t >> 6, kk = (ar & 3) * 8 + g, p = t & 63;
+        const bool chroma = ar >= 4, is8 = ((chroma ? t_hi : t_lo) >> kk) & 1;
+        const int slot = slot_of_entry(kk, chroma, is8) - base;
+        const int si = is8 ? p : 64 + (p & 15);
+        const int scale = (int)lds32(L, P_SC + si * 4);
+        if ((unsigned)slot < 16u) coef[slot * P_TILE + p] = __mul24(scale, level);
+      };
+#pragma unroll
+      for (int k = 0; k < CWR; k++) {
+        const bool mine = (uint32_t)(8 * k + j) < ncoef;
+        if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
+        uint32_t e = cwr[k];
+        asm volatile("" : "+v"(e));
+        if (mine) scatter(e);
+      }
+      for (uint32_t i = 8u * CWR + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 8) // beyond the registers: one exposed round trip per 8 words
+        if (i < ncoef) scatter(cw[i]);
+      wave_sync();
+      const int r = lane & 7;
+      int kx[2];
+      bool actx[2], is8x[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int idx = base + 8 * h + (lane >> 3);
+        actx[h] = idx < n_ent;
+        kx[h] = actx[h] ? L[P_TAB + idx] : 0;
+        is8x[h] = idx < n8;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int *tile = coef + P_TILE * (8 * h + (lane >> 3));
+        if (actx[h]) idct_pass1(tile, tile, is8x[h], r);
+      }
+      wave_sync();
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (actx[h]) {
+          const int ge = kx[h] & 7, a = kx[h] >> 3;
+          uint8_t *px = a < 4 ? L + P_OUT_Y + (a >> 1) * 8 * 128 + ge * 16 + (a & 1) * 8 : L + P_OUT_C + (a - 4) * 512 + ge * 8;
+          idct_pass2_q(coef + P_TILE * (8 * h + (lane >> 3)), is8x[h], r, px, a < 4 ? 128 : 64, lo, hi);
+        }
+      }
+      wave_sync();
+    }
+    if (lo < -64 || hi > 319) atomicOr(&A.fault[clip], 1); // clamp table domain (MobiConst.cs:587)
+  }
+  if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt[5] = prof_stamp(); }
+
+  // ---- stage D: whole rows, 128 B of luma and 8 B per macroblock of chroma ----
+  uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int i = lane + 64 * it, gq = i & 7, row16 = i >> 3;
+    if ((inter_mask >> gq) & 1) {
+      *(uint4 *)(y0 + (off0 + (row16 << lgS) + gq * 16)) = *(const uint4 *)(L + P_OUT_Y + row16 * 128 + gq * 16);
+      const int row = row16 & 7; // chroma: plane = it, row = (i >> 3) & 7
+      *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + P_OUT_C + it * 512 + row * 64 + gq * 8);
+    }
+  }
+  if (PROF && lane == 0) { // MOBI_DEBUG=9: where a wave's life goes (shader clock): A issue, fetch wait, MC, deep trees, residual, store issue
+    pt[6] = prof_stamp();   // one record per octet (the buffer holds 16 bytes per macroblock)
+    unsigned long long *rec = A.prof + (size_t)oi * 8;
+#pragma unroll
+    for (int k = 0; k < 6; k++) rec[k] = pt[k + 1] - pt[k];
+    rec[6] = 1ull | ((pa - pt[0]) << 8) | ((pb - pa) << 32); // + kernel arguments, descriptor
+    rec[7] = (unsigned long long)(__builtin_popcount(m_lo) + __builtin_popcount(m_hi));
+  }
+}
+#define MOBI_OCT_KERNEL(NAME, WAVES, PROF, NCWR)                                                      \
+  extern "C" __global__ __launch_bounds__(64, WAVES) void NAME(MobiReconArgs A) {                      \
+    __shared__ __attribute__((aligned(16))) uint8_t lds[P_BYTES];                                      \
+    const uint32_t oi = (blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3);                        \
+    if (oi >= A.qpc * (uint32_t)A.n_clips) return;                                                     \
+    recon_inter_oct<PROF, NCWR>(A, lds, oi, (int)threadIdx.x);                                         \
+  }
+// 5 waves per SIMD (96 VGPRs; the 8 KB of LDS allow exactly 20 waves per CU) with 96 level words per macroblock in registers:
+// 24576 clips 640x480: 7.59 ms per launch against 7.95 with 4 waves and 128 words (r2c/bench_variants.txt)
+MOBI_OCT_KERNEL(mobi_recon_inter8, 5, 0, 12)
+MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 5, 1, 12)
+MOBI_OCT_KERNEL(mobi_recon_inter8_w4, 4, 0, 16) // MOBI_OCT_VARIANT=1: A/B runs
 
 // =====================================================================================================
 // intra macroblocks of one dependency level
@@ -1151,7 +1544,7 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
   }
   if (A.prof && lane == 0 && it < A.n_clips * A.n_mbs / 2) { // MOBI_DEBUG=9: dependency wait, loads, blocks, store+publish (shader clock)
     const unsigned long long pt4 = __builtin_readcyclecounter();
-    ((uint4 *)A.prof)[(size_t)A.n_clips * A.n_mbs / 4 + it] = uint4{(uint32_t)(pt1 - pt0), (uint32_t)(pt2 - pt1), (uint32_t)(pt3 - pt2), (uint32_t)(pt4 - pt3)};
+    ((uint4 *)A.prof)[(size_t)A.n_clips * A.n_mbs / 2 + it] = uint4{(uint32_t)(pt1 - pt0), (uint32_t)(pt2 - pt1), (uint32_t)(pt3 - pt2), (uint32_t)(pt4 - pt3)};
   }
 }
 
@@ -1231,7 +1624,7 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s)
   MobiReconArgs b = *a;
   b.inter_per_xcd = grid / 8;
   static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
-  if (oct && !b.prof && !b.done) { // eight macroblocks per wave: the q* fields count octets for this kernel
+  if (oct && !b.done) { // eight macroblocks per wave: the q* fields count octets for this kernel
     b.qpr = ((uint32_t)b.mbw + 7) / 8;
     b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);
     auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };
@@ -1239,7 +1632,13 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s)
     b.magic_qpc = magic(b.qpc);
     const unsigned g8 = (unsigned)(((long)b.qpc * b.n_clips + 7) / 8 * 8);
     b.inter_per_xcd = g8 / 8;
-    hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), lds_pad, s, b);
+    if (oct == 2) hipLaunchKernelGGL(mobi_recon_inter8_r1, dim3(g8), dim3(64), lds_pad, s, b); // r01's octet kernel, kept for A/B runs
+    else if (b.prof) hipLaunchKernelGGL(mobi_recon_inter8_prof, dim3(g8), dim3(64), lds_pad, s, b);
+    else {
+      static const int variant = getenv("MOBI_OCT_VARIANT") ? atoi(getenv("MOBI_OCT_VARIANT")) : 0;
+      if (variant == 1) hipLaunchKernelGGL(mobi_recon_inter8_w4, dim3(g8), dim3(64), lds_pad, s, b);
+      else hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), lds_pad, s, b);
+    }
     return (int)hipGetLastError();
   }
   if (b.prof) hipLaunchKernelGGL(mobi_recon_inter_prof, dim3(grid), dim3(64 * INTER_WAVES), lds_pad, s, b);
