@@ -200,7 +200,7 @@ def main():
         if km["inter_launches"]:
             avg_ms = km["inter_ms"] / km["inter_launches"]
             ach = algo_bytes / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "mobi_recon_inter" if os.environ.get("MOBI_INTER_OCT", "1") == "0" else "mobi_recon_inter8", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": "mobi_recon_inter8", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_ms, 5),
                     "launches": km["inter_launches"],

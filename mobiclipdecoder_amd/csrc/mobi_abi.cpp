@@ -101,50 +101,71 @@ void step_write(const std::vector<const ParsedFrame *> &frames, int n_mbs, MbDes
   }
 }
 
-struct LevelPlan { // launch plan of one frame step: items of level L are items[start[L] .. start[L+1])
+struct LevelPlan { // launch plan of one frame step: the intra macroblocks of all clips, sorted by dependency level
+  // One item = MOBI_INTRA_ITEM_WORDS words, everything a wave needs to start (mobi_recon_intra): (clip << 13 | mb), MbDesc.w1,
+  // MbDesc.payload_off inside the step's arena, and flags: [0] 16x16 plane, [1] has intra dependencies (must poll their tags),
+  // [2] has intra dependents (must publish its own), [3] left column in the edge side buffer, [14:5] number of level words,
+  // [31:16] plane parameter.
   std::vector<uint32_t> items;
-  std::vector<uint32_t> start; // size n_levels + 2, index 0 unused
+  uint32_t n_items = 0;
   bool any_inter = false;
   uint64_t cmd_bytes = 0;
-  uint32_t K = 0; // one-launch layout: items = [clip][K] macroblock indices sorted by level, 0xFFFFFFFF padding
-  void build(const std::vector<const ParsedFrame *> &frames, bool one_launch) {
+  void build(const std::vector<const ParsedFrame *> &frames, int mbw) {
     uint32_t maxl = 0;
     any_inter = false;
     cmd_bytes = 0;
-    K = 0;
-    if (one_launch) {
-      for (auto *f : frames)
-        if (f) {
-          K = std::max(K, f->hdr.n_intra);
-          maxl = std::max(maxl, f->hdr.n_levels);
-          if (f->hdr.n_intra < f->hdr.n_mbs) any_inter = true;
-          cmd_bytes += f->hdr.cmd_bytes;
-        }
-      items.assign(frames.size() * (size_t)K, 0xFFFFFFFFu);
-      for (size_t c = 0; c < frames.size(); c++)
-        if (frames[c]) std::copy(frames[c]->intra_mbs.begin(), frames[c]->intra_mbs.end(), items.begin() + c * (size_t)K);
-      start.assign(maxl + 2, 0);
-      return;
-    }
     for (auto *f : frames)
       if (f) {
         maxl = std::max(maxl, f->hdr.n_levels);
         if (f->hdr.n_intra < f->hdr.n_mbs) any_inter = true;
         cmd_bytes += f->hdr.cmd_bytes;
       }
-    start.assign(maxl + 2, 0);
     items.clear();
+    std::vector<size_t> base(frames.size() + 1, 0); // where each clip's payload starts in the step's arena (as step_write lays it out)
+    for (size_t c = 0; c < frames.size(); c++) base[c + 1] = base[c] + (frames[c] ? frames[c]->payload.size() : 0);
     for (uint32_t L = 1; L <= maxl; L++) {
-      start[L] = (uint32_t)items.size();
       for (size_t c = 0; c < frames.size(); c++) {
         const ParsedFrame *f = frames[c];
         if (!f || L > f->hdr.n_levels) continue;
-        for (uint32_t i = f->level_start[L]; i < f->level_start[L + 1]; i++) items.push_back(MOBI_ITEM(c, f->intra_mbs[i]));
+        for (uint32_t i = f->level_start[L]; i < f->level_start[L + 1]; i++) {
+          const uint32_t mb = f->intra_mbs[i];
+          const MbDesc &d = f->desc[mb];
+          uint32_t flags = d.w3 & 0xFFFF0001u;
+          const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
+          for (int k = 0; k < MOBI_INTRA_DEPS; k++) {
+            const uint32_t dep = (deps[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) flags |= 2u;
+          }
+          flags |= (d.w2 & 0x3FFu) << 5;
+          if (mb % (uint32_t)mbw) flags |= 8u; // finish_levels flagged the left neighbour: its last column is in the edge side buffer
+          items.push_back(MOBI_ITEM(c, mb));
+          items.push_back(d.w1);
+          items.push_back(d.payload_off + (uint32_t)base[c]);
+          items.push_back(flags);
+        }
       }
     }
-    start[maxl + 1] = (uint32_t)items.size();
+    n_items = (uint32_t)(items.size() / MOBI_INTRA_ITEM_WORDS);
+    // second pass: "has dependents".  Index the items by (clip, mb), then mark what the polling ones name.
+    if (n_items) {
+      std::vector<std::vector<std::pair<uint32_t, uint32_t>>> by_clip(frames.size()); // (mb, item index)
+      for (uint32_t i = 0; i < n_items; i++) by_clip[items[4 * i] >> 13].push_back({items[4 * i] & 0x1FFFu, i});
+      for (auto &v : by_clip) std::sort(v.begin(), v.end());
+      for (uint32_t i = 0; i < n_items; i++) {
+        if (!(items[4 * i + 3] & 2u)) continue;
+        const uint32_t c = items[4 * i] >> 13, mb = items[4 * i] & 0x1FFFu;
+        const MbDesc &d = frames[c]->desc[mb];
+        const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
+        for (int k = 0; k < MOBI_INTRA_DEPS; k++) {
+          const uint32_t dep = (deps[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+          if (dep == MOBI_DEP_NONE || (dep & MOBI_DEP_INTER)) continue;
+          auto &v = by_clip[c];
+          auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(dep & 0x1FFFu, 0u));
+          if (it != v.end() && it->first == (dep & 0x1FFFu)) items[4 * it->second + 3] |= 4u;
+        }
+      }
+    }
   }
-  uint32_t n_levels() const { return start.empty() ? 0 : (uint32_t)start.size() - 2; }
 };
 
 } // namespace
@@ -217,11 +238,9 @@ struct mobi_batch {
   uint32_t *d_argb = nullptr;           // Bitmap output of mobi_batch_convert_argb / mobi_batch_get_argb (lazily allocated)
   size_t argb_bytes = 0;
   bool argb_all_valid = false;          // d_argb holds every clip's Bitmap of the current frame
+  uint8_t *d_edge = nullptr;            // [clip * n_mbs + mb][MOBI_EDGE_BYTES]: right-most columns of macroblocks left of an intra one (host-parsed steps)
   uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
   uint32_t step_tag = 0;                // bumped once per frame step, never 0
-  int inter_oct = 1;                    // inter kernel: eight macroblocks per wave (env MOBI_INTER_OCT=0: four per wave, 2: r01's octet kernel)
-  int step_mode = 1;                    // 1: inter launch + ONE intra launch for all dependency levels (default, fastest measured);
-                                        // 2: the whole step as one launch (mobi_recon_step); 0: one intra launch per level (env MOBI_STEP_MODE)
   // device-side parse (mobi_dparse.hip): parse_mode 1 = mobi_batch_decode parses on the GPU (env MOBI_DEVICE_PARSE=1 or
   // mobi_batch_set_parse_mode); the per-clip decoder state then lives in d_pstate and the host parsers stay untouched
   int parse_mode = 0; // explicit (env / mobi_batch_set_parse_mode), or by batch size and settled at the first frame (parse_auto)
@@ -276,10 +295,10 @@ struct mobi_batch {
     a.n_mbs = g.mbw * g.mbh;
     a.n_clips = n;
     auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); }; // d == 1 must not wrap to 0
-    a.magic_n_mbs = magic((uint32_t)a.n_mbs);
-    a.magic_mbw = magic((uint32_t)a.mbw);
+    static const bool no_edge = getenv("MOBI_NO_EDGE") != nullptr; // experiment: intra left columns from the planes, as in r01
+    a.edge = no_edge ? nullptr : d_edge;
     a.step_tag = step_tag;
-    a.done = step_mode ? d_done : nullptr;
+    a.done = d_done;
     a.prof = d_prof;
     a.qpr = (uint32_t)(a.mbw + 3) / 4;
     a.qpc = a.qpr * (uint32_t)g.mbh;
@@ -293,38 +312,19 @@ struct mobi_batch {
     (void)hipEventCreate(&e);
     return e;
   }
+  // one frame step = the inter launch, then ONE intra launch for all dependency levels (items sorted by level, waves wait for
+  // the tags of the macroblocks they depend on).  r01 also had a launch per level and a whole-step launch; both were slower.
   int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev) {
-    if (step_mode == 2) { // the whole step -- inter quads and intra macroblocks of every clip -- is one launch
-      EvPair ep{nullptr, nullptr, 0};
-      if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
-      if (mobi_launch_step(&a, items_dev, (int)plan.K, stream) != 0) return MOBI_E_DEVICE;
-      if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
-      return MOBI_OK;
-    }
     if (plan.any_inter) {
-      MobiReconArgs ai = a;
-      ai.done = nullptr; // a separate inter launch is complete before any intra wave starts: plain stores, nothing to publish
       EvPair ep{nullptr, nullptr, 0};
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
-      if (mobi_launch_inter(&ai, inter_oct, stream) != 0) return MOBI_E_DEVICE;
+      if (mobi_launch_inter(&a, stream) != 0) return MOBI_E_DEVICE;
       if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
-    if (step_mode == 1 && plan.n_levels() >= 1) { // every level in one launch: items are sorted by level, waves wait on their own dependencies
-      const int cnt = (int)(plan.start[plan.n_levels() + 1] - plan.start[1]);
-      if (cnt > 0) {
-        EvPair ep{nullptr, nullptr, 1};
-        if (ktiming >= 2) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
-        if (mobi_launch_intra(&a, items_dev + plan.start[1], cnt, stream) != 0) return MOBI_E_DEVICE;
-        if (ktiming >= 2) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
-      }
-      return MOBI_OK;
-    }
-    for (uint32_t L = 1; L <= plan.n_levels(); L++) {
-      int cnt = (int)(plan.start[L + 1] - plan.start[L]);
-      if (cnt <= 0) continue;
+    if (plan.n_items) {
       EvPair ep{nullptr, nullptr, 1};
       if (ktiming >= 2) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
-      if (mobi_launch_intra(&a, items_dev + plan.start[L], cnt, stream) != 0) return MOBI_E_DEVICE;
+      if (mobi_launch_intra(&a, items_dev, (int)plan.n_items, stream) != 0) return MOBI_E_DEVICE;
       if (ktiming >= 2) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
     }
     return MOBI_OK;
@@ -353,6 +353,7 @@ struct mobi_batch {
     if (d_scale) (void)hipFree(d_scale);
     if (d_prof) (void)hipFree(d_prof);
     if (d_done) (void)hipFree(d_done);
+    if (d_edge) (void)hipFree(d_edge);
     if (d_argb) (void)hipFree(d_argb);
     if (d_pstate) (void)hipFree(d_pstate);
     if (d_pres) (void)hipFree(d_pres);
@@ -391,7 +392,7 @@ long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *ite
   return (long long)b->last_pay_cap;
 }
 
-const char *mobi_build_info(void) { return "libmobiclip_hip 0.1 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_inter, mobi_recon_intra, mobi_recon_intra_cl, mobi_recon_step, mobi_parse_frames, mobi_yuv_to_argb, mobi_motion_search_2x2; no CPU reconstruction path)"; }
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.2 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_intra_cl, mobi_parse_frames, mobi_yuv_to_argb, mobi_motion_search_2x2; no CPU reconstruction path)"; }
 
 const char *mobi_error_string(int rc) {
   switch (rc) {
@@ -439,8 +440,13 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   if (hipMemsetAsync(b->d_fault, 0, sizeof(int) * n_clips, b->stream) != hipSuccess) return nullptr;
   if (hipEventCreate(&b->ev_begin) != hipSuccess || hipEventCreate(&b->ev_end) != hipSuccess) return nullptr;
   {
-    std::vector<int32_t> tab((size_t)64 * MOBI_SCALE_STRIDE, 0); // 64 rows: the 6-bit quantizer field of any descriptor stays inside
+    // 64 rows: the 6-bit quantizer field of any descriptor stays inside; the intra kernel's tap table rides behind them
+    std::vector<int32_t> tab((size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE + MOBI_TAP_ENTRIES * 2, 0);
     for (int q = 0; q < MOBI_SCALE_QMAX; q++) mobi_build_scale_table(q, &tab[(size_t)q * MOBI_SCALE_STRIDE]);
+    if (!mobi_build_intra_taps((int16_t *)&tab[(size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE], MOBI_TAP_PITCH)) {
+      snprintf(g_last_hip_error, sizeof(g_last_hip_error), "intra tap table self-check failed");
+      return nullptr;
+    }
     if (hipMalloc((void **)&b->d_scale, tab.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(b->d_scale, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   }
@@ -448,8 +454,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     const size_t dbytes = (size_t)n_clips * b->g.mbw * b->g.mbh * 4;
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
-    if (const char *sm = getenv("MOBI_STEP_MODE")) b->step_mode = std::max(0, std::min(2, atoi(sm)));
-    if (const char *io = getenv("MOBI_INTER_OCT")) b->inter_oct = std::max(0, std::min(2, atoi(io)));
+    if (hipMalloc((void **)&b->d_edge, dbytes / 4 * MOBI_EDGE_BYTES) != hipSuccess) return nullptr;
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     b->parse_auto = true;
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = std::max(0, std::min(2, atoi(dp))); b->parse_auto = false; }
@@ -622,11 +627,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   b->frames_started++;
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
   a.done = b->d_done;
-  {
-    MobiReconArgs ai = a;
-    ai.done = nullptr;
-    if (mobi_launch_inter(&ai, b->inter_oct, b->stream) != 0) return MOBI_E_DEVICE;
-  }
+  if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
   if (K && mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), (int)K, b->stream) != 0)
     return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
@@ -683,7 +684,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->argb_all_valid = false;
   b->frames_started++;
   LevelPlan plan;
-  plan.build(ok, b->step_mode == 2);
+  plan.build(ok, b->g.mbw);
   // 2. stage [desc table][payload arena][items] and upload
   const int n_mbs = b->g.mbw * b->g.mbh;
   const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign); // slack: a wave reads up to 8 descriptors at once
@@ -856,7 +857,7 @@ int mobi_batch_commit(mobi_batch *b) {
     b->r_desc_off[f] = cmd_bytes;
     b->r_payload_off[f] = cmd_bytes + desc_bytes;
     cmd_bytes += desc_bytes + align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
-    b->r_plan[f].build(ok, b->step_mode == 2);
+    b->r_plan[f].build(ok, b->g.mbw);
     b->r_items_off[f] = n_items;
     n_items += b->r_plan[f].items.size();
   }

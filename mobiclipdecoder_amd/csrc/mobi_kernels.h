@@ -12,7 +12,7 @@
 //   desc / payload : the command list of one frame step, all clips (mobi_cmd.h)
 // Ring: position r (0 = frame being written, 1..5 = references, MD.cs:102-106) lives in slot
 //   (ring_base + 6 - r) % 6 ; every clip of a batch rotates in lock step, so ring_base is a scalar.
-struct MobiReconArgs { // field order is part of the kernel ABI: mobi_recon_inter reads the kernarg block as two 16-dword tuples
+struct MobiReconArgs {
   uint8_t *planes;          // dwords 0-1
   const MbDesc *desc;       // 2-3   flat table of this frame step: [clip * n_mbs + mb]
   const uint32_t *payload;  // 4-5   payload arena of this frame step (MbDesc.payload_off indexes it)
@@ -23,28 +23,27 @@ struct MobiReconArgs { // field order is part of the kernel ABI: mobi_recon_inte
   int ring_base;            // 13
   int width, height;        // 14, 15
   int stride, mbw, n_mbs, n_clips;          // 16-19
-  uint32_t magic_n_mbs, magic_mbw;          // 20, 21  floor(2^32 / d): no integer divides on the GPU
-  uint32_t qpr, qpc, magic_qpr, magic_qpc;  // 22-25  quads (4 adjacent MBs = one wave) per MB row / per clip
+  uint8_t *edge;                            // 20-21  edge side buffer [clip * n_mbs + mb][MOBI_EDGE_BYTES] (mobi_cmd.h); null = not in use (device-parsed steps)
+  uint32_t qpr, qpc, magic_qpr, magic_qpc;  // 22-25  octets (8 adjacent MBs = one wave) per MB row / per clip: filled in by mobi_launch_inter
   uint32_t step_tag;                        // 26     frame-step counter (never 0): done[] == step_tag means "reconstructed in this step"
   uint32_t inter_per_xcd;                   // 27     inter launch: workgroups per XCD (= gridDim.x / 8)
-  uint32_t *done;                           // 28-29  [clip * n_mbs + mb] completion tags of intra macroblocks; null = one launch per level
+  uint32_t *done;                           // 28-29  [clip * n_mbs + mb] completion tags of intra macroblocks
   unsigned long long *prof;                 // 30-31  profiling accumulators (MOBI_DEBUG=9), else null
 };
 static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");
 
-// oct != 0: mobi_recon_inter8 (eight macroblocks per wave, the default: 5 % faster); 0: mobi_recon_inter (four per wave)
-extern "C" int mobi_launch_inter(const MobiReconArgs *a, int oct, hipStream_t s);
+// mobi_recon_inter8: every inter macroblock of the step, one wave per octet of macroblocks
+extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);
+// items_dev: n_items launch items of 16 bytes (MOBI_INTRA_ITEM_WORDS words), sorted by dependency level -- see LevelPlan in mobi_abi.cpp
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
 // device-parsed frames: items_dev = [clip][n_mbs] in raster order, n_intra_dev[clip * stride_words] of them valid; K = the largest count
 extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s);
-// whole frame step in one launch: items_dev = [clip][K] macroblock indices of the intra macroblocks of each clip sorted by
-// dependency level, padded with 0xFFFFFFFF; needs a->done
-extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int K, hipStream_t s);
 // MD.cs:260-323: ring slot 0 of clips [clip0, clip0 + n_clips) -> out_dev[clip][height][width] 0xAARRGGBB words (mobi_rgb.hip)
 extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, int n_clips, uint32_t *out_dev, hipStream_t s);
 extern "C" long long mobi_launch_div239_check(hipStream_t s); // mismatches of the RGB kernel's x/239 over all floats, or -1
 // Analyzer.cs:608-693: three-step 2x2 motion search of src_dev[clip][height][width] against ring slots 0..n_past-1 (mobi_analysis.hip)
 extern "C" int mobi_launch_motion_search(const MobiReconArgs *a, const uint8_t *src_dev, uint32_t *out_dev, int n_past, hipStream_t s);
-// intra launch item: (clip << 13) | mb
+// intra launch item, word 0: (clip << 13) | mb; words 1..3: MbDesc.w1, MbDesc.payload_off, flags (mobi_recon_intra in mobi_kernels.hip)
 #define MOBI_ITEM(clip, mb) (((uint32_t)(clip) << 13) | (uint32_t)(mb))
+#define MOBI_INTRA_ITEM_WORDS 4
 #endif

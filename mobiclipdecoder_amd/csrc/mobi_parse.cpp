@@ -1,7 +1,9 @@
 // mobi_parse.cpp -- serial bitstream parser -> per-macroblock command list (see mobi_parse.h).
 #include "mobi_parse.h"
+#include "mobi_recon_math.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/mobiclip_hip.h"
@@ -563,6 +565,7 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     }
     level[mb] = (uint16_t)(lv + 1);
     if (lv + 1 > maxl) maxl = lv + 1;
+    if (mb % g_.mbw) out.desc[mb - 1].w1 |= MOBI_W1_EDGE; // the left neighbour leaves its last column where this one finds it in one read
     for (int k = n_deps; k < MOBI_INTRA_DEPS; k++) deps[k] = MOBI_DEP_NONE;
     MbDesc &d = out.desc[mb];
     d.w4 = deps[0] | ((uint32_t)deps[1] << 16);
@@ -619,6 +622,62 @@ void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]) {
   const int sh = mobi_qdiv6[q] + 8, m = mobi_qmod6[q];
   for (int i = 0; i < 64; i++) out[mobi_zz8[i]] = (int32_t)((((uint32_t)mobi_dq8[m * 64 + i]) << (sh - 2)) >> 8);
   for (int i = 0; i < 16; i++) out[64 + mobi_zz4[i]] = (int32_t)((((uint32_t)mobi_dq4[m * 16 + i]) << sh) >> 8);
+}
+
+// Directional intra predictors (modes 0, 1, 4..8 of PredictIntra, MD.cs:1883-2774) as data: every predicted sample is
+// (t0 + t1 + t2 + t3 + 2) >> 2 over four neighbour samples -- F3(a, b, c) = taps a, b, b, c; F2(a, b) = a, a, b, b; a copy =
+// a, a, a, a -- so a table of four tile offsets per (mode, block size, sample) replaces the per-sample case analysis of
+// mobi_pred_px in the intra kernel (lane-divergent branches there are scalar work: 771 scalar instructions per macroblock in
+// r01).  The table is DERIVED from mobi_pred_px by probing it with unit impulses, then checked against it on random
+// neighbourhoods; offsets are relative to the block's top-left sample in a tile of the given pitch.
+bool mobi_build_intra_taps(int16_t *out, int pitch) {
+  static const int modes[MOBI_TAP_MODES] = {0, 1, 4, 5, 6, 7, 8};
+  uint32_t rng = 0x4D4F4249u;
+  auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (int)(rng >> 24); };
+  for (int mi = 0; mi < MOBI_TAP_MODES; mi++) {
+    for (int four = 0; four < 2; four++) {
+      const int n = four ? 4 : 8;
+      for (int y = 0; y < n; y++) {
+        for (int x = 0; x < n; x++) {
+          int16_t *e = out + 4 * ((four ? MOBI_TAP_4X4 + mi * 16 : mi * 64) + y * n + x);
+          int nt = 0;
+          // candidate neighbours: the row above from the corner to column n + 4 (mode 8 of an 8x8 block reads 13 of them), then the left column
+          auto probe = [&](int py, int px) {
+            auto nb = [&](int dy, int dx) { return (dy == py && dx == px) ? 4 : 0; };
+            return mobi_pred_px(modes[mi], n, y, x, 1, 1, nb);
+          };
+          auto add = [&](int py, int px) {
+            const int w = probe(py, px);
+            if (w < 0 || w > 4) return false; // 3: a clamped index names one neighbour twice (F3(L6, L7, L7))
+            for (int k = 0; k < w; k++) {
+              if (nt == 4) return false;
+              e[nt++] = (int16_t)(py * pitch + px);
+            }
+            return true;
+          };
+          for (int px = -1; px <= n + 4; px++)
+            if (!add(-1, px)) return false;
+          for (int py = 0; py < n; py++)
+            if (!add(py, -1)) return false;
+          if (nt != 4) return false;
+          for (int trial = 0; trial < 8; trial++) { // the table against the function it came from
+            int top[16], left[8];
+            for (int k = 0; k < 16; k++) top[k] = rnd();
+            for (int k = 0; k < 8; k++) left[k] = rnd();
+            auto nb = [&](int dy, int dx) { return dy < 0 ? top[dx + 1] : left[dy]; };
+            int sum = 2;
+            for (int k = 0; k < 4; k++) {
+              const int o = e[k];
+              const int dy = (o + pitch + 1) / pitch - 1, dx = o - dy * pitch; // o = dy * pitch + dx with dx in [-1, n + 4]
+              sum += nb(dy, dx);
+            }
+            if ((sum >> 2) != mobi_pred_px(modes[mi], n, y, x, 1, 1, nb)) return false;
+          }
+        }
+      }
+    }
+  }
+  return true;
 }
 
 // The tables the device-side parser (mobi_dparse.hip) keeps in LDS, as one blob (layout: MOBI_DT_* in mobi_dparse.h).

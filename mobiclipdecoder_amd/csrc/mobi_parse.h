@@ -46,6 +46,8 @@ struct MobiGeom {
 enum { MOBI_HALO_Y_RIGHT = 23, MOBI_HALO_C_RIGHT = 15 };
 
 void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]);
+// directional intra predictors as four tile offsets per sample (see mobi_parse.cpp); out: MOBI_TAP_ENTRIES x 4 int16; false = self-check failed
+bool mobi_build_intra_taps(int16_t *out, int pitch);
 
 class MobiStreamParser {
  public:

@@ -181,12 +181,10 @@ def test_clamp_domain_fault_is_reported():
     pytest.skip("no clamp-only fault found in the random search")
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
-def test_every_step_mode_is_bit_exact(mode, monkeypatch):
-    """The frame step can run as inter + one intra launch per dependency level (0), inter + ONE intra launch whose
-    waves wait on per-macroblock completion tags (1, default), or one launch for everything (2).  All three must
+def test_intra_heavy_steps_are_bit_exact():
+    """A frame step = the inter launch + ONE intra launch whose waves wait on per-macroblock completion tags.  It must
     reproduce the oracle, I-frames (deep dependency chains) and intra-heavy P-frames included, also in a batch."""
-    monkeypatch.setenv("MOBI_STEP_MODE", mode)  # read when the decoder / batch is created
+    mode = "1"
     _run_stream(default_params("B", BASE_SEED + 31, n_frames=8, pm_intra=300, iframe_interval=4))
     _run_stream(default_params("A", BASE_SEED + 32, n_frames=8, pm_intra=200, edge_mode=1, mv_range=40))
     nclips, nfr = 11, 6  # more clips than XCDs: the one-launch layout walks several clips per XCD
@@ -205,13 +203,12 @@ def test_every_step_mode_is_bit_exact(mode, monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_loaded_gpu_hand_offs_are_exact(mode, monkeypatch):
+def test_loaded_gpu_hand_offs_are_exact():
     """The completion-tag hand-off between waves (intra macroblocks waiting on other macroblocks of the same launch)
     must hold on a LOADED chip, not just for a handful of clips: 320 clips of 640x480 (every CU busy, waves of many
     clips interleaved), intra-heavy, 7 frames incl. the I-frame's ~100-level wavefront, replayed twice.  Every clip
     is a private copy of one of 8 streams, so every copy must equal the oracle's frame, word for word, every frame."""
-    monkeypatch.setenv("MOBI_STEP_MODE", mode)
+    mode = "1"
     nclips, distinct, nfr = 320, 8, 7
     ps = [default_params("B", BASE_SEED + 700 + i, n_frames=nfr, pm_intra=200, pm_deep=100) for i in range(distinct)]
     clips = [generate_clip(p) for p in ps]
@@ -243,12 +240,10 @@ def test_loaded_gpu_hand_offs_are_exact(mode, monkeypatch):
     b.close()
 
 
-def test_quad_and_octet_inter_kernels_agree_with_the_oracle(monkeypatch):
-    """The default inter kernel takes eight macroblocks per wave (mobi_recon_inter8); the four-per-wave kernel
-    (mobi_recon_inter) stays in use for the one-launch step mode.  Both must be bit-exact on a mix with every kind of
-    inter macroblock (single, two halves, deep trees, multi-reference, residual 8x8 and 4x4) and odd widths in
-    macroblocks (848 = 53: the last octet / quad of a row is partial)."""
-    for oct in ("0", "1"):
-        monkeypatch.setenv("MOBI_INTER_OCT", oct)  # read at the first launch of a process: set before any decoder exists in this test
-        _run_stream(default_params("C", BASE_SEED + 61, n_frames=6, pm_deep=150, pm_multiref=200))
-        _run_stream(default_params("A", BASE_SEED + 62, n_frames=6, pm_split1=400, t8_prob=500))
+def test_octet_inter_kernel_on_every_kind_of_inter_macroblock():
+    """mobi_recon_inter8 takes eight macroblocks per wave.  It must be bit-exact on a mix with every kind of inter
+    macroblock (single, two halves top/bottom and left/right, deep trees, multi-reference, residual 8x8 and 4x4) and odd
+    widths in macroblocks (848 = 53: the last octet of a row is partial)."""
+    _run_stream(default_params("C", BASE_SEED + 61, n_frames=6, pm_deep=150, pm_multiref=200))
+    _run_stream(default_params("A", BASE_SEED + 62, n_frames=6, pm_split1=400, t8_prob=500))
+    _run_stream(default_params("B", BASE_SEED + 63, n_frames=6, pm_split1=600, pm_deep=200, pm_multiref=300, cbp_prob=600))

@@ -6,7 +6,7 @@ lib = m.load_library()
 lib.mobi_debug_read_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 import numpy as np
 def run(tag, **kw):
-    clips, distinct = 512, 8
+    clips, distinct = int(os.environ.get('CLIPS', '512')), 8
     b = m.MobiclipBatch(clips, 640, 480, 2)
     for i in range(distinct):
         p = m.default_params("B", BASE_SEED + i, n_frames=33, **kw); data, fo = m.generate_clip(p)
@@ -28,7 +28,7 @@ def run(tag, **kw):
     ir = np.zeros((clips * 1200 // 4, 4), np.uint32)
     full = np.zeros((clips * 1200, 4), np.uint32)
     lib.mobi_debug_read_prof(b._h, full.ctypes.data, full.size)
-    ir = full[clips * 300:clips * 300 + clips * 150]
+    ir = full[clips * 600:clips * 600 + clips * 150]
     li = ir.sum(1) > 0
     if li.any():
         print(f"    intra items {li.sum()}: mean cycles: dep-wait {ir[li,0].mean():.0f}  loads {ir[li,1].mean():.0f}  blocks {ir[li,2].mean():.0f}  store+publish {ir[li,3].mean():.0f}; p90 {np.percentile(ir[li,0],90):.0f}/{np.percentile(ir[li,1],90):.0f}/{np.percentile(ir[li,2],90):.0f}/{np.percentile(ir[li,3],90):.0f}", flush=True)

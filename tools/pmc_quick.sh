@@ -24,5 +24,7 @@ TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TD_STORE_WAVEFRONT_sum
 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 GRBM_GUI_ACTIVE
+FETCH_SIZE
+WRITE_SIZE
 LIST
 python $REPO/tools/pmc_summary.py "$OUT" 6 > "$OUT/summary.txt" 2>&1
