@@ -9,15 +9,17 @@ object of the output line times the whole DecodeFrame path, bitstream in).  Work
 (default 24576 = 183 GB of the 288 GB; weak scaling: per-GPU work fixed).  Few, long launches (9 ms) are measurably
 more efficient on this part than many short ones: DESIGN.md has the same measurement from 512 to 24576 clips.
 
-  python bench.py                      # 1 GPU, defaults finish in well under a minute
+  python bench.py                      # 1 GPU, defaults finish in about a minute
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
 
 Clips shard across ranks with no data-path collective (decoder instances share nothing,
-MobiclipDecoder.cs:15-39); torch.distributed is used only for the barrier / max-over-ranks timing.
+MobiclipDecoder.cs:15-39); torch.distributed (a gloo group: nothing travels over RCCL) is used only for the barrier /
+max-over-ranks timing.
 
 Prints ONE JSON line (rank 0).  `roofline` = algorithmic bytes of the dominant kernel
-(mobi_recon_inter) per launch / its average duration from HIP events recorded on the launch stream
-inside the timed region.  `cpu_baseline` = the CPU oracle (a C restatement of the reference decoder;
+(mobi_recon_inter8: the inter macroblocks' pixels and commands only) per launch / its average duration from HIP events
+recorded on the launch stream inside the timed region; `roofline.whole_step_frac` = the same for the whole step (both
+kernels, every macroblock, every command byte).  `cpu_baseline` = the CPU oracle (a C restatement of the reference decoder;
 the C# original cannot run here) on this host, single thread, same stream, parse + reconstruction.
 """
 import argparse
@@ -89,10 +91,38 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps):
             "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)"}
 
 
+def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
+    """BASELINE config 4 ("64 clips sharded across 8 GPUs") as seen by ONE GPU: its share of 8 clips, replayed like the big batch.
+    150 octet waves per clip fill a few per cent of the chip, so this is the latency of two short launches per step, not a
+    throughput figure; it is reported next to the headline value, never as it."""
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device)
+    for c in range(n_clips):
+        p, data, fo = streams[c % len(streams)]
+        assert all(r == 0 for r in b.preload(c, data, fo))
+    b.commit()
+    b.replay(0)
+    for f in range(1, 5):
+        b.replay(f)
+    assert b.sync() == 0
+    b.set_kernel_timing(0)
+    t0 = time.perf_counter()
+    b.time_begin()
+    for i in range(n_steps):
+        b.replay(5 + i)  # frames 5 .. 5 + n_steps - 1 <= 32: stream order
+    stream_ms = b.time_end()
+    assert b.sync() == 0
+    wall = time.perf_counter() - t0
+    b.close()
+    return {"workload": f"{n_clips} clips of {W}x{H} on this GPU = the per-GPU share of 64 clips over 8 GPUs", "steps": n_steps,
+            "ms_per_step": round(stream_ms / n_steps, 4), "value": round(n_clips * n_steps * W * H / (stream_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+            "wall_ms_per_step": round(wall * 1e3 / n_steps, 4),
+            "note": "two launches per step (inter, intra) of 1200 and ~60 waves: launch latency, not bandwidth"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=192, help="timed P-frame steps (default: six 32-frame P-chains = ~2 s)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--clips", type=int, default=24576, help="independent clips resident per GPU (24576 x 640x480 = 109 GB of rings + 74 GB of command lists; halved if it does not fit)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated streams per GPU (others are private HBM copies)")
@@ -100,8 +130,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
     ap.add_argument("--e2e-steps", type=int, default=8)
+    ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
-    ap.add_argument("--intra-events", action="store_true", help="HIP events around the intra launches too (adds a few us per step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,9 +140,11 @@ def main():
     import torch
     dist = None
     if world > 1:
+        # no data-path collective exists (north_star: "no RCCL"): the process group only carries the barrier and the max of the
+        # elapsed times, so it is a gloo group (TCP between the ranks of the node), not an RCCL one
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU reconstruction path to time")
 
@@ -156,54 +188,89 @@ def main():
                 raise
             print(f"bench.py: rank {rank}: {clips} clips do not fit ({e}); retrying with {clips // 2}", file=sys.stderr, flush=True)
             clips //= 2
-    agreed = -int(sharding.max_over_ranks(dist, -clips, device=f"cuda:{local}"))  # the smallest size any rank settled on
+    agreed = -int(sharding.max_over_ranks(dist, -clips))  # the smallest size any rank settled on
     if agreed != clips:
         b.close()
         clips = agreed
         b = build_batch(clips)
     args.clips = clips
 
-    # warm-up: (the I-frame, frame 0, ran above) W P-frames, in stream order
-    step_frames = [1 + (i % N_PFRAMES) for i in range(args.warmup + args.steps)]
-    for f in step_frames[: args.warmup]:
-        b.replay(f)
+    # Stream order.  The generated clips are 1 I-frame + 32 P-frames; a step s of the run decodes P-frame 1 + (s mod 32), and every
+    # time the chain wraps the I-frame is decoded again first, so that each P-frame finds the ring history it was coded against
+    # (r01 wrapped straight from frame 32 to frame 1: the same work on a wrong history).  The I-frame is not a P-frame step: it
+    # runs OUTSIDE the timed region, which is therefore a sum of segments of up to 32 consecutive steps, each bracketed by the
+    # barrier + synchronize pair; `ms_per_step` is that sum over `steps`.
+    total = args.warmup + args.steps
+    b.set_kernel_timing(0)
+    s = 0
+    while s < args.warmup:  # (the I-frame, frame 0, ran above)
+        if s and s % N_PFRAMES == 0:
+            b.replay(0)
+        b.replay(1 + s % N_PFRAMES)
+        s += 1
     assert b.sync() == 0, "clamp-domain fault during warm-up"
 
-    b.set_kernel_timing(0 if args.no_kernel_events else (2 if args.intra_events else 1))
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    b.time_begin()
-    t0 = time.perf_counter()
-    for f in step_frames[args.warmup:]:
-        b.replay(f)
-    stream_ms = b.time_end()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    assert b.sync() == 0, "clamp-domain fault in the timed region"
-    km = b.kernel_ms()
+    b.set_kernel_timing(0 if args.no_kernel_events else 2)
+    elapsed, stream_ms, timed_frames = 0.0, 0.0, []
+    acc = {"inter_ms": 0.0, "intra_ms": 0.0, "inter_launches": 0, "intra_launches": 0}
+    while s < total:
+        if s % N_PFRAMES == 0:  # chain wrap: re-seed the ring, untimed
+            b.set_kernel_timing(0)
+            b.replay(0)
+            assert b.sync() == 0
+            b.set_kernel_timing(0 if args.no_kernel_events else 2)
+        seg = min(total - s, N_PFRAMES - s % N_PFRAMES)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        b.time_begin()
+        t0 = time.perf_counter()
+        for k in range(seg):
+            b.replay(1 + (s + k) % N_PFRAMES)
+        stream_ms += b.time_end()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed += time.perf_counter() - t0
+        km = b.kernel_ms()
+        for key in acc:
+            acc[key] += km[key]
+        timed_frames += [1 + (s + k) % N_PFRAMES for k in range(seg)]
+        s += seg
+        assert b.sync() == 0, "clamp-domain fault in the timed region"
+    km = acc
 
-    elapsed = sharding.max_over_ranks(dist, elapsed, device=f"cuda:{local}")
-    cmd_bytes_per_step = sum(b.cmd_bytes(f) for f in step_frames[args.warmup:]) / args.steps
+    elapsed = sharding.max_over_ranks(dist, elapsed)
+    steps = args.steps
+    cmd_bytes = sum(b.cmd_bytes(f) for f in timed_frames) / steps          # per step, all clips of this GPU
+    stats = [b.intra_stats(f) for f in timed_frames]
+    n_intra = sum(x[0] for x in stats) / steps
+    intra_cmd = sum(x[1] for x in stats) / steps
     b.close()
-    e2e = None
+    e2e = c4 = None
     if world == 1 and args.e2e_clips > 0 and args.config == "B":
         e2e = end_to_end(m, streams, W, H, p0.version, local, args.e2e_clips, args.e2e_steps)
+    if world == 1 and args.config4_clips > 0 and args.config == "B":
+        c4 = config4_leg(m, streams, W, H, p0.version, local, args.config4_clips, 24)
 
     if rank == 0:
-        steps = args.steps
-        cmd_bytes = cmd_bytes_per_step                                   # per launch, all clips of this GPU
-        algo_bytes = args.clips * 3.0 * W * H + cmd_bytes                # ref read 1.5WH + write 1.5WH + commands
+        n_mbs = (W // 16) * (H // 16)
+        step_bytes = args.clips * 3.0 * W * H + cmd_bytes                 # whole step: ref read 1.5WH + write 1.5WH + every command byte
+        # the dominant kernel, mobi_recon_inter8: the inter macroblocks only (384 B read + 384 B written each) and their commands;
+        # the intra macroblocks' pixels and records belong to mobi_recon_intra
+        algo_bytes = (args.clips * n_mbs - n_intra) * 768.0 + (cmd_bytes - intra_cmd)
         roof = None
         if km["inter_launches"]:
             avg_ms = km["inter_ms"] / km["inter_launches"]
             ach = algo_bytes / (avg_ms * 1e-3) / 1e9
+            step_ms = stream_ms / steps
             roof = {"bound": "hbm", "kernel": "mobi_recon_inter8", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_ms, 5),
                     "launches": km["inter_launches"],
+                    "whole_step_frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "whole_step_bytes": int(step_bytes), "whole_step_ms": round(step_ms, 5),
+                    "intra_macroblocks_per_step": round(n_intra, 1),
                     "intra_kernel_ms_per_step": round(km["intra_ms"] / steps, 5) if km["intra_launches"] else None,
                     "intra_launches_per_step": round(km["intra_launches"] / steps, 2) if km["intra_launches"] else None}
             prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -226,10 +293,11 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} {'Moflex3DS' if p0.version == 2 else 'ModsDS'} P-frame reconstruction "
                                    f"(SURVEY 8d generator mix), {args.clips} independent clips per GPU, "
-                                   f"{distinct} distinct streams, command lists resident in HBM",
+                                   f"{distinct} distinct streams, command lists resident in HBM, frames in stream order "
+                                   f"(the I-frame that re-seeds the ring every {N_PFRAMES} steps is outside the timed region)",
                        "generator_overrides": gen_over or None, "clips_per_gpu": args.clips, "parallelism": f"clips sharded over {world} GPU(s), no collective",
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
-            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e,
+            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "config4": c4,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

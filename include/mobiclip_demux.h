@@ -70,10 +70,11 @@ int mobi_moc5_open(const uint8_t *file, size_t len, mobi_moc5_info *info);
 int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_t *decode_offset, uint32_t *block_size);
 
 /* ---- Moflex (3DS) ------------------------------------------------------------------------------ */
-/* mirrors LibMobiclip.Containers.Moflex.MoLiveDemux (MoLiveDemux.cs:11-416) with the file held in memory as its Stream:
- * ReadPacket() is restated step for step (synchronisation search, synchro header + stream chunks, data block flags,
- * bit-packed EP headers, per-stream frame assembly) and keeps the reference's return codes; completed frames -- what
- * the reference hands to OnCompleteFrameReceived, two zero bytes appended (:353) -- are queued. */
+/* A reader for the container LibMobiclip.Containers.Moflex.MoLiveDemux reads (MoLiveDemux.cs:11-416), with the file held in
+ * memory: packets of the announced size, a sync header with a check word and the stream table, a flags byte per packet,
+ * bit-packed elementary-packet headers, per-stream frame assembly (grammar at the top of mobi_moflex.cpp).  It keeps the
+ * reference's ReadPacket() return codes; completed frames -- what the reference hands to OnCompleteFrameReceived, two zero
+ * bytes appended (:353) -- are queued. */
 typedef struct mobi_moflex mobi_moflex;
 
 /* MoLiveStream chunk of a frame (MoLiveStreamVideo.cs / ...WithLayout.cs / ...Audio.cs / ...Timeline.cs) */
@@ -94,8 +95,9 @@ void mobi_moflex_close(mobi_moflex *m);
 int mobi_moflex_read_packet(mobi_moflex *m);
 /* Pops the oldest completed frame; the data pointer stays valid until the next call on this handle.  1 = a frame, 0 = none. */
 int mobi_moflex_pop_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len);
-/* Convenience: ReadPacket() until a frame is available.  1 = a frame, 0 = the stream ended (code 73), <0 = demux error
- * (the negated ReadPacket code, or -1). */
+/* Convenience: ReadPacket() until a frame is available.  1 = a frame, 0 = the stream ended (code 73, or code 1: fewer than 14
+ * bytes left), <0 = demux error (the negated ReadPacket code, or -1; -0x43 also when a damaged packet makes the reader lose and
+ * regain synchronisation on the same bytes without ever advancing -- the reference's callers would spin there). */
 int mobi_moflex_next_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len);
 
 #ifdef __cplusplus

@@ -131,6 +131,10 @@ int mobi_batch_replay(mobi_batch *b, int frame_idx);
 int mobi_batch_sync(mobi_batch *b);
 /* command-list bytes the kernels read for frame `frame_idx`, summed over clips (roofline accounting) */
 uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx);
+/* of frame `frame_idx`, summed over clips: intra macroblocks, and the command-list bytes that belong to them (descriptor, block
+ * records, level words).  mobi_recon_inter8 neither reads those bytes nor touches those macroblocks' pixels: bench.py leaves them
+ * out of its algorithmic bytes */
+int mobi_batch_intra_stats(const mobi_batch *b, int frame_idx, uint64_t *n_intra_mbs, uint64_t *intra_cmd_bytes);
 /* milliseconds between two internally recorded HIP events bracketing the replay launches of the last
  * `mobi_batch_time_begin` .. `mobi_batch_time_end` region, measured on the batch's own stream */
 int mobi_batch_time_begin(mobi_batch *b);

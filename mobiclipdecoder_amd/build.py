@@ -4,6 +4,7 @@
   libmobi_streamgen.so    synthetic bitstream generator (input source)           (g++)
   oracle/_build/libmobi_oracle.so   CPU oracle = TEST INFRASTRUCTURE             (gcc)
   tests/tools/libmobi_cmdinterp.so  CPU command-list interpreter = TEST TOOL     (g++)
+  tests/tools/abi_caller            plain-C caller of the product's C ABI = TEST TOOL (gcc)
 
 hipcc cross-compiles gfx950 without a GPU.  The built .so files are git-ignored but travel to the
 GPU box with the gpurun snapshot.
@@ -23,6 +24,7 @@ LIB_HIP = os.path.join(PKG, "libmobiclip_hip.so")
 LIB_GEN = os.path.join(PKG, "libmobi_streamgen.so")
 LIB_ORACLE = os.path.join(ROOT, "oracle", "_build", "libmobi_oracle.so")
 LIB_INTERP = os.path.join(ROOT, "tests", "tools", "libmobi_cmdinterp.so")
+ABI_CALLER = os.path.join(ROOT, "tests", "tools", "abi_caller")  # plain-C caller of the product library (test tool)
 
 
 def _newer(target, sources):
@@ -89,8 +91,15 @@ def build_interp(force=False):
     return LIB_INTERP
 
 
+def build_caller(force=False):
+    src = os.path.join(ROOT, "tests", "tools", "abi_caller.c")
+    if force or _newer(ABI_CALLER, [src, os.path.join(ROOT, "include", "mobiclip_hip.h"), LIB_HIP]):
+        _run(["gcc", "-O2", "-std=c99", "-Wall", src, "-L" + PKG, "-lmobiclip_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath-link," + os.path.join(ROCM, "lib"), "-o", ABI_CALLER])
+    return ABI_CALLER
+
+
 def build_all(force=False):
-    return [build_hip(force), build_gen(force), build_oracle(force), build_interp(force)]
+    return [build_hip(force), build_gen(force), build_oracle(force), build_interp(force), build_caller(force)]
 
 
 if __name__ == "__main__":

@@ -109,11 +109,13 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
   std::vector<uint32_t> items;
   uint32_t n_items = 0;
   bool any_inter = false;
-  uint64_t cmd_bytes = 0;
+  uint64_t cmd_bytes = 0;       // descriptors + payload of every macroblock of the step
+  uint64_t intra_cmd_bytes = 0; // ... of the intra ones: descriptor, 24 block records, level words (the inter kernel never reads them)
   void build(const std::vector<const ParsedFrame *> &frames, int mbw) {
     uint32_t maxl = 0;
     any_inter = false;
     cmd_bytes = 0;
+    intra_cmd_bytes = 0;
     for (auto *f : frames)
       if (f) {
         maxl = std::max(maxl, f->hdr.n_levels);
@@ -137,6 +139,7 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
             if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) flags |= 2u;
           }
           flags |= (d.w2 & 0x3FFu) << 5;
+          intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + (d.w2 & 0x3FFu));
           if (mb % (uint32_t)mbw) flags |= 8u; // finish_levels flagged the left neighbour: its last column is in the edge side buffer
           items.push_back(MOBI_ITEM(c, mb));
           items.push_back(d.w1);
@@ -370,6 +373,7 @@ extern "C" {
 // (uint32 x 4 per macroblock: descriptor, pixels+MC, residual, store drain) of the last inter launch
 int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
   if (!b || !b->d_prof) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(out, b->d_prof, n_words * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(b->d_prof, 0, n_words * 4)); // read and clear: the next read sees only the steps in between
@@ -384,6 +388,7 @@ float mobi_debug_hostparse_ms(const mobi_batch *b) { return b ? b->last_hostpars
 long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *items_out, uint32_t *res_out, uint32_t *payload_out, size_t payload_words) {
   if (!b || !b->d_pres) return MOBI_E_ARG;
   const size_t n = (size_t)b->n, n_mbs = (size_t)b->g.mbw * b->g.mbh;
+  HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (desc_out) HIP_TRY(hipMemcpy(desc_out, b->d_pdesc.p, n * n_mbs * sizeof(MbDesc), hipMemcpyDeviceToHost));
   if (items_out) HIP_TRY(hipMemcpy(items_out, b->d_pitems.p, n * n_mbs * 4, hipMemcpyDeviceToHost));
@@ -487,18 +492,28 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
   }
   if (b->g.mbw > 64) return MOBI_E_ARG;
-  if (!b->d_pstate) { // first use: zeroed decoder state (a new MobiclipDecoder), result array, tables
-    HIP_TRY(hipMalloc((void **)&b->d_pstate, sizeof(MobiDevState) * n));
-    HIP_TRY(hipMemset(b->d_pstate, 0, sizeof(MobiDevState) * n));
-    HIP_TRY(hipMalloc((void **)&b->d_pres, sizeof(MobiDevResult) * n));
-    HIP_TRY(hipMemset(b->d_pres, 0, sizeof(MobiDevResult) * n));
-    std::vector<uint8_t> blob(MOBI_DT_BYTES);
-    mobi_dparse_build_tables(b->version, blob.data());
-    HIP_TRY(hipMalloc((void **)&b->d_ptables, MOBI_DT_BYTES));
-    HIP_TRY(hipMemcpy(b->d_ptables, blob.data(), MOBI_DT_BYTES, hipMemcpyHostToDevice));
+  if (!b->d_pstate) { // first use: zeroed decoder state (a new MobiclipDecoder), result array, tables -- all of it or none of it
+    auto init = [&]() -> int {
+      HIP_TRY(hipMalloc((void **)&b->d_pres, sizeof(MobiDevResult) * n));
+      HIP_TRY(hipMemset(b->d_pres, 0, sizeof(MobiDevResult) * n));
+      std::vector<uint8_t> blob(MOBI_DT_BYTES);
+      mobi_dparse_build_tables(b->version, blob.data());
+      HIP_TRY(hipMalloc((void **)&b->d_ptables, MOBI_DT_BYTES));
+      HIP_TRY(hipMemcpy(b->d_ptables, blob.data(), MOBI_DT_BYTES, hipMemcpyHostToDevice));
+      if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
+      MobiDevState *st = nullptr;
+      HIP_TRY(hipMalloc((void **)&st, sizeof(MobiDevState) * n));
+      if (hipMemset(st, 0, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
+      b->d_pstate = st; // last: its presence means "initialised"
+      return MOBI_OK;
+    };
+    if (int e = init()) {
+      if (b->d_pres) { (void)hipFree(b->d_pres); b->d_pres = nullptr; }
+      if (b->d_ptables) { (void)hipFree(b->d_ptables); b->d_ptables = nullptr; }
+      return e;
+    }
     b->dev_quant.assign(n, 0);
     b->dev_yuvfmt.assign(n, 0);
-    if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
   }
   // 1. stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded]
   const auto t_stage0 = std::chrono::steady_clock::now();
@@ -566,7 +581,8 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
       HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
     }
-    b->pool->run(nh, [&](int j) { const int i = nd + j; rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]); });
+    static const uint8_t kNoData2[2] = {0, 0};
+    b->pool->run(nh, [&](int j) { const int i = nd + j; rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData2, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); });
     std::vector<size_t> pbase(nh + 1, 0);
     for (int j = 0; j < nh; j++) pbase[j + 1] = pbase[j] + (rc[nd + j] == MOBI_OK ? b->cur[nd + j].payload.size() : 0);
     if (pbase[nh] > (size_t)nh * cap_words) return MOBI_E_DEVICE; // cannot happen: cap_words bounds any clip's payload
@@ -672,7 +688,8 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   std::vector<const ParsedFrame *> ok(n, nullptr);
   bool any_version_error = false;
   const auto t_parse0 = std::chrono::steady_clock::now();
-  b->pool->run(n, [&](int i) { rc[i] = b->parsers[i]->parse_frame(data[i], len[i], &offsets[i], b->cur[i]); });
+  static const uint8_t kNoData[2] = {0, 0};
+  b->pool->run(n, [&](int i) { rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); }); // Data == null: nothing readable, as Data.Length == 0
   b->last_hostparse_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
   for (int i = 0; i < n; i++) {
     if (rc[i] == MOBI_OK) ok[i] = &b->cur[i];
@@ -683,6 +700,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
+  if (step_payload_words(ok) + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
   LevelPlan plan;
   plan.build(ok, b->g.mbw);
   // 2. stage [desc table][payload arena][items] and upload
@@ -807,16 +825,17 @@ int mobi_batch_n_clips(const mobi_batch *b) { return b ? b->n : 0; }
 // ---- pre-parsed replay -----------------------------------------------------------------------------
 int mobi_batch_preload(mobi_batch *b, int clip, const uint8_t *data, size_t len, const uint32_t *frame_off, int n_frames, int *rc_per_frame) {
   if (!b || clip < 0 || clip >= b->n || !data || !frame_off || n_frames < 1) return MOBI_E_ARG;
+  for (int f = 0; f < n_frames; f++) // every frame boundary is checked before anything of the clip's staged state is replaced
+    if (frame_off[f + 1] > len || frame_off[f] > frame_off[f + 1]) return MOBI_E_ARG;
   if (b->staged.empty()) { b->staged.resize(b->n); b->staged_rc.resize(b->n); }
   b->committed = false;
   b->staged[clip] = std::make_shared<std::vector<ParsedFrame>>(n_frames);
-  b->staged_rc[clip] = std::make_shared<std::vector<int>>(n_frames, MOBI_OK);
+  b->staged_rc[clip] = std::make_shared<std::vector<int>>(n_frames, MOBI_E_ARG); // "not parsed": commit never executes such a frame
   auto &dst = *b->staged[clip];
   auto &rcs = *b->staged_rc[clip];
   MobiStreamParser parser((uint32_t)b->g.width, (uint32_t)b->g.height, b->version); // fresh decoder state for this clip
   int worst = MOBI_OK;
   for (int f = 0; f < n_frames; f++) {
-    if (frame_off[f + 1] > len || frame_off[f] > frame_off[f + 1]) return MOBI_E_ARG;
     int32_t off = (int32_t)frame_off[f];
     int rc = parser.parse_frame(data, frame_off[f + 1], &off, dst[f]);
     rcs[f] = rc;
@@ -853,7 +872,8 @@ int mobi_batch_commit(mobi_batch *b) {
   for (int f = 0; f < nf; f++) {
     auto &ok = per_frame[f];
     for (int c = 0; c < n; c++)
-      if ((*b->staged_rc[c])[f] == MOBI_OK) ok[c] = &(*b->staged[c])[f];
+      if ((*b->staged_rc[c])[f] == MOBI_OK && (int)(*b->staged[c])[f].desc.size() == n_mbs) ok[c] = &(*b->staged[c])[f]; // never a frame no parse filled
+    if (step_payload_words(ok) + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // 32-bit word offsets (split the batch)
     b->r_desc_off[f] = cmd_bytes;
     b->r_payload_off[f] = cmd_bytes + desc_bytes;
     cmd_bytes += desc_bytes + align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
@@ -890,6 +910,7 @@ int mobi_batch_commit(mobi_batch *b) {
 }
 int mobi_batch_replay(mobi_batch *b, int frame_idx) {
   if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
   b->ring_base = (b->ring_base + 1) % 6;
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
@@ -912,8 +933,15 @@ uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx) {
   if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return 0;
   return b->r_plan[frame_idx].cmd_bytes;
 }
+int mobi_batch_intra_stats(const mobi_batch *b, int frame_idx, uint64_t *n_intra_mbs, uint64_t *intra_cmd_bytes) {
+  if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
+  if (n_intra_mbs) *n_intra_mbs = b->r_plan[frame_idx].n_items;
+  if (intra_cmd_bytes) *intra_cmd_bytes = b->r_plan[frame_idx].intra_cmd_bytes;
+  return MOBI_OK;
+}
 int mobi_batch_time_begin(mobi_batch *b) {
   if (!b) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
   b->acc_ms[0] = b->acc_ms[1] = 0;
   b->acc_launches[0] = b->acc_launches[1] = 0;
   HIP_TRY(hipEventRecord(b->ev_begin, b->stream));
@@ -921,6 +949,7 @@ int mobi_batch_time_begin(mobi_batch *b) {
 }
 int mobi_batch_time_end(mobi_batch *b, float *ms_out) {
   if (!b || !ms_out) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipEventRecord(b->ev_end, b->stream));
   HIP_TRY(hipEventSynchronize(b->ev_end));
   HIP_TRY(hipEventElapsedTime(ms_out, b->ev_begin, b->ev_end));
@@ -934,6 +963,7 @@ int mobi_batch_set_kernel_timing(mobi_batch *b, int enable) {
 }
 int mobi_batch_kernel_ms(mobi_batch *b, float *inter_ms, float *intra_ms, int *inter_launches, int *intra_launches) {
   if (!b) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->drain_events();
   if (inter_ms) *inter_ms = b->acc_ms[0];

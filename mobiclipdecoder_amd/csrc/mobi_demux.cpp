@@ -2,6 +2,7 @@
 // Restated from LibMobiclip/Containers/Mods/ModsDemuxer.cs and MobiclipDecoder/Form1.cs:282-320; no GPU involved.
 #include "../../include/mobiclip_demux.h"
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -118,9 +119,10 @@ int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_
   const uint32_t bs = rd32(file + *offs);
   if (block_size) *block_size = bs;
   if (decode_offset) *decode_offset = (int32_t)(*offs + 8);
-  uint32_t o = *offs + 4 + (bs & ~1u);
-  while (o % 4) o++;
-  *offs = o;
+  // (64-bit: a block size near 2^32 must not wrap the offset backwards and make the caller loop for ever)
+  const uint64_t o = ((uint64_t)*offs + 4 + (bs & ~1u) + 3) & ~(uint64_t)3;
+  if (o <= *offs || o > len + 3) return -1;
+  *offs = (uint32_t)std::min<uint64_t>(o, 0xFFFFFFFFull);
   return 1;
 }
 

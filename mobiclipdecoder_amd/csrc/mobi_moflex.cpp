@@ -1,10 +1,26 @@
-// mobi_moflex.cpp -- Moflex (MoLive) demuxer, include/mobiclip_demux.h.
-// Restated from LibMobiclip/Containers/Moflex/MoLiveDemux.cs (ReadPacket :67, ReadSynchroChunk :164, ReadDataBlock :216,
-// ReadEp :266, ReadSynchroHeader :377), MoLive.cs (ReadVariableByte :38), MoLiveInBitStream.cs (Pop :18) and the stream
-// chunk readers (MoLiveStreamVideo.cs :33, ...WithLayout.cs :27, ...Audio.cs :16, ...Timeline.cs :14).  The file in memory
-// plays the Stream: Read() copies what is left, Position moves as in the source.  C# semantics kept on purpose: shift
-// counts are masked (& 63 for 64-bit, & 31 for 32-bit operands), uint arithmetic wraps, Dictionary.Add on an existing
-// key and reads past an array are exceptions (-> return -1).
+// mobi_moflex.cpp -- reader for the Moflex ("MoLive") container of 3DS Mobiclip files, include/mobiclip_demux.h.
+//
+// Written from the container grammar below; the reference's reader (LibMobiclip/Containers/Moflex/MoLiveDemux.cs:67-414, with
+// MoLive.cs:34-51, MoLiveInBitStream.cs:16-54 and the MoLiveStream*.cs chunk classes) is the authority for the grammar, the
+// return codes (callers stop on 73, Program.cs:164-166) and the corner cases named in the comments.
+//
+//   file    := packet*                       all packets have the size the last sync header announced (or the header-less
+//                                            default window of 4096 bytes before the first one)
+//   packet  := [sync] block ep* [pad]
+//   sync    := 'L' '2'  check:u16be  time:u64be  (size-1):u16be  chunk*        14 bytes + chunks
+//              check = the four 16-bit words of `time` XORed together, XOR 0xAAAA; bit 63 of `time` flags a reference
+//              time stamp and does not take part in the check
+//   chunk   := type:varint  size:varint  body[size]        type 0 ends the list (its body is skipped);
+//              1 video (12 bytes) / 3 video with layout (13): stream u8, codec u8, fps rate, fps scale, width, height u16be,
+//              pel ratio rate, scale u8 [, layout | rotation << 4 : u8]; 2 audio (6): stream, codec, (frequency - 1):u24be,
+//              (channels - 1):u8; 4 timeline (2): stream, associated stream.  A stream chunk opens an endpoint for its stream index.
+//   varint  := 1..4 bytes, 7 bits each, most significant first, bit 7 = "one more"; a fourth byte gives all its 8 bits
+//   block   := flags:u8 [counter:u16be]      bit 0: packets vary in size; bit 1: a packet counter follows; bits 7..2: sync counter
+//   ep      := header payload[size]          header, MSB first, padded to a byte: stream index as (unary length n, n bits);
+//              end-of-frame bit; if set: frame type (unary length, bits), a time stamp (sign bit, unary length 28 + 2k, bits);
+//              (size - 1):13 bits.  The payload is appended to the stream's frame; end-of-frame appends two zero bytes and
+//              hands the frame out.
+//   pad     := 0x00 ...                      a zero byte where an ep would start: the rest of a fixed-size packet is padding
 #include "../../include/mobiclip_demux.h"
 
 #include <cstring>
@@ -14,283 +30,296 @@
 #include <vector>
 
 namespace {
-struct Thrown {}; // "the reference would have thrown here"
-inline uint64_t shl64(uint64_t v, int n) { return v << (n & 63); }
-inline uint64_t shr64(uint64_t v, int n) { return v >> (n & 63); }
 
-struct Bytes { // byte[] with bounds checks
-  const uint8_t *p; size_t n;
-  uint8_t at(size_t i) const { if (i >= n) throw Thrown{}; return p[i]; }
-};
-inline uint32_t u16be(const Bytes &b, size_t o) { return ((uint32_t)b.at(o) << 8) | b.at(o + 1); }
-inline uint32_t u24be(const Bytes &b, size_t o) { return ((uint32_t)b.at(o) << 16) | ((uint32_t)b.at(o + 1) << 8) | b.at(o + 2); }
-inline uint32_t u32be(const Bytes &b, size_t o) { return (u16be(b, o) << 16) | u16be(b, o + 2); }
+struct Escape {}; // managed code would have thrown here (read past the byte[] it holds, duplicate dictionary key, Pop(> 64))
 
-struct BitStream { // MoLiveInBitStream.cs:10-56
-  uint64_t Value = 0; uint32_t Remaining = 0; Bytes Stream{nullptr, 0}; uint32_t Pos = 0;
-  uint64_t Pop(int NrBits) {
-    if (NrBits > 64) throw Thrown{};
-    const uint32_t v5 = 64 - ((64 - Remaining) & 7);
-    if ((uint32_t)NrBits > v5) {
-      const uint32_t v12 = (uint32_t)NrBits - v5;
-      if (Remaining < v5) {
-        do { Value |= shl64((uint64_t)Stream.at(Pos++), (int)(56 - Remaining)); Remaining += 8; } while (Remaining < v5);
-      }
-      const uint8_t data = Stream.at(Pos++);
-      const uint64_t res1 = shl64(shr64(Value, (int)(64 - v5)), (int)v12);
-      Value = shl64((uint64_t)data, (int)(v12 + 56));
-      Remaining = 8 - v12;
-      return res1 | shr64((uint64_t)data, (int)(8 - v12));
-    }
-    if (Remaining < (uint32_t)NrBits) {
-      do { Value |= shl64((uint64_t)Stream.at(Pos++), (int)(56 - Remaining)); Remaining += 8; } while (Remaining < (uint32_t)NrBits);
-    }
-    const uint64_t v10 = shr64(Value, 64 - NrBits);
-    Value = shl64(Value, NrBits);
-    Remaining -= (uint32_t)NrBits;
-    return v10;
+// What one ReadPacket() call can see: `n` bytes of the file starting at the reader position.  Indexing past it is the
+// reference's IndexOutOfRangeException.
+struct Window {
+  const uint8_t *p = nullptr;
+  size_t n = 0;
+  uint8_t operator[](size_t i) const {
+    if (i >= n) throw Escape{};
+    return p[i];
+  }
+  uint32_t be16(size_t i) const { return (uint32_t)(*this)[i] << 8 | (*this)[i + 1]; }
+  uint32_t be24(size_t i) const { return be16(i) << 8 | (*this)[i + 2]; }
+  uint64_t be64(size_t i) const {
+    uint64_t v = 0;
+    for (int k = 0; k < 8; k++) v = v << 8 | (*this)[i + k];
+    return v;
   }
 };
 
-bool ReadVariableByte(const Bytes &src, uint32_t &value, uint32_t &pos, uint32_t psize) { // MoLive.cs:38-55
+// Bits, most significant first.  A byte is fetched only when a bit of it is needed, so `next_byte` is where byte-aligned
+// data continues after a header (MoLiveInBitStream.Pop consumes exactly the same bytes for reads of up to 64 bits).
+class BitReader {
+ public:
+  BitReader(const Window &w, size_t at) : w_(w), next_byte(at) {}
+  uint64_t take(int n) {
+    if (n > 64) throw Escape{}; // Pop: ArgumentException
+    uint64_t v = 0;
+    while (n > 0) {
+      if (have_ == 0) { cur_ = w_[next_byte++]; have_ = 8; }
+      const int k = n < have_ ? n : have_;
+      v = v << k | ((uint64_t)(cur_ >> (have_ - k)) & ((1u << k) - 1u));
+      have_ -= k;
+      n -= k;
+    }
+    return v;
+  }
+  int unary() { // zeros before the first one bit
+    int z = 0;
+    while (take(1) == 0) z++;
+    return z;
+  }
+
+ private:
+  const Window &w_;
+  uint32_t cur_ = 0;
+  int have_ = 0;
+
+ public:
+  size_t next_byte;
+};
+
+struct SyncHeader {
+  uint64_t time = 0;
+  uint32_t packet_size = 0; // as the reference keeps it: a ushort (0xFFFF + 1 wraps to 0)
+};
+enum { kSyncBytes = 14, kDefaultWindow = 0x1000, kNoSyncCounter = 64, kNoPacketCounter = 65536 };
+
+bool parse_sync(const Window &w, size_t at, SyncHeader &h) {
+  if (w[at] != 'L' || w[at + 1] != '2') return false;
+  const uint32_t check = w.be16(at + 2);
+  const uint64_t t = w.be64(at + 4);
+  h.time = t;
+  h.packet_size = (w.be16(at + 12) + 1) & 0xFFFFu;
+  // the reference-time flag (bit 63) stays out of the check word -- except for the one value 0x80000000_xxxxxxxx whose upper
+  // half the reference's signed test ((int)(hi - 1) < 0) lets through unmasked
+  const uint32_t hi = (uint32_t)(t >> 32), folded = ((hi - 1u) & 0x80000000u) ? hi & 0x7FFFFFFFu : hi;
+  const uint32_t sum = (uint32_t)(t & 0xFFFF) ^ (uint32_t)(t >> 16 & 0xFFFF) ^ (folded & 0xFFFF) ^ (folded >> 16) ^ 0xAAAAu;
+  return check == sum;
+}
+// the time stamp as the demuxer uses it: flag bit dropped (same signed quirk: 0x8000000000000000 itself keeps it)
+uint64_t plain_time(uint64_t t) { return ((t - 1u) >> 63) ? t & 0x7FFFFFFFFFFFFFFFull : t; }
+
+bool read_varint(const Window &w, uint32_t &value, uint32_t &pos, uint32_t limit) {
   value = 0;
-  if (pos == psize) return false;
-  uint8_t data = src.at(pos++);
-  if ((data & 0x80) == 0) { value = data; return true; }
-  if (pos == psize) return false;
-  value = (uint32_t)(data & 0x7F) << 7;
-  data = src.at(pos++);
-  if ((data & 0x80) == 0) { value |= data; return true; }
-  if (pos == psize) return false;
-  value = ((uint32_t)(data & 0x7F) | value) << 7;
-  data = src.at(pos++);
-  if ((data & 0x80) == 0) { value |= data; return true; }
-  if (pos == psize) return false;
-  value = (((uint32_t)(data & 0x7F) | value) << 7) | src.at(pos++);
+  for (int k = 0; k < 4; k++) {
+    if (pos == limit) return false;
+    const uint8_t b = w[pos++];
+    if (k == 3) { value |= b; return true; } // all 8 bits of the fourth byte, OR-ed onto the 21 bits already shifted up by 7 (MoLive.cs:49)
+    if (!(b & 0x80)) { value |= b; return true; }
+    value = (value | (b & 0x7Fu)) << 7;
+  }
   return true;
 }
 
-bool ReadSynchroHeader(const Bytes &packet, int offset, uint64_t &ts, uint16_t &packetSize) { // MoLiveDemux.cs:377-414
-  ts = 0;
-  packetSize = 0;
-  if (!(packet.at(offset) == 0x4C && packet.at(offset + 1) == 0x32)) return false;
-  offset += 2;
-  const uint32_t v10 = u16be(packet, offset);
-  offset += 2;
-  const uint32_t v13 = (u32be(packet, offset) & 0xFFFFFF00u) | packet.at(offset + 3);
-  offset += 4;
-  const uint32_t v12 = (uint32_t)packet.at(offset++) << 24;
-  const uint32_t v14 = packet.at(offset++);
-  const uint32_t v15 = v12 | (v14 << 16);
-  const uint32_t v16 = v13 | (v14 >> 16);
-  const uint32_t v17 = packet.at(offset++);
-  ts = (uint64_t)(v15 | (v17 << 8) | (uint32_t)packet.at(offset++)) | ((uint64_t)(v16 | (v17 >> 24)) << 32);
-  uint32_t v19 = (uint32_t)(ts >> 32);
-  if ((int32_t)(uint32_t)((ts >> 32) - 1) < 0) v19 &= 0x7FFFFFFFu;
-  packetSize = (uint16_t)(u16be(packet, offset) + 1);
-  return v10 == (uint32_t)(((ts >> 16) & 0xFFFF) ^ (v19 >> 16) ^ 0xAAAA ^ (v19 & 0xFFFF) ^ (ts & 0xFFFF));
-}
+struct Endpoint {
+  mobi_moflex_stream info;
+  std::vector<uint8_t> frame; // payloads of the frame being assembled
+};
 
-struct Endpoint { mobi_moflex_stream chunk; std::vector<uint8_t> data; };
-struct Frame { mobi_moflex_stream chunk; std::vector<uint8_t> data; };
 } // namespace
 
 struct mobi_moflex {
-  const uint8_t *file = nullptr; size_t len = 0; size_t position = 0; // Reader
-  uint64_t Gts = 0, DeltaGts = 0;
-  uint32_t PacketSize = 0, SynchroCounter = 64, LastCounter = 0;
-  bool VariablePacketSize = true, HasReferenceTs = false, Synchronized = false, ReaderIsDatagramBased = false;
-  std::map<int, Endpoint> Streams;
-  std::deque<Frame> done;
-  Frame current; // what mobi_moflex_pop_frame handed out last
+  const uint8_t *file = nullptr;
+  size_t len = 0, pos = 0;
+  // demuxer state (MoLiveDemux.cs:22-33, :56-65)
+  bool in_sync = false;
+  uint32_t packet_size = 0;
+  uint64_t last_time = 0, time_step = 0;       // Gts, DeltaGts
+  uint32_t sync_counter = kNoSyncCounter, packet_counter = kNoPacketCounter;
+  bool variable_size = false;
+  std::map<int, Endpoint> streams;
+  // frames handed out
+  struct Frame { mobi_moflex_stream info; std::vector<uint8_t> data; };
+  std::deque<Frame> ready;
+  Frame current;
 
-  void Desynchronize() { // :54-65
-    Gts = 0; DeltaGts = 0; SynchroCounter = 64; LastCounter = 65536; Synchronized = false; Streams.clear();
+  void lose_sync() { // Desynchronize(), :56-65
+    last_time = time_step = 0;
+    sync_counter = kNoSyncCounter;
+    packet_counter = kNoPacketCounter;
+    in_sync = false;
+    streams.clear();
   }
 
-  uint32_t ReadSynchroChunk(const Bytes &packet, uint32_t &pos, uint32_t psize) { // :164-214
+  // ---- stream table -------------------------------------------------------------------------------------------------
+  // A chunk body is parsed against the WHOLE window, like chunk.Read(packet, pos): fields that do not fit stay 0 and the
+  // chunk is accepted all the same (Read returns -1, the caller only rejects 0).
+  static mobi_moflex_stream parse_stream(uint32_t type, const Window &w, size_t at) {
+    mobi_moflex_stream s;
+    std::memset(&s, 0, sizeof(s));
+    s.chunk_id = type;
+    s.stream_index = w[at];
+    if (at + 1 >= w.n) return s;
+    if (type == 4) { s.associated_stream_index = w[at + 1]; return s; }
+    s.codec_id = w[at + 1];
+    const size_t body = at + 2, left = w.n - body;
+    if (type == 2) {
+      if (left < 4) return s;
+      s.frequency = w.be24(body) + 1;
+      s.channel = (uint32_t)w[body + 3] + 1;
+      return s;
+    }
+    if (left < 10) return s;
+    s.fps_rate = w.be16(body);
+    s.fps_scale = w.be16(body + 2);
+    s.width = w.be16(body + 4);
+    s.height = w.be16(body + 6);
+    if (type == 1) {
+      s.pel_ratio_rate = w[body + 8];
+      s.pel_ratio_scale = w[body + 9];
+      return s;
+    }
+    s.pel_ratio_rate = w[body + 9]; // MoLiveStreamVideoWithLayout.cs:40-41 stores both bytes into PelRatioRate: the scale stays 0
+    if (body + 10 >= w.n) return s;
+    s.image_layout = w[body + 10] & 0xF;
+    s.image_rotation = w[body + 10] >> 4;
+    return s;
+  }
+  // one chunk of the list behind a sync header; 0x100 = the terminator was read
+  uint32_t read_chunk(const Window &w, uint32_t &pos, uint32_t limit) {
     uint32_t type, size;
-    if (!ReadVariableByte(packet, type, pos, psize) || !ReadVariableByte(packet, size, pos, psize)) { Desynchronize(); return 0x43; }
-    mobi_moflex_stream c;
-    memset(&c, 0, sizeof(c));
-    c.stream_index = -1;
-    uint32_t chunk_size;
+    if (!read_varint(w, type, pos, limit) || !read_varint(w, size, pos, limit)) { lose_sync(); return 0x43; }
+    if (type == 0) { pos += size; return 0x100; }
+    uint32_t want;
     switch (type) {
-      case 0: pos += size; return 0x100;
-      case 1: c.chunk_id = 1; chunk_size = 12; break;
-      case 2: c.chunk_id = 2; chunk_size = 6; break;
-      case 3: c.chunk_id = 3; chunk_size = 13; break;
-      case 4: c.chunk_id = 4; chunk_size = 2; break;
-      case 0x100000: throw Thrown{}; // MoLiveChunkFoo.Read: NotImplementedException
+      case 1: want = 12; break;
+      case 2: want = 6; break;
+      case 3: want = 13; break;
+      case 4: want = 2; break;
+      case 0x100000: want = 20; break;
       default: return 0x44;
     }
-    if (chunk_size != size) return 0x45;
-    // chunk.Read(packet, pos): -1 (not an error for the caller, which only tests == 0) or the end offset
-    int offset = (int)pos;
-    auto rd = [&]() -> int {
-      if (packet.n == 0) return -1;
-      c.stream_index = packet.at(offset++);
-      if ((size_t)offset >= packet.n) return -1;
-      if (type == 4) { c.associated_stream_index = packet.at(offset++); return offset; }
-      c.codec_id = packet.at(offset++);
-      if (type == 2) {
-        if ((long)packet.n - offset < 0x4) return -1;
-        c.frequency = u24be(packet, offset) + 1;
-        c.channel = (uint32_t)packet.at(offset + 3) + 1;
-        return offset + 4;
-      }
-      if ((long)packet.n - offset < 0xA) return -1;
-      c.fps_rate = u16be(packet, offset);
-      c.fps_scale = u16be(packet, offset + 2);
-      c.width = u16be(packet, offset + 4);
-      c.height = u16be(packet, offset + 6);
-      c.pel_ratio_rate = packet.at(offset + 8);
-      c.pel_ratio_scale = packet.at(offset + 9);
-      if (type == 3) c.pel_ratio_rate = packet.at(offset + 9); // MoLiveStreamVideoWithLayout.cs:40-41 assigns PelRatioRate twice; PelRatioScale stays 0
-      if (type == 3) c.pel_ratio_scale = 0;
-      offset += 0xA;
-      if (type == 3) {
-        if ((size_t)offset >= packet.n) return -1;
-        c.image_layout = packet.at(offset) & 0xF;
-        c.image_rotation = packet.at(offset) >> 4;
-        offset++;
-      }
-      return offset;
-    };
-    if (rd() == 0) return 0x45;
-    if (Streams.count(c.stream_index)) throw Thrown{}; // Dictionary.Add: ArgumentException
-    Streams[c.stream_index] = Endpoint{c, {}};
+    if (want != size) return 0x45;
+    if (type == 0x100000) throw Escape{}; // MoLiveChunkFoo.Read: NotImplementedException
+    const mobi_moflex_stream s = parse_stream(type, w, pos);
+    if (streams.count(s.stream_index)) throw Escape{}; // Dictionary.Add: the key exists
+    streams[s.stream_index].info = s;
     pos += size;
-    if (pos <= psize) return 0;
-    Desynchronize();
+    if (pos <= limit) return 0;
+    lose_sync();
     return 0x43;
   }
 
-  uint32_t ReadDataBlock(const Bytes &packet, uint32_t &pos, uint32_t psize) { // :216-259
-    if (pos >= psize) { Desynchronize(); return 67; }
-    const uint8_t flags = packet.at(pos++);
-    VariablePacketSize = (flags & 1) == 1;
-    const bool PacketCounting = ((flags >> 1) & 1) == 1;
-    const uint32_t synchrocounter = (uint32_t)(flags >> 2);
-    if (SynchroCounter == 64) SynchroCounter = synchrocounter;
-    else if (SynchroCounter != synchrocounter) {
-      if (DeltaGts == 0) { Desynchronize(); return 70; }
-      Gts += (uint64_t)(synchrocounter - SynchroCounter) * DeltaGts;
-      SynchroCounter = synchrocounter;
-      for (auto &kv : Streams) kv.second.data.clear();
+  // ---- data block ---------------------------------------------------------------------------------------------------
+  uint32_t read_block(const Window &w, uint32_t &pos, uint32_t limit) {
+    if (pos >= limit) { lose_sync(); return 67; }
+    const uint8_t flags = w[pos++];
+    variable_size = flags & 1;
+    const bool counted = flags & 2;
+    const uint32_t counter = flags >> 2;
+    if (sync_counter == kNoSyncCounter) sync_counter = counter;
+    else if (sync_counter != counter) {                 // sync headers were skipped: move the clock on, drop partial frames
+      if (time_step == 0) { lose_sync(); return 70; }
+      last_time += (uint64_t)(uint32_t)(counter - sync_counter) * time_step;
+      sync_counter = counter;
+      for (auto &kv : streams) kv.second.frame.clear();
     }
-    if (PacketCounting) {
-      const uint32_t val = u16be(packet, pos);
+    if (counted) {
+      const uint32_t seen = w.be16(pos);
       pos += 2;
-      if (pos > psize) { Desynchronize(); return 67; }
-      const uint32_t expectedval = LastCounter == 65536 ? val : LastCounter + 1;
-      if (expectedval != val) { LastCounter = 65536; return 0x50; }
-      LastCounter = val;
+      if (pos > limit) { lose_sync(); return 67; }
+      if (packet_counter != kNoPacketCounter && packet_counter + 1 != seen) { packet_counter = kNoPacketCounter; return 0x50; }
+      packet_counter = seen;
     }
     return 0;
   }
 
-  uint32_t ReadEp(const Bytes &packet, uint32_t &pos, uint32_t psize) { // :266-375
-    if (pos == psize) return 0x101;
-    if (pos > psize) { Desynchronize(); return 0x43; }
-    const uint8_t tmp = packet.at(pos);
-    if (tmp == 0) {
+  // ---- elementary packets -------------------------------------------------------------------------------------------
+  // 0 = one ep consumed and more may follow, 0x101 = the packet is finished
+  uint32_t read_ep(const Window &w, uint32_t &pos, uint32_t limit) {
+    if (pos == limit) return 0x101;
+    if (pos > limit) { lose_sync(); return 0x43; }
+    if (w[pos] == 0) { // padding
       pos++;
-      if (!VariablePacketSize) pos = PacketSize;
+      if (!variable_size) pos = packet_size;
       return 0x101;
     }
-    int NrStreamIdxBits = 1;
-    BitStream bs;
-    bs.Stream = packet;
-    bs.Pos = pos;
-    while (bs.Pop(1) == 0) NrStreamIdxBits++;
-    const int StreamIdx = (int)bs.Pop(NrStreamIdxBits);
-    const bool EndFrame = bs.Pop(1) == 1;
-    if (EndFrame) { // frame type and time stamp delta: parsed, not used (:303-318)
-      int FrameTypeNrBits = 1;
-      while (bs.Pop(1) == 0) FrameTypeNrBits++;
-      (void)bs.Pop(FrameTypeNrBits);
-      int v23 = 28;
-      (void)bs.Pop(1);
-      while (bs.Pop(1) == 0) v23 += 2;
-      (void)bs.Pop(v23);
+    BitReader bits(w, pos);
+    const int index_bits = bits.unary() + 1;
+    const int stream = (int)bits.take(index_bits);
+    const bool end_of_frame = bits.take(1) == 1;
+    if (end_of_frame) {               // frame type and time stamp: read and dropped, as in the reference
+      (void)bits.take(bits.unary() + 1);
+      (void)bits.take(1);
+      (void)bits.take(28 + 2 * bits.unary());
     }
-    const int EPSize = (int)bs.Pop(0xD) + 1;
-    pos = bs.Pos;
-    if (pos + (uint32_t)EPSize > psize) { Desynchronize(); return 0x43; }
-    if ((size_t)pos + (size_t)EPSize > packet.n) throw Thrown{}; // Array.Copy past the buffer
-    auto it = Streams.find(StreamIdx);
-    if (it != Streams.end()) it->second.data.insert(it->second.data.end(), packet.p + pos, packet.p + pos + EPSize);
-    pos += (uint32_t)EPSize;
-    if (EndFrame && it != Streams.end()) {
-      it->second.data.push_back(0); // AddData(new byte[2]), :353
-      it->second.data.push_back(0);
-      done.push_back(Frame{it->second.chunk, it->second.data}); // OnCompleteFrameReceived(Chunk, GetData())
-      it->second.data.clear();
+    const uint32_t size = (uint32_t)bits.take(13) + 1;
+    pos = (uint32_t)bits.next_byte;
+    if (pos + size > limit) { lose_sync(); return 0x43; }
+    auto it = streams.find(stream);
+    if (it != streams.end()) it->second.frame.insert(it->second.frame.end(), w.p + pos, w.p + pos + size);
+    pos += size;
+    if (end_of_frame && it != streams.end()) {
+      Frame f;
+      f.info = it->second.info;
+      f.data.swap(it->second.frame);
+      f.data.push_back(0); // what the decoder's 16-bit read-ahead may touch behind the last code (MoLiveDemux.cs:353)
+      f.data.push_back(0);
+      ready.push_back(std::move(f));
     }
-    if (pos < psize) return 0;
-    return 0x101;
+    return pos < limit ? 0 : 0x101;
   }
 
-  uint32_t ReadPacket() { // :67-160
-    uint64_t ts;
-    uint16_t packetsize;
-    const size_t want = PacketSize == 0 ? 0x1000 : PacketSize;
-    std::vector<uint8_t> buf(want, 0);
-    const size_t avail = position < len ? len - position : 0;
-    const int length = (int)(avail < want ? avail : want); // Reader.Read; Position is put back right away
-    if (length) memcpy(buf.data(), file + position, (size_t)length);
-    const Bytes packet{buf.data(), buf.size()};
-    if (!Synchronized) {
-      if (length < 0xE) return 1;
-      int offset = 0;
-      while (!ReadSynchroHeader(packet, offset, ts, packetsize)) {
-        offset++;
-        if (offset == length - 0xE) return 0x80;
+  // ---- one packet ---------------------------------------------------------------------------------------------------
+  uint32_t read_packet() {
+    Window w;
+    const size_t want = packet_size ? packet_size : kDefaultWindow;
+    w.p = file + pos;
+    w.n = pos < len ? (want < len - pos ? want : len - pos) : 0;
+    const uint32_t length = (uint32_t)w.n;
+    SyncHeader h;
+    if (!in_sync) { // look for a header whose check word fits
+      if (length < kSyncBytes) return 1;
+      uint32_t at = 0;
+      while (!parse_sync(w, at, h)) {
+        at++;
+        if (at == length - kSyncBytes) return 0x80; // none in this window
       }
-      if ((int64_t)ts - 1 < 0) { HasReferenceTs = true; ts &= 0x7FFFFFFFFFFFFFFFull; } else HasReferenceTs = false;
-      if (packetsize < 0x10) return 73;
-      Synchronized = true;
-      position += (size_t)offset;
+      if (h.packet_size < 0x10) return 73;
+      in_sync = true;
+      pos += at;
       return 0;
     }
-    if (!ReaderIsDatagramBased && PacketSize != 0 && PacketSize != (uint32_t)length) return 73;
-    uint32_t offset2 = 0;
-    if (length > 0xE && ReadSynchroHeader(packet, 0, ts, packetsize)) {
-      if ((int64_t)ts - 1 < 0) { HasReferenceTs = true; ts &= 0x7FFFFFFFFFFFFFFFull; } else HasReferenceTs = false;
-      if (packetsize < 0x10) return 73;
-      if (ts != 0) {
-        if (Gts != 0 && DeltaGts == 0) DeltaGts = ts - Gts;
-        Gts = ts;
-        Streams.clear();
+    if (packet_size != 0 && packet_size != length) return 73; // a short last packet: the end of the file for the callers
+    uint32_t cur = 0;
+    if (length > kSyncBytes && parse_sync(w, 0, h)) {
+      if (h.packet_size < 0x10) return 73;
+      const uint64_t t = plain_time(h.time);
+      if (t != 0) {
+        if (last_time != 0 && time_step == 0) time_step = t - last_time;
+        last_time = t;
+        streams.clear(); // the chunks that follow list the streams again
       }
-      if (PacketSize != packetsize) {
-        const bool retry = (PacketSize == 0 ? 0x1000u : PacketSize) < packetsize;
-        PacketSize = packetsize;
-        if (retry) return 0;
+      if (packet_size != h.packet_size) {
+        const bool window_too_small = want < h.packet_size;
+        packet_size = h.packet_size;
+        if (window_too_small) return 0; // look at this packet again, whole
       }
-      offset2 = 0xE;
-      const uint32_t size = PacketSize > (uint32_t)length ? (uint32_t)length : PacketSize;
+      cur = kSyncBytes;
+      const uint32_t limit = packet_size > length ? length : packet_size;
       for (;;) {
-        const uint32_t result = ReadSynchroChunk(packet, offset2, size);
-        if (result == 0x100) break;
-        if (result != 0) return result;
+        const uint32_t r = read_chunk(w, cur, limit);
+        if (r == 0x100) break;
+        if (r != 0) return r;
       }
-      if (offset2 > (uint32_t)length) return 0x43;
+      if (cur > length) return 0x43;
     }
-    uint32_t result2 = ReadDataBlock(packet, offset2, (uint32_t)length);
-    if (!Synchronized) return 0;
-    if (result2 == 0) {
-      for (;;) {
-        result2 = ReadEp(packet, offset2, (uint32_t)length);
-        if (result2 == 0x101) break;
-        if (result2 != 0) return result2;
-      }
-      if (offset2 > (uint32_t)length) return 0x43;
-      position += offset2;
-      return 0;
+    uint32_t r = read_block(w, cur, length);
+    if (!in_sync) return 0;
+    if (r != 0) return r;
+    for (;;) {
+      r = read_ep(w, cur, length);
+      if (r == 0x101) break;
+      if (r != 0) return r;
     }
-    return result2;
+    if (cur > length) return 0x43;
+    pos += cur;
+    return 0;
   }
 };
 
@@ -305,28 +334,42 @@ mobi_moflex *mobi_moflex_open(const uint8_t *file, size_t len) {
   return m;
 }
 void mobi_moflex_close(mobi_moflex *m) { delete m; }
+
 int mobi_moflex_read_packet(mobi_moflex *m) {
   if (!m) return -1;
-  try { return (int)m->ReadPacket(); } catch (const Thrown &) { return -1; } catch (const std::bad_alloc &) { return -1; }
+  try {
+    return (int)m->read_packet();
+  } catch (const Escape &) {
+    return -1;
+  } catch (const std::bad_alloc &) {
+    return -1;
+  }
 }
 int mobi_moflex_pop_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len) {
-  if (!m || m->done.empty()) return 0;
-  m->current = std::move(m->done.front());
-  m->done.pop_front();
-  if (stream) *stream = m->current.chunk;
+  if (!m || m->ready.empty()) return 0;
+  m->current = std::move(m->ready.front());
+  m->ready.pop_front();
+  if (stream) *stream = m->current.info;
   if (data) *data = m->current.data.data();
   if (len) *len = m->current.data.size();
   return 1;
 }
 int mobi_moflex_next_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len) {
   if (!m) return -1;
+  int idle = 0; // calls in a row that neither moved the reader nor produced a frame
   for (;;) {
     if (mobi_moflex_pop_frame(m, stream, data, len)) return 1;
+    const size_t before = m->pos;
+    const uint32_t before_size = m->packet_size;
     const int rc = mobi_moflex_read_packet(m);
-    if (rc == 73) return m->done.empty() ? 0 : mobi_moflex_pop_frame(m, stream, data, len);
-    if (rc < 0) return -1;
-    if (rc != 0 && rc != 1 && rc != 0x50) return -rc; // 1: too little data yet / 0x50: packet counter gap -- the callers just keep reading
-    if (rc == 1) return m->done.empty() ? 0 : mobi_moflex_pop_frame(m, stream, data, len); // fewer than 14 bytes left before synchronisation: nothing more will come
+    if (rc == 73 || rc == 1) return 0; // a short last packet, or fewer than 14 bytes left to search: the stream is over
+    if (rc != 0) return rc < 0 ? rc : -rc;
+    // A damaged packet can make the reader lose and regain synchronisation on the same header for ever (ReadPacket returns 0
+    // both times and the position never moves; the reference's callers would spin).  Three idle calls cover the legitimate
+    // cases (sync found at offset 0, then the window enlarged, then the packet read); after that: give up.
+    if (m->pos == before && m->packet_size == before_size && m->ready.empty()) {
+      if (++idle >= 3) return -0x43;
+    } else idle = 0;
   }
 }
 

@@ -32,6 +32,9 @@ class MobiclipError(RuntimeError):
     pass
 
 
+MOBI_E_ARG = -7  # include/mobiclip_hip.h
+
+
 # names must match include/mobiclip_hip.h (tests/test_abi_symbols.py checks the header against the .so)
 _SIGS = {
     "mobi_create": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
@@ -64,6 +67,7 @@ _SIGS = {
     "mobi_batch_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "mobi_batch_sync": (C.c_int, [C.c_void_p]),
     "mobi_batch_cmd_bytes": (C.c_uint64, [C.c_void_p, C.c_int]),
+    "mobi_batch_intra_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mobi_batch_time_begin": (C.c_int, [C.c_void_p]),
     "mobi_batch_time_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mobi_batch_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -286,7 +290,9 @@ class MobiclipBatch:
         fo = np.ascontiguousarray(frame_off, dtype=np.uint32)
         n_frames = fo.size - 1
         rcs = (C.c_int * n_frames)()
-        self._lib.mobi_batch_preload(self._h, clip, buf.ctypes.data, buf.size, fo.ctypes.data, n_frames, rcs)
+        rc = self._lib.mobi_batch_preload(self._h, clip, buf.ctypes.data, buf.size, fo.ctypes.data, n_frames, rcs)
+        if rc == MOBI_E_ARG:  # bad clip index / frame offsets: nothing was staged (a stream error comes back per frame instead)
+            raise MobiclipError(error_string(rc))
         return list(rcs)
 
     def preload_clone(self, clip, src):
@@ -309,6 +315,14 @@ class MobiclipBatch:
 
     def cmd_bytes(self, frame_idx):
         return int(self._lib.mobi_batch_cmd_bytes(self._h, frame_idx))
+
+    def intra_stats(self, frame_idx):
+        """(intra macroblocks, command-list bytes that belong to them) of one frame step, all clips."""
+        n, by = C.c_uint64(), C.c_uint64()
+        rc = self._lib.mobi_batch_intra_stats(self._h, frame_idx, C.byref(n), C.byref(by))
+        if rc != 0:
+            raise MobiclipError(error_string(rc))
+        return int(n.value), int(by.value)
 
     def time_begin(self):
         self._lib.mobi_batch_time_begin(self._h)

@@ -187,11 +187,22 @@ static void copy_block(D *d, barr Src, int Dx, int Dy, uint32_t W, uint32_t H, b
   }
 }
 
+/* ---- syntax coverage counters (tests/test_coverage.py): which parts of the syntax has this PROCESS decoded so far?  Test-side
+ * accounting only: they change no result.  Layout in mobi_oracle.h (MOBI_COV_*). ---- */
+static uint64_t g_cov[MOBI_COV_WORDS];
+#define COV(i) (g_cov[(i)]++)
+void mobi_oracle_coverage(uint64_t *out, int reset) {
+  if (out) memcpy(out, g_cov, sizeof(g_cov));
+  if (reset) memset(g_cov, 0, sizeof(g_cov));
+}
+
 /* loc_1147B0 / loc_114A64 / loc_114CAC / loc_114ED4 (MD.cs:409,592,692,795): one MC leaf, width w */
 static void mc_leaf(D *d, int io, uint32_t srcFrame, uint32_t w, uint32_t h, int dx, int dy, int Offset) {
   *IN(d, io) = (uint32_t)dx;
   *IN(d, io + 1) = (uint32_t)dy;
   uint32_t f = srcFrame / 4;
+  if (f >= 1 && f <= 5) COV(MOBI_COV_REF + f - 1);
+  COV(MOBI_COV_PHASE + ((dx & 1) | ((dy & 1) << 1)));
   copy_block(d, d->Y[f], dx, dy, w, h, d->Y[0], Offset);
   copy_block(d, d->UV[f], dx >> 1, dy >> 1, w >> 1, h >> 1, d->UV[0], Offset / 2);
   copy_block(d, d->UV[f], dx >> 1, dy >> 1, w >> 1, h >> 1, d->UV[0], Offset / 2 + d->Stride / 2);
@@ -225,6 +236,7 @@ static void pblock(D *d, int wi, int hi, int io, int Offset) {
   if (code >= mobi_part_nbits_len[ver][s]) THROW(d, ORA_E_INDEX); /* bit-count table shorter than code */
   int nb = mobi_part_bits[ver][s][code];
   TAKE(d, nb);
+  if (code < 10) COV(MOBI_COV_PART + (ver * 16 + s) * 10 + code);
   switch (code) {
     case 0:
       mc_leaf(d, io, 4, w, h, (int)d->Internal[219], (int)d->Internal[220], Offset);
@@ -262,6 +274,7 @@ static void read_dct(D *d, uint32_t *pr12) {
   const uint16_t *A = (d->Internal[218] == 1) ? mobi_vx2table1_a : mobi_vx2table0_a;
   const uint8_t *B = (d->Internal[218] == 1) ? mobi_vx2table1_b : mobi_vx2table0_b;
   uint32_t r12 = *pr12;
+  COV(MOBI_COV_VLCTAB + (d->Internal[218] == 1));
   for (;;) {
     int skip, value, nb, t;
     uint32_t e = d->r3 >> 25, r8;
@@ -269,6 +282,7 @@ static void read_dct(D *d, uint32_t *pr12) {
       d->r3 <<= 7;
       int c = (d->r3 >> 31) == 1;
       d->r3 <<= 1;
+      COV(MOBI_COV_ESCAPE + (!c ? 0 : ((d->r3 >> 31) == 1 ? 2 : 1)));
       if (!c) { /* escape 0: level offset */
         d->nbr -= 8;
         if (d->nbr < 0) fill_bits(d);
@@ -524,6 +538,7 @@ static void resid8(D *d, barr Dst, int Offset) {
   for (int i = 0; i < 64; i++) d->Internal[90 + i] = 0;
   uint32_t r12 = 10;
   read_dct(d, &r12);
+  COV(MOBI_COV_IDCT + (r12 <= 11 ? 0 : r12 <= 13 ? 1 : r12 <= 20 ? 2 : 3));
   if (r12 <= 11) idct1p(d, Dst, Offset, 8);
   else if (r12 <= 13) idct3p8(d, Dst, Offset);
   else if (r12 <= 20) idct16p8(d, Dst, Offset);
@@ -534,6 +549,7 @@ static void resid4(D *d, barr Dst, int Offset) {
   for (int i = 0; i < 16; i++) d->Internal[90 + i] = 0;
   uint32_t r12 = 74;
   read_dct(d, &r12);
+  COV(MOBI_COV_IDCT + (r12 <= 75 ? 4 : 5));
   if (r12 <= 75) idct1p(d, Dst, Offset, 4);
   else idct16p4(d, Dst, Offset);
 }
@@ -586,6 +602,7 @@ static void p_residual(D *d, int Offset) {
  * of its 4-pixel word exactly like `r5 |= (r12 << 8)` does. */
 static void plane_pred(D *d, barr Dst, int Offset, int n, int param) {
   const int S = d->Stride;
+  COV(MOBI_COV_PLANE + (n == 16 ? 0 : n == 8 ? 1 : 2));
   int T[16], acc[16], step[16];
   if (n == 4) {
     uint32_t w = RD32(d, Dst, (long)Offset - S);
@@ -632,6 +649,7 @@ static void plane_pred(D *d, barr Dst, int Offset, int n, int param) {
 /* PredictIntra, MD.cs:1883-2774 (modes 2 and 12 read `se` and are dispatched by the caller) */
 static void predict_intra(D *d, uint32_t mode, barr Dst, int Offset) {
   const int S = d->Stride;
+  if (mode < 20) COV(MOBI_COV_INTRA + mode);
   int vfix = (Dst.p == d->UV[0].p && (Offset % S) >= S / 2); /* MD.cs:1886 */
   int T[16], L[8], TL, px[8][8];
 #define RT(k) ((int)RD(d, Dst, (long)Offset - S + (k)))

@@ -68,6 +68,20 @@ int mobi_oracle_argb(const mobi_oracle *d, uint32_t *out);
  * Encoder/MacroBlock.cs:76-85).  out[(mb * 64) + Y*8 + X] = (Delta.X & 0xFF) | (Delta.Y & 0xFF) << 8 | Frame << 16 |
  * score << 20, Delta in half pels as the reference stores it; score = 0xFFF when there is no past frame at all. */
 void mobi_oracle_motion_search(const mobi_oracle *d, const uint8_t *src, uint32_t *out);
+/* Syntax coverage of everything this process has decoded through the oracle so far (tests/test_coverage.py): counters, copied to
+ * out[MOBI_COV_WORDS]; reset != 0 clears them afterwards.
+ *   MOBI_COV_PART + (ver * 16 + shape) * 10 + code   partition codes 0..9 per shape (wi * 4 + hi, 16 of them) and table version
+ *                                                     (0 = Moflex3DS, 1 = ModsDS), MD.cs:469-1746
+ *   MOBI_COV_INTRA + mode                             PredictIntra modes 0..19 (10..19: the 4x4 twins), MD.cs:1883-2774
+ *   MOBI_COV_PLANE + {0,1,2}                          plane predictors 16x16 / 8x8 / 4x4, MD.cs:3017-3327
+ *   MOBI_COV_ESCAPE + {0,1,2}                         ReadDCTMatrix escapes: level offset, run offset, raw (MD.cs:3342-3406)
+ *   MOBI_COV_VLCTAB + {0,1}                           residual VLC table 0 / 1 (Internal[218])
+ *   MOBI_COV_REF + {0..4}                             motion-compensated leaves from ring slot 1..5
+ *   MOBI_COV_PHASE + {0..3}                           luma CopyBlock phase (dx & 1) | (dy & 1) << 1
+ *   MOBI_COV_IDCT + {0..5}                            IDCT1Px8, 3Px8, 16Px8, 64Px8, 1Px4, 16Px4 (chosen by the last scan index) */
+enum { MOBI_COV_PART = 0, MOBI_COV_INTRA = 320, MOBI_COV_PLANE = 340, MOBI_COV_ESCAPE = 343, MOBI_COV_VLCTAB = 346, MOBI_COV_REF = 348,
+       MOBI_COV_PHASE = 353, MOBI_COV_IDCT = 357, MOBI_COV_WORDS = 363 };
+void mobi_oracle_coverage(uint64_t *out, int reset);
 /* testing hooks: direct access to the Internal[392] word array (MD.cs:28) */
 uint32_t *mobi_oracle_internal(mobi_oracle *d);
 

@@ -119,3 +119,25 @@ def test_low_quantizer_aliasing_domain():
         w = (w & ~(0x3F << 7)) | (q << 7)
         data[0], data[1] = w & 0xFF, w >> 8
         _diff(L, p, data, fo)
+
+
+@pytest.mark.parametrize("cfg", ["A", "B", "C"])
+def test_bench_streams(cfg):
+    """The exact streams bench.py times (mobiclipdecoder_amd.sharding.stream_seed(config, rank 0, index 0..3), 1 I + 32 P
+    frames, SURVEY 8(d) mix) and the streams of the GPU coverage suite: oracle and transliteration agree on every frame."""
+    from mobiclipdecoder_amd import sharding
+    L = _lib()
+    for i in range(4 if cfg == "B" else 2):
+        p = default_params(cfg, sharding.stream_seed(cfg, 0, i), n_frames=33)
+        data, fo = generate_clip(p)
+        ok, thrown = _diff(L, p, data, fo)
+        assert ok == 33 and thrown == 0
+
+
+def test_coverage_suite_streams():
+    from tests.gpu_streams import suite_params
+    L = _lib()
+    for p in suite_params():
+        data, fo = generate_clip(p)
+        ok, thrown = _diff(L, p, data, fo)
+        assert ok == p.n_frames and thrown == 0

@@ -159,3 +159,65 @@ def test_containers_drive_the_decoder():
         assert a is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and g.Offset == o.Offset, f
     assert f == 4
     g.close()
+
+
+def _hand_made_moflex():
+    """Two 64-byte Moflex packets assembled byte by byte from the container grammar as the reference's READER defines it
+    (MoLiveDemux.cs:375-414 sync header and check word, :164-214 stream chunks, :216-264 block flags, :266-373 bit-packed ep
+    headers) -- independent of tests/containers.py, which restates the reference's WRITER."""
+    time = 0x0000000000012345
+    check = (time & 0xFFFF) ^ (time >> 16 & 0xFFFF) ^ (time >> 32 & 0xFFFF) ^ (time >> 48 & 0xFFFF) ^ 0xAAAA
+    sync = b"L2" + check.to_bytes(2, "big") + time.to_bytes(8, "big") + (64 - 1).to_bytes(2, "big")
+    video = bytes([1, 12,            # chunk type 1 (video), 12 bytes
+                   0, 0,             # stream index, codec id
+                   0, 24, 0, 1,      # fps 24 / 1
+                   1, 0, 0, 192,     # 256 x 192
+                   1, 1])            # pel ratio 1 : 1
+    end_of_chunks = bytes([0, 0])    # type 0, no body
+
+    def ep(payload):  # stream 0 (unary length 1: "1", index "0"), end of frame "1", frame type ("1", "0"), time stamp (+, "1" = 28 bits, 0), size - 1
+        bits = "1" + "0" + "1" + "1" + "0" + "0" + "1" + "0" * 28 + format(len(payload) - 1, "013b")
+        assert len(bits) % 8 == 0
+        return int(bits, 2).to_bytes(len(bits) // 8, "big") + payload
+
+    p1 = sync + video + end_of_chunks + bytes([0x00]) + ep(bytes([0xAA, 0xBB, 0xCC, 0xDD, 0xEE]))  # flags 0: fixed size, no counter, sync counter 0
+    p2 = bytes([0x00]) + ep(bytes([1, 2, 3]))
+    return p1.ljust(64, b"\x00") + p2.ljust(64, b"\x00")
+
+
+def test_moflex_hand_assembled_packets():
+    d = MoLiveDemux(np.frombuffer(_hand_made_moflex(), np.uint8))
+    got = list(d.frames())
+    assert [bytes(f[1]) for f in got] == [bytes([0xAA, 0xBB, 0xCC, 0xDD, 0xEE, 0, 0]), bytes([1, 2, 3, 0, 0])]
+    st = got[0][0]
+    assert (st.chunk_id, st.stream_index, st.fps_rate, st.fps_scale, st.width, st.height) == (1, 0, 24, 1, 256, 192)
+    assert d.ReadPacket() == 73
+    d.close()
+    # the check word decides: one flipped bit in the time stamp and no synchronisation is found
+    bad = bytearray(_hand_made_moflex())
+    bad[7] ^= 1
+    d = MoLiveDemux(np.frombuffer(bytes(bad), np.uint8))
+    assert d.ReadPacket() == 0x80
+    d.close()
+
+
+def test_damaged_containers_do_not_hang_the_caller():
+    """A packet that ends right behind its stream table makes the reference's reader drop and regain synchronisation on the same
+    bytes for ever (ReadPacket returns 0 without moving); next_frame gives up instead.  A MOC5 block size near 2^32 must not
+    wrap the offset backwards."""
+    time = 5
+    check = (time & 0xFFFF) ^ 0xAAAA
+    blob = b"L2" + check.to_bytes(2, "big") + time.to_bytes(8, "big") + (16 - 1).to_bytes(2, "big") + bytes([0, 0])
+    d = MoLiveDemux(np.frombuffer(blob, np.uint8))
+    with pytest.raises(ValueError):
+        d.next_frame()
+    d.close()
+    import ctypes as C
+    from mobiclipdecoder_amd.demux import _lib as demux_lib
+    L = demux_lib()
+    moc = np.zeros(64, np.uint8)
+    moc[8:12] = [0xFE, 0xFF, 0xFF, 0xFF]  # block size 0xFFFFFFFE at offset 8
+    offs = C.c_uint32(8)
+    L.mobi_moc5_next_block.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    L.mobi_moc5_next_block.restype = C.c_int
+    assert L.mobi_moc5_next_block(moc.ctypes.data, moc.size, C.byref(offs), None, None) == -1 and offs.value == 8

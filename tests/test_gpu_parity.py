@@ -42,6 +42,15 @@ def test_default_streams_bit_exact(cfg, seed):
     _run_stream(default_params(cfg, BASE_SEED + seed, n_frames=9))
 
 
+def test_coverage_suite_streams():
+    """Every stream of tests/gpu_streams.py (whose union tests/test_coverage.py proves to reach the whole syntax: every partition
+    shape x table version x code, every intra mode in both sizes, the plane predictors, the escapes, both VLC tables, reference
+    slots 1..5, the four CopyBlock phases and the six transform classes), bit-exact against the oracle."""
+    from tests.gpu_streams import suite_params
+    for p in suite_params():
+        _run_stream(p)
+
+
 @pytest.mark.parametrize("cfg", ["A", "B"])
 def test_rich_streams_bit_exact(cfg):
     p = default_params(cfg, BASE_SEED + 77, n_frames=10, pm_intra=150, pm_deep=150, pm_multiref=300,
@@ -155,30 +164,20 @@ def test_848x480_wii_class_and_854_is_rejected():
 
 def test_clamp_domain_fault_is_reported():
     """A residual that pushes pred+res outside the clamp table's domain makes the reference throw
-    (MobiConst.cs:587; MD.cs:3551); the kernels flag it -> MOBI_E_CLAMP, and the oracle throws too."""
-    from mobiclipdecoder_amd.streamgen import GenParams  # noqa: F401
-    p = default_params("A", BASE_SEED + 77, n_frames=2, width=64, height=48, quantizer=52, cbp_prob=1000, max_coefs=1, scan_span=1)
-    data, fo = generate_clip(p)
-    # raise the coded DC levels by corrupting bits until the oracle reports the index fault on frame 0
-    rng = np.random.default_rng(5)
-    for trial in range(400):
-        d2 = data.copy()
-        for _ in range(3):
-            d2[int(rng.integers(4, fo[1]))] ^= 1 << int(rng.integers(0, 8))
-        ora = OracleDecoder(64, 48, MobiclipVersion.ModsDS)
-        ora.Data, ora.Offset = d2[: fo[1]], 0
-        ora.DecodeFrame()
-        if ora.last_error != -1:
-            continue
-        gpu = MobiclipDecoder(64, 48, MobiclipVersion.ModsDS)
-        gpu.Data, gpu.Offset = d2[: fo[1]], 0
-        assert gpu.DecodeFrame() is None
-        if gpu.last_error == -5:
-            gpu.close()
-            return  # found a stream whose only fault is the clamp-table domain: GPU flagged it
-        assert gpu.last_error in (-1, -6)
-        gpu.close()
-    pytest.skip("no clamp-only fault found in the random search")
+    (MobiConst.cs:587; MD.cs:3551); the kernels flag it -> MOBI_E_CLAMP, and the oracle throws too.
+    The stream is a committed fixture (tests/golden/clamp_fault_mods_64x48.bin: a 64x48 ModsDS I-frame at quantizer 52 with
+    three flipped bits, found by tests/golden/make_clamp_fault.py): its syntax parses, only the clamp domain fails."""
+    import os
+    data = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clamp_fault_mods_64x48.bin"), dtype=np.uint8)
+    ora = OracleDecoder(64, 48, MobiclipVersion.ModsDS)
+    ora.Data, ora.Offset = data, 0
+    assert ora.DecodeFrame() is None and ora.last_error == -1  # the reference's IndexOutOfRangeException
+    gpu = MobiclipDecoder(64, 48, MobiclipVersion.ModsDS)
+    gpu.Data, gpu.Offset = data, 0
+    assert gpu.DecodeFrame() is None
+    assert gpu.last_error == -5  # MOBI_E_CLAMP: found by the kernels, after a clean parse
+    assert gpu.Offset >= ora.Offset  # the oracle stops where it throws; the product's parse has run to the end of the frame (INTEGRATION.md)
+    gpu.close()
 
 
 def test_intra_heavy_steps_are_bit_exact():

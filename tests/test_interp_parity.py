@@ -124,3 +124,20 @@ def test_p_frame_before_any_i_frame_is_null_reference():
     assert a.DecodeFrame() is None and o.DecodeFrame() is None
     assert a.last_error == o.last_error == -2
     assert a.Quantizer == o.Quantizer == 12  # Moflex: Quantizer==0 -> Setup(0) clamps to 12 (MD.cs:123-126, 3886-3890)
+
+
+def test_clamp_fault_fixture_is_a_clamp_only_fault():
+    """tests/golden/clamp_fault_mods_64x48.bin (made by tests/golden/make_clamp_fault.py): the oracle throws its index fault, the
+    product's parser accepts the syntax and the kernels' arithmetic (here on the CPU) reports the clamp-table domain."""
+    import os
+    import numpy as np
+    from mobiclipdecoder_amd import MobiclipVersion
+    from tests.oracle_binding import OracleDecoder
+    from tests.interp_binding import InterpDecoder
+    data = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clamp_fault_mods_64x48.bin"), dtype=np.uint8)
+    o = OracleDecoder(64, 48, MobiclipVersion.ModsDS)
+    o.Data, o.Offset = data, 0
+    assert o.DecodeFrame() is None and o.last_error == -1
+    i = InterpDecoder(64, 48, MobiclipVersion.ModsDS)
+    i.Data, i.Offset = data, 0
+    assert i.DecodeFrame() is None and i.last_error == -5

@@ -1,0 +1,93 @@
+/* abi_caller.c -- a plain C caller of libmobiclip_hip.so, nothing but include/mobiclip_hip.h and libc: what a host written in
+ * any language with a C FFI does (the reference's would be C# P/Invoke).
+ *
+ *   abi_caller <stream.bin> <width> <height> <version> <n_frames> <off_0> ... <off_n>
+ *
+ * Decodes the frames the way the reference's callers drive MobiclipDecoder (Program.cs:69-71: d.Data = frame; d.Offset = o;
+ * d.DecodeFrame()), and prints for every frame one line
+ *   <frame> <rc> <offset_after> <quantizer> <sha256 of Y[0]> <sha256 of UV[0]>
+ * tests/test_abi_c_caller.py compares the lines with tests/golden/golden.json.  Test tool: not part of the product. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/mobiclip_hip.h"
+
+/* ---- SHA-256 (FIPS 180-4), small and slow ---- */
+static const uint32_t K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha_block(uint32_t h[8], const uint8_t *p) {
+  uint32_t w[64], a[8];
+  int i;
+  for (i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+  for (i = 16; i < 64; i++) {
+    const uint32_t s0 = ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  memcpy(a, h, sizeof(a));
+  for (i = 0; i < 64; i++) {
+    const uint32_t S1 = ROR(a[4], 6) ^ ROR(a[4], 11) ^ ROR(a[4], 25), ch = (a[4] & a[5]) ^ (~a[4] & a[6]);
+    const uint32_t t1 = a[7] + S1 + ch + K[i] + w[i];
+    const uint32_t S0 = ROR(a[0], 2) ^ ROR(a[0], 13) ^ ROR(a[0], 22), mj = (a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]);
+    const uint32_t t2 = S0 + mj;
+    a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+  }
+  for (i = 0; i < 8; i++) h[i] += a[i];
+}
+static void sha256_hex(const uint8_t *data, size_t len, char out[65]) {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint8_t tail[128];
+  size_t i, full = len / 64 * 64, rem = len - full, tl;
+  for (i = 0; i < full; i += 64) sha_block(h, data + i);
+  memset(tail, 0, sizeof(tail));
+  memcpy(tail, data + full, rem);
+  tail[rem] = 0x80;
+  tl = rem + 9 <= 64 ? 64 : 128;
+  for (i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(((uint64_t)len * 8) >> (8 * i));
+  for (i = 0; i < tl; i += 64) sha_block(h, tail + i);
+  for (i = 0; i < 8; i++) sprintf(out + 8 * i, "%08x", h[i]);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 7) { fprintf(stderr, "usage: abi_caller stream.bin width height version n_frames off_0 .. off_n\n"); return 2; }
+  const uint32_t w = (uint32_t)atoi(argv[2]), hgt = (uint32_t)atoi(argv[3]);
+  const int version = atoi(argv[4]), nf = atoi(argv[5]);
+  if (argc != 6 + nf + 1) { fprintf(stderr, "expected %d frame offsets\n", nf + 1); return 2; }
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  fseek(f, 0, SEEK_END);
+  const long flen = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  uint8_t *data = (uint8_t *)malloc((size_t)flen + 1);
+  if (fread(data, 1, (size_t)flen, f) != (size_t)flen) { fprintf(stderr, "short read\n"); return 2; }
+  fclose(f);
+
+  mobi_dec *d = mobi_create(w, hgt, version, 0);                    /* new MobiclipDecoder(Width, Height, Version) */
+  if (!d) { fprintf(stderr, "mobi_create failed: %s\n", mobi_error_string(MOBI_E_DEVICE)); return 3; }
+  const int stride = mobi_stride(d);
+  const size_t ysz = (size_t)stride * hgt;
+  uint8_t *y = (uint8_t *)malloc(ysz), *uv = (uint8_t *)malloc(ysz / 2);
+  char hy[65], huv[65];
+  int i, bad = 0;
+  for (i = 0; i < nf; i++) {
+    int32_t off = atoi(argv[6 + i]);                                  /* d.Offset = ... */
+    const size_t len = (size_t)atol(argv[6 + i + 1]);                 /* d.Data = the stream up to the end of this frame */
+    const int rc = mobi_decode(d, data, len, &off);                   /* d.DecodeFrame() */
+    hy[0] = huv[0] = '-'; hy[1] = huv[1] = 0;
+    if (rc == MOBI_OK && mobi_get_planes(d, 0, y, uv) == MOBI_OK) {   /* d.Y[0], d.UV[0] */
+      sha256_hex(y, ysz, hy);
+      sha256_hex(uv, ysz / 2, huv);
+    } else bad = 1;
+    printf("%d %d %d %u %s %s\n", i, rc, (int)off, mobi_quantizer(d), hy, huv);
+  }
+  mobi_destroy(d);
+  free(y); free(uv); free(data);
+  return bad;
+}
