@@ -209,8 +209,7 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
 // selects, compares, SDWA and 16-bit packed forms in ~4.3 (tools/ubench/oprate.hip).  Hence:
 //   * ONE fetch path for every macroblock with whole leaves (16x16, two 16x8, two 8x16): the DMA rounds take a per-lane
 //     source address, so the rows of a top/bottom pair and the 16-byte halves of a left/right pair simply come from the
-//     other leaf's position.  Windows start at a 4-byte boundary (not 16): 20 bytes of a row always fit the two chunks,
-//     9 + 3 chroma bytes fit ONE chunk, and the dword a lane reads no longer depends on the motion vector.
+//     other leaf's position.  Chroma windows start at a 4-byte boundary (not 16): 9 + 3 bytes then fit ONE 16-byte chunk.
 //     19 vector-memory instructions per wave instead of 44.
 //   * a lane owns 8 consecutive luma rows x 4 pixels (4 chroma rows x 4): it lies inside one leaf whatever the split, the
 //     row below of one row is the row of the next (masked bytes and the horizontal average are computed once per row),
@@ -268,12 +267,10 @@ __device__ __forceinline__ unsigned long long prof_stamp() { // shader clock, pi
   return t;
 }
 template <int PROF, int CWR>
-__device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t oi, int lane) {
+__device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t clip, uint32_t mby, uint32_t ox, int lane) {
   unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0};
   if (PROF) pt[0] = prof_stamp();
-  uint32_t rem, ox;
-  const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); // qpr / qpc: OCTETS per row / per clip for this kernel
-  const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);
+  const uint32_t oi = clip * A.qpc + mby * A.qpr + ox; // (index of the profiling record)
   const uint32_t mbx0 = ox * 8, mbw = (uint32_t)A.mbw;
   const int nmb = (int)(mbw - mbx0 < 8 ? mbw - mbx0 : 8);
   const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S);
@@ -316,8 +313,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     const uint32_t fT = win ? (rB ? refB : refA) : 0u;
     const int pU = tb ? posB : pT;
     const uint32_t fU = tb ? refB : fT;
-    const uint8_t *sT = clip_base + fT + (uint32_t)(((pT + (r4 << lgS)) & ~3) + xT);
-    const uint8_t *sU = clip_base + fU + (uint32_t)(((pU + ((8 + r4) << lgS)) & ~3) + xT);
+    // (16-byte aligned unless the row is shared by two leaves: a 32-byte window that starts on a 16-byte boundary crosses a
+    // 64-byte request boundary in one case out of four, one that starts on any 4-byte boundary in seven out of sixteen)
+    const int am = lr ? ~3 : ~15;
+    const uint8_t *sT = clip_base + fT + (uint32_t)(((pT + (r4 << lgS)) & am) + xT);
+    const uint8_t *sU = clip_base + fU + (uint32_t)(((pU + ((8 + r4) << lgS)) & am) + xT);
     const int s4 = win ? 4 << lgS : 0;
     MOBI_DMA16(sT, L + P_L, 0);
     MOBI_DMA16(sT + s4, L + P_L + 1024, 0);
@@ -445,7 +445,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + P_SC, 0);
   {
-    const int w0 = q + ((lr && q >= 2) ? 2 : 0), w1 = w0 + 1; // columns 8..15 of a LEFT/RIGHT pair start their own chunk
+    // the lane's 5 bytes start (ypos & 15) + 4q bytes into the row's 32-byte window; in a LEFT/RIGHT pair each half has its own
+    // 16-byte chunk that starts at the half's position rounded down to 4
+    const int w0 = lr ? q + (q >= 2 ? 2 : 0) : ((ypos & 15) + 4 * q) >> 2, w1 = w0 + 1;
     const int base = P_L + rr * 2048 + g * 16;
     const int a0 = base + (w0 >> 2) * 128 + (w0 & 3) * 4, a1 = base + (w1 >> 2) * 128 + (w1 & 3) * 4;
     uint32_t x0[9], x1[9];
@@ -600,17 +602,24 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     rec[7] = (unsigned long long)(__builtin_popcount(m_lo) + __builtin_popcount(m_hi));
   }
 }
+// One wave per workgroup.  Tried and measured (r2, 24576 clips 640x480, same box): workgroups of 2 / 3 / 5 / 6 vertically adjacent
+// octets, so that waves whose reference windows overlap share this CU's L1 -- 8.0 / 8.2 / 11.4 / 11.2 ms against 8.0 ms for
+// single waves (a workgroup's LDS and wave slots come and go as a block); non-temporal window fetches -- 8.5 ms (chroma only)
+// and 9.8 ms (all): the L1 hits between the macroblocks of an octet are worth more than the L1 they pollute.
 #define MOBI_OCT_KERNEL(NAME, WAVES, PROF, NCWR)                                                      \
   extern "C" __global__ __launch_bounds__(64, WAVES) void NAME(MobiReconArgs A) {                      \
     __shared__ __attribute__((aligned(16))) uint8_t lds[P_BYTES];                                      \
     const uint32_t oi = (blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3);                        \
     if (oi >= A.qpc * (uint32_t)A.n_clips) return;                                                     \
-    recon_inter_oct<PROF, NCWR>(A, lds, oi, (int)threadIdx.x);                                         \
+    uint32_t rem, ox;                                                                                  \
+    const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); /* qpr / qpc: octets per macroblock row / per clip */ \
+    const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);                                         \
+    recon_inter_oct<PROF, NCWR>(A, lds, clip, mby, ox, (int)threadIdx.x);                              \
   }
-// 5 waves per SIMD (96 VGPRs; the 8 KB of LDS allow exactly 20 waves per CU) with 96 level words per macroblock in registers:
-// 24576 clips 640x480: 7.59 ms per launch against 7.95 with 4 waves and 128 words (r2c/bench_variants.txt)
-MOBI_OCT_KERNEL(mobi_recon_inter8, 5, 0, 12)
-MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 5, 1, 12)
+// 4 waves per SIMD (108 VGPRs, no spills; 5 waves = 96 VGPRs spill 5 registers since the windows became 16-byte aligned and
+// measure the same) with 96 level words per macroblock in registers
+MOBI_OCT_KERNEL(mobi_recon_inter8, 4, 0, 12)
+MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 12)
 
 // =====================================================================================================
 // intra macroblocks of one dependency level
@@ -1012,9 +1021,8 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue; // 24-bit multiply in the kernel
   MobiReconArgs b = *a;
   static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
-  // octets per macroblock row / per clip
-  b.qpr = ((uint32_t)b.mbw + 7) / 8;
-  b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);
+  b.qpr = ((uint32_t)b.mbw + 7) / 8;                    // octets per macroblock row
+  b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);          // ... per clip
   auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };
   b.magic_qpr = magic(b.qpr);
   b.magic_qpc = magic(b.qpc);
