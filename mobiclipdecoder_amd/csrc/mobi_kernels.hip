@@ -617,9 +617,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     recon_inter_oct<PROF, NCWR>(A, lds, clip, mby, ox, (int)threadIdx.x);                              \
   }
 // 4 waves per SIMD (108 VGPRs, no spills; 5 waves = 96 VGPRs spill 5 registers since the windows became 16-byte aligned and
-// measure the same) with 96 level words per macroblock in registers
-MOBI_OCT_KERNEL(mobi_recon_inter8, 4, 0, 12)
-MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 12)
+// measure the same) with 128 level words per macroblock in registers (96: 848x480 with its dense blocks 8 % slower; 192: no better)
+MOBI_OCT_KERNEL(mobi_recon_inter8, 4, 0, 16)
+MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16)
 
 // =====================================================================================================
 // intra macroblocks of one dependency level

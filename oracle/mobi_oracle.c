@@ -187,9 +187,9 @@ static void copy_block(D *d, barr Src, int Dx, int Dy, uint32_t W, uint32_t H, b
   }
 }
 
-/* ---- syntax coverage counters (tests/test_coverage.py): which parts of the syntax has this PROCESS decoded so far?  Test-side
+/* ---- syntax coverage counters (tests/test_coverage.py): which parts of the syntax has this THREAD decoded so far (thread-local: shared counters made 256 decoder threads fight over one cache line)?  Test-side
  * accounting only: they change no result.  Layout in mobi_oracle.h (MOBI_COV_*). ---- */
-static uint64_t g_cov[MOBI_COV_WORDS];
+static __thread uint64_t g_cov[MOBI_COV_WORDS];
 #define COV(i) (g_cov[(i)]++)
 void mobi_oracle_coverage(uint64_t *out, int reset) {
   if (out) memcpy(out, g_cov, sizeof(g_cov));
