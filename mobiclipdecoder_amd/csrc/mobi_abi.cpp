@@ -107,7 +107,8 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
   // [2] has intra dependents (must publish its own), [3] left column in the edge side buffer, [14:5] number of level words,
   // [31:16] plane parameter.
   std::vector<uint32_t> items;
-  uint32_t n_items = 0;
+  uint32_t n_items = 0;         // launch items, padding included
+  uint32_t n_intra = 0;         // intra macroblocks among them
   bool any_inter = false;
   uint64_t cmd_bytes = 0;       // descriptors + payload of every macroblock of the step
   uint64_t intra_cmd_bytes = 0; // ... of the intra ones: descriptor, 24 block records, level words (the inter kernel never reads them)
@@ -125,37 +126,53 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
     items.clear();
     std::vector<size_t> base(frames.size() + 1, 0); // where each clip's payload starts in the step's arena (as step_write lays it out)
     for (size_t c = 0; c < frames.size(); c++) base[c + 1] = base[c] + (frames[c] ? frames[c]->payload.size() : 0);
+    n_intra = 0;
     for (uint32_t L = 1; L <= maxl; L++) {
-      for (size_t c = 0; c < frames.size(); c++) {
-        const ParsedFrame *f = frames[c];
-        if (!f || L > f->hdr.n_levels) continue;
-        for (uint32_t i = f->level_start[L]; i < f->level_start[L + 1]; i++) {
-          const uint32_t mb = f->intra_mbs[i];
-          const MbDesc &d = f->desc[mb];
-          uint32_t flags = d.w3 & 0xFFFF0001u;
-          const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
-          for (int k = 0; k < MOBI_INTRA_DEPS; k++) {
-            const uint32_t dep = (deps[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-            if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) flags |= 2u;
+      // two passes per level: macroblocks away from the picture's edges first, the others (whose halo needs the per-sample
+      // ownership test, mobi_recon_intra) behind them, so that few waves of four carry one
+      for (int edge_pass = 0; edge_pass < 2; edge_pass++)
+        for (size_t c = 0; c < frames.size(); c++) {
+          const ParsedFrame *f = frames[c];
+          if (!f || L > f->hdr.n_levels) continue;
+          for (uint32_t i = f->level_start[L]; i < f->level_start[L + 1]; i++) {
+            const uint32_t mb = f->intra_mbs[i];
+            const uint32_t mbx = mb % (uint32_t)mbw;
+            const bool interior = mbx >= 1 && mbx + 1 < (uint32_t)mbw && mb >= (uint32_t)mbw;
+            if (interior == (edge_pass != 0)) continue;
+            const MbDesc &d = f->desc[mb];
+            uint32_t flags = d.w3 & 0xFFFF0001u;
+            const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
+            for (int k = 0; k < MOBI_INTRA_DEPS; k++) {
+              const uint32_t dep = (deps[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+              if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) flags |= 2u;
+            }
+            flags |= (d.w2 & 0x3FFu) << 5;
+            intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + (d.w2 & 0x3FFu));
+            if (mbx) flags |= 8u; // finish_levels flagged the left neighbour: its last column is in the edge side buffer
+            items.push_back(MOBI_ITEM(c, mb));
+            items.push_back(d.w1);
+            items.push_back(d.payload_off + (uint32_t)base[c]);
+            items.push_back(flags);
+            n_intra++;
           }
-          flags |= (d.w2 & 0x3FFu) << 5;
-          intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + (d.w2 & 0x3FFu));
-          if (mb % (uint32_t)mbw) flags |= 8u; // finish_levels flagged the left neighbour: its last column is in the edge side buffer
-          items.push_back(MOBI_ITEM(c, mb));
-          items.push_back(d.w1);
-          items.push_back(d.payload_off + (uint32_t)base[c]);
-          items.push_back(flags);
         }
+      // a wave carries four macroblocks, and a macroblock may wait for one of the level before: levels start on a wave boundary
+      while ((items.size() / MOBI_INTRA_ITEM_WORDS) & 3) {
+        items.push_back(MOBI_ITEM_NONE);
+        items.push_back(0);
+        items.push_back(0);
+        items.push_back(0);
       }
     }
     n_items = (uint32_t)(items.size() / MOBI_INTRA_ITEM_WORDS);
     // second pass: "has dependents".  Index the items by (clip, mb), then mark what the polling ones name.
     if (n_items) {
       std::vector<std::vector<std::pair<uint32_t, uint32_t>>> by_clip(frames.size()); // (mb, item index)
-      for (uint32_t i = 0; i < n_items; i++) by_clip[items[4 * i] >> 13].push_back({items[4 * i] & 0x1FFFu, i});
+      for (uint32_t i = 0; i < n_items; i++)
+        if (items[4 * i] != MOBI_ITEM_NONE) by_clip[items[4 * i] >> 13].push_back({items[4 * i] & 0x1FFFu, i});
       for (auto &v : by_clip) std::sort(v.begin(), v.end());
       for (uint32_t i = 0; i < n_items; i++) {
-        if (!(items[4 * i + 3] & 2u)) continue;
+        if (items[4 * i] == MOBI_ITEM_NONE || !(items[4 * i + 3] & 2u)) continue;
         const uint32_t c = items[4 * i] >> 13, mb = items[4 * i] & 0x1FFFu;
         const MbDesc &d = frames[c]->desc[mb];
         const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
@@ -446,7 +463,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   if (hipEventCreate(&b->ev_begin) != hipSuccess || hipEventCreate(&b->ev_end) != hipSuccess) return nullptr;
   {
     // 64 rows: the 6-bit quantizer field of any descriptor stays inside; the intra kernel's tap table rides behind them
-    std::vector<int32_t> tab((size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE + MOBI_TAP_ENTRIES * 2, 0);
+    std::vector<int32_t> tab((size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE + MOBI_TAP_ENTRIES * 2 + 8, 0) /* + 8: the kernel fetches four entries at a time */;
     for (int q = 0; q < MOBI_SCALE_QMAX; q++) mobi_build_scale_table(q, &tab[(size_t)q * MOBI_SCALE_STRIDE]);
     if (!mobi_build_intra_taps((int16_t *)&tab[(size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE], MOBI_TAP_PITCH)) {
       snprintf(g_last_hip_error, sizeof(g_last_hip_error), "intra tap table self-check failed");
@@ -935,7 +952,7 @@ uint64_t mobi_batch_cmd_bytes(const mobi_batch *b, int frame_idx) {
 }
 int mobi_batch_intra_stats(const mobi_batch *b, int frame_idx, uint64_t *n_intra_mbs, uint64_t *intra_cmd_bytes) {
   if (!b || !b->committed || frame_idx < 0 || frame_idx >= b->n_frames_loaded) return MOBI_E_ARG;
-  if (n_intra_mbs) *n_intra_mbs = b->r_plan[frame_idx].n_items;
+  if (n_intra_mbs) *n_intra_mbs = b->r_plan[frame_idx].n_intra;
   if (intra_cmd_bytes) *intra_cmd_bytes = b->r_plan[frame_idx].intra_cmd_bytes;
   return MOBI_OK;
 }

@@ -46,4 +46,5 @@ extern "C" int mobi_launch_motion_search(const MobiReconArgs *a, const uint8_t *
 // intra launch item, word 0: (clip << 13) | mb; words 1..3: MbDesc.w1, MbDesc.payload_off, flags (mobi_recon_intra in mobi_kernels.hip)
 #define MOBI_ITEM(clip, mb) (((uint32_t)(clip) << 13) | (uint32_t)(mb))
 #define MOBI_INTRA_ITEM_WORDS 4
+#define MOBI_ITEM_NONE 0xFFFFFFFFu /* padding: every dependency level starts on a wave of four items */
 #endif

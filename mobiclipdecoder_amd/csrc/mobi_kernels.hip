@@ -622,213 +622,162 @@ MOBI_OCT_KERNEL(mobi_recon_inter8, 4, 0, 16)
 MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16)
 
 // =====================================================================================================
-// intra macroblocks of one dependency level
+// intra macroblocks, FOUR per wavefront (sixteen lanes each)
 // =====================================================================================================
+// r01 / early r02 ran one macroblock per wave: the block list of a macroblock is serial (every block predicts from the ones
+// before it), so the wave walked it with scalar control -- 783 scalar + 611 vector instructions per macroblock, and a SIMD issues
+// one scalar instruction every four clocks: the kernel was bound by scalar issue.  Here a macroblock is a ROW of 16 lanes (the DPP
+// row), a wave carries four independent macroblocks of the same dependency level, and the serial list is data: one step per
+// unsplit area (an 8x8 block's predictors read only samples outside the block: 16 lanes x 4 samples do it at once), four per split
+// area (4x4 blocks, one sample per lane), 6..24 steps, two descriptor words per step, built once by the lane that holds the block's
+// record and read back by all 16.  The wave runs as many steps as its longest macroblock has (95 % of the areas are unsplit in the
+// generator's mix); the wave-level branches inside a step ask "does any of the four need a plane / a DC / an 8x8 / a 4x4 now".
 namespace {
-// byte load that bypasses this CU's L1 (sc1): issued now, valid only after ld_wait6() -- the compiler puts a full wait
-// behind every __hip_atomic_load, which serialises the halo into six round trips
-__device__ __forceinline__ uint32_t ld_u8_sc1(const uint8_t *base, uint32_t off) { // base: wave-uniform
-  uint32_t v;
+enum { IQ_TCU = 17 * TP, IQ_TCV = IQ_TCU + 9 * TP,                       // chroma tiles behind the luma tile (bytes)
+       IQ_COEF = (IQ_TCV + 9 * TP) / 4, IQ_STEP = IQ_COEF + 384, IQ_WORDS = IQ_STEP + 48 }; // words per macroblock: 2848 B
+// step descriptor, word 0
+enum { SD_O = 0,           // [10:0]  byte offset of the block's top-left sample inside the macroblock's tiles
+       SD_TAP = 11,        // [20:11] first tap table entry of this step (+ lane)
+       SD_IS4 = 1 << 21,   // 4x4 block (lane = y * 4 + x); else an 8x8 block (lane = row * 2 + half row: four samples)
+       SD_CODED = 1 << 22, // add the residual
+       SD_KTAP = 1 << 23, SD_KDC = 1 << 24, SD_KPLANE = 1 << 25, // predictor kind; none of them: what is there stays (plane passes, mode 9)
+       SD_TA = 1 << 26, SD_LA = 1 << 27,                         // DC: row above / column to the left available (MD.cs:1923-1924)
+       SD_P4 = 1 << 30 };  // the plane is a 4x4 one
+// word 1: [8:0] index of the step's first residual (+ lane's), [31:16] plane parameter
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t ldg_u8_sc1(const uint8_t *p) { // past this CU's L1; valid after vm_wait*
+  uint32_t v = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  // s_nop 4: when the compiler has to make `base` scalar with v_readfirstlane, a VMEM instruction may not read that
-  // SGPR for 5 wait states, and nothing inside an asm string is padded for us (cdna_hip_programming.md 5.7)
-  asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory");
-#else
-  v = base[off];
+  asm volatile("global_load_ubyte %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
 #endif
   return v;
 }
-__device__ __forceinline__ void ld_wait6(uint32_t (&v)[6]) {
+__device__ __forceinline__ u32x4 ldg_x4_sc1(const uint8_t *p) {
+  u32x4 v = {0, 0, 0, 0};
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+#endif
+  return v;
+}
+// The wait sits right behind its loads and names every destination: an asm load's register is only reserved up to the asm
+// statement, so a wait further away lets the register allocator reuse it while the data is still in flight (seen in r02).
+__device__ __forceinline__ void vm_wait(u32x4 &a, uint32_t &b, uint32_t &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
 #endif
 }
-struct TileNb {
+__device__ __forceinline__ void vm_wait7(uint32_t (&v)[7]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]) : : "memory");
+#endif
+}
+struct QNb { // neighbour samples of the block at tile offset o
   const uint8_t *t;
-  int by, bx;
-  __device__ __forceinline__ int operator()(int dy, int dx) const { return t[(by + dy + 1) * TP + 4 + bx + dx]; }
+  int o;
+  __device__ __forceinline__ int operator()(int dy, int dx) const { return t[o + dy * TP + dx]; }
 };
-// predict one block on the tile (all lanes call; lanes >= n*n idle) and add its residual when coded.  The residuals of the whole
-// macroblock were computed beforehand (they do not depend on the prediction): res = the area's 8x8 residual tile.
-} // namespace
-
-// One block of the list (see recon_intra_item): n = 1 << lgn is 4, 8 or 16 (16: the 16x16 plane only) and arrives as a scalar, so ONE
-// copy of this code serves every block of every macroblock (r01 inlined a specialised copy per call site: 25 of them, 770 scalar
-// instructions per macroblock, and the kernel was bound by scalar issue: one scalar instruction per SIMD every four cycles).
-__device__ __forceinline__ void run_block_g(uint8_t *tile, uint2 e, int by, int bx, int lgn, int mode, int param, bool coded,
-                                            const int *res, int sub, int block_off, bool is_uv, int S, int lane, int *fault) {
-  const int n = 1 << lgn, nn = n << lgn;
-  TileNb nb{tile, by, bx};
-  uint8_t *o = tile + (by + 1) * TP + 4 + bx; // the block's top-left sample
-  const int y = lane >> lgn, x = lane & (n - 1);
-  const int ri = lgn == 3 ? lane : ((sub >> 1) * 4 + y) * 8 + (sub & 1) * 4 + x; // this lane's place in the area's residual tile
-  bool add_pending = coded;
-  if (mode == 2) { // plane with delta (MD.cs:3017-3327): a lane makes a word of four samples
-    const int lw = lgn - 2;
-    if (lane < (nn >> 2)) {
-      const int yy = lane >> lw, x0 = (lane & ((1 << lw) - 1)) * 4;
-      *(uint32_t *)(o + yy * TP + x0) = mobi_plane_word(n, param, yy, x0, nb);
-    }
-    wave_sync();
-  } else if (mode == 3) { // DC with availability (MD.cs:1920-2022, :2501-2580)
-    const int vfix = is_uv && (block_off & (S - 1)) >= (S >> 1);                                             // MD.cs:1886
-    const bool left_avail = ((block_off - (vfix ? (S >> 1) : 0)) & (S - 1)) != 0, top_avail = block_off >= S; // :1923-1924
-    // lanes 0..n-1 fetch the row above, lanes n..2n-1 the left column; a row-wide DPP prefix sum leaves the total in lane 15
-    int v = 0;
-    if (lane < 2 * n) {
-      const bool top = lane < n;
-      const int i = top ? lane : lane - n;
-      const int t = o[top ? i - TP : i * TP - 1];
-      v = (top ? top_avail : left_avail) ? t : 0;
-    }
+__device__ __forceinline__ int row_sum16(int v) { // sum over the 16 lanes of a DPP row, left in all of them
 #if defined(__HIP_DEVICE_COMPILE__)
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); // row_shr:8
-    const int sum = __builtin_amdgcn_readlane(v, 15);
-#else
-    const int sum = 0;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); // row_ror:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); // row_ror:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, true); // row_ror:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, true); // row_ror:1
 #endif
-    const int dc = (top_avail && left_avail) ? (sum + n) >> (lgn + 1) : (top_avail || left_avail) ? (sum + (n >> 1)) >> lgn : 0x80;
-    if (lane < nn) {
-      int p = dc;
-      if (coded) p = mobi_add_clamp(p, res[ri], fault);
-      o[y * TP + x] = (uint8_t)p;
-    }
-    add_pending = false;
-    wave_sync();
-  } else if (mode != 9) { // the directional predictors: four neighbour samples per predicted sample, named by the tap table entry e (fetched one block ahead)
-    if (lane < nn) {
-      int p = (o[(int16_t)(e.x & 0xFFFF)] + o[(int16_t)(e.x >> 16)] + o[(int16_t)(e.y & 0xFFFF)] + o[(int16_t)(e.y >> 16)] + 2) >> 2;
-      if (coded) p = mobi_add_clamp(p, res[ri], fault);
-      o[y * TP + x] = (uint8_t)p;
-    }
-    add_pending = false;
-    wave_sync();
-  }
-  if (add_pending) { // predicted by a plane (mode 2) or by an earlier plane pass (mode 9): add on top of what is there
-    if (lane < nn) {
-      uint8_t *px = o + y * TP + x;
-      *px = (uint8_t)mobi_add_clamp(*px, res[ri], fault);
-    }
-    wave_sync();
-  }
+  return v;
+}
+__device__ __forceinline__ uint32_t quad_first(uint32_t v) { // lane 4k's value in lanes 4k..4k+3
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true); // quad_perm:[0,0,0,0]
+#else
+  return v;
+#endif
 }
 
-enum { INTRA_LDS_WORDS = 136 + 72 + 72 + 384 + MOBI_SCALE_STRIDE }; // 2976 B per wave: tiles, residuals (transformed in place), scales
-// What a wave needs to know to start on an intra macroblock.  The host-built launch list (mobi_abi.cpp, LevelPlan) carries it as one
-// 16-byte item, so the wave's first load already tells it where its records are and whether it must wait for anybody: r01 went
-// item -> descriptor -> records -> dependency tags -> halo, five memory round trips in series before the first block.
-struct IntraItem {
-  int clip, mb;
+// What a row of lanes needs to know to start on its macroblock.  The host-built launch list (mobi_abi.cpp, LevelPlan) carries it
+// as one 16-byte item, so the first load already says where the records are and whether anybody has to be waited for.
+struct QItem {
+  bool valid;        // false: padding (levels are padded to whole waves); the row works on zeros and stores nothing
+  uint32_t clip, mb;
   uint32_t w1;       // MbDesc.w1
   uint32_t pay;      // MbDesc.payload_off
   uint32_t w3;       // MbDesc.w3: [0] 16x16 plane present, [31:16] its parameter
-  int ncoef;
+  uint32_t ncoef;
   bool has_deps;     // some macroblock its halo reads is an intra one of this step: poll the tags, read the halo afterwards
   bool publish;      // an intra macroblock of this step may read these pixels: write through, drain, publish the tag
-  bool left_edge;    // the left neighbour's last column is in the edge side buffer (host-built lists, macroblocks with a left neighbour)
+  bool left_edge;    // the left neighbour's last column is in the edge side buffer
 };
-// one intra macroblock by one wave; L = INTRA_LDS_WORDS words of LDS private to the wave; `it` only labels the profiling record
-__device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_t *L, const IntraItem &I, int lane, int it) {
-  const int clip = I.clip, mb = I.mb;
-  const uint32_t w1 = I.w1, w3 = I.w3;
+} // namespace
+
+__device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_t *Lw, const QItem &I, int lane) {
+  const int l = lane & 15;
+  uint32_t *G = Lw + (lane >> 4) * IQ_WORDS;
+  uint8_t *tile = (uint8_t *)G;
+  int *coef = (int *)(G + IQ_COEF);
+  uint32_t *steps = G + IQ_STEP;
+  const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S), mbw = A.mbw;
+  const uint32_t clip = I.clip, mb = I.mb, w1 = I.w1, w3 = I.w3, ncoef = I.ncoef;
+  const int t8 = (w1 >> 14) & 0x3F;
   const uint32_t *rec = A.payload + I.pay;
-  const int32_t *sc_g = A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE;
-  const uint2 *taps = (const uint2 *)(A.scale + MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE); // 4480 B every wave reads: they stay in the L1
-  const int t8 = (w1 >> 14) & 0x3F, ncoef = I.ncoef;
-  const int S = A.stride;
-  const Geo g{A.width, A.height, S, A.mbw, 31 - __builtin_clz((unsigned)S)};
+  const int mby = (int)(((float)mb + 0.5f) / (float)mbw), mbx = (int)mb - mby * mbw; // mb < 8192: the quotient is never within rounding of an integer
+  const int off = ((mby * 16) << lgS) + mbx * 16;                                       // < 2^20
   uint8_t *y0 = A.planes + (size_t)clip * A.clip_bytes + (size_t)(A.ring_base % 6) * A.slot_bytes;
   uint8_t *uv0 = y0 + (size_t)S * A.height;
-  const int mbx = mb % A.mbw, mby = mb / A.mbw;
-  const int off = mby * 16 * S + mbx * 16; // < 2^20
+  const uint2 *taps = (const uint2 *)(A.scale + MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE); // 4480 B every wave reads: they stay in the L1
 
-  // block records and the first 64 residual level words
-  const uint32_t myrec = lane < MOBI_INTRA_RECORDS ? rec[lane] : 0u;
-  const uint32_t mycw = lane < ncoef ? rec[MOBI_INTRA_RECORDS + lane] : 0u;
-  const int32_t sc_lo = sc_g[lane], sc_hi = lane < MOBI_SCALE_STRIDE - 64 ? sc_g[64 + lane] : 0; // dequant scales -> LDS
-
-  // ---- halo: real pixels only from raster-earlier macroblocks; the rest is the reference's fresh 0 ----
-  // Addresses and tile positions first (pure arithmetic), the loads when they may go: at once if nobody has to be waited for.
-  const bool interior = mbx >= 1 && mbx + 1 < A.mbw && mby >= 1;
-  int hpos[6], hadr[6];
+  // ---- everything that can be asked for at once: block records, dequant scales, the first 64 level words, the halo ----
+  const uint32_t recA = I.valid ? rec[l] : 0u, recB = I.valid && l < MOBI_INTRA_RECORDS - 16 ? rec[16 + l] : 0u;
+  const uint4 *sc_g = (const uint4 *)(A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE);
+  const uint4 sc0 = sc_g[l], sc1 = sc_g[16 + (l & 3)];
+  uint32_t cw[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cw[k] = (uint32_t)(l + 16 * k) < ncoef ? rec[MOBI_INTRA_RECORDS + l + 16 * k] : 0u;
+  // Halo.  Away from the picture's left, right and top edges ownership needs no arithmetic: the row above (left, above, above-right
+  // macroblocks) and the column to the left are raster-earlier; everything to the right in the macroblock's own rows is
+  // raster-later and reads the fresh plane's 0.  Row above: six 16-byte loads (luma columns -4..27, U and V -4..27; the tiles keep
+  // column c at byte 4 + c, so they land aligned and the surplus falls on bytes nothing reads).  Left column: two bytes per lane,
+  // from the edge side buffer when the left neighbour left them there (32 consecutive bytes instead of 32 lines).
+  const bool interior = I.valid && mbx >= 1 && mbx + 1 < mbw && mby >= 1;
+  const uint8_t *wp = y0 + off, *b0p = wp, *b1p = wp; // lanes with nothing to fetch read the macroblock's own first sample and drop it
   if (interior) {
-    // away from the picture's left, right and top edges ownership is known without arithmetic: the row above (left,
-    // above, above-right macroblocks) and the column to the left are raster-earlier, everything to the right in the
-    // macroblock's own rows is raster-later (reads the fresh plane's 0).  Two loads per lane instead of six.
-#pragma unroll
-    for (int k = 0; k < 6; k++) { hpos[k] = -1; hadr[k] = k < 3 ? off : off / 2; }
-    hadr[1] = 0;
-    if (lane < 25) { hadr[0] = off - S + lane - 1; hpos[0] = 4 + lane - 1; }                               // luma row -1, columns -1..23
-    else if (lane < 41 && !I.left_edge) { hadr[0] = off + ((lane - 25) << g.lg) - 1; hpos[0] = (lane - 25 + 1) * TP + 3; } // luma column -1
-    const int vv = lane >> 5, jl = lane & 31; // lanes 0..24 U, 32..56 V
-    const int cb = off / 2 + vv * (S >> 1), tb = (136 + vv * 72) * 4;
-    if (jl < 17) { hadr[3] = cb - S + jl - 1; hpos[3] = tb + 4 + jl - 1; }
-    else if (jl < 25 && !I.left_edge) { hadr[3] = cb + ((jl - 17) << g.lg) - 1; hpos[3] = tb + (jl - 17 + 1) * TP + 3; }
-    if (I.left_edge && lane < MOBI_EDGE_BYTES) { // the three left columns: 32 consecutive bytes of the edge side buffer, slot 1 of the halo loads
-      hadr[1] = lane;
-      hpos[1] = lane < 16 ? (lane + 1) * TP + 3 : (136 + ((lane - 16) >> 3) * 72) * 4 + (((lane - 16) & 7) + 1) * TP + 3;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int i = lane + 64 * k;
-      int r, c;
-      if (i < 25) { r = -1; c = i - 1; }
-      else if (i < 41) { r = i - 25; c = -1; }
-      else { r = (i - 41) >> 3; c = 16 + ((i - 41) & 7); }
-      const int a = off + (r << g.lg) + c;
-      const int o = g.owner_luma(a);
-      const bool take = i < 25 + 16 + 128 && o >= 0 && o < mb;
-      hpos[k] = take ? (r + 1) * TP + 4 + c : -1;
-      hadr[k] = take ? a : off; // not ours to read: load our own first pixel instead, and drop it
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int i = lane + 64 * k;
-      const int v = i >= 89, j = v ? i - 89 : i;
-      int r, c;
-      if (j < 17) { r = -1; c = j - 1; }
-      else if (j < 25) { r = j - 17; c = -1; }
-      else { r = (j - 25) >> 3; c = 8 + ((j - 25) & 7); }
-      const int a = off / 2 + v * (S >> 1) + (r << g.lg) + c;
-      const int o = g.owner_chroma(a);
-      const bool take = i < 2 * (17 + 8 + 64) && o >= 0 && o < mb;
-      hpos[3 + k] = take ? (136 + v * 72) * 4 + (r + 1) * TP + 4 + c : -1; // tcu / tcv follow the luma tile
-      hadr[3 + k] = take ? a : off / 2;
+    if (l < 2) wp = y0 + (off - S - 4 + 16 * l);
+    else if (l < 6) wp = uv0 + ((off >> 1) + (l & 1) * (S >> 1) - S + (l < 4 ? -4 : 12));
+    if (I.left_edge) {
+      const uint8_t *eb = A.edge + ((size_t)clip * A.n_mbs + mb - 1) * MOBI_EDGE_BYTES;
+      b0p = eb + l;
+      b1p = eb + 16 + l;
+    } else {
+      b0p = y0 + (off + (l << lgS) - 1);
+      b1p = uv0 + ((off >> 1) + (l >> 3) * (S >> 1) + ((l & 7) << lgS) - 1);
     }
   }
-  uint32_t hval[6] = {0, 0, 0, 0, 0, 0};
-  const uint8_t *ebase = A.edge + (size_t)((size_t)clip * A.n_mbs + (interior ? mb - 1 : mb)) * MOBI_EDGE_BYTES;
-  if (!I.has_deps) {
-    // Everything the halo reads was written by the inter launch before this one: ordinary loads, issued now and in flight beside the
-    // records.  (They must be loads the compiler counts: the destination of an asm load is only "reserved" up to the asm
-    // statement, and with the wait far away the register allocator hands it to another value -- the late byte then lands in
-    // the dequant scales.  Seen, not imagined.)
-    hval[0] = y0[hadr[0]];
-    hval[3] = uv0[hadr[3]];
-    if (interior && I.left_edge) hval[1] = ebase[hadr[1]];
-    if (!interior) {
-      hval[1] = y0[hadr[1]];
-      hval[2] = y0[hadr[2]];
-      hval[4] = uv0[hadr[4]];
-      hval[5] = uv0[hadr[5]];
-    }
+  const int wdst = l < 2 ? 16 * l : (l & 1 ? IQ_TCV : IQ_TCU) + (l < 4 ? 0 : 16);
+  const int b0dst = (l + 1) * TP + 3, b1dst = (l < 8 ? IQ_TCU : IQ_TCV) + ((l & 7) + 1) * TP + 3;
+  // ordinary loads, in flight beside the records (whoever has to wait for a producer loads again below and drops these)
+  const uint4 w_early = *(const uint4_a4 *)wp;
+  const uint32_t b0_early = *b0p, b1_early = *b1p;
+
+  { // zero the coefficients; dequant scales into the (still unused) tile area
+    uint4 *G4 = (uint4 *)G;
+    const uint4 z = uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; k++) G4[IQ_COEF / 4 + l + 16 * k] = z;
+    G4[l] = sc0;
+    if (l < 4) G4[16 + l] = sc1;
   }
 
-  const unsigned long long pt0 = A.prof ? __builtin_readcyclecounter() : 0;
   // All dependency levels of a frame step run in ONE launch: items are sorted by level, workgroups are dispatched in order, and a
-  // wave waits here until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this step's tag.  Hand-off across CUs: the
-  // producer stores pixels write-through (sc1), drains them, then publishes its tag (sc1); the consumer polls the tag with sc1 loads
-  // and reads the halo with sc1 loads, so neither a stale L1 line nor a dirty L2 line can sit in between (MI355X_MICROARCH.md,
-  // inter-workgroup visibility).
-  if (I.has_deps) {
-    if (lane < MOBI_INTRA_DEPS) {
-      const MbDesc *desc = A.desc + (long)clip * A.n_mbs + mb;
-      const uint32_t wv = (&desc->w4)[lane >> 1];
-      const uint32_t dep = (wv >> (16 * (lane & 1))) & 0xFFFFu;
+  // row waits here until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this step's tag.  Hand-off across CUs: the
+  // producer stores pixels write-through (sc1), drains them, then publishes its tag; the consumer polls the tag with agent-scope
+  // loads and reads the halo with sc1 loads, so neither a stale L1 line nor a dirty L2 line can sit in between.
+  u32x4 wv = {w_early.x, w_early.y, w_early.z, w_early.w};
+  uint32_t b0 = b0_early, b1 = b1_early;
+  const bool waits = I.valid && I.has_deps;
+  if (__builtin_amdgcn_ballot_w64(waits) != 0) {
+    if (waits && l < MOBI_INTRA_DEPS) {
+      const MbDesc *desc = A.desc + (size_t)clip * A.n_mbs + mb;
+      const uint32_t wd = (&desc->w4)[l >> 1];
+      const uint32_t dep = (wd >> (16 * (l & 1))) & 0xFFFFu;
       if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) { // inter macroblocks ran in the launch before this one
         const uint32_t *f = A.done + (size_t)clip * A.n_mbs + (dep & 0x1FFFu);
         int spins = 0;
@@ -839,178 +788,313 @@ __device__ __forceinline__ void recon_intra_item(const MobiReconArgs &A, uint32_
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the halo after the tags, past this CU's L1 (sc1): all loads issued, then one wait right behind them
-    hval[0] = ld_u8_sc1(y0, (uint32_t)hadr[0]);
-    hval[3] = ld_u8_sc1(uv0, (uint32_t)hadr[3]);
-    if (interior && I.left_edge) hval[1] = ld_u8_sc1(ebase, (uint32_t)hadr[1]);
-    if (!interior) {
-      hval[1] = ld_u8_sc1(y0, (uint32_t)hadr[1]);
-      hval[2] = ld_u8_sc1(y0, (uint32_t)hadr[2]);
-      hval[4] = ld_u8_sc1(uv0, (uint32_t)hadr[4]);
-      hval[5] = ld_u8_sc1(uv0, (uint32_t)hadr[5]);
-    }
-    ld_wait6(hval);
-  }
-  const unsigned long long pt1 = A.prof ? __builtin_readcyclecounter() : 0;
-
-  uint8_t *ty = (uint8_t *)L;                 // 17 rows x TP
-  uint8_t *tcu = (uint8_t *)(L + 136);        // 9 rows x TP
-  uint8_t *tcv = (uint8_t *)(L + 136 + 72);
-  int *coef = (int *)(L + 136 + 144);
-  int32_t *sc = (int32_t *)(coef + 384);
-  { // tiles (280 words) and coefficients (384 words): 664 words = 2656 B, as 16-byte stores
-    const uint4 z = uint4{0, 0, 0, 0};
-    uint4 *L4 = (uint4 *)L;
-    L4[lane] = z;
-    L4[64 + lane] = z;
-    if (lane < 166 - 128) L4[128 + lane] = z;
-  }
-  sc[lane] = sc_lo;
-  if (lane < MOBI_SCALE_STRIDE - 64) sc[64 + lane] = sc_hi;
-  wave_sync();
-#pragma unroll
-  for (int k = 0; k < 6; k++)
-    if (hpos[k] >= 0) ty[hpos[k]] = (uint8_t)hval[k];
-  if (lane < ncoef) scatter_one(sc, mycw, t8, coef);
-  scatter_coefs(sc, rec + MOBI_INTRA_RECORDS, 64, ncoef, t8, coef, lane);
-  wave_sync();
-  // residuals of all coded areas at once, eight lanes per area, transformed in place (the block loop below only predicts and adds)
-  {
-    const int a = lane >> 3, r = lane & 7;
-    const bool act = a < 6 && ((w1 >> (8 + a)) & 1), is8a = (t8 >> a) & 1;
-    if (act) idct_pass1(coef + 64 * a, coef + 64 * a, is8a, r);
-    wave_sync();
-    if (act) idct_pass2_res(coef + 64 * a, is8a, r, coef + 64 * a);
-    wave_sync();
+    u32x4 wl = ldg_x4_sc1(wp);
+    uint32_t c0 = ldg_u8_sc1(b0p), c1 = ldg_u8_sc1(b1p);
+    vm_wait(wl, c0, c1);
+    if (waits) { wv = wl; b0 = c0; b1 = c1; }
   }
 
-  unsigned long long pt2 = 0;
-  if (A.prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt2 = __builtin_readcyclecounter(); }
-  // ---- block list, in decode order ----
-  // Lane k < 31 turns "its" record into a list entry: k = 0 the 16x16 plane; for area a, k = 1 + 5a the 8x8 plane that runs before
-  // the area, k = 2 + 5a + s block s of the area (s = 0: the whole 8x8 area unless it is split into four 4x4 blocks).  The wave then
-  // walks the valid entries with scalar control: readlane, a few bit fields, one generic block routine.
-  int fault = 0;
-  uint32_t e0;
-  int e1;
-  bool ev;
-  {
-    const int k = lane, a = k ? ((k - 1) * 205) >> 10 : 0, jj = k ? (k - 1) - 5 * a : 0, sb = jj ? jj - 1 : 0; // (k - 1) / 5, (k - 1) % 5
-    const uint32_t r0 = (uint32_t)__shfl((int)myrec, a * 4), rs = (uint32_t)__shfl((int)myrec, a * 4 + sb);
-    const bool pre = (r0 >> 6) & 1, split = (r0 >> 5) & 1, plane_entry = k == 0 || jj == 0;
-    ev = k == 0 ? (w3 & 1) != 0 : k > 30 ? false : jj == 0 ? pre : (sb == 0 || split);
-    const int lgn = k == 0 ? 4 : (jj && split) ? 2 : 3;
-    const int mode = plane_entry ? 2 : (int)(rs & 15);
-    const int coded = plane_entry ? 0 : (int)((rs >> 4) & 1);
-    e1 = k == 0 ? (int)(int16_t)(w3 >> 16) : jj == 0 ? (int)(int16_t)(r0 >> 16) : (sb == 0 && pre) ? 0 : (int)(int16_t)(rs >> 16);
-    const int sel = a < 4 ? 0 : a - 3;
-    const int sy = (jj && split) ? (sb >> 1) * 4 : 0, sx = (jj && split) ? (sb & 1) * 4 : 0;
-    const int by = (k && a < 4 ? (a >> 1) * 8 : 0) + sy, bx = (k && a < 4 ? (a & 1) * 8 : 0) + sx;
-    e0 = (uint32_t)(mode | (coded << 4) | (lgn << 5) | (sel << 8) | (by << 10) | (bx << 15) | (a << 20) | ((split ? sb : 0) << 23));
-  }
-  uint32_t todo = (uint32_t)__builtin_amdgcn_ballot_w64(ev);
-  // the tap table entry of a directional block does not depend on pixels: it is fetched while the block before it runs
-  auto tap_fetch = [&](uint32_t E) {
-    const int mode = E & 15, lgn = (E >> 5) & 7, mi = mode < 2 ? mode : mode - 2;
-    uint2 e = uint2{0, 0};
-    if (mode != 2 && mode != 3 && mode != 9) e = taps[(lgn == 3 ? mi * 64 + lane : MOBI_TAP_4X4 + mi * 16 + (lane & 15))];
-    return e;
+  // ---- dequantise and scatter the level words ----
+  wave_sync();
+  auto scatter = [&](uint32_t e) {
+    const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63;
+    const int si = ((t8 >> (t >> 6)) & 1) ? p : 64 + (p & 15);
+    coef[t] = __mul24((int)G[si], level);
   };
-  uint32_t En = todo ? (uint32_t)__builtin_amdgcn_readlane((int)e0, __builtin_ctz(todo)) : 0u;
-  uint2 tn = tap_fetch(En);
-  while (todo) {
-    const int k = __builtin_ctz(todo);
-    todo &= todo - 1;
-    const uint32_t E = En;
-    const uint2 te = tn;
-    if (todo) {
-      En = (uint32_t)__builtin_amdgcn_readlane((int)e0, __builtin_ctz(todo));
-      tn = tap_fetch(En);
-    }
-    const int param = __builtin_amdgcn_readlane(e1, k);
-    const int sel = (E >> 8) & 3, by = (E >> 10) & 31, bx = (E >> 15) & 31, area = (E >> 20) & 7;
-    uint8_t *tile = sel == 0 ? ty : sel == 1 ? tcu : tcv;
-    const int boff = (sel == 0 ? off : off / 2 + (sel - 1) * (S >> 1)) + by * S + bx;
-    run_block_g(tile, te, by, bx, (E >> 5) & 7, E & 15, param, (E >> 4) & 1, coef + 64 * area, (E >> 23) & 3, boff, sel != 0, S, lane, &fault);
-  }
-  if (fault) atomicOr(&A.fault[clip], 1);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((uint32_t)(l + 16 * k) < ncoef) scatter(cw[k]);
+  for (uint32_t i = 64 + (uint32_t)l; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 16)
+    if (i < ncoef) scatter(rec[MOBI_INTRA_RECORDS + i]);
+  wave_sync();
 
-  unsigned long long pt3 = 0;
-  if (A.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt3 = __builtin_readcyclecounter(); }
-  // ---- the right neighbour is intra too: leave it the last column (edge side buffer, 32 consecutive bytes) ----
-  if ((w1 & MOBI_W1_EDGE) && A.edge && lane < MOBI_EDGE_BYTES) {
-    const uint8_t *src = lane < 16 ? ty + (lane + 1) * TP + 4 + 15 : (lane < 24 ? tcu : tcv) + (((lane - 16) & 7) + 1) * TP + 4 + 7;
-    const uint32_t v = *src;
-    uint8_t *dst = A.edge + ((size_t)clip * A.n_mbs + mb) * MOBI_EDGE_BYTES + lane;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (I.publish) asm volatile("global_store_byte %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-    else asm volatile("global_store_byte %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-#endif
-  }
-  // ---- store interiors: whole rows (16 B of luma, 8 B of chroma per lane).  Write-through (sc1), drained and followed by the tag
-  // only when an intra macroblock of this step may be waiting for them on another CU; plain stores otherwise (the next launch is
-  // a kernel boundary away).  (r01 stored dwords: 96 write-through stores per macroblock.) ----
+  // ---- tiles: zero (what nobody owns yet reads 0, as the reference's fresh plane does), then the halo ----
   {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint4 *G4 = (uint4 *)G;
+    const uint4 z = uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) G4[l + 16 * k] = z;
+    if (l < IQ_COEF / 4 - 64) G4[64 + l] = z;
+  }
+  wave_sync();
+  if (interior) {
+    if (l < 6) *(u32x4 *)(tile + wdst) = wv;
+    tile[b0dst] = (uint8_t)b0;
+    tile[b1dst] = (uint8_t)b1;
+  }
+  // At the picture's edges the linear offsets of the reference wrap into the previous / next row or fall into the padding: every
+  // halo sample asks who owns its address (217 luma + 178 chroma samples, 7 per lane and round).  One macroblock in twelve; the
+  // host sorts them to the end of their level so that few waves come here.
+  if (__builtin_amdgcn_ballot_w64(I.valid && !interior) != 0) {
+    const Geo g{A.width, A.height, S, mbw, lgS};
+    const bool mine = I.valid && !interior;
+#pragma unroll 1
+    for (int round = 0; round < 4; round++) {
+      const bool chroma = round >= 2;
+      uint32_t hv[7];
+      int hp[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const int i = l + 16 * (7 * (round & 1) + k);
+        int r, c, a, o, pos;
+        bool in;
+        if (!chroma) {
+          if (i < 25) { r = -1; c = i - 1; }
+          else if (i < 41) { r = i - 25; c = -1; }
+          else { r = (i - 41) >> 3; c = 16 + ((i - 41) & 7); }
+          a = off + r * S + c;
+          o = g.owner_luma(a);
+          in = i < 25 + 16 + 128;
+          pos = (r + 1) * TP + 4 + c;
+        } else {
+          const int v = i >= 89, j = v ? i - 89 : i;
+          if (j < 17) { r = -1; c = j - 1; }
+          else if (j < 25) { r = j - 17; c = -1; }
+          else { r = (j - 25) >> 3; c = 8 + ((j - 25) & 7); }
+          a = (off >> 1) + v * (S >> 1) + r * S + c;
+          o = g.owner_chroma(a);
+          in = i < 2 * (17 + 8 + 64);
+          pos = (v ? IQ_TCV : IQ_TCU) + (r + 1) * TP + 4 + c;
+        }
+        const bool take = mine && in && o >= 0 && o < (int)mb;
+        hp[k] = take ? pos : -1;
+        hv[k] = ldg_u8_sc1((chroma ? uv0 : y0) + (take ? a : 0)); // not ours to read: load the plane's first sample instead, and drop it
+      }
+      vm_wait7(hv);
+#pragma unroll
+      for (int k = 0; k < 7; k++)
+        if (hp[k] >= 0) tile[hp[k]] = (uint8_t)hv[k];
+    }
+  }
+  wave_sync();
+
+  // ---- residuals of all coded areas, transformed in place: eight lanes per area, two areas of each macroblock per round ----
+#pragma unroll 1
+  for (int rd = 0; rd < 3; rd++) {
+    const int a = 2 * rd + (l >> 3), r = l & 7;
+    const bool act = (w1 >> (8 + a)) & 1, is8a = (t8 >> a) & 1;
+    if (__builtin_amdgcn_ballot_w64(act) != 0) {
+      if (act) idct_pass1(coef + 64 * a, coef + 64 * a, is8a, r);
+      wave_sync();
+      if (act) idct_pass2_res(coef + 64 * a, is8a, r, coef + 64 * a);
+      wave_sync();
+    }
+  }
+
+  // ---- the schedule: one step per unsplit area, four per split one, in decode order.  Lane 4a + s of the row owns the candidate
+  // (area a, block s); its place in the list follows from how many areas before a are split. ----
+  int n_iter;
+  {
+    const uint64_t balA = __builtin_amdgcn_ballot_w64(((recA >> 5) & 1) != 0 && (l & 3) == 0);          // areas 0..3: lanes 0, 4, 8, 12 of the row
+    const uint64_t balB = __builtin_amdgcn_ballot_w64(((recB >> 5) & 1) != 0 && (l & 3) == 0 && l < 8); // areas 4, 5: lanes 0, 4
+    const uint32_t mA = (uint32_t)(balA >> (lane & 48)) & 0x1111u, mB = (uint32_t)(balB >> (lane & 48)) & 0x11u;
+    const uint32_t splits = (mA & 1) | ((mA >> 3) & 2) | ((mA >> 6) & 4) | ((mA >> 9) & 8) | ((mB & 1) << 4) | ((mB >> 4) << 5);
+    const int nst = 6 + 3 * __builtin_popcount(splits);
+    n_iter = max(max(__builtin_amdgcn_readlane(nst, 0), __builtin_amdgcn_readlane(nst, 16)), max(__builtin_amdgcn_readlane(nst, 32), __builtin_amdgcn_readlane(nst, 48)));
+    // rows with fewer steps than the longest of the four idle through the rest: a descriptor that does nothing
+    const uint2 idle = uint2{(uint32_t)(TP + 4), 0u};
+    *(uint2 *)(steps + 2 * l) = idle;
+    if (l < 8) *(uint2 *)(steps + 2 * (16 + l)) = idle;
+    wave_sync();
+    auto build = [=](int t, uint32_t rown, uint32_t r0, int &pos) -> uint2 {
+      const int a = t >> 2, s = t & 3;
+      const bool split = (r0 >> 5) & 1, pre = (r0 >> 6) & 1;
+      pos = (s == 0 || split) ? a + 3 * __builtin_popcount(splits & ((1u << a) - 1u)) + s : -1;
+      const uint32_t rs = split ? rown : r0;
+      const int mode = (int)(rs & 15);
+      const bool coded = (rs >> 4) & 1, luma = a < 4;
+      const int by = (luma ? (a >> 1) * 8 : 0) + (split ? (s >> 1) * 4 : 0), bx = (luma ? (a & 1) * 8 : 0) + (split ? (s & 1) * 4 : 0);
+      const int o_blk = (luma ? 0 : a == 4 ? IQ_TCU : IQ_TCV) + (by + 1) * TP + 4 + bx;
+      const bool k_dc = mode == 3, k_tap = mode < 2 || (mode >= 4 && mode <= 8);
+      const bool plane_blk = mode == 2, plane_pre = pre && s == 0;
+      const uint32_t param = plane_blk ? rs >> 16 : r0 >> 16;
+      const int mi = !k_tap ? 0 : mode < 2 ? mode : mode - 2;
+      const int tapbase = split ? MOBI_TAP_4X4 + mi * 16 : mi * 64;
+      const int boff = (luma ? off : (off >> 1) + (a - 4) * (S >> 1)) + by * S + bx;
+      const bool vfix = !luma && (boff & (S - 1)) >= (S >> 1);                                              // MD.cs:1886
+      const bool la = ((boff - (vfix ? (S >> 1) : 0)) & (S - 1)) != 0, ta = boff >= S;                      // :1923-1924
+      const int ri = a * 64 + (split ? (s >> 1) * 32 + (s & 1) * 4 : 0);
+      uint32_t d0 = (uint32_t)o_blk | ((uint32_t)tapbase << SD_TAP);
+      if (split) d0 |= SD_IS4;
+      if (coded) d0 |= SD_CODED;
+      if (k_tap) d0 |= SD_KTAP;
+      if (k_dc) d0 |= SD_KDC;
+      if (plane_blk || plane_pre) d0 |= SD_KPLANE;
+      if (ta) d0 |= SD_TA;
+      if (la) d0 |= SD_LA;
+      if (plane_blk && split) d0 |= SD_P4;
+      return uint2{d0, (uint32_t)ri | (param << 16)};
+    };
+    int posA, posB;
+    const uint2 dA = build(l, recA, quad_first(recA), posA);
+    const uint2 dB = build(16 + (l & 7), recB, quad_first(recB), posB);
+    if (posA >= 0) *(uint2 *)(steps + 2 * posA) = dA;
+    if (l < 8 && posB >= 0) *(uint2 *)(steps + 2 * posB) = dB;
+  }
+  wave_sync();
+
+  // ---- 16x16 plane (MD.cs:3017-3166): 64 words, four per lane ----
+  if (__builtin_amdgcn_ballot_w64((w3 & 1) != 0) != 0) {
+    if (w3 & 1) {
+      const QNb nb{tile, TP + 4};
+      const int param = (int)(int16_t)(w3 >> 16);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int w = u * 16 + l, yy = w >> 2, x0 = (w & 3) * 4;
+        *(uint32_t *)(tile + TP + 4 + yy * TP + x0) = mobi_plane_word(16, param, yy, x0, nb);
+      }
+    }
+    wave_sync();
+  }
+
+  // ---- the steps.  An 8x8 block is one step, four samples per lane (its predictors read only samples outside the block); a 4x4
+  // block one sample per lane ----
+  const int po8 = (l >> 1) * TP + (l & 1) * 4, ro8 = (l >> 1) * 8 + (l & 1) * 4;
+  const int po4 = (l >> 2) * TP + (l & 3), ro4 = (l >> 2) * 8 + (l & 3);
+  int fault = 0;
+  uint2 dn = *(const uint2 *)steps;
+  uint4 ean, ebn;
+  { // the tap table entries of a directional block do not depend on pixels: they are fetched while the step before it runs
+    const uint2 *tp = taps + (((dn.x >> SD_TAP) & 0x3FF) + ((dn.x & SD_IS4) ? l : 4 * l));
+    ean = *(const uint4_a4 *)tp;
+    ebn = *(const uint4_a4 *)(tp + 2);
+  }
+#pragma unroll 1
+  for (int t = 0; t < n_iter; t++) {
+    const uint2 d = dn;
+    const uint4 ea = ean, eb = ebn;
+    if (t + 1 < n_iter) {
+      dn = *(const uint2 *)(steps + 2 * (t + 1));
+      const uint2 *tp = taps + (((dn.x >> SD_TAP) & 0x3FF) + ((dn.x & SD_IS4) ? l : 4 * l));
+      ean = *(const uint4_a4 *)tp;
+      ebn = *(const uint4_a4 *)(tp + 2);
+    }
+    const int o = (int)(d.x & 0x7FF);
+    const bool is4 = (d.x & SD_IS4) != 0;
+    if (__builtin_amdgcn_ballot_w64((d.x & SD_KPLANE) != 0) != 0) { // plane with delta, 8x8 (MD.cs:3168-3251) or 4x4 (:3253-3327): a lane makes a word of four samples
+      const bool p4 = (d.x & SD_P4) != 0;
+      if ((d.x & SD_KPLANE) && l < (p4 ? 4 : 16)) {
+        const int yy = p4 ? l : l >> 1, x0 = p4 ? 0 : (l & 1) * 4;
+        *(uint32_t *)(tile + o + yy * TP + x0) = mobi_plane_word(p4 ? 4 : 8, (int)(int16_t)(d.y >> 16), yy, x0, QNb{tile, o});
+      }
+      wave_sync();
+    }
+    int dcv = 0;
+    if (__builtin_amdgcn_ballot_w64((d.x & SD_KDC) != 0) != 0) { // DC with availability (MD.cs:1920-2022, :2501-2580)
+      const int n = is4 ? 4 : 8, lgn = is4 ? 2 : 3;
+      const bool top = l < n, ta = (d.x & SD_TA) != 0, la = (d.x & SD_LA) != 0;
+      const int i = top ? l : l - n;
+      const int nbv = tile[o + (top ? i - TP : i * TP - 1)];
+      const int sum = row_sum16((l < 2 * n && (top ? ta : la)) ? nbv : 0);
+      dcv = (ta && la) ? (sum + n) >> (lgn + 1) : (ta || la) ? (sum + (n >> 1)) >> lgn : 0x80;
+    }
+    const bool wr = (d.x & (SD_KTAP | SD_KDC | SD_CODED)) != 0; // else: what a plane pass left there stays
+    const bool w8 = wr && !is4, w4 = wr && is4;
+    if (__builtin_amdgcn_ballot_w64(w8) != 0) {
+      if (w8) {
+        uint8_t *px = tile + o + po8;
+        uint32_t word = *(const uint32_t *)px;
+        if (d.x & SD_KTAP) { // the directional predictors: four neighbour samples per predicted sample, named by the tap table
+          const uint8_t *tb = tile + o;
+          const uint32_t t0 = (tb[(int16_t)(ea.x & 0xFFFF)] + tb[(int16_t)(ea.x >> 16)] + tb[(int16_t)(ea.y & 0xFFFF)] + tb[(int16_t)(ea.y >> 16)] + 2) >> 2;
+          const uint32_t t1 = (tb[(int16_t)(ea.z & 0xFFFF)] + tb[(int16_t)(ea.z >> 16)] + tb[(int16_t)(ea.w & 0xFFFF)] + tb[(int16_t)(ea.w >> 16)] + 2) >> 2;
+          const uint32_t t2 = (tb[(int16_t)(eb.x & 0xFFFF)] + tb[(int16_t)(eb.x >> 16)] + tb[(int16_t)(eb.y & 0xFFFF)] + tb[(int16_t)(eb.y >> 16)] + 2) >> 2;
+          const uint32_t t3 = (tb[(int16_t)(eb.z & 0xFFFF)] + tb[(int16_t)(eb.z >> 16)] + tb[(int16_t)(eb.w & 0xFFFF)] + tb[(int16_t)(eb.w >> 16)] + 2) >> 2;
+          word = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);
+        } else if (d.x & SD_KDC) {
+          word = (uint32_t)dcv * 0x01010101u;
+        }
+        if (d.x & SD_CODED) {
+          const int4 r = *(const int4 *)(coef + (d.y & 0x1FF) + ro8);
+          const uint32_t q0 = (uint32_t)mobi_add_clamp((int)(word & 0xFF), r.x, &fault), q1 = (uint32_t)mobi_add_clamp((int)((word >> 8) & 0xFF), r.y, &fault);
+          const uint32_t q2 = (uint32_t)mobi_add_clamp((int)((word >> 16) & 0xFF), r.z, &fault), q3 = (uint32_t)mobi_add_clamp((int)(word >> 24), r.w, &fault);
+          word = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+        }
+        *(uint32_t *)px = word;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(w4) != 0) {
+      if (w4) {
+        uint8_t *px = tile + o + po4;
+        const uint8_t *tb = tile + o;
+        int p = *px;
+        if (d.x & SD_KTAP) p = (tb[(int16_t)(ea.x & 0xFFFF)] + tb[(int16_t)(ea.x >> 16)] + tb[(int16_t)(ea.y & 0xFFFF)] + tb[(int16_t)(ea.y >> 16)] + 2) >> 2;
+        else if (d.x & SD_KDC) p = dcv;
+        if (d.x & SD_CODED) p = mobi_add_clamp(p, coef[(d.y & 0x1FF) + ro4], &fault);
+        *px = (uint8_t)p;
+      }
+    }
+    wave_sync();
+  }
+  if (fault && I.valid) atomicOr(&A.fault[clip], 1);
+
+  // ---- store.  Write-through (sc1), drained and followed by the tag only when an intra macroblock of this step may be waiting for
+  // these pixels on another CU; plain stores otherwise (the next launch is a kernel boundary away). ----
+  const bool anyp = __builtin_amdgcn_ballot_w64(I.valid && I.publish) != 0;
+  if (I.valid) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    if (lane < 16) {
-      const uint8_t *src = ty + (lane + 1) * TP + 4;
-      const u32x4 v = {*(const uint32_t *)src, *(const uint32_t *)(src + 4), *(const uint32_t *)(src + 8), *(const uint32_t *)(src + 12)};
-      uint8_t *dst = y0 + off + lane * S;
+    if ((w1 & MOBI_W1_EDGE) && A.edge && l < 8) { // the right neighbour is intra too: leave it the last column (edge side buffer)
+      const uint8_t *src = l < 4 ? tile + (4 * l + 1) * TP + 4 + 15 : tile + (l < 6 ? IQ_TCU : IQ_TCV) + (4 * (l & 1) + 1) * TP + 4 + 7;
+      const uint32_t v = (uint32_t)src[0] | ((uint32_t)src[TP] << 8) | ((uint32_t)src[2 * TP] << 16) | ((uint32_t)src[3 * TP] << 24);
+      uint8_t *dst = A.edge + ((size_t)clip * A.n_mbs + mb) * MOBI_EDGE_BYTES + 4 * l;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (I.publish) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-      else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+      if (anyp) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+      else asm volatile("global_store_dword %0, %1, off" : : "v"(dst), "v"(v) : "memory");
 #endif
-    } else if (lane < 32) {
-      const int v01 = (lane >> 3) & 1, crow = lane & 7;
-      const uint8_t *src = (v01 ? tcv : tcu) + (crow + 1) * TP + 4;
-      const u32x2 v = {*(const uint32_t *)src, *(const uint32_t *)(src + 4)};
-      uint8_t *dst = uv0 + off / 2 + v01 * (S >> 1) + crow * S;
+    }
+    {
+      const uint8_t *src = tile + (l + 1) * TP + 4;
+      const u32x4 v = {*(const uint32_t *)src, *(const uint32_t *)(src + 4), *(const uint32_t *)(src + 8), *(const uint32_t *)(src + 12)};
+      uint8_t *dst = y0 + (off + (l << lgS));
+      const uint8_t *srcc = tile + (l < 8 ? IQ_TCU : IQ_TCV) + ((l & 7) + 1) * TP + 4;
+      const u32x2 vc = {*(const uint32_t *)srcc, *(const uint32_t *)(srcc + 4)};
+      uint8_t *dstc = uv0 + ((off >> 1) + (l >> 3) * (S >> 1) + ((l & 7) << lgS));
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (I.publish) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
-      else asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+      if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v), "v"(dstc), "v"(vc) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx2 %2, %3, off\n\ts_nop 1" : : "v"(dst), "v"(v), "v"(dstc), "v"(vc) : "memory");
 #endif
     }
   }
-  if (I.publish) {
+  if (anyp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pixels have left this CU before the tag does
-    if (lane == 0) __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + mb, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (A.prof && lane == 0 && it < A.n_clips * A.n_mbs / 2) { // MOBI_DEBUG=9: dependency wait, loads, blocks, store+publish (shader clock)
-    const unsigned long long pt4 = __builtin_readcyclecounter();
-    ((uint4 *)A.prof)[(size_t)A.n_clips * A.n_mbs / 2 + it] = uint4{(uint32_t)(pt1 - pt0), (uint32_t)(pt2 - pt1), (uint32_t)(pt3 - pt2), (uint32_t)(pt4 - pt3)};
+    if (I.valid && I.publish && l == 0) __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + mb, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// Launch list built on the host (mobi_abi.cpp, LevelPlan): 16 bytes per intra macroblock, sorted by dependency level.
+// Launch list built on the host (mobi_abi.cpp, LevelPlan): 16 bytes per intra macroblock, sorted by dependency level, every level
+// padded to a whole number of waves with null items (x = ~0).
 //   x = clip << 13 | mb   y = MbDesc.w1   z = MbDesc.payload_off (inside this step's arena)
 //   w = [0] 16x16 plane present  [1] has intra dependencies  [2] has intra dependents  [3] the left neighbour's last column is in the
 //       edge side buffer  [14:5] number of level words  [31:16] plane parameter
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs A, const uint4 *items, int n_items) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[INTRA_LDS_WORDS];
-  const int lane = threadIdx.x, it = blockIdx.x;
-  const uint4 item = items[it];
-  const IntraItem I{(int)(item.x >> 13), (int)(item.x & 0x1FFF), item.y, item.z, item.w & 0xFFFF0001u, (int)((item.w >> 5) & 0x3FF), (item.w & 2) != 0, (item.w & 4) != 0,
-                    (item.w & 8) != 0 && A.edge != nullptr};
-  recon_intra_item(A, lds, I, lane, it);
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
+  const int lane = threadIdx.x;
+  const uint4 item = items[blockIdx.x * 4 + (lane >> 4)];
+  const bool valid = item.x != 0xFFFFFFFFu;
+  const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
+                (item.w & 2) != 0, (item.w & 4) != 0, (item.w & 8) != 0 && A.edge != nullptr};
+  recon_intra_quad(A, lds, I, lane);
 }
 
-// Items as the device-side parser leaves them (mobi_dparse.hip): per clip, raster order, n_intra[clip] of them at a stride
-// of n_mbs.  Workgroup it = slot * n_clips + clip: neighbours in the dispatch order belong to different clips, so every
-// clip advances along its own dependency chain at the same time, and what a wave waits for (raster-earlier, same clip)
-// always sits in an earlier slot, i.e. was dispatched before it.  Nothing here knows who depends on whom before the descriptor
-// has been read: every macroblock looks at its dependency list and publishes its tag.
+// Items as the device-side parser leaves them (mobi_dparse.hip): per clip, raster order, n_intra[clip] of them at a stride of
+// n_mbs.  Workgroup = slot * ceil(n_clips / 4) + clip quad: the four rows of a wave are the same slot of four clips, neighbours in
+// the dispatch order belong to different clips, so every clip advances along its own dependency chain at the same time, and what
+// a row waits for (raster-earlier, same clip) always sits in an earlier slot, i.e. was dispatched before it.  Nothing here
+// knows who depends on whom before the descriptor has been read: every macroblock looks at its dependency list and publishes its tag.
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconArgs A, const uint32_t *items, const uint32_t *n_intra, uint32_t n_intra_stride,
-                                                                      uint32_t magic_n_clips) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[INTRA_LDS_WORDS];
+                                                                      uint32_t quads, uint32_t magic_quads) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
   const int lane = threadIdx.x;
-  uint32_t clip;
-  const uint32_t slot = fastdiv(blockIdx.x, (uint32_t)A.n_clips, magic_n_clips, clip);
-  if (slot >= n_intra[(size_t)clip * n_intra_stride]) return;
-  const int mb = (int)(items[(size_t)clip * A.n_mbs + slot] & 0x1FFF);
-  const MbDesc *desc = A.desc + (long)clip * A.n_mbs + mb;
-  const IntraItem I{(int)clip, mb, desc->w1, desc->payload_off, desc->w3 & 0xFFFF0001u, (int)(desc->w2 & 0x3FF), true, true, false};
-  recon_intra_item(A, lds, I, lane, (int)blockIdx.x);
+  uint32_t cq;
+  const uint32_t slot = fastdiv(blockIdx.x, quads, magic_quads, cq);
+  const uint32_t clip = 4 * cq + (uint32_t)(lane >> 4);
+  const bool valid = clip < (uint32_t)A.n_clips && slot < n_intra[(size_t)(clip < (uint32_t)A.n_clips ? clip : 0) * n_intra_stride];
+  if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
+  const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
+  const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
+  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
+                valid ? desc->w2 & 0x3FFu : 0u, true, true, false};
+  recon_intra_quad(A, lds, I, lane);
 }
 
 // =====================================================================================================
@@ -1034,13 +1118,15 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
 }
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
   if (n_items <= 0) return 0;
-  hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items), dim3(64), 0, s, *a, (const uint4 *)items_dev, n_items);
+  if (n_items & 3) return (int)hipErrorInvalidValue; // levels are padded to whole waves of four macroblocks
+  hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items / 4), dim3(64), 0, s, *a, (const uint4 *)items_dev, n_items);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s) {
   if (K <= 0 || a->n_clips <= 0) return 0;
-  const uint64_t m = ((uint64_t)1 << 32) / (uint32_t)a->n_clips;
-  hipLaunchKernelGGL(mobi_recon_intra_cl, dim3((unsigned)K * (unsigned)a->n_clips), dim3(64), 0, s, *a, items_dev, n_intra_dev, (uint32_t)n_intra_stride_words,
+  const uint32_t quads = ((uint32_t)a->n_clips + 3) / 4;
+  const uint64_t m = ((uint64_t)1 << 32) / quads;
+  hipLaunchKernelGGL(mobi_recon_intra_cl, dim3((unsigned)K * quads), dim3(64), 0, s, *a, items_dev, n_intra_dev, (uint32_t)n_intra_stride_words, quads,
                      (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m));
   return (int)hipGetLastError();
 }
