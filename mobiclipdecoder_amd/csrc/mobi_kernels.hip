@@ -566,7 +566,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int i = lane + 64 * it, gq = i & 7, row16 = i >> 3;
-    if ((inter_mask >> gq) & 1) {
+    if (gq < nmb) { // intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them): a row with a hole is a partial
+                    // line, and HBM turns every store below 64 B into a read-modify-write (tools/ubench/pwrite.hip: 26 vs 69 pieces per ns)
       *(uint4 *)(y0 + (off0 + (row16 << lgS) + gq * 16)) = *(const uint4 *)(L + P_OUT_Y + row16 * 128 + gq * 16);
       const int row = row16 & 7; // chroma: plane = it, row = (i >> 3) & 7
       *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + P_OUT_C + it * 512 + row * 64 + gq * 8);
@@ -709,7 +710,7 @@ struct QItem {
 };
 } // namespace
 
-__device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_t *Lw, const QItem &I, int lane) {
+__device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_t *Lw, const QItem &I, int lane, int dbg = 0) {
   const int l = lane & 15;
   uint32_t *G = Lw + (lane >> 4) * IQ_WORDS;
   uint8_t *tile = (uint8_t *)G;
@@ -729,9 +730,9 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const uint32_t recA = I.valid ? rec[l] : 0u, recB = I.valid && l < MOBI_INTRA_RECORDS - 16 ? rec[16 + l] : 0u;
   const uint4 *sc_g = (const uint4 *)(A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE);
   const uint4 sc0 = sc_g[l], sc1 = sc_g[16 + (l & 3)];
-  uint32_t cw[4];
+  uint32_t cw[8]; // the first 128 level words of the macroblock
 #pragma unroll
-  for (int k = 0; k < 4; k++) cw[k] = (uint32_t)(l + 16 * k) < ncoef ? rec[MOBI_INTRA_RECORDS + l + 16 * k] : 0u;
+  for (int k = 0; k < 8; k++) cw[k] = (uint32_t)(l + 16 * k) < ncoef && !(dbg & 32) ? rec[MOBI_INTRA_RECORDS + l + 16 * k] : 0u;
   // Halo.  Away from the picture's left, right and top edges ownership needs no arithmetic: the row above (left, above, above-right
   // macroblocks) and the column to the left are raster-earlier; everything to the right in the macroblock's own rows is
   // raster-later and reads the fresh plane's 0.  Row above: six 16-byte loads (luma columns -4..27, U and V -4..27; the tiles keep
@@ -754,8 +755,9 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const int wdst = l < 2 ? 16 * l : (l & 1 ? IQ_TCV : IQ_TCU) + (l < 4 ? 0 : 16);
   const int b0dst = (l + 1) * TP + 3, b1dst = (l < 8 ? IQ_TCU : IQ_TCV) + ((l & 7) + 1) * TP + 3;
   // ordinary loads, in flight beside the records (whoever has to wait for a producer loads again below and drops these)
-  const uint4 w_early = *(const uint4_a4 *)wp;
-  const uint32_t b0_early = *b0p, b1_early = *b1p;
+  uint4 w_early = uint4{0, 0, 0, 0};
+  uint32_t b0_early = 0, b1_early = 0;
+  if (!(dbg & 16)) { w_early = *(const uint4_a4 *)wp; b0_early = *b0p; b1_early = *b1p; }
 
   { // zero the coefficients; dequant scales into the (still unused) tile area
     uint4 *G4 = (uint4 *)G;
@@ -802,10 +804,15 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     coef[t] = __mul24((int)G[si], level);
   };
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if ((uint32_t)(l + 16 * k) < ncoef) scatter(cw[k]);
-  for (uint32_t i = 64 + (uint32_t)l; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 16)
-    if (i < ncoef) scatter(rec[MOBI_INTRA_RECORDS + i]);
+  for (int k = 0; k < 8; k++)
+    if ((uint32_t)(l + 16 * k) < ncoef && !(dbg & 4)) scatter(cw[k]);
+  for (uint32_t base = 128; __builtin_amdgcn_ballot_w64(base < ncoef) != 0; base += 128) { // dense macroblocks: 128 more per round trip
+#pragma unroll
+    for (int k = 0; k < 8; k++) cw[k] = base + (uint32_t)(l + 16 * k) < ncoef ? rec[MOBI_INTRA_RECORDS + base + l + 16 * k] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (base + (uint32_t)(l + 16 * k) < ncoef) scatter(cw[k]);
+  }
   wave_sync();
 
   // ---- tiles: zero (what nobody owns yet reads 0, as the reference's fresh plane does), then the halo ----
@@ -870,7 +877,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
 
   // ---- residuals of all coded areas, transformed in place: eight lanes per area, two areas of each macroblock per round ----
 #pragma unroll 1
-  for (int rd = 0; rd < 3; rd++) {
+  for (int rd = 0; rd < ((dbg & 1) ? 0 : 3); rd++) {
     const int a = 2 * rd + (l >> 3), r = l & 7;
     const bool act = (w1 >> (8 + a)) & 1, is8a = (t8 >> a) & 1;
     if (__builtin_amdgcn_ballot_w64(act) != 0) {
@@ -959,6 +966,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     ean = *(const uint4_a4 *)tp;
     ebn = *(const uint4_a4 *)(tp + 2);
   }
+  if (dbg & 2) n_iter = 0;
 #pragma unroll 1
   for (int t = 0; t < n_iter; t++) {
     const uint2 d = dn;
@@ -1026,12 +1034,12 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     }
     wave_sync();
   }
-  if (fault && I.valid) atomicOr(&A.fault[clip], 1);
+  if (fault && I.valid && !dbg) atomicOr(&A.fault[clip], 1);
 
   // ---- store.  Write-through (sc1), drained and followed by the tag only when an intra macroblock of this step may be waiting for
   // these pixels on another CU; plain stores otherwise (the next launch is a kernel boundary away). ----
   const bool anyp = __builtin_amdgcn_ballot_w64(I.valid && I.publish) != 0;
-  if (I.valid) {
+  if (I.valid && !(dbg & 8)) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if ((w1 & MOBI_W1_EDGE) && A.edge && l < 8) { // the right neighbour is intra too: leave it the last column (edge side buffer)
       const uint8_t *src = l < 4 ? tile + (4 * l + 1) * TP + 4 + 15 : tile + (l < 6 ? IQ_TCU : IQ_TCV) + (4 * (l & 1) + 1) * TP + 4 + 7;
@@ -1066,14 +1074,14 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
 //   x = clip << 13 | mb   y = MbDesc.w1   z = MbDesc.payload_off (inside this step's arena)
 //   w = [0] 16x16 plane present  [1] has intra dependencies  [2] has intra dependents  [3] the left neighbour's last column is in the
 //       edge side buffer  [14:5] number of level words  [31:16] plane parameter
-extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs A, const uint4 *items, int n_items) {
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs A, const uint4 *items, int n_items, int dbg) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
   const int lane = threadIdx.x;
   const uint4 item = items[blockIdx.x * 4 + (lane >> 4)];
   const bool valid = item.x != 0xFFFFFFFFu;
   const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
                 (item.w & 2) != 0, (item.w & 4) != 0, (item.w & 8) != 0 && A.edge != nullptr};
-  recon_intra_quad(A, lds, I, lane);
+  recon_intra_quad(A, lds, I, lane, dbg);
 }
 
 // Items as the device-side parser leaves them (mobi_dparse.hip): per clip, raster order, n_intra[clip] of them at a stride of
@@ -1119,7 +1127,9 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
   if (n_items <= 0) return 0;
   if (n_items & 3) return (int)hipErrorInvalidValue; // levels are padded to whole waves of four macroblocks
-  hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items / 4), dim3(64), 0, s, *a, (const uint4 *)items_dev, n_items);
+  static const int dbg = getenv("MOBI_INTRA_DBG") ? atoi(getenv("MOBI_INTRA_DBG")) : 0; // timing ablations only: 1 no transform, 2 no steps, 4 no scatter
+  static const int pad = getenv("MOBI_INTRA_LDS_PAD") ? atoi(getenv("MOBI_INTRA_LDS_PAD")) : 0;
+  hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items / 4), dim3(64), pad, s, *a, (const uint4 *)items_dev, n_items, dbg);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s) {
