@@ -4,7 +4,7 @@
 //                        macroblocks: half-pel truncating motion compensation from the reference planes (CopyBlock,
 //                        MD.cs:418-456), dequant + 8x8/4x4 integer inverse transforms + clamp-add of the residual
 //                        (MD.cs:3424-3429, :3435-3798), whole-row stores of Y/U/V.
-//   mobi_recon_intra   : intra macroblocks (I-frames and codes 6/7 inside P-frames), one wavefront each: halo load
+//   mobi_recon_intra   : intra macroblocks (I-frames and codes 6/7 inside P-frames), four per wavefront (16 lanes each): halo load
 //   mobi_recon_intra_cl  with raster-order availability masking, predictors (MD.cs:1883-2774, :3017-3327) and
 //                        residuals in decode order inside LDS; all dependency levels of a step in one launch, ordered by
 //                        per-macroblock completion tags.
@@ -606,7 +606,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 // One wave per workgroup.  Tried and measured (r2, 24576 clips 640x480, same box): workgroups of 2 / 3 / 5 / 6 vertically adjacent
 // octets, so that waves whose reference windows overlap share this CU's L1 -- 8.0 / 8.2 / 11.4 / 11.2 ms against 8.0 ms for
 // single waves (a workgroup's LDS and wave slots come and go as a block); non-temporal window fetches -- 8.5 ms (chroma only)
-// and 9.8 ms (all): the L1 hits between the macroblocks of an octet are worth more than the L1 they pollute.
+// and 9.8 ms (all): the L1 hits between the macroblocks of an octet are worth more than the L1 they pollute; non-temporal row
+// stores (so that output lines do not compete with window lines for the L2): 7.76 against 7.77 ms, nothing.
 #define MOBI_OCT_KERNEL(NAME, WAVES, PROF, NCWR)                                                      \
   extern "C" __global__ __launch_bounds__(64, WAVES) void NAME(MobiReconArgs A) {                      \
     __shared__ __attribute__((aligned(16))) uint8_t lds[P_BYTES];                                      \
@@ -959,23 +960,29 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const int po8 = (l >> 1) * TP + (l & 1) * 4, ro8 = (l >> 1) * 8 + (l & 1) * 4;
   const int po4 = (l >> 2) * TP + (l & 3), ro4 = (l >> 2) * 8 + (l & 3);
   int fault = 0;
-  uint2 dn = *(const uint2 *)steps;
-  uint4 ean, ebn;
-  { // the tap table entries of a directional block do not depend on pixels: they are fetched while the step before it runs
-    const uint2 *tp = taps + (((dn.x >> SD_TAP) & 0x3FF) + ((dn.x & SD_IS4) ? l : 4 * l));
-    ean = *(const uint4_a4 *)tp;
-    ebn = *(const uint4_a4 *)(tp + 2);
+  // The tap table entries of a directional block do not depend on pixels: they are fetched two steps ahead (a step is shorter than
+  // an L2 round trip; with few waves on the chip -- small batches, the tail of an I-frame's levels -- nobody else hides it).
+  uint2 d1 = *(const uint2 *)steps, d2 = *(const uint2 *)(steps + 2);
+  uint4 ea1, eb1, ea2, eb2;
+  {
+    const uint2 *tp = taps + (((d1.x >> SD_TAP) & 0x3FF) + ((d1.x & SD_IS4) ? l : 4 * l));
+    ea1 = *(const uint4_a4 *)tp;
+    eb1 = *(const uint4_a4 *)(tp + 2);
+    tp = taps + (((d2.x >> SD_TAP) & 0x3FF) + ((d2.x & SD_IS4) ? l : 4 * l));
+    ea2 = *(const uint4_a4 *)tp;
+    eb2 = *(const uint4_a4 *)(tp + 2);
   }
   if (dbg & 2) n_iter = 0;
 #pragma unroll 1
   for (int t = 0; t < n_iter; t++) {
-    const uint2 d = dn;
-    const uint4 ea = ean, eb = ebn;
-    if (t + 1 < n_iter) {
-      dn = *(const uint2 *)(steps + 2 * (t + 1));
-      const uint2 *tp = taps + (((dn.x >> SD_TAP) & 0x3FF) + ((dn.x & SD_IS4) ? l : 4 * l));
-      ean = *(const uint4_a4 *)tp;
-      ebn = *(const uint4_a4 *)(tp + 2);
+    const uint2 d = d1;
+    const uint4 ea = ea1, eb = eb1;
+    d1 = d2; ea1 = ea2; eb1 = eb2;
+    if (t + 2 < n_iter) {
+      d2 = *(const uint2 *)(steps + 2 * (t + 2));
+      const uint2 *tp = taps + (((d2.x >> SD_TAP) & 0x3FF) + ((d2.x & SD_IS4) ? l : 4 * l));
+      ea2 = *(const uint4_a4 *)tp;
+      eb2 = *(const uint4_a4 *)(tp + 2);
     }
     const int o = (int)(d.x & 0x7FF);
     const bool is4 = (d.x & SD_IS4) != 0;

@@ -246,3 +246,27 @@ def test_octet_inter_kernel_on_every_kind_of_inter_macroblock():
     _run_stream(default_params("C", BASE_SEED + 61, n_frames=6, pm_deep=150, pm_multiref=200))
     _run_stream(default_params("A", BASE_SEED + 62, n_frames=6, pm_split1=400, t8_prob=500))
     _run_stream(default_params("B", BASE_SEED + 63, n_frames=6, pm_split1=600, pm_deep=200, pm_multiref=300, cbp_prob=600))
+
+
+@pytest.mark.parametrize("w,h,ver,nclips", [(16, 16, 2, 1), (32, 16, 1, 3), (48, 32, 2, 6), (256, 16, 1, 5), (512, 32, 2, 2), (80, 48, 2, 7)])
+def test_intra_rows_of_four_padding_and_picture_edges(w, h, ver, nclips):
+    """mobi_recon_intra carries four macroblocks per wave and pads every dependency level to whole waves; macroblocks at the picture's
+    edges take the per-sample ownership path and are sorted behind the others.  Tiny pictures (every macroblock on an edge, width ==
+    stride for 256 and 512: the halo wraps into neighbouring rows), intra-heavy P-frames, clip counts that leave 1..3 rows of the last
+    wave of a level empty."""
+    ps = [default_params("A", BASE_SEED + 900 + 17 * i + w, n_frames=6, width=w, height=h, version=ver, pm_intra=400, mv_range=6,
+                         iframe_interval=4 if i & 1 else 0) for i in range(nclips)]
+    clips = [generate_clip(p) for p in ps]
+    b = MobiclipBatch(nclips, w, h, ver, device_parse=False)
+    oras = [OracleDecoder(w, h, ver) for _ in ps]
+    for f in range(6):
+        rcs, offs = b.decode([c[0] for c in clips], [int(c[1][f]) for c in clips])
+        for c in range(nclips):
+            oras[c].Data, oras[c].Offset = clips[c][0], int(clips[c][1][f])
+            o = oras[c].DecodeFrame()
+            assert rcs[c] == 0 and offs[c] == oras[c].Offset, (f, c, rcs[c])
+            y, uv = b.planes(c)
+            assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (f, c)
+    b.close()
+    for o in oras:
+        o.close()

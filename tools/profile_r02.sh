@@ -30,6 +30,8 @@ timeout 60 $REPO/tools/ubench/oprate.bin 4 > "$OUT/oprate.txt" 2>&1
 timeout 60 $REPO/tools/ubench/fetchpat.bin 4096 > "$OUT/fetchpat.txt" 2>&1
 timeout 60 $REPO/tools/ubench/pitch.bin 640 480 16384 > "$OUT/pitch.txt" 2>&1
 timeout 60 $REPO/tools/ubench/wavelaunch.bin > "$OUT/wavelaunch.txt" 2>&1
+{ timeout 60 $REPO/tools/ubench/pwrite.bin 400000 8192; timeout 60 $REPO/tools/ubench/pwrite.bin 400000 64; } > "$OUT/pwrite.txt" 2>&1
+for D in 0 1 2 4 7 15 63; do echo "MOBI_INTRA_DBG=$D"; MOBI_INTRA_DBG=$D timeout 200 python $REPO/bench.py --clips 8192 --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --steps 32 2>/dev/null | python $REPO/tools/brief.py; done > "$OUT/intra_ablation.txt" 2>&1
 for N in 64 512 4096; do timeout 200 python $REPO/bench.py --clips $N --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --steps 96 2>/dev/null; done > "$OUT/bench_small.jsonl"
 timeout 200 python $REPO/tools/exp_iframe.py 4096 > "$OUT/iframe.txt" 2>&1
 ls -R "$OUT" | head -5 > /dev/null
