@@ -566,11 +566,17 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int i = lane + 64 * it, gq = i & 7, row16 = i >> 3;
-    if (gq < nmb) { // intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them): a row with a hole is a partial
-                    // line, and HBM turns every store below 64 B into a read-modify-write (tools/ubench/pwrite.hip: 26 vs 69 pieces per ns)
-      *(uint4 *)(y0 + (off0 + (row16 << lgS) + gq * 16)) = *(const uint4 *)(L + P_OUT_Y + row16 * 128 + gq * 16);
+    // Whole rows always.  Intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them), and behind the
+    // picture's last macroblock (848 = 53 macroblocks: the seventh octet holds five) the zeros the padding already holds: a row with a
+    // hole is a partial line, and HBM turns every store below 64 B into a read-modify-write (tools/ubench/pwrite.hip: 26 against 69
+    // pieces per ns).  Octets are 128-byte aligned and the pitch is a multiple of 128, so the padding written is this row's own.
+    {
+      const bool in = gq < nmb;
+      const uint4 vy = *(const uint4 *)(L + P_OUT_Y + row16 * 128 + gq * 16);
+      *(uint4 *)(y0 + (off0 + (row16 << lgS) + gq * 16)) = in ? vy : uint4{0, 0, 0, 0};
       const int row = row16 & 7; // chroma: plane = it, row = (i >> 3) & 7
-      *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = *(const uint2 *)(L + P_OUT_C + it * 512 + row * 64 + gq * 8);
+      const uint2 vc = *(const uint2 *)(L + P_OUT_C + it * 512 + row * 64 + gq * 8);
+      *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = in ? vc : uint2{0, 0};
     }
   }
   // macroblocks whose right neighbour is intra also leave their last column in the edge side buffer (mobi_cmd.h): lane (g, j = 0)
