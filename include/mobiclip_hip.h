@@ -58,7 +58,10 @@ int mobi_decode(mobi_dec *d, const uint8_t *data, size_t len, int32_t *offset_in
 /* d.Y[ring_idx] / d.UV[ring_idx]  (MD.cs:19-20), copied in the reference layout:
  * y_out: Stride*Height bytes; uv_out: Stride*Height/2 bytes, U in columns [0,Stride/2), V in
  * [Stride/2,Stride) of each row (MD.cs:414-415).  Either pointer may be NULL.
- * Returns MOBI_E_NULLREF when that ring slot has never been produced. */
+ * Returns MOBI_E_NULLREF when that ring slot has never been produced.  After a call that returned an error, slot 0 of that
+ * stream is not the reference's partial picture (a frame that failed in the parse is not reconstructed at all: the slot still
+ * holds the picture of six frames earlier); and P-frames that predict from it differ from the reference's (which predict from its
+ * partial picture) until the next I-frame, from which on both are identical again. */
 int mobi_get_planes(mobi_dec *d, int ring_idx, uint8_t *y_out, uint8_t *uv_out);
 /* The Bitmap that DecodeFrame() returns (MD.cs:260-323) for the frame just decoded: width*height 0xAARRGGBB
  * words, row pitch = width (Format32bppArgb as LockBits hands it out: bytes B,G,R,A).  Chroma is averaged from up
