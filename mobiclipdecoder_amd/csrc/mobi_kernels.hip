@@ -27,7 +27,6 @@
 namespace {
 
 enum { TP = 32 };                     // intra tile pitch: interior col c at byte 4+c, halo col -1 at byte 3
-enum { HALO_Y_RIGHT = 23, HALO_C_RIGHT = 15 }; // must match MOBI_HALO_* in mobi_parse.h
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
@@ -73,15 +72,7 @@ __device__ __forceinline__ uint32_t mc4_select(const Win &w, int phase) {
   const uint32_t p1 = ha + hb, p2 = ha + hc, p3 = ((p1 >> 1) & M) + (((hc + hd) >> 1) & M);
   return phase == 0 ? a : phase == 1 ? p1 : phase == 2 ? p2 : p3;
 }
-// ---- residual helpers (LDS: coef[6*64] ints, tmp[6*64] ints) --------------------------------------
-__device__ __forceinline__ void scatter_one(const int32_t *sc, uint32_t e, uint32_t t8, int *coef) {
-  const int t = e & 0x1FF, level = (int32_t)e >> 16, area = t >> 6, p = t & 63;
-  const int scale = ((t8 >> area) & 1) ? sc[p] : sc[64 + (p & 15)];
-  coef[t] = scale * level;
-}
-__device__ __forceinline__ void scatter_coefs(const int32_t *sc, const uint32_t *cw, int first, int n, uint32_t t8, int *coef, int lane) {
-  for (int i = first + lane; i < n; i += 64) scatter_one(sc, cw[i], t8, coef);
-}
+// ---- residual helpers ----------------------------------------------------------------------------
 // pass 1 of area b by lane r (0..7): 8x8 -> coefficient group r; 4x4 -> sub-block r>>1, groups (r&1)*2+{0,1}.
 // t may be c itself (in-place transpose): every read of the area is issued before its first write, and the 8
 // lanes of an area always take the same branch (LDS executes a wave's instructions in order)
