@@ -11,8 +11,8 @@
  * Split of work: the serial VLC / Exp-Golomb parse (MD.cs bit reader and syntax, :113-259,
  * :469-3432) runs on the host inside these calls and emits a flat per-macroblock command list;
  * dequant + inverse transforms, intra prediction, motion compensation and residual add
- * (MD.cs:418-456, :1883-2774, :3017-3327, :3435-3798) run as HIP kernels, one wavefront per
- * macroblock.  There is NO CPU reconstruction path in this library: without a HIP device every
+ * (MD.cs:418-456, :1883-2774, :3017-3327, :3435-3798) run as HIP kernels (one wavefront per eight
+ * adjacent inter macroblocks, one per four intra macroblocks).  There is NO CPU reconstruction path in this library: without a HIP device every
  * create call fails.
  */
 #ifndef MOBICLIP_HIP_H
