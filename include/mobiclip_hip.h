@@ -96,6 +96,19 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * host pool parses a fixed share of them (a fifth, at most 1024; MOBI_HYBRID_HOST_CLIPS) at the same time; one set of
  * reconstruction launches serves both.  Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
+/* Asynchronous frame steps, for callers that already hold the next frame of every clip (demuxed Moflex / Mods packets: the Offset
+ * to start from does not depend on the previous frame's parse).  The batch must parse on the GPU (the default from 1024 clips;
+ * mobi_batch_set_parse_mode(b, 1) otherwise; not the hybrid mode) and at most two steps may be in flight.
+ *   mobi_batch_submit: copies the bytes data[i][offsets[i] .. len[i]) of every clip into pinned memory and enqueues upload, parse and
+ *                      reconstruction of one frame step behind the step before; returns without waiting for the GPU.  The caller's
+ *                      buffers may be reused as soon as it returns.
+ *   mobi_batch_wait:   waits for the OLDEST step in flight and reports what mobi_batch_decode would have: rc[i] per clip,
+ *                      offsets_out[i] = Offset after the frame (may be NULL).
+ * mobi_batch_decode, mobi_batch_get_planes and the other calls that read results wait for everything enqueued; mobi_batch_decode is
+ * refused (MOBI_E_ARG) while steps are in flight.  What it buys: the host gathers and uploads step n + 1 while the GPU parses step
+ * n, and the GPU goes from parse to reconstruction without asking the host for launch sizes. */
+int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets);
+int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc);
 /* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
 float mobi_batch_last_decode_ms(const mobi_batch *b);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);

@@ -294,6 +294,19 @@ struct mobi_batch {
   uint8_t *d_ptables = nullptr;
   PinnedBuf h_pres;
   std::vector<uint32_t> dev_quant, dev_yuvfmt;
+  // asynchronous steps (mobi_batch_submit / mobi_batch_wait, device parse only): two sets of staging so that the bytes of step
+  // n + 1 are gathered and uploaded while the GPU works on step n; everything else follows stream order
+  struct AsyncSlot {
+    PinnedBuf h_stage, h_pres, h_fault;
+    DevBuf d_bits;
+    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    std::vector<int32_t> offs; // Offset of every clip at submission
+    int n_dev = 0;
+  };
+  AsyncSlot aslot[2];
+  int async_head = 0, async_count = 0; // oldest step in flight, number of steps in flight (<= 2)
+  size_t dp_len_hint = 0;              // longest frame seen so far (+ 25 %): sizes the payload arena of the device-side parser
+  uint64_t async_seq = 0;
   // preloaded replay
   // [clip] -> frames; clones share the host copy (each clip still gets its own bytes in HBM at commit)
   std::vector<std::shared_ptr<std::vector<ParsedFrame>>> staged;
@@ -377,6 +390,10 @@ struct mobi_batch {
     drain_events();
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (ev_up) (void)hipEventDestroy(ev_up);
+    for (auto &sl : aslot) {
+      if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+      if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
     if (stream2) (void)hipStreamDestroy(stream2);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
@@ -515,38 +532,37 @@ void mobi_batch_destroy(mobi_batch *b) {
 
 // DecodeFrame() of every clip with the bitstream parse on the GPU: upload Data[Offset..) of every clip, one parse launch
 // (one wave per clip) that leaves descriptors, payload and intra lists in HBM, then the usual reconstruction launches.
-static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
+// first use of the device-side parser: zeroed decoder state (a new MobiclipDecoder), result array, tables -- all of it or none of it
+static int dp_init(mobi_batch *b) {
+  const int n = b->n;
+  if (b->d_pstate) return MOBI_OK;
+  auto init = [&]() -> int {
+    HIP_TRY(hipMalloc((void **)&b->d_pres, sizeof(MobiDevResult) * n));
+    HIP_TRY(hipMemset(b->d_pres, 0, sizeof(MobiDevResult) * n));
+    std::vector<uint8_t> blob(MOBI_DT_BYTES);
+    mobi_dparse_build_tables(b->version, blob.data());
+    HIP_TRY(hipMalloc((void **)&b->d_ptables, MOBI_DT_BYTES));
+    HIP_TRY(hipMemcpy(b->d_ptables, blob.data(), MOBI_DT_BYTES, hipMemcpyHostToDevice));
+    if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
+    MobiDevState *st = nullptr;
+    HIP_TRY(hipMalloc((void **)&st, sizeof(MobiDevState) * n));
+    if (hipMemset(st, 0, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
+    b->d_pstate = st; // last: its presence means "initialised"
+    return MOBI_OK;
+  };
+  if (int e = init()) {
+    if (b->d_pres) { (void)hipFree(b->d_pres); b->d_pres = nullptr; }
+    if (b->d_ptables) { (void)hipFree(b->d_ptables); b->d_ptables = nullptr; }
+    return e;
+  }
+  b->dev_quant.assign(n, 0);
+  b->dev_yuvfmt.assign(n, 0);
+  return MOBI_OK;
+}
+// stage [bit_off u64 x nd][bit_len u32 x nd][bits: each clip 8-byte aligned, zero padded] of clips [0, nd) into pinned memory
+struct DpStaged { size_t hdr_bytes = 0, bytes = 0, max_len = 0; };
+static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const size_t *len, const int32_t *offsets, PinnedBuf &stage, DpStaged &st) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
-  const int nd = n - b->hybrid_host, nh = b->hybrid_host; // clips [0, nd): parsed on the GPU; [nd, n): by the host pool meanwhile
-  if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) {
-    for (int i = 0; i < n; i++) rc[i] = MOBI_E_VERSION;
-    return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
-  }
-  if (b->g.mbw > 64) return MOBI_E_ARG;
-  if (!b->d_pstate) { // first use: zeroed decoder state (a new MobiclipDecoder), result array, tables -- all of it or none of it
-    auto init = [&]() -> int {
-      HIP_TRY(hipMalloc((void **)&b->d_pres, sizeof(MobiDevResult) * n));
-      HIP_TRY(hipMemset(b->d_pres, 0, sizeof(MobiDevResult) * n));
-      std::vector<uint8_t> blob(MOBI_DT_BYTES);
-      mobi_dparse_build_tables(b->version, blob.data());
-      HIP_TRY(hipMalloc((void **)&b->d_ptables, MOBI_DT_BYTES));
-      HIP_TRY(hipMemcpy(b->d_ptables, blob.data(), MOBI_DT_BYTES, hipMemcpyHostToDevice));
-      if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
-      MobiDevState *st = nullptr;
-      HIP_TRY(hipMalloc((void **)&st, sizeof(MobiDevState) * n));
-      if (hipMemset(st, 0, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
-      b->d_pstate = st; // last: its presence means "initialised"
-      return MOBI_OK;
-    };
-    if (int e = init()) {
-      if (b->d_pres) { (void)hipFree(b->d_pres); b->d_pres = nullptr; }
-      if (b->d_ptables) { (void)hipFree(b->d_ptables); b->d_ptables = nullptr; }
-      return e;
-    }
-    b->dev_quant.assign(n, 0);
-    b->dev_yuvfmt.assign(n, 0);
-  }
-  // 1. stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded]
   const auto t_stage0 = std::chrono::steady_clock::now();
   constexpr size_t kBitPad = 32; // the reader runs two 8-byte registers ahead
   std::vector<uint64_t> boff(nd);
@@ -567,9 +583,9 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     pos += align_up(l + kBitPad, 8);
   }
   const size_t hdr_bytes = align_up((size_t)nd * 12, 16);
-  if (int e = b->h_stage.reserve(hdr_bytes + pos)) return e;
-  if (int e = b->d_bits.reserve(hdr_bytes + pos)) return e;
-  uint8_t *hs = b->h_stage.p;
+  if (hdr_bytes + pos > stage.cap) // pinned memory is slow to allocate: leave room for the longer frames to come
+    if (int e = stage.reserve(hdr_bytes + pos + (hdr_bytes + pos) / 4)) return e;
+  uint8_t *hs = stage.p;
   memcpy(hs, boff.data(), (size_t)nd * 8);
   memcpy(hs + (size_t)nd * 8, blen.data(), (size_t)nd * 4);
   b->pool->run(nd, [&](int i) {
@@ -578,18 +594,32 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
   });
   b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
-  HIP_TRY(hipMemcpyAsync(b->d_bits.p, hs, hdr_bytes + pos, hipMemcpyHostToDevice, b->stream));
-  // 2. output buffers: a clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level per bit read
-  const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * max_len) + 448 + 64;
+  st.hdr_bytes = hdr_bytes;
+  st.bytes = hdr_bytes + pos;
+  st.max_len = max_len;
+  return MOBI_OK;
+}
+// output buffers + the parse launch.  A clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level
+// per bit read.  `busy`: earlier steps may still be using the buffers (asynchronous steps): drain the stream before growing one.
+static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged &st, bool busy) {
+  const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
+  // (the longest frame of a step varies from step to step: the bound follows it upwards in steps of a quarter, so that the payload
+  // arena -- gigabytes for thousands of clips -- is not freed and allocated again every few frames)
+  if (st.max_len > b->dp_len_hint) b->dp_len_hint = st.max_len + st.max_len / 4;
+  size_t cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * b->dp_len_hint) + 448 + 64;
+  if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * st.max_len) + 448 + 64;
   if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // payload offsets are 32-bit words
-  if (int e = b->d_pdesc.reserve(align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign))) return e;
-  if (int e = b->d_ppay.reserve(align_up((size_t)n * cap_words * 4 + kPaySlack, kAlign))) return e;
-  if (int e = b->d_pitems.reserve((size_t)n * n_mbs * 4)) return e;
+  const size_t want_desc = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), want_pay = align_up((size_t)n * cap_words * 4 + kPaySlack, kAlign),
+               want_items = (size_t)n * n_mbs * 4;
+  if (busy && (want_desc > b->d_pdesc.cap || want_pay > b->d_ppay.cap || want_items > b->d_pitems.cap)) HIP_TRY(hipStreamSynchronize(b->stream));
+  if (int e = b->d_pdesc.reserve(want_desc)) return e;
+  if (int e = b->d_ppay.reserve(want_pay)) return e;
+  if (int e = b->d_pitems.reserve(want_items)) return e;
   MobiDevParseArgs pa;
   memset(&pa, 0, sizeof(pa));
-  pa.bits = b->d_bits.p + hdr_bytes;
-  pa.bit_off = (const uint64_t *)b->d_bits.p;
-  pa.bit_len = (const uint32_t *)(b->d_bits.p + (size_t)nd * 8);
+  pa.bits = d_bits + st.hdr_bytes;
+  pa.bit_off = (const uint64_t *)d_bits;
+  pa.bit_len = (const uint32_t *)(d_bits + (size_t)nd * 8);
   pa.tables = b->d_ptables;
   pa.state = b->d_pstate;
   pa.desc = (MbDesc *)b->d_pdesc.p;
@@ -605,13 +635,30 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   if (ptime) (void)hipEventRecord(b->ev_p0, b->stream);
   if (mobi_launch_parse(&pa, b->stream) != 0) return MOBI_E_DEVICE;
   if (ptime) (void)hipEventRecord(b->ev_p1, b->stream);
+  return MOBI_OK;
+}
+
+static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
+  const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
+  const int nd = n - b->hybrid_host, nh = b->hybrid_host; // clips [0, nd): parsed on the GPU; [nd, n): by the host pool meanwhile
+  if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) {
+    for (int i = 0; i < n; i++) rc[i] = MOBI_E_VERSION;
+    return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
+  }
+  if (b->g.mbw > 64 || b->async_count) return MOBI_E_ARG; // (asynchronous steps in flight: mobi_batch_wait for them first)
+  if (int e = dp_init(b)) return e;
+  DpStaged st;
+  if (int e = dp_stage(b, nd, data, len, offsets, b->h_stage, st)) return e;
+  if (int e = b->d_bits.reserve(st.bytes)) return e;
+  HIP_TRY(hipMemcpyAsync(b->d_bits.p, b->h_stage.p, st.bytes, hipMemcpyHostToDevice, b->stream));
+  if (int e = dp_parse(b, nd, b->d_bits.p, st, false)) return e;
+  const size_t cap_words = b->last_pay_cap;
+  const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
   MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
   HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * nd, hipMemcpyDeviceToHost, b->stream));
   if (nh > 0) { // hybrid: while the GPU parses its clips, the host pool parses the others and sends their command lists up beside it
-    if (!b->stream2) {
-      HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
-    }
+    if (!b->stream2) HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+    if (!b->ev_up) HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
     static const uint8_t kNoData2[2] = {0, 0};
     b->pool->run(nh, [&](int j) { const int i = nd + j; rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData2, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); });
     std::vector<size_t> pbase(nh + 1, 0);
@@ -682,6 +729,79 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   HIP_TRY(hipStreamSynchronize(b->stream));
   for (int i = 0; i < n; i++)
     if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+  return MOBI_OK;
+}
+
+// ---- asynchronous frame steps (device parse) -------------------------------------------------------------------------------
+// mobi_batch_decode is DecodeFrame(): it returns when the frame is there.  A caller that already holds the next frame of every clip
+// (demuxed Moflex / Mods packets: Offset does not depend on the previous frame's parse) can keep two steps in flight instead:
+// submit gathers the bytes into pinned memory, uploads them on a second stream and enqueues parse + reconstruction behind the
+// previous step without a host round trip in between (the intra launch covers every slot a clip could use; workgroups past a
+// clip's count leave at once); wait hands out rc[] / Offset of the oldest step when its reconstruction is done.  The host gathers
+// step n + 1 while the GPU parses step n, and the GPU never waits for the host between parse and reconstruction.
+int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets) {
+  if (!b || !data || !len || !offsets) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
+  if (b->frames_started == 0 && b->async_seq == 0) { // an asynchronous batch parses on the GPU from its first frame
+    if (b->parse_auto || b->parse_mode == 1) { b->parse_mode = 1; b->parse_auto = false; b->hybrid_host = 0; }
+  }
+  if (b->parse_mode != 1 || b->hybrid_host != 0) return MOBI_E_ARG; // the decoder state of this batch lives in the host parsers
+  if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) return MOBI_E_VERSION;
+  if (b->g.mbw > 64 || b->async_count >= 2) return MOBI_E_ARG;
+  if (int e = dp_init(b)) return e;
+  mobi_batch::AsyncSlot &S = b->aslot[(b->async_head + b->async_count) & 1];
+  if (!S.ev_up) {
+    HIP_TRY(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming));
+  }
+  if (!b->stream2) HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+  DpStaged st;
+  if (int e = dp_stage(b, n, data, len, offsets, S.h_stage, st)) return e; // (this slot's previous step was waited for: its upload is done)
+  if (st.bytes > S.d_bits.cap) // growing frees and allocates (a device-wide stall): leave room for the longer frames to come
+    if (int e = S.d_bits.reserve(st.bytes + st.bytes / 4)) return e;
+  if (int e = S.h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
+  if (int e = S.h_fault.reserve(sizeof(int) * n)) return e;
+  S.offs.assign(offsets, offsets + n);
+  S.n_dev = n;
+  HIP_TRY(hipMemcpyAsync(S.d_bits.p, S.h_stage.p, st.bytes, hipMemcpyHostToDevice, b->stream2)); // beside whatever the step before is doing
+  HIP_TRY(hipEventRecord(S.ev_up, b->stream2));
+  HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_up, 0));
+  if (int e = dp_parse(b, n, S.d_bits.p, st, b->async_count > 0)) return e;
+  HIP_TRY(hipMemcpyAsync(S.h_pres.p, b->d_pres, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream));
+  // reconstruction straight from what the parse leaves in HBM (failed clips: blank descriptors, no items)
+  b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse throws
+  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
+  b->argb_all_valid = false;
+  b->frames_started++;
+  MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
+  a.done = b->d_done;
+  if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
+  if (mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), n_mbs, b->stream) != 0) return MOBI_E_DEVICE;
+  HIP_TRY(hipMemcpyAsync(S.h_fault.p, b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+  HIP_TRY(hipEventRecord(S.ev_done, b->stream));
+  b->async_count++;
+  b->async_seq++;
+  return MOBI_OK;
+}
+int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
+  if (!b || !rc) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->async_count == 0) return MOBI_E_ARG;
+  mobi_batch::AsyncSlot &S = b->aslot[b->async_head & 1];
+  HIP_TRY(hipEventSynchronize(S.ev_done));
+  const MobiDevResult *res = (const MobiDevResult *)S.h_pres.p;
+  const int *fault = (const int *)S.h_fault.p;
+  for (int i = 0; i < S.n_dev; i++) {
+    rc[i] = res[i].rc;
+    if (offsets_out) offsets_out[i] = S.offs[i] + (int32_t)res[i].consumed;
+    b->dev_quant[i] = res[i].quant;
+    b->dev_yuvfmt[i] = res[i].yuvfmt;
+    if (rc[i] == MOBI_OK && fault[i]) rc[i] = (fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+  }
+  b->async_head ^= 1;
+  b->async_count--;
   return MOBI_OK;
 }
 

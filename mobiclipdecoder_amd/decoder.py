@@ -51,6 +51,8 @@ _SIGS = {
     "mobi_batch_create": (C.c_void_p, [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "mobi_batch_destroy": (None, [C.c_void_p]),
     "mobi_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
     "mobi_batch_get_argb": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -234,6 +236,26 @@ class MobiclipBatch:
         offs = (C.c_int32 * self.n)(*[int(o) for o in offsets])
         rcs = (C.c_int * self.n)()
         e = self._lib.mobi_batch_decode(self._h, ptrs, lens, offs, rcs)
+        if e != 0:
+            raise MobiclipError(error_string(e))
+        return list(rcs), list(offs)
+
+    def submit(self, datas, offsets):
+        """Asynchronous decode(): enqueue one frame step (device parse only, at most two in flight); the buffers may be reused at
+        once.  Results come from wait(), oldest step first."""
+        bufs = [_as_u8(d) for d in datas]
+        ptrs = (C.c_void_p * self.n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * self.n)(*[b.size for b in bufs])
+        offs = (C.c_int32 * self.n)(*[int(o) for o in offsets])
+        e = self._lib.mobi_batch_submit(self._h, ptrs, lens, offs)
+        if e != 0:
+            raise MobiclipError(error_string(e))
+
+    def wait(self):
+        """(rc list, new offsets list) of the oldest submitted step, when its reconstruction is done."""
+        offs = (C.c_int32 * self.n)()
+        rcs = (C.c_int * self.n)()
+        e = self._lib.mobi_batch_wait(self._h, offs, rcs)
         if e != 0:
             raise MobiclipError(error_string(e))
         return list(rcs), list(offs)

@@ -283,3 +283,76 @@ def test_parse_mode_cannot_change_after_the_first_frame():
     b.decode([data[fo[0]:fo[1]]], [0])
     assert load_library().mobi_batch_set_parse_mode(b._h, 0) != 0
     b.close()
+
+
+@pytest.mark.parametrize("cfg,nclips", [("A", 5), ("B", 3)])
+def test_asynchronous_steps_equal_the_oracle(cfg, nclips):
+    """mobi_batch_submit / mobi_batch_wait: two frame steps in flight (upload of step n + 1 beside the parse of step n, no host round
+    trip between parse and reconstruction).  rc, Offset and the planes of every step must be what DecodeFrame() gives, also for a
+    stream that stops decoding half way, and the synchronous call must be refused while steps are in flight."""
+    nfr = 8
+    ps = [default_params(cfg, BASE_SEED + 1500 + i, n_frames=nfr, pm_intra=120, iframe_interval=5 if i == 1 else 0) for i in range(nclips)]
+    clips = [generate_clip(p) for p in ps]
+    clips[0] = (clips[0][0].copy(), clips[0][1])
+    clips[0][0][int(clips[0][1][4]) + 9] ^= 0x5A  # clip 0 breaks somewhere in frame 4
+    p0 = ps[0]
+    b = MobiclipBatch(nclips, p0.width, p0.height, p0.version, device_parse=True)
+    oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(nclips)]
+    frames = [[c[0][c[1][f]:c[1][f + 1]] for c in clips] for f in range(nfr)]
+    want = []
+    for f in range(nfr):
+        row = []
+        for i in range(nclips):
+            oras[i].Data, oras[i].Offset = frames[f][i], 0
+            o = oras[i].DecodeFrame()
+            row.append((oras[i].last_error, oras[i].Offset, None if o is None else (o[0].copy(), o[1].copy())))
+        want.append(row)
+
+    def check(f, rcs, offs, planes):
+        for i in range(nclips):
+            err, off, pl = want[f][i]
+            if rcs[i] in (-5, -6) or err in (-5,):  # documented divergences (clamp fault found after the parse; refusals)
+                continue
+            assert rcs[i] == err, (f, i, rcs[i], err)
+            assert offs[i] == off, (f, i)
+            if planes and err == 0 and all(want[g][i][0] == 0 for g in range(f + 1)):
+                y, uv = b.planes(i)
+                assert np.array_equal(y, pl[0]) and np.array_equal(uv, pl[1]), (f, i)
+
+    b.submit(frames[0], [0] * nclips)
+    with pytest.raises(Exception):
+        b.decode(frames[1], [0] * nclips)  # refused while a step is in flight
+    for f in range(1, nfr):
+        b.submit(frames[f], [0] * nclips)      # step f enqueued behind step f - 1 ...
+        rcs, offs = b.wait()                    # ... whose results arrive now; the planes on the device are already one step further
+        check(f - 1, rcs, offs, planes=False)
+    rcs, offs = b.wait()
+    check(nfr - 1, rcs, offs, planes=True)
+    with pytest.raises(Exception):
+        b.wait()  # nothing in flight
+    # the synchronous call works again, on the same decoder state
+    b.close()
+    for o in oras:
+        o.close()
+
+
+def test_asynchronous_steps_every_frame_checked():
+    """Same, with the planes of EVERY step compared: wait for a step before the next one is submitted (depth 1)."""
+    nfr, nclips = 6, 4
+    ps = [default_params("A", BASE_SEED + 1600 + i, n_frames=nfr, pm_intra=200) for i in range(nclips)]
+    clips = [generate_clip(p) for p in ps]
+    b = MobiclipBatch(nclips, ps[0].width, ps[0].height, ps[0].version, device_parse=True)
+    oras = [OracleDecoder(ps[0].width, ps[0].height, ps[0].version) for _ in range(nclips)]
+    for f in range(nfr):
+        datas = [c[0][c[1][f]:c[1][f + 1]] for c in clips]
+        b.submit(datas, [0] * nclips)
+        rcs, offs = b.wait()
+        for i in range(nclips):
+            oras[i].Data, oras[i].Offset = datas[i], 0
+            o = oras[i].DecodeFrame()
+            assert rcs[i] == 0 and offs[i] == oras[i].Offset
+            y, uv = b.planes(i)
+            assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (f, i)
+    b.close()
+    for o in oras:
+        o.close()
