@@ -140,7 +140,7 @@ def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
     return {"workload": f"{n_clips} clips of {W}x{H} on this GPU = the per-GPU share of 64 clips over 8 GPUs", "steps": n_steps,
             "ms_per_step": round(stream_ms / n_steps, 4), "value": round(n_clips * n_steps * W * H / (stream_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
             "wall_ms_per_step": round(wall * 1e3 / n_steps, 4),
-            "note": "two launches per step (inter, intra) of 1200 and ~60 waves: launch latency, not bandwidth"}
+            "note": "two launches per step (inter: 1200 octet waves; intra: ~480 waves, one macroblock each at this size): launch latency and two or three dependency levels, not bandwidth"}
 
 
 def main():
