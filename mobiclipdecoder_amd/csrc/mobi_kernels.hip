@@ -367,10 +367,18 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
   uint2 yc0 = uint2{0, 0};
   uint4 c4v0 = uint4{0, 0, 0, 0};
+  uint2 yc1 = uint2{0, 0}; // ... and the second one's (6 % of the octets have two): one of its two round trips
+  uint4 c4v1 = uint4{0, 0, 0, 0};
   if (multi_mask) {
     const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, __builtin_ctz(multi_mask));
     yc0 = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
     c4v0 = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+    const uint32_t m2 = multi_mask & (multi_mask - 1);
+    if (m2) {
+      const uint32_t *cells1 = A.payload + __builtin_amdgcn_readlane(d.x, __builtin_ctz(m2));
+      yc1 = *(const uint2_a4 *)(cells1 + (yrow >> 1) * 8 + (yc4 >> 1));
+      c4v1 = *(const uint4_a4 *)(cells1 + crow * 8 + cc4);
+    }
   }
   if (PROF) pt[1] = prof_stamp();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -460,12 +468,18 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the scales too)
     deep_finish(__builtin_ctz(multi_mask), D0);
     uint32_t mm = multi_mask & (multi_mask - 1);
-    while (mm) { // a second, third ... macroblock with a deep tree in the same octet: one exposed round trip each (rare)
+    bool second = true;
+    while (mm) { // a second, third ... macroblock with a deep tree in the same octet: exposed round trips (rare)
       const int gm = __builtin_ctz(mm);
       mm &= mm - 1;
-      const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
-      const uint2 yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
-      const uint4 c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+      uint2 yc = yc1;
+      uint4 c4v = c4v1;
+      if (!second) {
+        const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
+        yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
+        c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
+      }
+      second = false;
       Deep Dn;
       deep_fetch(Dn, gm, yc, c4v);
       asm volatile("" ::: "memory");
@@ -605,6 +619,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 // single waves (a workgroup's LDS and wave slots come and go as a block); non-temporal window fetches -- 8.5 ms (chroma only)
 // and 9.8 ms (all): the L1 hits between the macroblocks of an octet are worth more than the L1 they pollute; non-temporal row
 // stores (so that output lines do not compete with window lines for the L2): 7.76 against 7.77 ms, nothing.
+// Persistent waves (a wave walks many octets and asks for the next one's descriptors while it works -- a fresh wave spends 11 % of its
+// life waiting for its own, MOBI_DEBUG=9): the loop around this much inlined code spills (24 VGPRs, 26 SGPRs at best: the kernel
+// arguments stay live across it), and as a real function the callee-saved registers go through scratch.  Not kept.
 #define MOBI_OCT_KERNEL(NAME, WAVES, PROF, NCWR)                                                      \
   extern "C" __global__ __launch_bounds__(64, WAVES) void NAME(MobiReconArgs A) {                      \
     __shared__ __attribute__((aligned(16))) uint8_t lds[P_BYTES];                                      \
