@@ -621,7 +621,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 // stores (so that output lines do not compete with window lines for the L2): 7.76 against 7.77 ms, nothing.
 // Persistent waves (a wave walks many octets and asks for the next one's descriptors while it works -- a fresh wave spends 11 % of its
 // life waiting for its own, MOBI_DEBUG=9): the loop around this much inlined code spills (24 VGPRs, 26 SGPRs at best: the kernel
-// arguments stay live across it), and as a real function the callee-saved registers go through scratch.  Not kept.
+// arguments stay live across it), and as a real function the callee-saved registers go through scratch.  Not kept.  Touching the
+// descriptors of the octet an XCD starts 512 ... 8192 workgroups later (a DMA of two lines into unused LDS): 2.81 against 2.71 ms per
+// 8192 clips -- two more requests per wave in a kernel bound by requests cost more than the shorter wait gives.
 #define MOBI_OCT_KERNEL(NAME, WAVES, PROF, NCWR)                                                      \
   extern "C" __global__ __launch_bounds__(64, WAVES) void NAME(MobiReconArgs A) {                      \
     __shared__ __attribute__((aligned(16))) uint8_t lds[P_BYTES];                                      \
