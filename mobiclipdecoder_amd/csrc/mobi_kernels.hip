@@ -98,34 +98,28 @@ __device__ __forceinline__ void idct_pass1(const int *c, int *t, bool is8, int r
     for (int m = 0; m < 4; m++) { t[16 * s + 4 * m + k0] = out[m]; t[16 * s + 4 * m + k0 + 1] = out[4 + m]; }
   }
 }
-// pass 2 of area b by lane r: adds the residual into the 8x8 pixel area at `px` (pitch in bytes)
-// pass 2 that keeps the residual instead of adding it: res[y * 8 + x] for the 8x8 pixel area (all four 4x4 blocks of a split area).
-// res may be t itself: every lane reads all it needs before the first store (LDS executes a wave's instructions in order)
-__device__ __forceinline__ void idct_pass2_res(const int *t, bool is8, int r, int *res) {
+// pass 2 whose eight residuals stay with the lane, as four int16 pairs (saturated): 8x8 -> row r; 4x4 -> rows i0, i0 + 1 of block r >> 1
+__device__ __forceinline__ uint4 idct_pass2_pk(const int *t, bool is8, int r) {
   int in[8], out[8];
   if (is8) {
 #pragma unroll
     for (int m = 0; m < 8; m++) in[m] = t[8 * r + m];
     mobi_bfly8(in, out);
-    wave_sync();
-#pragma unroll
-    for (int j = 0; j < 8; j++) res[8 * r + j] = out[j] >> 6;
   } else {
     const int s = r >> 1, i0 = (r & 1) * 2;
 #pragma unroll
     for (int m = 0; m < 8; m++) in[m] = t[16 * s + 4 * i0 + m]; // groups i0 and i0 + 1
     mobi_bfly4(in, out);
     mobi_bfly4(in + 4, out + 4);
-    wave_sync();
-#pragma unroll
-    for (int g = 0; g < 2; g++) {
-      int *row = res + ((s >> 1) * 4 + i0 + g) * 8 + (s & 1) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; j++) row[j] = out[4 * g + j] >> 6;
-    }
   }
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  union { s16x2 v; uint32_t u; } p0, p1, p2, p3;
+  p0.v = __builtin_amdgcn_cvt_pk_i16(out[0] >> 6, out[1] >> 6);
+  p1.v = __builtin_amdgcn_cvt_pk_i16(out[2] >> 6, out[3] >> 6);
+  p2.v = __builtin_amdgcn_cvt_pk_i16(out[4] >> 6, out[5] >> 6);
+  p3.v = __builtin_amdgcn_cvt_pk_i16(out[6] >> 6, out[7] >> 6);
+  return uint4{p0.u, p1.u, p2.u, p3.u};
 }
-
 } // namespace
 
 // q = x / d, r = x % d with magic = floor(2^32 / d): the estimate is at most one short
@@ -651,8 +645,16 @@ MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16)
 // record and read back by all 16.  The wave runs as many steps as its longest macroblock has (95 % of the areas are unsplit in the
 // generator's mix); the wave-level branches inside a step ask "does any of the four need a plane / a DC / an 8x8 / a 4x4 now".
 namespace {
-enum { IQ_TCU = 17 * TP, IQ_TCV = IQ_TCU + 9 * TP,                       // chroma tiles behind the luma tile (bytes)
-       IQ_COEF = (IQ_TCV + 9 * TP) / 4, IQ_STEP = IQ_COEF + 384, IQ_WORDS = IQ_STEP + 48 }; // words per macroblock: 2848 B
+// LDS of one macroblock, 2080 bytes, two lives:
+//   while the residuals are made    [0, 1536) coefficients, int32 [6][64]               [1536, 1856) dequant scales
+//   from then on                    [0, 768) residuals, int16 [6][64]   [768, 1888) the three tiles   [1888, 2080) step descriptors
+// (pass 2 of the transforms writes the int16 residuals of areas 2k, 2k + 1 over the int32 words of area k, which is done with by then;
+// r02's first version kept all three side by side: 2848 bytes, 14 waves per CU instead of 19, and the launch is latency-bound
+// wherever it is not bound by its stores.)
+enum { IQ_TILE = 768,                                                      // bytes
+       IQ_TCU = 17 * TP, IQ_TCV = IQ_TCU + 9 * TP,                         // chroma tiles behind the luma tile (bytes from the tile's start)
+       IQ_SCALE = 1536 / 4, IQ_STEP = (IQ_TILE + IQ_TCV + 9 * TP) / 4, IQ_WORDS = IQ_STEP + 48 }; // words
+static_assert(IQ_STEP * 4 == 1888 && IQ_WORDS * 4 == 2080 && IQ_SCALE * 4 + 320 <= IQ_STEP * 4, "intra LDS map");
 // step descriptor, word 0
 enum { SD_O = 0,           // [10:0]  byte offset of the block's top-left sample inside the macroblock's tiles
        SD_TAP = 11,        // [20:11] first tap table entry of this step (+ lane)
@@ -730,8 +732,9 @@ struct QItem {
 __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_t *Lw, const QItem &I, int lane, int dbg = 0) {
   const int l = lane & 15;
   uint32_t *G = Lw + (lane >> 4) * IQ_WORDS;
-  uint8_t *tile = (uint8_t *)G;
-  int *coef = (int *)(G + IQ_COEF);
+  uint8_t *tile = (uint8_t *)G + IQ_TILE;
+  int *coef = (int *)G;
+  const int16_t *res16 = (const int16_t *)G;
   uint32_t *steps = G + IQ_STEP;
   const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S), mbw = A.mbw;
   const uint32_t clip = I.clip, mb = I.mb, w1 = I.w1, w3 = I.w3, ncoef = I.ncoef;
@@ -776,13 +779,13 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   uint32_t b0_early = 0, b1_early = 0;
   if (!(dbg & 16)) { w_early = *(const uint4_a4 *)wp; b0_early = *b0p; b1_early = *b1p; }
 
-  { // zero the coefficients; dequant scales into the (still unused) tile area
+  { // zero the coefficients; dequant scales behind them
     uint4 *G4 = (uint4 *)G;
     const uint4 z = uint4{0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 6; k++) G4[IQ_COEF / 4 + l + 16 * k] = z;
-    G4[l] = sc0;
-    if (l < 4) G4[16 + l] = sc1;
+    for (int k = 0; k < 6; k++) G4[l + 16 * k] = z;
+    G4[IQ_SCALE / 4 + l] = sc0;
+    if (l < 4) G4[IQ_SCALE / 4 + 16 + l] = sc1;
   }
 
   // All dependency levels of a frame step run in ONE launch: items are sorted by level, workgroups are dispatched in order, and a
@@ -818,7 +821,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   auto scatter = [&](uint32_t e) {
     const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63;
     const int si = ((t8 >> (t >> 6)) & 1) ? p : 64 + (p & 15);
-    coef[t] = __mul24((int)G[si], level);
+    coef[t] = __mul24((int)G[IQ_SCALE + si], level);
   };
 #pragma unroll
   for (int k = 0; k < 8; k++)
@@ -832,13 +835,41 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   }
   wave_sync();
 
+  // ---- residuals of all coded areas: eight lanes per area, two areas of each macroblock per round.  Pass 1 in place; pass 2 leaves
+  // int16 residuals (saturated: whatever does not fit is a clamp-table fault anyway) of areas 2k, 2k + 1 over the words of area k ----
+#pragma unroll 1
+  for (int rd = 0; rd < ((dbg & 1) ? 0 : 3); rd++) {
+    const int a = 2 * rd + (l >> 3), r = l & 7;
+    const bool act = (w1 >> (8 + a)) & 1, is8a = (t8 >> a) & 1;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0; // this lane's eight residuals, int16 pairs
+    if (__builtin_amdgcn_ballot_w64(act) != 0) {
+      if (act) idct_pass1(coef + 64 * a, coef + 64 * a, is8a, r);
+      wave_sync();
+      const uint4 pk = idct_pass2_pk(coef + 64 * a, is8a, r); // (lanes of uncoded areas transform whatever is there and drop it)
+      wave_sync(); // every lane has read its words: the stores below land on area rd's (round 0: on what areas 0 and 1 have just read)
+      const uint32_t keep = act ? 0xFFFFFFFFu : 0u;
+      q0 = pk.x & keep; q1 = pk.y & keep; q2 = pk.z & keep; q3 = pk.w & keep;
+    }
+    {
+      uint8_t *dst = (uint8_t *)G + 128 * a; // the area's int16 [8][8]
+      if (!act || is8a) { // row r (zeros where nothing is coded: the words underneath belonged to another area)
+        *(uint4 *)(dst + 16 * r) = uint4{q0, q1, q2, q3};
+      } else {            // 4x4 blocks: lane r made rows i0, i0 + 1 of block r >> 1
+        const int sb = r >> 1, row0 = (sb >> 1) * 4 + (r & 1) * 2, c0 = (sb & 1) * 4;
+        *(uint2 *)(dst + 16 * row0 + 2 * c0) = uint2{q0, q1};
+        *(uint2 *)(dst + 16 * (row0 + 1) + 2 * c0) = uint2{q2, q3};
+      }
+    }
+    wave_sync();
+  }
+
   // ---- tiles: zero (what nobody owns yet reads 0, as the reference's fresh plane does), then the halo ----
   {
-    uint4 *G4 = (uint4 *)G;
+    uint4 *T4 = (uint4 *)tile; // 1120 bytes
     const uint4 z = uint4{0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; k++) G4[l + 16 * k] = z;
-    if (l < IQ_COEF / 4 - 64) G4[64 + l] = z;
+    for (int k = 0; k < 4; k++) T4[l + 16 * k] = z;
+    if (l < (IQ_TCV + 9 * TP) / 16 - 64) T4[64 + l] = z;
   }
   wave_sync();
   if (interior) {
@@ -891,19 +922,6 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     }
   }
   wave_sync();
-
-  // ---- residuals of all coded areas, transformed in place: eight lanes per area, two areas of each macroblock per round ----
-#pragma unroll 1
-  for (int rd = 0; rd < ((dbg & 1) ? 0 : 3); rd++) {
-    const int a = 2 * rd + (l >> 3), r = l & 7;
-    const bool act = (w1 >> (8 + a)) & 1, is8a = (t8 >> a) & 1;
-    if (__builtin_amdgcn_ballot_w64(act) != 0) {
-      if (act) idct_pass1(coef + 64 * a, coef + 64 * a, is8a, r);
-      wave_sync();
-      if (act) idct_pass2_res(coef + 64 * a, is8a, r, coef + 64 * a);
-      wave_sync();
-    }
-  }
 
   // ---- the schedule: one step per unsplit area, four per split one, in decode order.  Lane 4a + s of the row owns the candidate
   // (area a, block s); its place in the list follows from how many areas before a are split. ----
@@ -1036,7 +1054,8 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
           word = (uint32_t)dcv * 0x01010101u;
         }
         if (d.x & SD_CODED) {
-          const int4 r = *(const int4 *)(coef + (d.y & 0x1FF) + ro8);
+          const uint2 rr = *(const uint2 *)(res16 + (d.y & 0x1FF) + ro8);
+          const int4 r = int4{(int)(int16_t)(rr.x & 0xFFFF), (int)rr.x >> 16, (int)(int16_t)(rr.y & 0xFFFF), (int)rr.y >> 16};
           const uint32_t q0 = (uint32_t)mobi_add_clamp((int)(word & 0xFF), r.x, &fault), q1 = (uint32_t)mobi_add_clamp((int)((word >> 8) & 0xFF), r.y, &fault);
           const uint32_t q2 = (uint32_t)mobi_add_clamp((int)((word >> 16) & 0xFF), r.z, &fault), q3 = (uint32_t)mobi_add_clamp((int)(word >> 24), r.w, &fault);
           word = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
@@ -1051,7 +1070,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
         int p = *px;
         if (d.x & SD_KTAP) p = (tb[(int16_t)(ea.x & 0xFFFF)] + tb[(int16_t)(ea.x >> 16)] + tb[(int16_t)(ea.y & 0xFFFF)] + tb[(int16_t)(ea.y >> 16)] + 2) >> 2;
         else if (d.x & SD_KDC) p = dcv;
-        if (d.x & SD_CODED) p = mobi_add_clamp(p, coef[(d.y & 0x1FF) + ro4], &fault);
+        if (d.x & SD_CODED) p = mobi_add_clamp(p, (int)res16[(d.y & 0x1FF) + ro4], &fault);
         *px = (uint8_t)p;
       }
     }
