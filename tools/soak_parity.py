@@ -1,0 +1,43 @@
+"""Soak: N clips (private copies of 16 generated streams) replayed for a whole 33-frame clip, twice, on a loaded chip; EVERY clip's
+planes are compared with the oracle's at the I-frame, in the middle and at the end.  Looks for rare hand-off races (completion tags,
+write-through stores) that a handful of clips would never show.  python tools/soak_parity.py [clips] [config]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import mobiclipdecoder_amd as m
+from mobiclipdecoder_amd import sharding
+from tests.oracle_binding import OracleDecoder
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
+distinct, nfr = 16, 33
+ps = [m.default_params(cfg, sharding.stream_seed(cfg, 0, i), n_frames=nfr, pm_intra=120 if i & 1 else 50, iframe_interval=11 if i % 5 == 0 else 0) for i in range(distinct)]
+clips = [m.generate_clip(p) for p in ps]
+W, H, ver = ps[0].width, ps[0].height, ps[0].version
+b = m.MobiclipBatch(n, W, H, ver)
+for i in range(distinct):
+    assert all(r == 0 for r in b.preload(i, clips[i][0], clips[i][1]))
+for c in range(distinct, n):
+    b.preload_clone(c, c % distinct)
+b.commit()
+oras = [OracleDecoder(W, H, ver) for _ in range(distinct)]
+bad = 0
+t0 = time.time()
+for f in range(nfr):
+    b.replay(f)
+    for i in range(distinct):
+        oras[i].Data, oras[i].Offset = clips[i][0], int(clips[i][1][f])
+        assert oras[i].DecodeFrame() is not None
+    if f in (0, 11, 16, 22, nfr - 1):
+        assert b.sync() == 0
+        for c in range(n):
+            y, uv = b.planes(c)
+            o = oras[c % distinct]
+            if not (np.array_equal(y, o.y(0)) and np.array_equal(uv, o.uv(0))):
+                bad += 1
+                if bad < 5:
+                    print("MISMATCH frame", f, "clip", c, "stream", c % distinct, np.argwhere(y != o.y(0))[:3].tolist())
+        print("frame %2d: %d clips checked, %d mismatches so far, %.0f s" % (f, n, bad, time.time() - t0), flush=True)
+b.close()
+print("soak:", "OK" if bad == 0 else "FAILED", n, "clips of", cfg)
+sys.exit(0 if bad == 0 else 1)
