@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
-    ap.add_argument("--e2e-steps", type=int, default=8)
+    ap.add_argument("--e2e-steps", type=int, default=12)
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
     args = ap.parse_args()
