@@ -6,6 +6,11 @@
  * Decodes the frames the way the reference's callers drive MobiclipDecoder (Program.cs:69-71: d.Data = frame; d.Offset = o;
  * d.DecodeFrame()), and prints for every frame one line
  *   <frame> <rc> <offset_after> <quantizer> <sha256 of Y[0]> <sha256 of UV[0]>
+ *
+ *   abi_caller --batch-async <stream.bin> <width> <height> <version> <n_frames> <off_0> ... <off_n>
+ *
+ * The same stream as three clips of a batch that parses on the GPU, through mobi_batch_submit / mobi_batch_wait with two frame steps
+ * in flight; prints the same lines (for clip 2).
  * tests/test_abi_c_caller.py compares the lines with tests/golden/golden.json.  Test tool: not part of the product. */
 #include <stdint.h>
 #include <stdio.h>
@@ -55,7 +60,44 @@ static void sha256_hex(const uint8_t *data, size_t len, char out[65]) {
   for (i = 0; i < 8; i++) sprintf(out + 8 * i, "%08x", h[i]);
 }
 
+static int run_batch_async(const uint8_t *data, uint32_t w, uint32_t hgt, int version, int nf, char **offs) {
+  enum { N = 3 };
+  mobi_batch *b = mobi_batch_create(N, w, hgt, version, 0);
+  if (!b) { fprintf(stderr, "mobi_batch_create failed\n"); return 3; }
+  if (mobi_batch_set_parse_mode(b, 1) != MOBI_OK) return 3;             /* the bitstreams are parsed on the GPU */
+  const size_t ysz = (size_t)mobi_batch_stride(b) * hgt;
+  uint8_t *y = (uint8_t *)malloc(ysz), *uv = (uint8_t *)malloc(ysz / 2);
+  const uint8_t *ptrs[N] = {data, data, data};
+  char hy[65], huv[65];
+  int i, bad = 0;
+  for (i = 0; i <= nf; i++) {
+    if (i < nf) {                                                        /* frame i goes in behind frame i - 1 ... */
+      const size_t l = (size_t)atol(offs[i + 1]);
+      const size_t lens[N] = {l, l, l};
+      const int32_t o = atoi(offs[i]), off[N] = {o, o, o};
+      if (mobi_batch_submit(b, ptrs, lens, off) != MOBI_OK) { fprintf(stderr, "submit %d failed\n", i); return 3; }
+    }
+    if (i > 0) {                                                         /* ... whose results are collected now */
+      int32_t after[N];
+      int rc[N];
+      if (mobi_batch_wait(b, after, rc) != MOBI_OK) { fprintf(stderr, "wait %d failed\n", i - 1); return 3; }
+      hy[0] = huv[0] = '-'; hy[1] = huv[1] = 0;
+      /* frame i - 1 is ring position 1 once frame i has been submitted (Y[1], MD.cs:102-106), position 0 after the last frame */
+      if (rc[2] == MOBI_OK && mobi_batch_get_planes(b, 2, i < nf ? 1 : 0, y, uv) == MOBI_OK) {
+        sha256_hex(y, ysz, hy);
+        sha256_hex(uv, ysz / 2, huv);
+      } else bad = 1;
+      printf("%d %d %d %u %s %s\n", i - 1, rc[2], (int)after[2], mobi_batch_quantizer(b, 2), hy, huv);
+    }
+  }
+  mobi_batch_destroy(b);
+  free(y); free(uv);
+  return bad;
+}
+
 int main(int argc, char **argv) {
+  const int batch_async = argc > 1 && strcmp(argv[1], "--batch-async") == 0;
+  if (batch_async) { argv++; argc--; }
   if (argc < 7) { fprintf(stderr, "usage: abi_caller stream.bin width height version n_frames off_0 .. off_n\n"); return 2; }
   const uint32_t w = (uint32_t)atoi(argv[2]), hgt = (uint32_t)atoi(argv[3]);
   const int version = atoi(argv[4]), nf = atoi(argv[5]);
@@ -69,6 +111,7 @@ int main(int argc, char **argv) {
   if (fread(data, 1, (size_t)flen, f) != (size_t)flen) { fprintf(stderr, "short read\n"); return 2; }
   fclose(f);
 
+  if (batch_async) { const int e = run_batch_async(data, w, hgt, version, nf, argv + 6); free(data); return e; }
   mobi_dec *d = mobi_create(w, hgt, version, 0);                    /* new MobiclipDecoder(Width, Height, Version) */
   if (!d) { fprintf(stderr, "mobi_create failed: %s\n", mobi_error_string(MOBI_E_DEVICE)); return 3; }
   const int stride = mobi_stride(d);
