@@ -1,6 +1,7 @@
 """Soak: N clips (private copies of 16 generated streams) replayed for a whole 33-frame clip, twice, on a loaded chip; EVERY clip's
 planes are compared with the oracle's at the I-frame, in the middle and at the end.  Looks for rare hand-off races (completion tags,
-write-through stores) that a handful of clips would never show.  python tools/soak_parity.py [clips] [config]"""
+write-through stores) that a handful of clips would never show.  python tools/soak_parity.py [clips] [config] [dparse]
+"dparse": the same through mobi_batch_decode with the parse on the GPU (mobi_recon_intra_cl: items per clip in raster order), 12 frames."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,29 +11,35 @@ from tests.oracle_binding import OracleDecoder
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
-distinct, nfr = 16, 33
+dparse = len(sys.argv) > 3 and sys.argv[3] == "dparse"
+distinct, nfr = 16, (12 if dparse else 33)
 ps = [m.default_params(cfg, sharding.stream_seed(cfg, 0, i), n_frames=nfr, pm_intra=120 if i & 1 else 50, iframe_interval=11 if i % 5 == 0 else 0) for i in range(distinct)]
 clips = [m.generate_clip(p) for p in ps]
 W, H, ver = ps[0].width, ps[0].height, ps[0].version
-b = m.MobiclipBatch(n, W, H, ver)
-for i in range(distinct):
-    assert all(r == 0 for r in b.preload(i, clips[i][0], clips[i][1]))
-for c in range(distinct, n):
-    b.preload_clone(c, c % distinct)
-b.commit()
+b = m.MobiclipBatch(n, W, H, ver, device_parse=True if dparse else None)
+if not dparse:
+    for i in range(distinct):
+        assert all(r == 0 for r in b.preload(i, clips[i][0], clips[i][1]))
+    for c in range(distinct, n):
+        b.preload_clone(c, c % distinct)
+    b.commit()
 oras = [OracleDecoder(W, H, ver) for _ in range(distinct)]
 bad = 0
 t0 = time.time()
 for f in range(nfr):
-    b.replay(f)
+    if dparse:
+        rcs, _ = b.decode([clips[c % distinct][0][clips[c % distinct][1][f]:clips[c % distinct][1][f + 1]] for c in range(n)], [0] * n)
+        assert not any(rcs)
+    else:
+        b.replay(f)
     for i in range(distinct):
         oras[i].Data, oras[i].Offset = clips[i][0], int(clips[i][1][f])
         assert oras[i].DecodeFrame() is not None
-    if f in (0, 11, 16, 22, nfr - 1):
-        assert b.sync() == 0
+    if f in (0, 11, 16, 22, nfr - 1) or (dparse and f % 3 == 0):
+        assert dparse or b.sync() == 0
         for c in range(n):
             y, uv = b.planes(c)
-            o = oras[c % distinct]
+            o = oras[(c + (1 if os.environ.get('SOAK_SELFTEST') and c == 7 else 0)) % distinct]  # SOAK_SELFTEST=1: clip 7 against the wrong stream must be reported
             if not (np.array_equal(y, o.y(0)) and np.array_equal(uv, o.uv(0))):
                 bad += 1
                 if bad < 5:
