@@ -1,0 +1,48 @@
+"""Randomised GPU-vs-oracle sweep aimed at the intra path: many small intra-heavy streams (every prediction mode, plane predictors, split
+and unsplit areas, picture edges, width == stride wrap, chains of dependencies, I-frames every few frames), batches of 1..7 clips so
+that the rows of the last wave of a level are partly empty, host-parsed and device-parsed alternately.  Stops at the first difference.
+python tools/fuzz_intra_gpu.py [rounds] [seed0]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import mobiclipdecoder_amd as m
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+from tests.oracle_binding import OracleDecoder
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+geoms = [(16, 16, 2), (32, 32, 1), (48, 16, 2), (64, 48, 1), (96, 64, 2), (256, 32, 1), (512, 16, 2), (160, 112, 2), (272, 48, 1), (128, 128, 2)]
+rng = np.random.default_rng(1234 + seed0)
+t0, frames, mbs = time.time(), 0, 0
+for it in range(rounds):
+    w, h, ver = geoms[int(rng.integers(len(geoms)))]
+    nclips = int(rng.integers(1, 8))
+    nfr = int(rng.integers(3, 7))
+    kw = dict(width=w, height=h, version=ver, n_frames=nfr, pm_intra=int(rng.choice([150, 400, 800])), intra_sub_prob=int(rng.choice([100, 500, 900])),
+              plane_prob=int(rng.choice([0, 300, 700])), iframe_interval=int(rng.choice([0, 2, 3])), mv_range=int(rng.choice([4, 12])),
+              cbp_prob=int(rng.choice([100, 300, 700])), dense_prob=int(rng.choice([0, 200])), qdelta_prob=int(rng.choice([0, 300])),
+              table1_prob=int(rng.choice([0, 500])), escape_prob=int(rng.choice([0, 80])), quantizer=int(rng.choice([12, 25, 40, 52])),
+              intra_dc_only=int(rng.choice([0, 0, 1])), edge_mode=int(rng.choice([0, 1])))
+    ps = [m.default_params("A", BASE_SEED + 100000 + 1000 * (seed0 + it) + i, **kw) for i in range(nclips)]
+    clips = [m.generate_clip(p) for p in ps]
+    dev = bool(it & 1)
+    b = m.MobiclipBatch(nclips, w, h, ver, device_parse=dev)
+    oras = [OracleDecoder(w, h, ver) for _ in ps]
+    for f in range(nfr):
+        rcs, offs = b.decode([c[0][c[1][f]:c[1][f + 1]] for c in clips], [0] * nclips)
+        for i in range(nclips):
+            oras[i].Data, oras[i].Offset = clips[i][0][clips[i][1][f]:clips[i][1][f + 1]], 0
+            o = oras[i].DecodeFrame()
+            ok = rcs[i] == 0 and o is not None and offs[i] == oras[i].Offset
+            if ok:
+                y, uv = b.planes(i)
+                ok = np.array_equal(y, o[0]) and np.array_equal(uv, o[1])
+            if not ok:
+                print("DIFFERENCE round", it, "frame", f, "clip", i, "device_parse", dev, "rc", rcs[i], oras[i].last_error, kw, "seed", ps[i].seed)
+                sys.exit(1)
+        frames += nclips
+        mbs += nclips * (w // 16) * (h // 16)
+    b.close()
+    for o in oras:
+        o.close()
+print("fuzz_intra_gpu: %d rounds, %d clip-frames, %d macroblocks, no difference, %.0f s" % (rounds, frames, mbs, time.time() - t0))
