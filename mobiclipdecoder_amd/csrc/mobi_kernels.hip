@@ -632,7 +632,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 // measure the same) with 128 level words per macroblock in registers (96: 848x480 with its dense blocks 8 % slower; 192: no better).
 // Re-measured at the end of r02 on one box: 5 waves with 64 level words (96 VGPRs, one spill) 2.696 ms per 8192 clips of 640x480
 // against 2.696, and 2.81 against 2.50 on 848x480; 5 waves with 96 words (5 spills) 2.84.  Fewer waves do cost (15 per CU +3 %,
-// 12 per CU +12 %, MOBI_LDS_PAD); more do not pay.
+// 12 per CU +12 %, MOBI_LDS_PAD); more do not pay.  Output rows padded in LDS (pitch 144 / 80 instead of 128 / 64, so that the eight
+// lanes of an area do not meet in one bank when they add the residual: 55 % of the LDS cycles are bank conflicts): 2.754 against 2.758 --
+// LDS time is not on the critical path of a kernel that waits for memory requests.
 MOBI_OCT_KERNEL(mobi_recon_inter8, 4, 0, 16)
 MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16)
 
