@@ -527,8 +527,15 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         asm volatile("" : "+v"(e));
         if (mine) scatter(e);
       }
-      for (uint32_t i = 8u * CWR + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 8) // beyond the registers: one exposed round trip per 8 words
-        if (i < ncoef) scatter(cw[i]);
+      // beyond the registers (dense macroblocks): 64 more words of a macroblock per round trip, eight loads in flight per lane
+      for (uint32_t i = 8u * CWR + (uint32_t)j; __builtin_amdgcn_ballot_w64(i < ncoef) != 0; i += 64) {
+        uint32_t tw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) tw[k] = i + 8u * k < ncoef ? cw[i + 8u * k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (i + 8u * k < ncoef) scatter(tw[k]);
+      }
       wave_sync();
       const int r = lane & 7;
       int kx[2];
