@@ -386,6 +386,7 @@ struct mobi_batch {
     evs.clear();
   }
   ~mobi_batch() {
+    if (stream2) (void)hipStreamSynchronize(stream2); // an upload of a submitted step may still be reading pinned memory we are about to free
     if (stream) (void)hipStreamSynchronize(stream);
     drain_events();
     for (auto e : ev_pool) (void)hipEventDestroy(e);
