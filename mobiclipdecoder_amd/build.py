@@ -43,10 +43,12 @@ def _hdrs(d):
     return [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
 
 
-def build_hip(force=False):
+def build_hip(force=False, profiling=False):
+    """profiling=True (python build.py --profiling, tools/ only): -DMOBI_PROFILING compiles the ablation / occupancy switches
+    (MOBI_INTRA_DBG, MOBI_LDS_PAD, MOBI_INTRA_LDS_PAD) in; the default build has none of them."""
     srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip", "mobi_dparse.hip", "mobi_analysis.hip")]
     deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h"), os.path.join(ROOT, "include", "mobiclip_demux.h")]
-    if not force and not _newer(LIB_HIP, deps):
+    if not force and not profiling and not _newer(LIB_HIP, deps):
         return LIB_HIP
     obj = os.path.join(PKG, "_obj")
     os.makedirs(obj, exist_ok=True)
@@ -61,7 +63,7 @@ def build_hip(force=False):
     extra = {"mobi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     for s in srcs[4:]:
         ko = os.path.join(obj, os.path.basename(s) + ".o")
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DMOBI_PROFILING"] if profiling else []) + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
         objs.append(ko)
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_HIP])
     return LIB_HIP
@@ -103,5 +105,8 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--profiling" in sys.argv:
+        build_hip(force=True, profiling=True)
+    else:
+        build_all(force="--force" in sys.argv)
     print("ok")

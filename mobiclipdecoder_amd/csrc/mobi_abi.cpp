@@ -26,7 +26,8 @@
 namespace {
 
 constexpr size_t kPaySlack = 2048; // lanes of the inter kernel with nothing to fetch re-read up to ~1 KB past their macroblock's payload
-constexpr size_t kGuard = 4096; // slack on both ends of the plane arena: MC fetches whole aligned dwords
+constexpr size_t kGuard = 65536; // slack on both ends of the plane arena: the slow MC path fetches the dwords of the row below a window's last
+                                 // row whether its phase needs them or not, and in the tiled planes (mobi_tile.h) that row may be a tile row (<= 16 KB) away
 constexpr size_t kAlign = 16;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -104,7 +105,7 @@ void step_write(const std::vector<const ParsedFrame *> &frames, int n_mbs, MbDes
 struct LevelPlan { // launch plan of one frame step: the intra macroblocks of all clips, sorted by dependency level
   // One item = MOBI_INTRA_ITEM_WORDS words, everything a wave needs to start (mobi_recon_intra): (clip << 13 | mb), MbDesc.w1,
   // MbDesc.payload_off inside the step's arena, and flags: [0] 16x16 plane, [1] has intra dependencies (must poll their tags),
-  // [2] has intra dependents (must publish its own), [3] left column in the edge side buffer, [14:5] number of level words,
+  // [2] has intra dependents (must publish its own), [14:5] number of level words,
   // [31:16] plane parameter.
   std::vector<uint32_t> items;
   uint32_t n_items = 0;         // launch items, padding included
@@ -156,7 +157,6 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
             }
             flags |= (d.w2 & 0x3FFu) << 5;
             intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + (d.w2 & 0x3FFu));
-            if (mbx) flags |= 8u; // finish_levels flagged the left neighbour: its last column is in the edge side buffer
             items.push_back(MOBI_ITEM(c, mb));
             items.push_back(d.w1);
             items.push_back(d.payload_off + (uint32_t)base[c]);
@@ -272,7 +272,7 @@ struct mobi_batch {
   uint32_t *d_argb = nullptr;           // Bitmap output of mobi_batch_convert_argb / mobi_batch_get_argb (lazily allocated)
   size_t argb_bytes = 0;
   bool argb_all_valid = false;          // d_argb holds every clip's Bitmap of the current frame
-  uint8_t *d_edge = nullptr;            // [clip * n_mbs + mb][MOBI_EDGE_BYTES]: right-most columns of macroblocks left of an intra one (host-parsed steps)
+  uint8_t *d_lin = nullptr;             // one frame in the reference's linear layout: what mobi_batch_get_planes copies out (lazily allocated)
   uint32_t *d_done = nullptr;           // [clip * n_mbs + mb]: step tag of the last step that reconstructed this intra macroblock
   uint32_t step_tag = 0;                // bumped once per frame step, never 0
   // device-side parse (mobi_dparse.hip): parse_mode 1 = mobi_batch_decode parses on the GPU (env MOBI_DEVICE_PARSE=1 or
@@ -342,8 +342,6 @@ struct mobi_batch {
     a.n_mbs = g.mbw * g.mbh;
     a.n_clips = n;
     auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); }; // d == 1 must not wrap to 0
-    static const bool no_edge = getenv("MOBI_NO_EDGE") != nullptr; // experiment: intra left columns from the planes, as in r01
-    a.edge = no_edge ? nullptr : d_edge;
     a.step_tag = step_tag;
     a.done = d_done;
     a.prof = d_prof;
@@ -405,7 +403,7 @@ struct mobi_batch {
     if (d_scale) (void)hipFree(d_scale);
     if (d_prof) (void)hipFree(d_prof);
     if (d_done) (void)hipFree(d_done);
-    if (d_edge) (void)hipFree(d_edge);
+    if (d_lin) (void)hipFree(d_lin);
     if (d_argb) (void)hipFree(d_argb);
     if (d_pstate) (void)hipFree(d_pstate);
     if (d_pres) (void)hipFree(d_pres);
@@ -508,7 +506,6 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     const size_t dbytes = (size_t)n_clips * b->g.mbw * b->g.mbh * 4;
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
-    if (hipMalloc((void **)&b->d_edge, dbytes / 4 * MOBI_EDGE_BYTES) != hipSuccess) return nullptr;
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     b->parse_auto = true;
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = std::max(0, std::min(2, atoi(dp))); b->parse_auto = false; }
@@ -898,9 +895,12 @@ int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out,
   HIP_TRY(hipSetDevice(b->device));
   const uint8_t *slot = b->arena + kGuard + (size_t)clip * b->clip_bytes + (size_t)((b->ring_base + 6 - ring_idx) % 6) * b->slot_bytes;
   const size_t ysz = (size_t)b->g.stride * b->g.height;
+  // the planes live in HBM as macroblock tiles (mobi_tile.h); callers get the reference's row-major arrays (MD.cs:107-108, 414-415)
+  if (!b->d_lin) HIP_TRY(hipMalloc((void **)&b->d_lin, b->slot_bytes));
+  if (mobi_launch_untile(slot, b->d_lin, b->g.stride, b->g.height, b->stream) != 0) return MOBI_E_DEVICE;
   HIP_TRY(hipStreamSynchronize(b->stream));
-  if (y_out) HIP_TRY(hipMemcpy(y_out, slot, ysz, hipMemcpyDeviceToHost));
-  if (uv_out) HIP_TRY(hipMemcpy(uv_out, slot + ysz, ysz / 2, hipMemcpyDeviceToHost));
+  if (y_out) HIP_TRY(hipMemcpy(y_out, b->d_lin, ysz, hipMemcpyDeviceToHost));
+  if (uv_out) HIP_TRY(hipMemcpy(uv_out, b->d_lin + ysz, ysz / 2, hipMemcpyDeviceToHost));
   return MOBI_OK;
 }
 // ---- the Bitmap of DecodeFrame(), MD.cs:260-323 ---------------------------------------------------------

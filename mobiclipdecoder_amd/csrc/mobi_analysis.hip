@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mobi_kernels.h"
+#include "mobi_tile.h"
 
 namespace {
 enum { WIN_ROWS = 36, WIN_DW = 10, REACH = 10 }; // 6 + 3 + 1 pels either way around a 16 x 16 macroblock; 40 bytes per row from column BX - 12
@@ -22,7 +23,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_motion_search_2x2(MobiReco
   const uint32_t clip = blockIdx.x / (uint32_t)A.n_mbs;
   mb = blockIdx.x - clip * (uint32_t)A.n_mbs;
   const int mby = (int)(mb / (uint32_t)A.mbw), mbx = (int)mb - mby * A.mbw;
-  const int W = A.width, H = A.height, S = A.stride, BX = mbx * 16, BY = mby * 16;
+  const int W = A.width, H = A.height, S = A.stride, BX = mbx * 16, BY = mby * 16, lgS = 31 - __builtin_clz((unsigned)S);
   const int bx = BX + 2 * X, by = BY + 2 * Y; // this lane's block
   const uint8_t *c0 = src + (size_t)clip * W * H + (size_t)by * W + bx;
   const uint32_t c01 = *(const uint16_t *)c0, c23 = *(const uint16_t *)(c0 + W); // cmp[0..3], Encoder/MacroBlock.cs:80-83
@@ -37,7 +38,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_motion_search_2x2(MobiReco
     for (int idx = lane; idx < WIN_ROWS * WIN_DW; idx += 64) {
       const int r = idx / WIN_DW, dw = idx - r * WIN_DW, row = BY - REACH + r, col = BX - 12 + 4 * dw;
       uint32_t v = 0;
-      if (row >= 0 && row < H && col >= 0 && col < S) v = *(const uint32_t *)(plane + (size_t)row * S + col);
+      if (row >= 0 && row < H && col >= 0 && col < S) v = *(const uint32_t *)(plane + mobi_ty((uint32_t)(row * S + col), lgS)); // tiled planes (mobi_tile.h)
       win[idx] = v; // bytes outside the picture are never used: the bounds tests below skip those candidates (:630, :633)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -31,8 +31,7 @@ enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 //     [13:8]   cbp6       coded 8x8 areas: bits 0-3 luma TL,TR,BL,BR; 4 U; 5 V   (MD.cs:1820-1832)
 //     [19:14]  t8mask     coded area uses ONE 8x8 transform (else four 4x4s)      (MD.cs:2911)
 //     [25:20]  quantizer  of the frame (selects the dequant scale table, MD.cs:3884-3912)
-//     [28]     MOBI_W1_EDGE: the macroblock to the right (same row) is an intra one: whoever reconstructs this macroblock also
-//              leaves its right-most column (16 luma + 8 U + 8 V samples) in the edge side buffer (see MOBI_EDGE_BYTES)
+//     [28]     reserved (r02: "right neighbour is intra", for the edge side buffer the tiled planes made unnecessary)
 //     [27:26]  MOBI_DUAL_*: the macroblock is exactly two halves (partition codes 8 / 9 at the 16x16 level with two
 //              plain leaves, MD.cs:585-600 -- by far the most common split), leaf A = top / left, B = bottom / right
 // w2  [9:0]    n_coefs (<= 384)
@@ -58,11 +57,6 @@ struct MbDesc {
   uint32_t w6;
   uint32_t w7;
 };
-#define MOBI_W1_EDGE (1u << 28)
-// Edge side buffer: [clip][mb][32]: bytes 0..15 = luma column 15 (rows 0..15), 16..23 = U column 7, 24..31 = V column 7 of a
-// macroblock whose right neighbour is intra.  An intra macroblock's left halo column is then ONE 32-byte read instead of 32 reads
-// of 32 different lines of the planes (r01: 6.1 KB of HBM traffic per intra macroblock, 5 KB of them these columns).
-#define MOBI_EDGE_BYTES 32
 #define MOBI_DEP_NONE 0xFFFFu
 #define MOBI_DEP_INTER 0x8000u /* flag on a dependency index: that macroblock is an inter one (index = low 13 bits) */
 #define MOBI_INTRA_DEPS 8

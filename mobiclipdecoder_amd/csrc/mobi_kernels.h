@@ -7,8 +7,8 @@
 #include "mobi_cmd.h"
 
 // Everything one reconstruction launch needs.  HBM layout:
-//   planes : [clip][slot 0..5][ Y: stride*height | UV: stride*height/2 ]   (the reference's own plane
-//            layout, MD.cs:107-108,414-415, so linear offsets in the command list apply unchanged)
+//   planes : [clip][slot 0..5][ Y: stride*height | UV: stride*height/2 ], each plane as macroblock TILES (mobi_tile.h): a
+//            bijection of the reference's linear plane offsets (MD.cs:107-108,414-415), which the command list keeps using
 //   desc / payload : the command list of one frame step, all clips (mobi_cmd.h)
 // Ring: position r (0 = frame being written, 1..5 = references, MD.cs:102-106) lives in slot
 //   (ring_base + 6 - r) % 6 ; every clip of a batch rotates in lock step, so ring_base is a scalar.
@@ -23,7 +23,7 @@ struct MobiReconArgs {
   int ring_base;            // 13
   int width, height;        // 14, 15
   int stride, mbw, n_mbs, n_clips;          // 16-19
-  uint8_t *edge;                            // 20-21  edge side buffer [clip * n_mbs + mb][MOBI_EDGE_BYTES] (mobi_cmd.h); null = not in use (device-parsed steps)
+  uint8_t *reserved20;                      // 20-21  (r02: the edge side buffer; the tiled planes made it unnecessary)
   uint32_t qpr, qpc, magic_qpr, magic_qpc;  // 22-25  octets (8 adjacent MBs = one wave) per MB row / per clip: filled in by mobi_launch_inter
   uint32_t step_tag;                        // 26     frame-step counter (never 0): done[] == step_tag means "reconstructed in this step"
   uint32_t inter_per_xcd;                   // 27     inter launch: workgroups per XCD (= gridDim.x / 8)
@@ -43,6 +43,8 @@ extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, 
 extern "C" long long mobi_launch_div239_check(hipStream_t s); // mismatches of the RGB kernel's x/239 over all floats, or -1
 // Analyzer.cs:608-693: three-step 2x2 motion search of src_dev[clip][height][width] against ring slots 0..n_past-1 (mobi_analysis.hip)
 extern "C" int mobi_launch_motion_search(const MobiReconArgs *a, const uint8_t *src_dev, uint32_t *out_dev, int n_past, hipStream_t s);
+// slot (tiled Y + UV planes of one frame) -> lin_dev: the same frame as the reference's row-major Y[stride*height] then UV[stride*height/2]
+extern "C" int mobi_launch_untile(const uint8_t *slot, uint8_t *lin_dev, int stride, int height, hipStream_t s);
 // intra launch item, word 0: (clip << 13) | mb; words 1..3: MbDesc.w1, MbDesc.payload_off, flags (mobi_recon_intra in mobi_kernels.hip)
 #define MOBI_ITEM(clip, mb) (((uint32_t)(clip) << 13) | (uint32_t)(mb))
 #define MOBI_INTRA_ITEM_WORDS 4

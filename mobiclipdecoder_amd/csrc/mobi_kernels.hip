@@ -23,6 +23,7 @@
 #include "mobi_cmd.h"
 #include "mobi_kernels.h"
 #include "mobi_recon_math.h"
+#include "mobi_tile.h"
 
 namespace {
 
@@ -47,18 +48,33 @@ struct Geo { // stride is 256/512/1024 (MD.cs:50-52): divide/modulo by shifts
   }
 };
 
-// ---- reference fetch: a lane needs 5 consecutive bytes (4 pixels + the half-pel neighbour) of a row, and
-// the same of the row below, at an arbitrary byte offset `o` of a 4-byte-aligned plane.  They are fetched as
-// aligned dword pairs (global_load_dwordx2, never flat) and cut out with v_alignbyte.  All loads of a
-// macroblock are issued before the first one is consumed: no control flow sits between them.
+// ---- reference fetch of the SLOW path (macroblocks with deeper partition trees; windows that wrap around the end of a plane row):
+// a lane needs 5 consecutive bytes (4 pixels + the half-pel neighbour) of a row, and the same of the row below, at an arbitrary LINEAR
+// byte offset `o` of a reference plane.  They are fetched as four aligned dwords, each at its own tiled address (mobi_tile.h: a dword
+// never leaves a quadrant row, and the linear offset -> tile map handles wrap-around and padding by construction), and cut out with
+// v_alignbyte.  All loads of a macroblock are issued before the first one is consumed: no control flow sits between them.
 typedef uint2 __attribute__((aligned(4))) uint2_a4;
 typedef uint4 __attribute__((aligned(4))) uint4_a4;
 struct Win { uint2 r0, r1; uint32_t sh; }; // row, row below, byte shift 0..3
-__device__ __forceinline__ Win fetch_win(const uint32_t *plane32, int o, int S) {
+__device__ __forceinline__ Win fetch_win_y(const uint8_t *plane, int o, int S, int lgS) {
   Win w;
-  const uint32_t *q = plane32 + (o >> 2);
-  w.r0 = *(const uint2_a4 *)q;
-  w.r1 = *(const uint2_a4 *)(q + (S >> 2));
+  // (o may be as low as -3: the pixels of a lane that lie under its second .. fourth cell start that many bytes into the window, and
+  // only they are used.  The dword below the plane is never needed: fetch the plane's first one instead.)
+  const uint32_t o4 = (uint32_t)o & ~3u;
+  w.r0.x = *(const uint32_t *)(plane + mobi_ty(o < 0 ? 0u : o4, lgS));
+  w.r0.y = *(const uint32_t *)(plane + mobi_ty(o4 + 4, lgS));
+  w.r1.x = *(const uint32_t *)(plane + mobi_ty(o4 + (uint32_t)S, lgS));
+  w.r1.y = *(const uint32_t *)(plane + mobi_ty(o4 + (uint32_t)S + 4, lgS));
+  w.sh = (uint32_t)o & 3;
+  return w;
+}
+__device__ __forceinline__ Win fetch_win_c(const uint8_t *plane, int o, int S, int lgS) {
+  Win w;
+  const uint32_t o4 = (uint32_t)o & ~3u;
+  w.r0.x = *(const uint32_t *)(plane + mobi_tc(o < 0 ? 0u : o4, lgS));
+  w.r0.y = *(const uint32_t *)(plane + mobi_tc(o4 + 4, lgS));
+  w.r1.x = *(const uint32_t *)(plane + mobi_tc(o4 + (uint32_t)S, lgS));
+  w.r1.y = *(const uint32_t *)(plane + mobi_tc(o4 + (uint32_t)S + 4, lgS));
   w.sh = (uint32_t)o & 3;
   return w;
 }
@@ -142,23 +158,18 @@ __device__ __forceinline__ uint32_t lds32(const uint8_t *L, int byte_off) { retu
 // butterflies differ between one 8x8 transform (lane r = pixel row r) and four 4x4s (lane r = rows (r&1)*2, +1 of
 // sub-block r>>1): both leave 8 residuals for two 4-pixel words, so the pixel update is one shared instruction stream
 // (the 8 lanes of an area agree on the kind, the lanes of a wave do not).
-__device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint8_t *px, int pitch, int &lo, int &hi) {
-  int in[8], out[8];
-  uint8_t *wa, *wb; // the two 4-pixel words (4-byte aligned)
+__device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint8_t *wa, uint8_t *wb, int &lo, int &hi) {
+  int in[8], out[8]; // wa, wb: the two 4-pixel words (4-byte aligned) the lane's eight residuals belong to
   if (is8) {
 #pragma unroll
     for (int m = 0; m < 8; m++) in[m] = t[8 * r + m];
     mobi_bfly8(in, out);
-    wa = px + r * pitch;
-    wb = wa + 4;
   } else {
     const int s = r >> 1, i0 = (r & 1) * 2;
 #pragma unroll
     for (int m = 0; m < 8; m++) in[m] = t[16 * s + 4 * i0 + m]; // groups i0 and i0 + 1
     mobi_bfly4(in, out);
     mobi_bfly4(in + 4, out + 4);
-    wa = px + ((s >> 1) * 4 + i0) * pitch + (s & 1) * 4;
-    wb = wa + pitch;
   }
   const uint32_t pa = *(const uint32_t *)wa, pb = *(const uint32_t *)wb;
   int pix[8];
@@ -205,19 +216,33 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
 //   * coefficient tiles at a pitch of 72 words (the transposing stores of the 8 lanes of 4 areas hit 32 different banks),
 //     8x8 areas sorted in front of 4x4 ones so that a half round usually runs one kind of butterfly.
 namespace {
+// LDS of one octet (10 KB: sixteen waves per CU).  While the windows are in flight / being interpolated:
+//   P_L   luma windows: chunk (row pair p = 0..9, quadrant column s = 0..3) of macroblock g at p * 512 + s * 128 + g * 16; a chunk =
+//         two rows x 8 samples of one quadrant (mobi_tile.h).  A whole leaf's window is 9 pairs x 3 columns (17 rows x 17..24 samples
+//         from an even row and a column that is a multiple of 8); a TOP/BOTTOM pair keeps leaf A in pairs 0..4 and leaf B in 5..9,
+//         a LEFT/RIGHT pair leaf A in columns 0, 1 and leaf B in 2, 3 (9 samples never span more than two quadrant columns).
+//   P_C   chroma windows: chunk (row r = 0..9, column s = 0..1) at (r * 2 + s) * 128 + g * 16; a chunk = one row of [U 8 B | V 8 B]:
+//         both planes of a leaf share one window.  TOP/BOTTOM: leaf A rows 0..4, leaf B rows 5..9.
+//   P_C1  the same for the right half of a LEFT/RIGHT pair.
+// After motion compensation (the windows are dead):
+//   P_OUT_Y  luma sample (row R, column c) of macroblock g at (R & 7) * 256 + (R >> 3) * 128 + (((g ^ (R & 7)) * 16) + c): a row's eight
+//            macroblocks are rotated by the row number, so that the 64 lanes of a motion-compensation store, the eight lanes that add
+//            one area's residual (one row each) and the 16-byte reads of the final copy all spread over the banks.
+//   P_OUT_C  chroma (row R, plane pl, sample x) at (R & 3) * 256 + (R >> 2) * 128 + ((g ^ (R & 3)) * 16) + pl * 8 + x.
 enum {
-  P_L = 0,        // luma windows: dword w (0..7) of row y (0..15) of macroblock g at y*256 + (w>>2)*128 + g*16 + (w&3)*4
-  P_C = 4096,     // chroma windows, chunk 0: plane pl, row r at pl*1024 + r*128 + g*16
-  P_C1 = 6144,    //   chunk 1: the right half of a LEFT/RIGHT pair (other macroblocks leave it unused)
-  P_BYTES = 8192,
-  // after motion compensation:
-  P_OUT_Y = 0,    // 16 rows x 128 B
-  P_OUT_C = 2048, // 2 planes x 8 rows x 64 B
+  P_L = 0,
+  P_C = 5120,
+  P_C1 = 7680,
+  P_BYTES = 10240,
+  P_OUT_Y = 0,    // 2048 B
+  P_OUT_C = 2048, // 1024 B
   P_COEF = 3072,  // 16 tiles of P_TILE words
   P_TILE = 72,
   P_TAB = 7680,   // entry -> area*8 + g (<= 48 bytes)
-  P_SC = 7744     // dequant scales (320 B): on top of the last V rows of chunk 1, once the chroma has been interpolated
+  P_SC = 7744     // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
 };
+__device__ __forceinline__ int out_y(int g, int R, int c) { return P_OUT_Y + (R & 7) * 256 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
+__device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return P_OUT_C + (R & 3) * 256 + (R >> 2) * 128 + ((g ^ (R & 3)) << 4) + pl * 8 + x; }
 // N output rows of 4 pixels from N + 1 window rows (x0[i], x1[i] = the two aligned dwords holding row i's 5 bytes)
 template <int N>
 __device__ __forceinline__ void mc_rows(const uint32_t (&x0)[N + 1], const uint32_t (&x1)[N + 1], uint32_t sh, int phase, uint32_t *out) {
@@ -259,9 +284,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const uint32_t mbx0 = ox * 8, mbw = (uint32_t)A.mbw;
   const int nmb = (int)(mbw - mbx0 < 8 ? mbw - mbx0 : 8);
   const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S);
-  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height, slot_w = A.slot_bytes >> 2, ysz_w = ysz >> 2;
+  const uint32_t ysz = (uint32_t)S * (uint32_t)A.height;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
-  const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16);
+  const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16); // the octet's first sample as a linear offset (the slow path's currency)
   const int g = lane & 7, j = lane >> 3; // adjacent lanes = adjacent macroblocks: chunk j of the 8 macroblocks lies side by side in LDS
   unsigned long long pa = 0, pb = 0;
   if (PROF) { asm volatile("" : : "s"(off0), "s"(clip)); pa = prof_stamp(); }
@@ -272,16 +297,15 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pb = prof_stamp(); }
   const bool valid = g < nmb && (d.y & 1) == MOBI_MB_INTER;
   const int nl = (d.y >> 1) & 0x7F, kind2 = (d.y >> 26) & 3;
-  const bool win = valid && (nl == 1 || kind2 != 0);         // whole leaves: fetched through the LDS windows
-  const bool multi = valid && nl > 1 && kind2 == 0;          // deeper tree: MV cell map
-  const bool tb = valid && kind2 == MOBI_DUAL_TB, lr = valid && kind2 == MOBI_DUAL_LR;
+  const bool leaves = valid && (nl == 1 || kind2 != 0);       // whole leaves (16x16, two 16x8, two 8x16)
+  const bool multi = valid && nl > 1 && kind2 == 0;           // deeper tree: MV cell map in the payload
+  const bool tb = leaves && kind2 == MOBI_DUAL_TB, lr = leaves && kind2 == MOBI_DUAL_LR;
   const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
   const unsigned long long mb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((cbp6 >> j) & 1));      // bit area*8 + g
   const unsigned long long tb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((d.y >> (14 + j)) & 1));
   const uint32_t m_lo = (uint32_t)mb64, m_hi = (uint32_t)(mb64 >> 32), t_lo = (uint32_t)tb64, t_hi = (uint32_t)(tb64 >> 32);
   const uint32_t inter_mask = (uint32_t)__builtin_amdgcn_ballot_w64(valid) & 0xFFu, multi_mask = (uint32_t)__builtin_amdgcn_ballot_w64(multi) & 0xFFu;
   if (inter_mask == 0) return; // nothing but intra macroblocks here
-  const bool any_lr = __builtin_amdgcn_ballot_w64(lr) != 0;
   auto slot_off = [&](uint32_t ref) {
     int sl = A.ring_base - (int)ref;
     sl = sl < 0 ? sl + 6 : sl;
@@ -289,57 +313,72 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   };
   const uint32_t refA = slot_off((d.z >> 10) & 7), refB = slot_off((d.z >> 13) & 7);
   const int posA = (int)d.w, cposA = (int)d2.x, posB = (int)d2.y, cposB = (int)d2.z;
+  const int phA = (d.z >> 16) & 3, cphA = (d.z >> 18) & 3, phB = (d.z >> 20) & 3, cphB = (d.z >> 22) & 3;
+  // A leaf's window starts at its first sample's position: leaf B's is row 8 (TOP/BOTTOM) or column 8 (LEFT/RIGHT) of the macroblock
+  const int topB = tb ? posB + (8 << lgS) : posB + 8, ctopB = tb ? cposB + (4 << lgS) : cposB + 4;
+  const int wpx = lr ? 8 : 16, cwpx = lr ? 4 : 8;
+  // quadrant columns a window touches: (start & 7) + samples + half-pel neighbour, in units of 8
+  const int ncA = ((posA & 7) + wpx + (phA & 1) + 7) >> 3, ncB = ((topB & 7) + wpx + (phB & 1) + 7) >> 3;
+  const int cncA = ((cposA & 7) + cwpx + (cphA & 1) + 7) >> 3, cncB = ((ctopB & 7) + cwpx + (cphB & 1) + 7) >> 3;
+  // A window that runs over the end of its plane row continues in the next row (or, chroma, in the other plane's half): the
+  // reference's linear offsets mean exactly that (Stride == Width streams; vectors far outside the picture), and only the slow
+  // path's per-dword addressing follows it.  Whole rows of chunks would not.
+  const bool wrapA = (((posA & (S - 1)) & ~7) + 8 * ncA > S) || (((cposA & (S - 1)) & ~7) + 8 * cncA > (S >> 1));
+  const bool wrapB = (((topB & (S - 1)) & ~7) + 8 * ncB > S) || (((ctopB & (S - 1)) & ~7) + 8 * cncB > (S >> 1));
+  const bool wrap = leaves && (wrapA || ((tb || lr) && wrapB));
+  const bool win = leaves && !wrap;                           // fetched through the LDS windows
+  const bool slow = multi || wrap;
+  const uint32_t slow_mask = (uint32_t)__builtin_amdgcn_ballot_w64(slow) & 0xFFu;
+  const bool any_lr = __builtin_amdgcn_ballot_w64(lr && win) != 0;
   {
-    // luma rounds: lane (g, j) brings chunk (row 4t + (j >> 1), half j & 1).  A row's two chunks start at the leaf's position
-    // rounded down to 4 bytes; the right half of a LEFT/RIGHT pair is the first chunk of leaf B's columns 8..15
-    const int h = j & 1, r4 = win ? j >> 1 : 0;
-    const bool rB = lr && h;
-    const int pT = win ? (rB ? posB + 8 : posA) : 0, xT = (win && !lr) ? h * 16 : 0;
-    const uint32_t fT = win ? (rB ? refB : refA) : 0u;
-    const int pU = tb ? posB : pT;
-    const uint32_t fU = tb ? refB : fT;
-    // (16-byte aligned unless the row is shared by two leaves: a 32-byte window that starts on a 16-byte boundary crosses a
-    // 64-byte request boundary in one case out of four, one that starts on any 4-byte boundary in seven out of sixteen)
-    const int am = lr ? ~3 : ~15;
-    const uint8_t *sT = clip_base + fT + (uint32_t)(((pT + (r4 << lgS)) & am) + xT);
-    const uint8_t *sU = clip_base + fU + (uint32_t)(((pU + ((8 + r4) << lgS)) & am) + xT);
-    const int s4 = win ? 4 << lgS : 0;
-    MOBI_DMA16(sT, L + P_L, 0);
-    MOBI_DMA16(sT + s4, L + P_L + 1024, 0);
-    MOBI_DMA16(sU, L + P_L + 2048, 0);
-    MOBI_DMA16(sU + s4, L + P_L + 3072, 0);
-    // chroma rounds: round = plane, lane j = row; one chunk per row
-    const bool cB = tb && j >= 4;
-    const int cp = win ? (cB ? cposB : cposA) : 0;
-    const uint32_t cf = win ? (cB ? refB : refA) + ysz : 0u;
-    const uint8_t *sC = clip_base + cf + (uint32_t)((cp + ((win ? j : 0) << lgS)) & ~3);
-    MOBI_DMA16(sC, L + P_C, 0);
-    MOBI_DMA16(sC + (win ? S >> 1 : 0), L + P_C + 1024, 0);
+    // luma rounds: lane (g, j) brings chunk (pair 2t + (j >> 2), column j & 3) of its macroblock.  The column is the lane's for all
+    // rounds, so the leaf it serves changes only in a TOP/BOTTOM pair (pairs 5..9 are leaf B's).
+    const int s = j & 3, ph = j >> 2;
+    const bool colB = lr && s >= 2;                           // LEFT/RIGHT: columns 2, 3 belong to leaf B
+    const int sw = lr ? s & 1 : s;
+    // window of the rounds that serve leaf A (or B's columns of a LEFT/RIGHT pair), and of the rounds that serve a bottom half
+    const int top0 = colB ? topB : posA, top1 = topB;
+    const int yo0 = (top0 >> lgS) & 1, yo1 = (top1 >> lgS) & 1;
+    const uint32_t lin0 = (uint32_t)(((top0 - (yo0 << lgS)) & ~7) + 8 * sw), lin1 = (uint32_t)(((top1 - (yo1 << lgS)) & ~7) + 8 * sw);
+    const uint32_t row0 = lin0 >> lgS, row1 = lin1 >> lgS;
+    const uint8_t *b0 = clip_base + (colB ? refB : refA) + mobi_ty_col(lin0 & (uint32_t)(S - 1));
+    const uint8_t *b1 = clip_base + refB + mobi_ty_col(lin1 & (uint32_t)(S - 1));
+    const int vp0 = ((colB ? phB : phA) >> 1) & 1, vp1 = (phB >> 1) & 1;
+    const int np0 = (yo0 + (tb ? 8 : 16) + vp0 + 1) >> 1, np1 = (yo1 + 8 + vp1 + 1) >> 1;
+    const bool on0 = win && sw < (colB ? ncB : ncA), on1 = tb && win && sw < ncB;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const int p = 2 * t + ph;
+      const bool useB = tb && p >= 5;
+      const int pp = useB ? p - 5 : p;
+      const bool on = useB ? on1 && pp < np1 : on0 && pp < np0 && (!tb || p < 5);
+      const uint8_t *src = (useB ? b1 : b0) + mobi_ty_row((useB ? row1 : row0) + 2u * (uint32_t)pp, lgS);
+      if (on) MOBI_DMA16(src, L + P_L + t * 1024, 0);
+    }
+    // chroma rounds: lane (g, j) brings chunk (row 4t + (j >> 1), column j & 1): both planes of that row
+    const int cs = j & 1, ch2 = j >> 1;
+    const uint32_t clin0 = (uint32_t)((cposA & ~7) + 8 * cs), clin1 = (uint32_t)((ctopB & ~7) + 8 * cs);
+    const uint8_t *c0 = clip_base + refA + ysz + mobi_tc_x(clin0 & (uint32_t)(S - 1));
+    const uint8_t *c1 = clip_base + refB + ysz + mobi_tc_x(clin1 & (uint32_t)(S - 1));
+    const uint32_t crow0 = clin0 >> lgS, crow1 = clin1 >> lgS;
+    const int cnr0 = (tb ? 4 : 8) + ((cphA >> 1) & 1), cnr1 = (tb ? 4 : 8) + ((cphB >> 1) & 1);
+    const bool con0 = win && cs < cncA, con1 = win && cs < cncB;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int r = 4 * t + ch2;
+      const bool useB = tb && r >= 5;
+      const int rin = useB ? r - 5 : r;
+      const bool on = useB ? con1 && rin < cnr1 : con0 && rin < cnr0 && (!tb || r < 5);
+      const uint8_t *src = (useB ? c1 : c0) + mobi_tc_row((useB ? crow1 : crow0) + (uint32_t)rin, lgS);
+      if (on) MOBI_DMA16(src, L + P_C + t * 1024, 0);
+    }
     if (any_lr) {
-      if (lr) {
-        const uint8_t *sD = clip_base + refB + ysz + (uint32_t)((cposB + 4 + (j << lgS)) & ~3);
-        MOBI_DMA16(sD, L + P_C1, 0);
-        MOBI_DMA16(sD + (S >> 1), L + P_C1 + 1024, 0);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int r = 4 * t + ch2;
+        if (lr && con1 && r < cnr1) MOBI_DMA16(c1 + mobi_tc_row(crow1 + (uint32_t)r, lgS), L + P_C1 + t * 1024, 0);
       }
     }
-  }
-  // this lane's leaf for the luma rows it interpolates: lane (g, rr = j >> 2, q = j & 3) = rows 8rr..8rr+7, pixels 4q..4q+3
-  const int rr = j >> 2, q = j & 3;
-  const bool yB = (tb && rr) || (lr && q >= 2);
-  const int ypos = yB ? posB : posA, yph = (d.z >> (yB ? 20 : 16)) & 3;
-  // ... and for its chroma samples: lane (g, pl = j >> 2, ch = (j >> 1) & 1, qc = j & 1) = plane pl, rows 4ch..4ch+3, samples 4qc..4qc+3
-  const int pl = j >> 2, ch = (j >> 1) & 1, qc = j & 1;
-  const bool cBl = (tb && ch) || (lr && qc);
-  const int cpos = cBl ? cposB : cposA, cph = (d.z >> (cBl ? 22 : 18)) & 3;
-  // the row under the lane's rows (luma row 8rr + 8, chroma row 4ch + 4): straight into registers
-  uint2 hy, hc;
-  {
-    // (only a vertical half-pel reads it: the other lanes all point at one line instead -- the kernel is bound by the number of
-    // 64-byte requests a CU's L1 can send to the L2, ~0.15 per clock, and a row costs at least one)
-    const uint32_t oy = (win && (yph & 2)) ? (yB ? refB : refA) + (uint32_t)((ypos + ((8 * rr + 8) << lgS) + 4 * q) & ~3) : 0u;
-    const uint32_t oc = (win && (cph & 2)) ? (cBl ? refB : refA) + ysz + (uint32_t)((cpos + pl * (S >> 1) + ((4 * ch + 4) << lgS) + 4 * qc) & ~3) : 0u;
-    hy = *(const uint2_a4 *)(clip_base + oy);
-    hc = *(const uint2_a4 *)(clip_base + oc);
   }
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
   const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
@@ -355,124 +394,147 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
     }
   }
-  // deeper trees: the first such macroblock's MV cells travel with everything else (the whole wave works for it later:
-  // lane = (row lane >> 2, pixels 4 * (lane & 3)) for luma, lanes 0..31 = (plane, row, 4 samples) for chroma)
+  // slow path (deeper trees; wrapping windows): the whole wave works for one such macroblock later: lane = (row lane >> 2, pixels
+  // 4 * (lane & 3)) for luma, lanes 0..31 = (plane, row, 4 samples) for chroma.  The MV cells of the first two deep trees travel with
+  // everything else (6 % of the octets have two): one of their two round trips.
   const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
   const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-  uint2 yc0 = uint2{0, 0};
-  uint4 c4v0 = uint4{0, 0, 0, 0};
-  uint2 yc1 = uint2{0, 0}; // ... and the second one's (6 % of the octets have two): one of its two round trips
-  uint4 c4v1 = uint4{0, 0, 0, 0};
-  if (multi_mask) {
-    const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, __builtin_ctz(multi_mask));
-    yc0 = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
-    c4v0 = *(const uint4_a4 *)(cells + crow * 8 + cc4);
-    const uint32_t m2 = multi_mask & (multi_mask - 1);
-    if (m2) {
-      const uint32_t *cells1 = A.payload + __builtin_amdgcn_readlane(d.x, __builtin_ctz(m2));
-      yc1 = *(const uint2_a4 *)(cells1 + (yrow >> 1) * 8 + (yc4 >> 1));
-      c4v1 = *(const uint4_a4 *)(cells1 + crow * 8 + cc4);
+  uint2 yc0 = uint2{0, 0}, yc1 = uint2{0, 0};
+  uint4 c4v0 = uint4{0, 0, 0, 0}, c4v1 = uint4{0, 0, 0, 0};
+  auto load_cells = [&](int gm, uint2 &yc, uint4 &c4v) {
+    if ((multi_mask >> gm) & 1) {
+      const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
+      yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
+      c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
     }
+  };
+  if (slow_mask) {
+    load_cells(__builtin_ctz(slow_mask), yc0, c4v0);
+    const uint32_t m2 = slow_mask & (slow_mask - 1);
+    if (m2) load_cells(__builtin_ctz(m2), yc1, c4v1);
   }
   if (PROF) pt[1] = prof_stamp();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
   if (PROF) pt[2] = prof_stamp();
 
-  // deeper trees: issue the first one's pixel fetches now, consume them after the others' motion compensation
-  const uint32_t *clip32 = (const uint32_t *)clip_base;
-  auto slot_of = [&](uint32_t c) { int s2 = A.ring_base - mobi_cell_ref(c); return __umul24((uint32_t)(s2 < 0 ? s2 + 6 : s2), slot_w); };
-  struct Deep { Win wa, wb, wq[4]; uint2 yc; uint32_t cell[4]; bool ysplit, csplit; };
+  // slow path: issue the first one's pixel fetches now, consume them after the others' motion compensation
+  struct Deep { Win wa, wb, wq[4]; int pha, phb, phq[4]; bool ysplit, csplit; };
   auto deep_fetch = [&](Deep &D, int gm, uint2 yc, uint4 c4v) {
-    D.yc = yc;
-    D.cell[0] = c4v.x; D.cell[1] = c4v.y; D.cell[2] = c4v.z; D.cell[3] = c4v.w;
     const int offm = off0 + gm * 16;
-    const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
-    // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits they are the same cell
-    D.ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
-    D.csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (D.cell[0] != D.cell[1] || D.cell[0] != D.cell[2] || D.cell[0] != D.cell[3])) != 0;
-    const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
-    D.wa = fetch_win(clip32 + slot_of(yc.x), ybase + ((dya >> 1) << lgS) + (dxa >> 1), S);
-    if (D.ysplit) D.wb = fetch_win(clip32 + slot_of(yc.y), ybase + ((dyb >> 1) << lgS) + (dxb >> 1), S);
-    {
-      const int qx = mobi_cell_dx(D.cell[0]) >> 1, qy = mobi_cell_dy(D.cell[0]) >> 1;
-      D.wq[0] = fetch_win(clip32 + slot_of(D.cell[0]) + ysz_w, cbase + ((qy >> 1) << lgS) + (qx >> 1), S);
+    uint32_t sa, sb, sq[4];
+    int la, lb, lq[4];
+    if ((multi_mask >> gm) & 1) {
+      // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits they are the same cell
+      const uint32_t cell[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+      const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
+      D.ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
+      D.csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
+      const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
+      la = ybase + ((dya >> 1) << lgS) + (dxa >> 1); D.pha = (dxa & 1) | ((dya & 1) << 1); sa = slot_off((uint32_t)mobi_cell_ref(yc.x));
+      lb = ybase + ((dyb >> 1) << lgS) + (dxb >> 1); D.phb = (dxb & 1) | ((dyb & 1) << 1); sb = slot_off((uint32_t)mobi_cell_ref(yc.y));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int qx = mobi_cell_dx(cell[k]) >> 1, qy = mobi_cell_dy(cell[k]) >> 1;
+        lq[k] = cbase + ((qy >> 1) << lgS) + (qx >> 1); D.phq[k] = (qx & 1) | ((qy & 1) << 1); sq[k] = slot_off((uint32_t)mobi_cell_ref(cell[k]));
+      }
+    } else { // whole leaves whose windows wrap: the leaf records of lane gm
+      const uint32_t w1m = __builtin_amdgcn_readlane(d.y, gm), w2m = __builtin_amdgcn_readlane(d.z, gm);
+      const int pAm = (int)__builtin_amdgcn_readlane(d.w, gm), cAm = (int)__builtin_amdgcn_readlane(d2.x, gm);
+      const int pBm = (int)__builtin_amdgcn_readlane(d2.y, gm), cBm = (int)__builtin_amdgcn_readlane(d2.z, gm);
+      const int k2 = (w1m >> 26) & 3;
+      const bool yBm = k2 == MOBI_DUAL_TB ? yrow >= 8 : k2 == MOBI_DUAL_LR ? yc4 >= 8 : false;
+      const bool cBl2 = k2 == MOBI_DUAL_TB ? crow >= 4 : k2 == MOBI_DUAL_LR ? cc4 >= 4 : false;
+      D.ysplit = D.csplit = false;
+      la = lb = (yBm ? pBm : pAm) + (yrow << lgS) + yc4;
+      D.pha = D.phb = (w2m >> (yBm ? 20 : 16)) & 3;
+      sa = sb = slot_off((w2m >> (yBm ? 13 : 10)) & 7);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        lq[k] = (cBl2 ? cBm : cAm) + cv * (S >> 1) + (crow << lgS) + cc4;
+        D.phq[k] = (w2m >> (cBl2 ? 22 : 18)) & 3;
+        sq[k] = slot_off((w2m >> (cBl2 ? 13 : 10)) & 7);
+      }
     }
+    D.wa = fetch_win_y(clip_base + sa, la, S, lgS);
+    if (D.ysplit) D.wb = fetch_win_y(clip_base + sb, lb, S, lgS);
+    D.wq[0] = fetch_win_c(clip_base + sq[0] + ysz, lq[0], S, lgS);
     if (D.csplit) {
 #pragma unroll
-      for (int k = 1; k < 4; k++) {
-        const int qx = mobi_cell_dx(D.cell[k]) >> 1, qy = mobi_cell_dy(D.cell[k]) >> 1;
-        D.wq[k] = fetch_win(clip32 + slot_of(D.cell[k]) + ysz_w, cbase + ((qy >> 1) << lgS) + (qx >> 1), S);
-      }
+      for (int k = 1; k < 4; k++) D.wq[k] = fetch_win_c(clip_base + sq[k] + ysz, lq[k], S, lgS);
     }
   };
   auto deep_finish = [&](int gm, const Deep &D) {
-    const int dxa = mobi_cell_dx(D.yc.x), dya = mobi_cell_dy(D.yc.x), dxb = mobi_cell_dx(D.yc.y), dyb = mobi_cell_dy(D.yc.y);
-    const uint32_t va = mc4_select(D.wa, (dxa & 1) | ((dya & 1) << 1));
-    const uint32_t vb = D.ysplit ? mc4_select(D.wb, (dxb & 1) | ((dyb & 1) << 1)) : va;
-    auto cph_of = [&](uint32_t c) { const int qx = mobi_cell_dx(c) >> 1, qy = mobi_cell_dy(c) >> 1; return (qx & 1) | ((qy & 1) << 1); };
-    uint32_t cpred = mc4_select(D.wq[0], cph_of(D.cell[0]));
+    const uint32_t va = mc4_select(D.wa, D.pha);
+    const uint32_t vb = D.ysplit ? mc4_select(D.wb, D.phb) : va;
+    uint32_t cpred = mc4_select(D.wq[0], D.phq[0]);
     if (D.csplit) {
       cpred &= 0xFFu;
 #pragma unroll
-      for (int k = 1; k < 4; k++) cpred |= mc4_select(D.wq[k], cph_of(D.cell[k])) & (0xFFu << (8 * k));
+      for (int k = 1; k < 4; k++) cpred |= mc4_select(D.wq[k], D.phq[k]) & (0xFFu << (8 * k));
     }
-    *(uint32_t *)(L + P_OUT_Y + yrow * 128 + gm * 16 + yc4) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
-    if (lane < 32) *(uint32_t *)(L + P_OUT_C + cv * 512 + crow * 64 + gm * 8 + cc4) = cpred;
+    *(uint32_t *)(L + out_y(gm, yrow, yc4)) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
+    if (lane < 32) *(uint32_t *)(L + out_c(gm, crow, cv, cc4)) = cpred;
   };
   Deep D0;
-  if (multi_mask) deep_fetch(D0, __builtin_ctz(multi_mask), yc0, c4v0);
+  if (slow_mask) deep_fetch(D0, __builtin_ctz(slow_mask), yc0, c4v0);
 
-  // ---- stage B: motion compensation ----
+  // ---- stage B: motion compensation.  Lane (g, rr = j >> 2, q = j & 3) = luma rows 8rr..8rr+7, pixels 4q..4q+3; lane (g, pl = j >> 2,
+  // ch = (j >> 1) & 1, qc = j & 1) = plane pl, chroma rows 4ch..4ch+3, samples 4qc..4qc+3: either lies inside one leaf whatever the split ----
   uint32_t mcv[12];
+  const int rr = j >> 2, q = j & 3;
+  const int pl = j >> 2, ch = (j >> 1) & 1, qc = j & 1;
   {
     // chroma first: its windows make room for the dequant scales
-    const bool c1 = lr && qc; // the right half of a LEFT/RIGHT pair has its own chunk; everybody else reads dwords qc, qc + 1 of chunk 0
-    const int base = (c1 ? P_C1 : P_C + qc * 4) + pl * 1024 + ch * 512 + g * 16;
+    const bool cBl = (tb && ch) || (lr && qc);
+    const int ctop = cBl ? ctopB : cposA, cph = cBl ? cphB : cphA;
+    const int cxo = ctop & 7, d0 = (cxo + (lr ? 0 : 4 * qc)) >> 2, d1 = d0 + 1;
+    const int base = ((lr && qc) ? P_C1 : P_C) + ((tb && ch) ? 5 : 4 * ch) * 256 + g * 16 + pl * 8;
+    const int a0 = base + (d0 >> 1) * 128 + (d0 & 1) * 4, a1 = base + (d1 >> 1) * 128 + (d1 & 1) * 4;
     uint32_t x0[5], x1[5];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { x0[k] = lds32(L, base + k * 128); x1[k] = lds32(L, base + k * 128 + 4); }
-    x0[4] = hc.x; x1[4] = hc.y;
-    mc_rows<4>(x0, x1, (uint32_t)cpos & 3u, cph, mcv + 8);
+    for (int k = 0; k < 5; k++) { x0[k] = lds32(L, a0 + k * 256); x1[k] = lds32(L, a1 + k * 256); }
+    mc_rows<4>(x0, x1, (uint32_t)cxo & 3u, cph, mcv + 8);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + P_SC, 0);
   {
-    // the lane's 5 bytes start (ypos & 15) + 4q bytes into the row's 32-byte window; in a LEFT/RIGHT pair each half has its own
-    // 16-byte chunk that starts at the half's position rounded down to 4
-    const int w0 = lr ? q + (q >= 2 ? 2 : 0) : ((ypos & 15) + 4 * q) >> 2, w1 = w0 + 1;
-    const int base = P_L + rr * 2048 + g * 16;
-    const int a0 = base + (w0 >> 2) * 128 + (w0 & 3) * 4, a1 = base + (w1 >> 2) * 128 + (w1 & 3) * 4;
+    // window row w of the lane's leaf sits in pair (yo + w) >> 1, row (yo + w) & 1 of it (yo = the window's first row is odd)
+    const bool rB = tb && rr, qB = lr && q >= 2;
+    const int ytop = rB || qB ? topB : posA, yph = rB || qB ? phB : phA;
+    const int yo = (ytop >> lgS) & 1, xo = ytop & 7;
+    const int d0 = (xo + 4 * (qB ? q - 2 : q)) >> 2, d1 = d0 + 1;
+    const int base = P_L + (rB ? 5 : 4 * rr) * 512 + g * 16 + (qB ? 256 : 0);
+    const int a0 = base + (d0 >> 1) * 128 + (d0 & 1) * 4, a1 = base + (d1 >> 1) * 128 + (d1 & 1) * 4;
+    const int ev = yo * 8, od = yo ? 512 : 8;
     uint32_t x0[9], x1[9];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { x0[k] = lds32(L, a0 + k * 256); x1[k] = lds32(L, a1 + k * 256); }
-    x0[8] = hy.x; x1[8] = hy.y;
-    mc_rows<8>(x0, x1, (uint32_t)ypos & 3u, yph, mcv);
+    for (int k = 0; k < 9; k++) {
+      const int o = (k >> 1) * 512 + ((k & 1) ? od : ev);
+      x0[k] = lds32(L, a0 + o);
+      x1[k] = lds32(L, a1 + o);
+    }
+    mc_rows<8>(x0, x1, (uint32_t)xo & 3u, yph, mcv);
   }
   wave_sync();
   {
-    const int oy = P_OUT_Y + rr * 1024 + g * 16 + q * 4, oc = P_OUT_C + pl * 512 + ch * 256 + g * 8 + qc * 4;
 #pragma unroll
-    for (int k = 0; k < 8; k++) *(uint32_t *)(L + oy + 128 * k) = mcv[k];
+    for (int k = 0; k < 8; k++) *(uint32_t *)(L + out_y(g, 8 * rr + k, 4 * q)) = mcv[k];
 #pragma unroll
-    for (int k = 0; k < 4; k++) *(uint32_t *)(L + oc + 64 * k) = mcv[8 + k];
+    for (int k = 0; k < 4; k++) *(uint32_t *)(L + out_c(g, 4 * ch + k, pl, 4 * qc)) = mcv[8 + k];
   }
   if (PROF) pt[3] = prof_stamp();
-  if (multi_mask) {
+  if (slow_mask) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the scales too)
-    deep_finish(__builtin_ctz(multi_mask), D0);
-    uint32_t mm = multi_mask & (multi_mask - 1);
+    deep_finish(__builtin_ctz(slow_mask), D0);
+    uint32_t mm = slow_mask & (slow_mask - 1);
     bool second = true;
-    while (mm) { // a second, third ... macroblock with a deep tree in the same octet: exposed round trips (rare)
+    while (mm) { // a second, third ... such macroblock in the same octet: exposed round trips (rare)
       const int gm = __builtin_ctz(mm);
       mm &= mm - 1;
       uint2 yc = yc1;
       uint4 c4v = c4v1;
-      if (!second) {
-        const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
-        yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
-        c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
-      }
+      if (!second) load_cells(gm, yc, c4v);
       second = false;
       Deep Dn;
       deep_fetch(Dn, gm, yc, c4v);
@@ -556,9 +618,20 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         if (actx[h]) {
+          // the lane's two 4-pixel words: one row of the area (8x8), or rows i0, i0 + 1 of 4x4 block r >> 1
           const int ge = kx[h] & 7, a = kx[h] >> 3;
-          uint8_t *px = a < 4 ? L + P_OUT_Y + (a >> 1) * 8 * 128 + ge * 16 + (a & 1) * 8 : L + P_OUT_C + (a - 4) * 512 + ge * 8;
-          idct_pass2_q(coef + P_TILE * (8 * h + (lane >> 3)), is8x[h], r, px, a < 4 ? 128 : 64, lo, hi);
+          const bool is8 = is8x[h];
+          const int s4 = r >> 1, rowa = is8 ? r : (s4 >> 1) * 4 + (r & 1) * 2, cola = is8 ? 0 : (s4 & 1) * 4;
+          const int rowb = is8 ? r : rowa + 1, colb = is8 ? 4 : cola;
+          uint8_t *wa, *wb;
+          if (a < 4) {
+            wa = L + out_y(ge, (a >> 1) * 8 + rowa, (a & 1) * 8 + cola);
+            wb = L + out_y(ge, (a >> 1) * 8 + rowb, (a & 1) * 8 + colb);
+          } else {
+            wa = L + out_c(ge, rowa, a - 4, cola);
+            wb = L + out_c(ge, rowb, a - 4, colb);
+          }
+          idct_pass2_q(coef + P_TILE * (8 * h + (lane >> 3)), is8, r, wa, wb, lo, hi);
         }
       }
       wave_sync();
@@ -567,43 +640,23 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
   if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt[5] = prof_stamp(); }
 
-  // ---- stage D: whole rows, 128 B of luma and 8 B per macroblock of chroma ----
-  uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
-#pragma unroll
-  for (int it = 0; it < 2; it++) {
-    const int i = lane + 64 * it, gq = i & 7, row16 = i >> 3;
-    // Whole rows always.  Intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them), and behind the
-    // picture's last macroblock (848 = 53 macroblocks: the seventh octet holds five) the zeros the padding already holds: a row with a
-    // hole is a partial line, and HBM turns every store below 64 B into a read-modify-write (tools/ubench/pwrite.hip: 26 against 69
-    // pieces per ns).  Octets are 128-byte aligned and the pitch is a multiple of 128, so the padding written is this row's own.
-    {
-      const bool in = gq < nmb;
-      const uint4 vy = *(const uint4 *)(L + P_OUT_Y + row16 * 128 + gq * 16);
-      *(uint4 *)(y0 + (off0 + (row16 << lgS) + gq * 16)) = in ? vy : uint4{0, 0, 0, 0};
-      const int row = row16 & 7; // chroma: plane = it, row = (i >> 3) & 7
-      const uint2 vc = *(const uint2 *)(L + P_OUT_C + it * 512 + row * 64 + gq * 8);
-      *(uint2 *)(y0 + ysz + ((off0 >> 1) + it * (S >> 1) + (row << lgS) + gq * 8)) = in ? vc : uint2{0, 0};
-    }
-  }
-  // macroblocks whose right neighbour is intra also leave their last column in the edge side buffer (mobi_cmd.h): lane (g, j = 0)
-  // gathers the 16 luma samples, lane (g, j = 1) the 8 U and 8 V ones (5 % of the macroblocks: a third of the waves get here)
+  // ---- stage D: the octet's tiles are contiguous: 2 KB of luma, 1 KB of chroma, whole lines ----
+  // Intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them), and behind the picture's last
+  // macroblock (848 = 53 macroblocks: the seventh octet holds five) the zeros the padding already holds: HBM turns every store
+  // below 64 B into a read-modify-write (tools/ubench/pwrite.hip), and a run with a hole has such ends.
   {
-    const bool edge = valid && (d.y & MOBI_W1_EDGE) != 0 && A.edge != nullptr && j < 2;
-    if (__builtin_amdgcn_ballot_w64(edge) != 0) {
-      if (edge) {
-        const int base = j == 0 ? P_OUT_Y + g * 16 + 15 : P_OUT_C + g * 8 + 7;
-        uint32_t w[4];
+    uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
+    uint8_t *ty0 = y0 + mobi_tile_y(mbx0, mby, lgS), *tc0 = y0 + ysz + mobi_tile_c(mbx0, mby, lgS);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          w[k] = 0;
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int i = 4 * k + b;
-            w[k] |= (uint32_t)L[base + (j == 0 ? i * 128 : (i >> 3) * 512 + (i & 7) * 64)] << (8 * b);
-          }
-        }
-        *(uint4 *)(A.edge + ((size_t)(clip * (uint32_t)A.n_mbs + mby * mbw + mbx0 + (uint32_t)g) * MOBI_EDGE_BYTES + (size_t)j * 16)) = uint4{w[0], w[1], w[2], w[3]};
-      }
+    for (int it = 0; it < 2; it++) {
+      const int i = lane + 64 * it, gq = i >> 4, quad = (i >> 2) & 3, R0 = (quad >> 1) * 8 + 2 * (i & 3), c0 = (quad & 1) * 8;
+      const uint2 v0 = *(const uint2 *)(L + out_y(gq, R0, c0)), v1 = *(const uint2 *)(L + out_y(gq, R0 + 1, c0));
+      *(uint4 *)(ty0 + i * 16) = gq < nmb ? uint4{v0.x, v0.y, v1.x, v1.y} : uint4{0, 0, 0, 0};
+    }
+    {
+      const int gq = lane >> 3, R = lane & 7;
+      const uint4 vc = *(const uint4 *)(L + out_c(gq, R, 0, 0));
+      *(uint4 *)(tc0 + lane * 16) = gq < nmb ? vc : uint4{0, 0, 0, 0};
     }
   }
   if (PROF && lane == 0) { // MOBI_DEBUG=9: where a wave's life goes (shader clock): A issue, fetch wait, MC, deep trees, residual, store issue
@@ -685,16 +738,17 @@ __device__ __forceinline__ uint32_t ldg_u8_sc1(const uint8_t *p) { // past this 
 #endif
   return v;
 }
-__device__ __forceinline__ u32x4 ldg_x4_sc1(const uint8_t *p) {
-  u32x4 v = {0, 0, 0, 0};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 ldg_x2_sc1(const uint8_t *p) {
+  u32x2 v = {0, 0};
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
 #endif
   return v;
 }
 // The wait sits right behind its loads and names every destination: an asm load's register is only reserved up to the asm
 // statement, so a wait further away lets the register allocator reuse it while the data is still in flight (seen in r02).
-__device__ __forceinline__ void vm_wait(u32x4 &a, uint32_t &b, uint32_t &c) {
+__device__ __forceinline__ void vm_wait(u32x2 &a, uint32_t &b, uint32_t &c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
 #endif
@@ -737,7 +791,6 @@ struct QItem {
   uint32_t ncoef;
   bool has_deps;     // some macroblock its halo reads is an intra one of this step: poll the tags, read the halo afterwards
   bool publish;      // an intra macroblock of this step may read these pixels: write through, drain, publish the tag
-  bool left_edge;    // the left neighbour's last column is in the edge side buffer
 };
 } // namespace
 
@@ -753,9 +806,10 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const int t8 = (w1 >> 14) & 0x3F;
   const uint32_t *rec = A.payload + I.pay;
   const int mby = (int)(((float)mb + 0.5f) / (float)mbw), mbx = (int)mb - mby * mbw; // mb < 8192: the quotient is never within rounding of an integer
-  const int off = ((mby * 16) << lgS) + mbx * 16;                                       // < 2^20
+  const int off = ((mby * 16) << lgS) + mbx * 16;                                       // < 2^20: the macroblock's linear offset (MD.cs:212-217)
   uint8_t *y0 = A.planes + (size_t)clip * A.clip_bytes + (size_t)(A.ring_base % 6) * A.slot_bytes;
   uint8_t *uv0 = y0 + (size_t)S * A.height;
+  uint8_t *ty = y0 + mobi_tile_y((uint32_t)mbx, (uint32_t)mby, lgS), *tc = uv0 + mobi_tile_c((uint32_t)mbx, (uint32_t)mby, lgS); // its tiles (mobi_tile.h)
   const uint2 *taps = (const uint2 *)(A.scale + MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE); // 4480 B every wave reads: they stay in the L1
 
   // ---- everything that can be asked for at once: block records, dequant scales, the first 64 level words, the halo ----
@@ -767,29 +821,29 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   for (int k = 0; k < 8; k++) cw[k] = (uint32_t)(l + 16 * k) < ncoef && !(dbg & 32) ? rec[MOBI_INTRA_RECORDS + l + 16 * k] : 0u;
   // Halo.  Away from the picture's left, right and top edges ownership needs no arithmetic: the row above (left, above, above-right
   // macroblocks) and the column to the left are raster-earlier; everything to the right in the macroblock's own rows is
-  // raster-later and reads the fresh plane's 0.  Row above: six 16-byte loads (luma columns -4..27, U and V -4..27; the tiles keep
-  // column c at byte 4 + c, so they land aligned and the surplus falls on bytes nothing reads).  Left column: two bytes per lane,
-  // from the edge side buffer when the left neighbour left them there (32 consecutive bytes instead of 32 lines).
+  // raster-later and reads the fresh plane's 0.  Row above = the last rows of the neighbours' bottom quadrants / last chroma rows: ten
+  // 8-byte loads (luma columns -4..23, U and V -4..15 each; the tiles keep column c at byte 4 + c).  Left column: two bytes per lane out
+  // of the left neighbour's right quadrants (2 lines) and its chroma tile (1 line) -- in the reference's linear planes they were 32
+  // different lines, which is what r02's edge side buffer was for.
   const bool interior = I.valid && mbx >= 1 && mbx + 1 < mbw && mby >= 1;
-  const uint8_t *wp = y0 + off, *b0p = wp, *b1p = wp; // lanes with nothing to fetch read the macroblock's own first sample and drop it
+  const uint8_t *wp = ty, *b0p = ty, *b1p = ty; // lanes with nothing to fetch read the macroblock's own first sample and drop it
   if (interior) {
-    if (l < 2) wp = y0 + (off - S - 4 + 16 * l);
-    else if (l < 6) wp = uv0 + ((off >> 1) + (l & 1) * (S >> 1) - S + (l < 4 ? -4 : 12));
-    if (I.left_edge) {
-      const uint8_t *eb = A.edge + ((size_t)clip * A.n_mbs + mb - 1) * MOBI_EDGE_BYTES;
-      b0p = eb + l;
-      b1p = eb + 16 + l;
-    } else {
-      b0p = y0 + (off + (l << lgS) - 1);
-      b1p = uv0 + ((off >> 1) + (l >> 3) * (S >> 1) + ((l & 7) << lgS) - 1);
-    }
+    const int up = S << 4;                                 // a tile row of luma tiles in bytes (S / 16 tiles of 256 B); chroma: half
+    if (l == 0) wp = ty - up - 256 + 192 + 56;             // above-left, BR quadrant, row 7: columns -8..-1
+    else if (l < 3) wp = ty - up + (l == 1 ? 128 : 192) + 56; // above, BL / BR, row 7
+    else if (l == 3) wp = ty - up + 256 + 128 + 56;        // above-right, BL, row 7
+    else if (l < 10) wp = tc - (up >> 1) + ((l - 4) >> 1) * 128 - 128 + 112 + (l & 1) * 8; // chroma row 7 of above-left / above / above-right: U, V
+    b0p = ty - 256 + (1 + 2 * (l >> 3)) * 64 + (l & 7) * 8 + 7;
+    b1p = tc - 128 + (l & 7) * 16 + (l >> 3) * 8 + 7;
   }
-  const int wdst = l < 2 ? 16 * l : (l & 1 ? IQ_TCV : IQ_TCU) + (l < 4 ? 0 : 16);
+  // where the 8 bytes go: column c at byte 4 + c of tile row 0; the above-left pieces keep their last four columns only
+  const int wdst = l < 4 ? (l == 0 ? 0 : 8 * l - 4) : ((l & 1) ? IQ_TCV : IQ_TCU) + (l < 6 ? 0 : l < 8 ? 4 : 12);
+  const bool whalf = l == 0 || l == 4 || l == 5;
   const int b0dst = (l + 1) * TP + 3, b1dst = (l < 8 ? IQ_TCU : IQ_TCV) + ((l & 7) + 1) * TP + 3;
   // ordinary loads, in flight beside the records (whoever has to wait for a producer loads again below and drops these)
-  uint4 w_early = uint4{0, 0, 0, 0};
+  uint2 w_early = uint2{0, 0};
   uint32_t b0_early = 0, b1_early = 0;
-  if (!(dbg & 16)) { w_early = *(const uint4_a4 *)wp; b0_early = *b0p; b1_early = *b1p; }
+  if (!(dbg & 16)) { w_early = *(const uint2 *)wp; b0_early = *b0p; b1_early = *b1p; }
 
   { // zero the coefficients; dequant scales behind them
     uint4 *G4 = (uint4 *)G;
@@ -804,7 +858,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   // row waits here until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this step's tag.  Hand-off across CUs: the
   // producer stores pixels write-through (sc1), drains them, then publishes its tag; the consumer polls the tag with agent-scope
   // loads and reads the halo with sc1 loads, so neither a stale L1 line nor a dirty L2 line can sit in between.
-  u32x4 wv = {w_early.x, w_early.y, w_early.z, w_early.w};
+  u32x2 wv = {w_early.x, w_early.y};
   uint32_t b0 = b0_early, b1 = b1_early;
   const bool waits = I.valid && I.has_deps;
   if (__builtin_amdgcn_ballot_w64(waits) != 0) {
@@ -822,7 +876,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    u32x4 wl = ldg_x4_sc1(wp);
+    u32x2 wl = ldg_x2_sc1(wp);
     uint32_t c0 = ldg_u8_sc1(b0p), c1 = ldg_u8_sc1(b1p);
     vm_wait(wl, c0, c1);
     if (waits) { wv = wl; b0 = c0; b1 = c1; }
@@ -885,7 +939,10 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   }
   wave_sync();
   if (interior) {
-    if (l < 6) *(u32x4 *)(tile + wdst) = wv;
+    if (l < 10) {
+      if (!whalf) *(uint32_t *)(tile + wdst) = wv.x;
+      *(uint32_t *)(tile + wdst + (whalf ? 0 : 4)) = wv.y;
+    }
     tile[b0dst] = (uint8_t)b0;
     tile[b1dst] = (uint8_t)b1;
   }
@@ -925,7 +982,8 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
         }
         const bool take = mine && in && o >= 0 && o < (int)mb;
         hp[k] = take ? pos : -1;
-        hv[k] = ldg_u8_sc1((chroma ? uv0 : y0) + (take ? a : 0)); // not ours to read: load the plane's first sample instead, and drop it
+        const uint32_t ta = take ? (uint32_t)a : 0u; // not ours to read: load the plane's first sample instead, and drop it
+        hv[k] = ldg_u8_sc1(chroma ? uv0 + mobi_tc(ta, lgS) : y0 + mobi_ty(ta, lgS));
       }
       vm_wait7(hv);
 #pragma unroll
@@ -1094,28 +1152,23 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   // these pixels on another CU; plain stores otherwise (the next launch is a kernel boundary away). ----
   const bool anyp = __builtin_amdgcn_ballot_w64(I.valid && I.publish) != 0;
   if (I.valid && !(dbg & 8)) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    if ((w1 & MOBI_W1_EDGE) && A.edge && l < 8) { // the right neighbour is intra too: leave it the last column (edge side buffer)
-      const uint8_t *src = l < 4 ? tile + (4 * l + 1) * TP + 4 + 15 : tile + (l < 6 ? IQ_TCU : IQ_TCV) + (4 * (l & 1) + 1) * TP + 4 + 7;
-      const uint32_t v = (uint32_t)src[0] | ((uint32_t)src[TP] << 8) | ((uint32_t)src[2 * TP] << 16) | ((uint32_t)src[3 * TP] << 24);
-      uint8_t *dst = A.edge + ((size_t)clip * A.n_mbs + mb) * MOBI_EDGE_BYTES + 4 * l;
+    // the macroblock's tiles are contiguous: lane l stores chunk l of the luma tile (quadrant l >> 2, rows 2 * (l & 3) and the next one)
+    // and, lanes 0..7, row l of the chroma tile ([U | V]): three whole 128-byte lines per macroblock
+    const int quad = l >> 2, R0 = (quad >> 1) * 8 + 2 * (l & 3), c0 = (quad & 1) * 8;
+    const uint8_t *src = tile + (R0 + 1) * TP + 4 + c0;
+    const u32x4 v = {*(const uint32_t *)src, *(const uint32_t *)(src + 4), *(const uint32_t *)(src + TP), *(const uint32_t *)(src + TP + 4)};
+    uint8_t *dst = ty + l * 16;
+    const uint8_t *su = tile + IQ_TCU + ((l & 7) + 1) * TP + 4, *sv = tile + IQ_TCV + ((l & 7) + 1) * TP + 4;
+    const u32x4 vc = {*(const uint32_t *)su, *(const uint32_t *)(su + 4), *(const uint32_t *)sv, *(const uint32_t *)(sv + 4)};
+    uint8_t *dstc = tc + (l & 7) * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (anyp) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
-      else asm volatile("global_store_dword %0, %1, off" : : "v"(dst), "v"(v) : "memory");
-#endif
+    if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+    if (l < 8) {
+      if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dstc), "v"(vc) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dstc), "v"(vc) : "memory");
     }
-    {
-      const uint8_t *src = tile + (l + 1) * TP + 4;
-      const u32x4 v = {*(const uint32_t *)src, *(const uint32_t *)(src + 4), *(const uint32_t *)(src + 8), *(const uint32_t *)(src + 12)};
-      uint8_t *dst = y0 + (off + (l << lgS));
-      const uint8_t *srcc = tile + (l < 8 ? IQ_TCU : IQ_TCV) + ((l & 7) + 1) * TP + 4;
-      const u32x2 vc = {*(const uint32_t *)srcc, *(const uint32_t *)(srcc + 4)};
-      uint8_t *dstc = uv0 + ((off >> 1) + (l >> 3) * (S >> 1) + ((l & 7) << lgS));
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v), "v"(dstc), "v"(vc) : "memory");
-      else asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx2 %2, %3, off\n\ts_nop 1" : : "v"(dst), "v"(v), "v"(dstc), "v"(vc) : "memory");
 #endif
-    }
   }
   if (anyp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pixels have left this CU before the tag does
@@ -1134,7 +1187,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs 
   const uint4 item = items[blockIdx.x * 4 + (lane >> 4)];
   const bool valid = item.x != 0xFFFFFFFFu;
   const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
-                (item.w & 2) != 0, (item.w & 4) != 0, (item.w & 8) != 0 && A.edge != nullptr};
+                (item.w & 2) != 0, (item.w & 4) != 0};
   recon_intra_quad(A, lds, I, lane, dbg);
 }
 
@@ -1155,18 +1208,38 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconAr
   const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
   const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
   const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
-                valid ? desc->w2 & 0x3FFu : 0u, true, true, false};
+                valid ? desc->w2 & 0x3FFu : 0u, true, true};
   recon_intra_quad(A, lds, I, lane);
 }
 
 // =====================================================================================================
 // launch wrappers (called from mobi_abi.cpp)
 // =====================================================================================================
+// Untile one frame: lin = the reference's Y[stride * height] followed by UV[stride * height / 2] (MD.cs:107-108, 414-415).  One lane = 8
+// bytes of a plane row (an 8-aligned run never leaves a quadrant row / one plane's half of a chroma tile row).
+extern "C" __global__ __launch_bounds__(256) void mobi_untile(const uint8_t *slot, uint8_t *lin, uint32_t ysz, int lgS) {
+  const uint32_t a = (blockIdx.x * 256u + threadIdx.x) * 8u; // linear offset inside Y (a < ysz) or ysz + offset inside UV
+  if (a >= ysz + (ysz >> 1)) return;
+  const uint32_t t = a < ysz ? mobi_ty(a, lgS) : ysz + mobi_tc(a - ysz, lgS);
+  *(uint2 *)(lin + a) = *(const uint2 *)(slot + t);
+}
+extern "C" int mobi_launch_untile(const uint8_t *slot, uint8_t *lin_dev, int stride, int height, hipStream_t s) {
+  const uint32_t ysz = (uint32_t)stride * (uint32_t)height;
+  hipLaunchKernelGGL(mobi_untile, dim3((ysz + (ysz >> 1)) / 8 / 256 + 1), dim3(256), 0, s, slot, lin_dev, ysz, 31 - __builtin_clz((unsigned)stride));
+  return (int)hipGetLastError();
+}
+// Profiling switches (extra LDS per workgroup to lower occupancy; ablations of the intra kernel that produce WRONG pictures on purpose)
+// exist only in builds with -DMOBI_PROFILING (tools/): a drop-in decoder must not be one environment variable away from them.
+#if defined(MOBI_PROFILING)
+static int prof_env(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+#else
+static int prof_env(const char *) { return 0; }
+#endif
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue; // 24-bit multiply in the kernel
   MobiReconArgs b = *a;
-  static const int lds_pad = getenv("MOBI_LDS_PAD") ? atoi(getenv("MOBI_LDS_PAD")) : 0; // experiment: extra LDS per workgroup lowers occupancy
+  static const int lds_pad = prof_env("MOBI_LDS_PAD");
   b.qpr = ((uint32_t)b.mbw + 7) / 8;                    // octets per macroblock row
   b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);          // ... per clip
   auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };
@@ -1181,8 +1254,8 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
   if (n_items <= 0) return 0;
   if (n_items & 3) return (int)hipErrorInvalidValue; // levels are padded to whole waves of four macroblocks
-  static const int dbg = getenv("MOBI_INTRA_DBG") ? atoi(getenv("MOBI_INTRA_DBG")) : 0; // timing ablations only: 1 no transform, 2 no steps, 4 no scatter
-  static const int pad = getenv("MOBI_INTRA_LDS_PAD") ? atoi(getenv("MOBI_INTRA_LDS_PAD")) : 0;
+  static const int dbg = prof_env("MOBI_INTRA_DBG"); // timing ablations only: 1 no transform, 2 no steps, 4 no scatter, 8 no stores, 16 no halo, 32 no levels
+  static const int pad = prof_env("MOBI_INTRA_LDS_PAD");
   hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items / 4), dim3(64), pad, s, *a, (const uint4 *)items_dev, n_items, dbg);
   return (int)hipGetLastError();
 }

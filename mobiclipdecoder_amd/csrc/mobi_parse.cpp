@@ -565,7 +565,6 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     }
     level[mb] = (uint16_t)(lv + 1);
     if (lv + 1 > maxl) maxl = lv + 1;
-    if (mb % g_.mbw) out.desc[mb - 1].w1 |= MOBI_W1_EDGE; // the left neighbour leaves its last column where this one finds it in one read
     for (int k = n_deps; k < MOBI_INTRA_DEPS; k++) deps[k] = MOBI_DEP_NONE;
     MbDesc &d = out.desc[mb];
     d.w4 = deps[0] | ((uint32_t)deps[1] << 16);

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "mobi_kernels.h"
+#include "mobi_tile.h"
 
 namespace {
 // x / 239f, correctly rounded, in three instructions instead of the ~10 of a generic IEEE division: q0 = x*r,
@@ -51,18 +52,23 @@ extern "C" __global__ __launch_bounds__(256) void mobi_yuv_to_argb(const uint8_t
   if (x0 >= width) return;
   const uint8_t *Y = planes + (size_t)(clip0 + clip) * clip_bytes + (size_t)ring_base * slot_bytes;
   const uint8_t *UV = Y + (size_t)stride * height;
-  const int S = stride, hS = stride >> 1;
-  const uint32_t yw = *(const uint32_t *)(Y + (size_t)y * S + x0); // width is a multiple of 16: all four pixels exist
+  const int S = stride, lgS = 31 - __builtin_clz((unsigned)stride);
+  // the planes are tiled (mobi_tile.h): every access names the reference's linear offset and is mapped
+  const uint32_t yw = *(const uint32_t *)(Y + mobi_ty((uint32_t)(y * S + x0), lgS)); // width is a multiple of 16: all four pixels exist
   const int c = (y >> 1) * S + (x0 >> 1);
   const bool lastrow = y == height - 1, odd = (y & 1) != 0, vert = odd && !lastrow;
   // chroma samples this lane may touch: columns c .. c+2 of this chroma row and, for odd luma rows, of the next one.
-  // c is even, so the four bytes c .. c+3 are one 2-byte-aligned dword (it stays inside the row: c + 3 < Stride/2).
-  typedef uint32_t __attribute__((aligned(2))) u32_a2;
+  // c is even: samples c, c+1 and c+2, c+3 are two 2-byte pieces, each inside one 8-sample tile row (c + 3 < Stride/2).
   float u[2][3], v[2][3];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const bool need = r == 0 || vert;
-    const uint32_t uw = need ? *(const u32_a2 *)(UV + c + r * S) : 0u, vw = need ? *(const u32_a2 *)(UV + c + r * S + hS) : 0u;
+    uint32_t uw = 0, vw = 0;
+    if (need) {
+      const uint32_t t0 = mobi_tc((uint32_t)(c + r * S), lgS), t1 = mobi_tc((uint32_t)(c + 2 + r * S), lgS); // U half; V = + 8 in the tile row
+      uw = (uint32_t) * (const uint16_t *)(UV + t0) | ((uint32_t) * (const uint16_t *)(UV + t1) << 16);
+      vw = (uint32_t) * (const uint16_t *)(UV + t0 + 8) | ((uint32_t) * (const uint16_t *)(UV + t1 + 8) << 16);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       u[r][k] = __fsub_rn((float)((uw >> (8 * k)) & 0xFF), 128.f);
