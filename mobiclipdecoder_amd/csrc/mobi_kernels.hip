@@ -56,26 +56,55 @@ struct Geo { // stride is 256/512/1024 (MD.cs:50-52): divide/modulo by shifts
 typedef uint2 __attribute__((aligned(4))) uint2_a4;
 typedef uint4 __attribute__((aligned(4))) uint4_a4;
 struct Win { uint2 r0, r1; uint32_t sh; }; // row, row below, byte shift 0..3
-__device__ __forceinline__ Win fetch_win_y(const uint8_t *plane, int o, int S, int lgS) {
+// The four dwords of a window (o4, o4 + 4, o4 + S, o4 + S + 4 in linear terms) in tiled terms: the next dword is + 4 inside a
+// quadrant row, else the next quadrant column's first (+ 60, or + 188 into the next tile); the row below is + 8 inside a quadrant,
+// + 72 into the quadrant below, or the tile below's first row.  Column and row parts add.  That holds while o4 + 4 stays in its
+// plane row; `general` (wave-uniform: some lane's window touches the last 8 bytes of a row) maps every dword on its own.
+// (o may be as low as -3: the pixels of a lane that lie under its second .. fourth cell start that many bytes into the window, and
+// only they are used.  The dword below the plane is never needed: the plane's first one is fetched instead.)
+__device__ __forceinline__ Win fetch_win_y(const uint8_t *base, uint32_t slot, int o, int S, int lgS, bool general) {
   Win w;
-  // (o may be as low as -3: the pixels of a lane that lie under its second .. fourth cell start that many bytes into the window, and
-  // only they are used.  The dword below the plane is never needed: fetch the plane's first one instead.)
   const uint32_t o4 = (uint32_t)o & ~3u;
-  w.r0.x = *(const uint32_t *)(plane + mobi_ty(o < 0 ? 0u : o4, lgS));
-  w.r0.y = *(const uint32_t *)(plane + mobi_ty(o4 + 4, lgS));
-  w.r1.x = *(const uint32_t *)(plane + mobi_ty(o4 + (uint32_t)S, lgS));
-  w.r1.y = *(const uint32_t *)(plane + mobi_ty(o4 + (uint32_t)S + 4, lgS));
   w.sh = (uint32_t)o & 3;
+  if (general) {
+    w.r0.x = *(const uint32_t *)(base + (slot + mobi_ty(o < 0 ? 0u : o4, lgS)));
+    w.r0.y = *(const uint32_t *)(base + (slot + mobi_ty(o4 + 4, lgS)));
+    w.r1.x = *(const uint32_t *)(base + (slot + mobi_ty(o4 + (uint32_t)S, lgS)));
+    w.r1.y = *(const uint32_t *)(base + (slot + mobi_ty(o4 + (uint32_t)S + 4, lgS)));
+  } else {
+    const uint32_t oc = o < 0 ? 0u : o4;
+    const uint32_t t = slot + mobi_ty(oc, lgS), row = oc >> lgS;
+    const uint32_t dc = (oc & 4u) ? ((oc & 8u) ? 188u : 60u) : 4u;
+    const uint32_t dr = (row & 7u) != 7u ? 8u : (row & 8u) ? ((16u << lgS) - 184u) : 72u;
+    const uint32_t t1 = o < 0 ? slot + mobi_ty(0u, lgS) : t + dc; // (o < 0: o4 + 4 = 0)
+    w.r0.x = *(const uint32_t *)(base + t);
+    w.r0.y = *(const uint32_t *)(base + t1);
+    w.r1.x = *(const uint32_t *)(base + (t + dr));
+    w.r1.y = *(const uint32_t *)(base + (t1 + dr));
+  }
   return w;
 }
-__device__ __forceinline__ Win fetch_win_c(const uint8_t *plane, int o, int S, int lgS) {
+// chroma: the next dword is + 4 inside a tile row's plane half, else the next tile's (+ 124); the row below + 16, or the tile below's first row
+__device__ __forceinline__ Win fetch_win_c(const uint8_t *base, uint32_t slot, int o, int S, int lgS, bool general) {
   Win w;
   const uint32_t o4 = (uint32_t)o & ~3u;
-  w.r0.x = *(const uint32_t *)(plane + mobi_tc(o < 0 ? 0u : o4, lgS));
-  w.r0.y = *(const uint32_t *)(plane + mobi_tc(o4 + 4, lgS));
-  w.r1.x = *(const uint32_t *)(plane + mobi_tc(o4 + (uint32_t)S, lgS));
-  w.r1.y = *(const uint32_t *)(plane + mobi_tc(o4 + (uint32_t)S + 4, lgS));
   w.sh = (uint32_t)o & 3;
+  if (general) {
+    w.r0.x = *(const uint32_t *)(base + (slot + mobi_tc(o < 0 ? 0u : o4, lgS)));
+    w.r0.y = *(const uint32_t *)(base + (slot + mobi_tc(o4 + 4, lgS)));
+    w.r1.x = *(const uint32_t *)(base + (slot + mobi_tc(o4 + (uint32_t)S, lgS)));
+    w.r1.y = *(const uint32_t *)(base + (slot + mobi_tc(o4 + (uint32_t)S + 4, lgS)));
+  } else {
+    const uint32_t oc = o < 0 ? 0u : o4;
+    const uint32_t t = slot + mobi_tc(oc, lgS), row = oc >> lgS;
+    const uint32_t dc = (oc & 4u) ? 124u : 4u;
+    const uint32_t dr = (row & 7u) != 7u ? 16u : (8u << lgS) - 112u;
+    const uint32_t t1 = o < 0 ? slot + mobi_tc(0u, lgS) : t + dc;
+    w.r0.x = *(const uint32_t *)(base + t);
+    w.r0.y = *(const uint32_t *)(base + t1);
+    w.r1.x = *(const uint32_t *)(base + (t + dr));
+    w.r1.y = *(const uint32_t *)(base + (t1 + dr));
+  }
   return w;
 }
 __device__ __forceinline__ uint32_t cut(uint2 r, uint32_t sh) { return __builtin_amdgcn_alignbyte(r.y, r.x, sh); }
@@ -316,15 +345,15 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const int phA = (d.z >> 16) & 3, cphA = (d.z >> 18) & 3, phB = (d.z >> 20) & 3, cphB = (d.z >> 22) & 3;
   // A leaf's window starts at its first sample's position: leaf B's is row 8 (TOP/BOTTOM) or column 8 (LEFT/RIGHT) of the macroblock
   const int topB = tb ? posB + (8 << lgS) : posB + 8, ctopB = tb ? cposB + (4 << lgS) : cposB + 4;
-  const int wpx = lr ? 8 : 16, cwpx = lr ? 4 : 8;
-  // quadrant columns a window touches: (start & 7) + samples + half-pel neighbour, in units of 8
-  const int ncA = ((posA & 7) + wpx + (phA & 1) + 7) >> 3, ncB = ((topB & 7) + wpx + (phB & 1) + 7) >> 3;
-  const int cncA = ((cposA & 7) + cwpx + (cphA & 1) + 7) >> 3, cncB = ((ctopB & 7) + cwpx + (cphB & 1) + 7) >> 3;
-  // A window that runs over the end of its plane row continues in the next row (or, chroma, in the other plane's half): the
+  // What is fetched is a fixed shape, not the window's exact needs (the kernel is bound by instruction issue since the planes are
+  // tiled, and the exact shape costs more instructions than the few chunks it saves cost requests): 9 row pairs (TOP/BOTTOM: 5 + 5)
+  // from an even row, 3 quadrant columns (LEFT/RIGHT: 2 + 2) from a multiple of 8; chroma 9 rows (5 + 5) x 2 columns.
+  // A window that would run over the end of its plane row continues in the next row (or, chroma, in the other plane's half): the
   // reference's linear offsets mean exactly that (Stride == Width streams; vectors far outside the picture), and only the slow
   // path's per-dword addressing follows it.  Whole rows of chunks would not.
-  const bool wrapA = (((posA & (S - 1)) & ~7) + 8 * ncA > S) || (((cposA & (S - 1)) & ~7) + 8 * cncA > (S >> 1));
-  const bool wrapB = (((topB & (S - 1)) & ~7) + 8 * ncB > S) || (((ctopB & (S - 1)) & ~7) + 8 * cncB > (S >> 1));
+  const int ncol8 = lr ? 16 : 24;
+  const bool wrapA = (((posA & (S - 1)) & ~7) + ncol8 > S) || (((cposA & (S - 1)) & ~7) + 16 > (S >> 1));
+  const bool wrapB = (((topB & (S - 1)) & ~7) + ncol8 > S) || (((ctopB & (S - 1)) & ~7) + 16 > (S >> 1));
   const bool wrap = leaves && (wrapA || ((tb || lr) && wrapB));
   const bool win = leaves && !wrap;                           // fetched through the LDS windows
   const bool slow = multi || wrap;
@@ -332,52 +361,55 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const bool any_lr = __builtin_amdgcn_ballot_w64(lr && win) != 0;
   {
     // luma rounds: lane (g, j) brings chunk (pair 2t + (j >> 2), column j & 3) of its macroblock.  The column is the lane's for all
-    // rounds, so the leaf it serves changes only in a TOP/BOTTOM pair (pairs 5..9 are leaf B's).
+    // rounds, so the leaf it serves changes only in a TOP/BOTTOM pair (pairs 5..9 are leaf B's).  No lane is masked off: one with
+    // nothing to bring (column 3 of a whole leaf; the tenth pair; macroblocks that are not fetched this way) repeats a chunk that
+    // another lane or itself brings anyway -- same line, no request -- or the clip's first bytes.
     const int s = j & 3, ph = j >> 2;
     const bool colB = lr && s >= 2;                           // LEFT/RIGHT: columns 2, 3 belong to leaf B
-    const int sw = lr ? s & 1 : s;
-    // window of the rounds that serve leaf A (or B's columns of a LEFT/RIGHT pair), and of the rounds that serve a bottom half
-    const int top0 = colB ? topB : posA, top1 = topB;
-    const int yo0 = (top0 >> lgS) & 1, yo1 = (top1 >> lgS) & 1;
-    const uint32_t lin0 = (uint32_t)(((top0 - (yo0 << lgS)) & ~7) + 8 * sw), lin1 = (uint32_t)(((top1 - (yo1 << lgS)) & ~7) + 8 * sw);
-    const uint32_t row0 = lin0 >> lgS, row1 = lin1 >> lgS;
-    const uint8_t *b0 = clip_base + (colB ? refB : refA) + mobi_ty_col(lin0 & (uint32_t)(S - 1));
-    const uint8_t *b1 = clip_base + refB + mobi_ty_col(lin1 & (uint32_t)(S - 1));
-    const int vp0 = ((colB ? phB : phA) >> 1) & 1, vp1 = (phB >> 1) & 1;
-    const int np0 = (yo0 + (tb ? 8 : 16) + vp0 + 1) >> 1, np1 = (yo1 + 8 + vp1 + 1) >> 1;
-    const bool on0 = win && sw < (colB ? ncB : ncA), on1 = tb && win && sw < ncB;
+    const int sw = lr ? s & 1 : (s < 3 ? s : 2);
+    auto chunk0 = [&](int top, uint32_t ref, uint32_t &u) {   // byte offset (inside the clip) of the column's chunk in tile row 0; u = half the window's first row
+      const int yo = (top >> lgS) & 1;
+      const uint32_t lin = (uint32_t)(((top - (yo << lgS)) & ~7) + 8 * sw);
+      u = lin >> (lgS + 1);
+      return ref + mobi_ty_col(lin & (uint32_t)(S - 1));
+    };
+    uint32_t uP, uB;
+    const uint32_t bP = chunk0(colB ? topB : posA, colB ? refB : refA, uP), bB = chunk0(topB, refB, uB);
+    // pair p of a window that starts at row 2u: row 2(u + p): tile row (u + p) >> 3, quadrant row ((u + p) >> 2) & 1, rows 2((u + p) & 3)
+    auto rowpart = [&](uint32_t v) { return ((v & ~7u) << (lgS + 1)) + (((v & 7u) + (v & 4u)) << 4); };
+    const uint32_t vP = uP + (uint32_t)ph, vB = uB + (uint32_t)ph - 5u; // round t: pair 2t + ph of P, pair 2t + ph - 5 of B
+    // rounds 0, 1: pairs 0..3 (P); round 2: pairs 4, 5 (TOP/BOTTOM: 5 is B's first); rounds 3, 4: pairs 6..9 (TOP/BOTTOM: B's)
+    const bool b2 = tb && ph, b34 = tb;
+    const uint32_t base2 = b2 ? bB : bP, v2 = b2 ? vB : vP, base34 = b34 ? bB : bP, v34 = b34 ? vB : vP;
+    const uint32_t v4 = (!tb && ph) ? v34 - 1u : v34;         // a whole leaf has no tenth pair: the ninth again
+    uint32_t o[5] = {bP + rowpart(vP), bP + rowpart(vP + 2), base2 + rowpart(v2 + 4), base34 + rowpart(v34 + 6), base34 + rowpart(v4 + 8)};
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      const int p = 2 * t + ph;
-      const bool useB = tb && p >= 5;
-      const int pp = useB ? p - 5 : p;
-      const bool on = useB ? on1 && pp < np1 : on0 && pp < np0 && (!tb || p < 5);
-      const uint8_t *src = (useB ? b1 : b0) + mobi_ty_row((useB ? row1 : row0) + 2u * (uint32_t)pp, lgS);
-      if (on) MOBI_DMA16(src, L + P_L + t * 1024, 0);
-    }
+    for (int t = 0; t < 5; t++) MOBI_DMA16(clip_base + (win ? o[t] : 0u), L + P_L + t * 1024, 0);
     // chroma rounds: lane (g, j) brings chunk (row 4t + (j >> 1), column j & 1): both planes of that row
     const int cs = j & 1, ch2 = j >> 1;
-    const uint32_t clin0 = (uint32_t)((cposA & ~7) + 8 * cs), clin1 = (uint32_t)((ctopB & ~7) + 8 * cs);
-    const uint8_t *c0 = clip_base + refA + ysz + mobi_tc_x(clin0 & (uint32_t)(S - 1));
-    const uint8_t *c1 = clip_base + refB + ysz + mobi_tc_x(clin1 & (uint32_t)(S - 1));
-    const uint32_t crow0 = clin0 >> lgS, crow1 = clin1 >> lgS;
-    const int cnr0 = (tb ? 4 : 8) + ((cphA >> 1) & 1), cnr1 = (tb ? 4 : 8) + ((cphB >> 1) & 1);
-    const bool con0 = win && cs < cncA, con1 = win && cs < cncB;
+    auto cchunk0 = [&](int ctop, uint32_t ref, uint32_t &r) {
+      const uint32_t lin = (uint32_t)((ctop & ~7) + 8 * cs);
+      r = lin >> lgS;
+      return ref + ysz + mobi_tc_x(lin & (uint32_t)(S - 1));
+    };
+    auto crowpart = [&](uint32_t r) { return ((r & ~7u) << lgS) + ((r & 7u) << 4); };
+    uint32_t rA, rB;
+    const uint32_t cA = cchunk0(cposA, refA, rA), cB = cchunk0(ctopB, refB, rB);
+    const uint32_t qA = rA + (uint32_t)ch2, qB = rB + (uint32_t)ch2 - 5u; // round t: row 4t + ch2 of A, row 4t + ch2 - 5 of B
+    // round 0: rows 0..3 (A); round 1: rows 4..7 (TOP/BOTTOM: 5.. are B's); round 2: rows 8..11 (TOP/BOTTOM: B's 3, 4; there is no row
+    // past 8 resp. 9: those lanes bring the last one again)
+    const bool cb1 = tb && ch2 >= 1;
+    const uint32_t cbase1 = cb1 ? cB : cA, q1 = cb1 ? qB : qA, cbase2 = tb ? cB : cA;
+    const uint32_t q2 = tb ? qB - (ch2 >= 2 ? (uint32_t)ch2 - 1u : 0u) : qA - (uint32_t)ch2;
+    const uint32_t co[3] = {cA + crowpart(qA), cbase1 + crowpart(q1 + 4), cbase2 + crowpart(q2 + 8)};
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const int r = 4 * t + ch2;
-      const bool useB = tb && r >= 5;
-      const int rin = useB ? r - 5 : r;
-      const bool on = useB ? con1 && rin < cnr1 : con0 && rin < cnr0 && (!tb || r < 5);
-      const uint8_t *src = (useB ? c1 : c0) + mobi_tc_row((useB ? crow1 : crow0) + (uint32_t)rin, lgS);
-      if (on) MOBI_DMA16(src, L + P_C + t * 1024, 0);
-    }
-    if (any_lr) {
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const int r = 4 * t + ch2;
-        if (lr && con1 && r < cnr1) MOBI_DMA16(c1 + mobi_tc_row(crow1 + (uint32_t)r, lgS), L + P_C1 + t * 1024, 0);
-      }
+    for (int t = 0; t < 3; t++) MOBI_DMA16(clip_base + (win ? co[t] : 0u), L + P_C + t * 1024, 0);
+    if (any_lr) { // the right halves of LEFT/RIGHT pairs: rows 0..8 of leaf B's own window
+      const uint32_t q3 = rB + (uint32_t)ch2;
+      const bool on = lr && win;
+      MOBI_DMA16(clip_base + (on ? cB + crowpart(q3) : 0u), L + P_C1, 0);
+      MOBI_DMA16(clip_base + (on ? cB + crowpart(q3 + 4) : 0u), L + P_C1 + 1024, 0);
+      MOBI_DMA16(clip_base + (on ? cB + crowpart(q3 + 8 - (uint32_t)ch2) : 0u), L + P_C1 + 2048, 0);
     }
   }
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
@@ -456,12 +488,20 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         sq[k] = slot_off((w2m >> (cBl2 ? 13 : 10)) & 7);
       }
     }
-    D.wa = fetch_win_y(clip_base + sa, la, S, lgS);
-    if (D.ysplit) D.wb = fetch_win_y(clip_base + sb, lb, S, lgS);
-    D.wq[0] = fetch_win_c(clip_base + sq[0] + ysz, lq[0], S, lgS);
+    // some lane's window within 8 bytes of the end of a plane row (chroma: of a plane's half): every dword is mapped on its own
+    bool gen = (((uint32_t)la & (uint32_t)(S - 1)) >= (uint32_t)(S - 8)) || (((uint32_t)lq[0] & (uint32_t)((S >> 1) - 1)) >= (uint32_t)((S >> 1) - 8));
+    if (D.ysplit) gen = gen || (((uint32_t)lb & (uint32_t)(S - 1)) >= (uint32_t)(S - 8));
     if (D.csplit) {
 #pragma unroll
-      for (int k = 1; k < 4; k++) D.wq[k] = fetch_win_c(clip_base + sq[k] + ysz, lq[k], S, lgS);
+      for (int k = 1; k < 4; k++) gen = gen || (((uint32_t)lq[k] & (uint32_t)((S >> 1) - 1)) >= (uint32_t)((S >> 1) - 8));
+    }
+    const bool general = __builtin_amdgcn_ballot_w64(gen) != 0;
+    D.wa = fetch_win_y(clip_base, sa, la, S, lgS, general);
+    if (D.ysplit) D.wb = fetch_win_y(clip_base, sb, lb, S, lgS, general);
+    D.wq[0] = fetch_win_c(clip_base, sq[0] + ysz, lq[0], S, lgS, general);
+    if (D.csplit) {
+#pragma unroll
+      for (int k = 1; k < 4; k++) D.wq[k] = fetch_win_c(clip_base, sq[k] + ysz, lq[k], S, lgS, general);
     }
   };
   auto deep_finish = [&](int gm, const Deep &D) {
