@@ -187,7 +187,22 @@ __device__ __forceinline__ uint32_t lds32(const uint8_t *L, int byte_off) { retu
 // butterflies differ between one 8x8 transform (lane r = pixel row r) and four 4x4s (lane r = rows (r&1)*2, +1 of
 // sub-block r>>1): both leave 8 residuals for two 4-pixel words, so the pixel update is one shared instruction stream
 // (the 8 lanes of an area agree on the kind, the lanes of a wave do not).
-__device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint8_t *wa, uint8_t *wb, int &lo, int &hi) {
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sat_pk_u8(s16x2 v) { // two int16 -> two bytes, each clamped to 0..255 (the clamp table's identity range, MobiConst.cs:587)
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(v));
+  return d;
+#else
+  const int a = v.x < 0 ? 0 : v.x > 255 ? 255 : v.x, b = v.y < 0 ? 0 : v.y > 255 ? 255 : v.y;
+  return (uint32_t)a | ((uint32_t)b << 8);
+#endif
+}
+// Two pixels per instruction: the residual pairs saturate to int16 on the way (v_cvt_pk_i16_i32, then a packed >> 6; the sum with
+// a saturating add), which changes nothing the reference can see -- a residual that does not fit 16 bits before the shift is at least
+// 512 in magnitude after it, the clamp table's domain is prediction + residual in [-64, 319] (MobiConst.cs:587), and lo / hi see the
+// saturated sums.
+__device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint8_t *wa, uint8_t *wb, s16x2 &lo, s16x2 &hi) {
   int in[8], out[8]; // wa, wb: the two 4-pixel words (4-byte aligned) the lane's eight residuals belong to
   if (is8) {
 #pragma unroll
@@ -200,27 +215,21 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
     mobi_bfly4(in, out);
     mobi_bfly4(in + 4, out + 4);
   }
-  const uint32_t pa = *(const uint32_t *)wa, pb = *(const uint32_t *)wb;
-  int pix[8];
+  const uint32_t pw[2] = {*(const uint32_t *)wa, *(const uint32_t *)wb};
+  uint32_t res[2];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int v = (int)(((j < 4 ? pa : pb) >> (8 * (j & 3))) & 0xFF) + (out[j] >> 6);
-    lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-    pix[j] = v < 0 ? 0 : (v > 255 ? 255 : v);
+  for (int h = 0; h < 2; h++) {
+    union { s16x2 v; uint32_t u; } p01, p23;
+    p01.u = __builtin_amdgcn_perm(0u, pw[h], 0x0c010c00u); // bytes 0, 1 as two uint16
+    p23.u = __builtin_amdgcn_perm(0u, pw[h], 0x0c030c02u);
+    const s16x2 r01 = __builtin_amdgcn_cvt_pk_i16(out[4 * h], out[4 * h + 1]) >> (short)6, r23 = __builtin_amdgcn_cvt_pk_i16(out[4 * h + 2], out[4 * h + 3]) >> (short)6;
+    const s16x2 s01 = __builtin_elementwise_add_sat(p01.v, r01), s23 = __builtin_elementwise_add_sat(p23.v, r23);
+    lo = __builtin_elementwise_min(lo, __builtin_elementwise_min(s01, s23));
+    hi = __builtin_elementwise_max(hi, __builtin_elementwise_max(s01, s23));
+    res[h] = __builtin_amdgcn_perm(sat_pk_u8(s23), sat_pk_u8(s01), 0x05040100u);
   }
-  // byte stores, spelled out: LDS has issue slots to spare and the VALU has not, but left to itself the compiler packs the
-  // eight results into two words with a dozen VALU instructions (and a volatile store through a generic pointer becomes a
-  // flat_store with system scope)
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef uint8_t __attribute__((address_space(3))) *lds_u8p;
-  const uint32_t aa = (uint32_t)(uintptr_t)(lds_u8p)wa, ab = (uint32_t)(uintptr_t)(lds_u8p)wb;
-  asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8 %0, %3 offset:2\n\tds_write_b8 %0, %4 offset:3"
-               : : "v"(aa), "v"(pix[0]), "v"(pix[1]), "v"(pix[2]), "v"(pix[3]) : "memory");
-  asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8 %0, %3 offset:2\n\tds_write_b8 %0, %4 offset:3"
-               : : "v"(ab), "v"(pix[4]), "v"(pix[5]), "v"(pix[6]), "v"(pix[7]) : "memory");
-#else
-  for (int j = 0; j < 4; j++) { wa[j] = (uint8_t)pix[j]; wb[j] = (uint8_t)pix[4 + j]; }
-#endif
+  *(uint32_t *)wa = res[0];
+  *(uint32_t *)wb = res[1];
 }
 } // namespace
 
@@ -414,7 +423,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
   const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
-  uint32_t cwr[CWR] = {}; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
+  uint32_t cwr[CWR]; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
+#pragma unroll
+  for (int k = 0; k < CWR; k++) asm volatile("" : "=v"(cwr[k])); // (whatever is there: a word is only looked at when it was loaded)
   if ((uint32_t)j < ncoef) cwr[0] = cw[j];
   if (__builtin_amdgcn_ballot_w64(ncoef > 8) != 0) {
 #pragma unroll
@@ -604,7 +615,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       const int kk = lane & 31;
       if (((hi ? m_hi : m_lo) >> kk) & 1) L[P_TAB + slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1)] = (uint8_t)lane;
     }
-    int lo = 0, hi = 0;
+    s16x2 lo = {0, 0}, hi = {0, 0};
     for (int base = 0; base < n_ent; base += 16) {
       {
         const uint4 z = uint4{0, 0, 0, 0};
@@ -676,7 +687,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       }
       wave_sync();
     }
-    if (lo < -64 || hi > 319) atomicOr(&A.fault[clip], 1); // clamp table domain (MobiConst.cs:587)
+    if (lo.x < -64 || lo.y < -64 || hi.x > 319 || hi.y > 319) atomicOr(&A.fault[clip], 1); // clamp table domain (MobiConst.cs:587)
   }
   if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt[5] = prof_stamp(); }
 
