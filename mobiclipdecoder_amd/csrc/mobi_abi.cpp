@@ -21,6 +21,7 @@
 #include "mobi_cmd.h"
 #include "mobi_dparse.h"
 #include "mobi_kernels.h"
+#include "mobi_tile.h"
 #include "mobi_parse.h"
 
 namespace {
@@ -427,6 +428,24 @@ int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
   return MOBI_OK;
 }
 
+// test aid, not part of the public header: overwrite ring slot `ring_idx` of one clip with planes given in the reference layout
+// (Y: Stride * Height, UV: Stride * Height / 2) -- tests/test_unit_vectors.py predicts intra macroblocks from chosen halos this way.
+// The caller keeps the padding zero (MD.cs:107: fresh planes are zeroed and nothing ever writes the padding).
+int mobi_debug_write_planes(mobi_batch *b, int clip, int ring_idx, const uint8_t *y, const uint8_t *uv) {
+  if (!b || clip < 0 || clip >= b->n || ring_idx < 0 || ring_idx > 5 || !y || !uv) return MOBI_E_ARG;
+  if (ring_idx >= b->frames_started) return MOBI_E_NULLREF;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const uint32_t ysz = (uint32_t)b->g.stride * (uint32_t)b->g.height;
+  std::vector<uint8_t> t(b->slot_bytes);
+  for (uint32_t a = 0; a < ysz; a++) t[mobi_ty(a, b->g.lg)] = y[a];
+  for (uint32_t a = 0; a < ysz / 2; a++) t[ysz + mobi_tc(a, b->g.lg)] = uv[a];
+  uint8_t *slot = b->arena + kGuard + (size_t)clip * b->clip_bytes + (size_t)((b->ring_base + 6 - ring_idx) % 6) * b->slot_bytes;
+  HIP_TRY(hipMemcpy(slot, t.data(), t.size(), hipMemcpyHostToDevice));
+  b->argb_all_valid = false;
+  return MOBI_OK;
+}
+mobi_batch *mobi_debug_dec_batch(mobi_dec *d) { return d ? d->b : nullptr; }
 // test aid, not part of the public header: what the last device-side parse left in HBM.  desc_out: n_clips*n_mbs*8 words,
 // items_out: n_clips*n_mbs words, res_out: n_clips*8 words, payload_out: n_clips*pay_cap words (any may be null); returns pay_cap
 float mobi_debug_parse_ms(const mobi_batch *b) { return b ? b->last_parse_ms : 0.f; }
