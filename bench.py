@@ -115,6 +115,63 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps):
     return out
 
 
+def single_stream_leg(m, stream, W, H, version, device):
+    """What the drop-in boundary replaces is ONE MobiclipDecoder used by one thread (MobiConverter/Program.cs:57-71, Form1.cs:199-215):
+    d.Data = frame; d.DecodeFrame().  One clip through mobi_decode (+ mobi_get_argb, the Bitmap DecodeFrame() returns), wall time per
+    call, next to the oracle's time per frame on one host thread for the same stream.  Latency of a 1200-macroblock frame on a 256-CU part,
+    not throughput: reported beside the headline value, never as it."""
+    import ctypes as C
+    from tests.oracle_binding import OracleDecoder  # the checker, here only as the reported CPU figure beside it
+    p, data, fo = stream
+    lib = m.decoder.load_library()
+    lib.mobi_create.restype = C.c_void_p
+    lib.mobi_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    lib.mobi_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32)]
+    lib.mobi_get_argb.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mobi_destroy.argtypes = [C.c_void_p]
+    argb = np.empty(W * H, np.uint32)
+    res = {}
+    for with_bitmap in (False, True):
+        t_i, t_p = [], []
+        for rep in range(3):  # the first pass pays the allocations
+            h = lib.mobi_create(W, H, int(version), device)
+            assert h
+            for f in range(p.n_frames):
+                buf = data[fo[f]:fo[f + 1]]
+                off = C.c_int32(0)
+                t0 = time.perf_counter()
+                rc = lib.mobi_decode(h, buf.ctypes.data, buf.size, C.byref(off))
+                if with_bitmap:
+                    rc |= lib.mobi_get_argb(h, argb.ctypes.data)
+                dt = (time.perf_counter() - t0) * 1e3
+                assert rc == 0
+                if rep:
+                    (t_i if f == 0 else t_p).append(dt)
+            lib.mobi_destroy(h)
+        res["with_bitmap" if with_bitmap else "planes"] = {"p_frame_ms": round(float(np.median(t_p)), 4), "i_frame_ms": round(float(np.median(t_i)), 4)}
+    o = OracleDecoder(W, H, p.version)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 1.0:
+        assert o.decode_clip(data, fo, False) == p.n_frames
+        n += 1
+    cpu_ms = (time.perf_counter() - t0) * 1e3 / (n * p.n_frames)
+    o.close()
+    res.update({"workload": f"one {W}x{H} clip, {p.n_frames} frames, mobi_create / mobi_decode per frame (host parse, upload, two launches, sync)",
+                "value": round(W * H / res["planes"]["p_frame_ms"] / 1e3, 1), "unit": "Mpixels/s (P-frames, planes)",
+                "oracle_ms_per_frame_1_thread": round(cpu_ms, 4)})
+    return res
+
+
+def kernels_sha16():
+    """identity of the reconstruction kernels a counter profile was taken with: sha256 of their sources"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("mobi_kernels.hip", "mobi_tile.h", "mobi_cmd.h", "mobi_recon_math.h"):
+        hsh.update(open(os.path.join(ROOT, "mobiclipdecoder_amd", "csrc", f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
     """BASELINE config 4 ("64 clips sharded across 8 GPUs") as seen by ONE GPU: its share of 8 clips, replayed like the big batch.
     150 octet waves per clip fill a few per cent of the chip, so this is the latency of two short launches per step, not a
@@ -155,6 +212,7 @@ def main():
     ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
     ap.add_argument("--e2e-steps", type=int, default=12)
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
+    ap.add_argument("--single-stream", type=int, default=1, help="1: time one clip through mobi_decode / mobi_get_argb (the boundary's own shape); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
     args = ap.parse_args()
 
@@ -271,7 +329,9 @@ def main():
     n_intra = sum(x[0] for x in stats) / steps
     intra_cmd = sum(x[1] for x in stats) / steps
     b.close()
-    e2e = c4 = None
+    e2e = c4 = single = None
+    if world == 1 and args.single_stream and args.config == "B":
+        single = single_stream_leg(m, streams[0], W, H, p0.version, local)
     if world == 1 and args.e2e_clips > 0 and args.config == "B":
         e2e = end_to_end(m, streams, W, H, p0.version, local, args.e2e_clips, args.e2e_steps)
     if world == 1 and args.config4_clips > 0 and args.config == "B":
@@ -301,9 +361,12 @@ def main():
             if os.path.exists(prof):  # HBM bytes per launch from a separate rocprofv3 --pmc run (see profiles/README.md)
                 try:
                     t = json.load(open(prof)).get(f"{args.config}:{args.clips}")
-                    if t:
+                    # a counter profile describes the kernels it was taken with: it is only quoted while their sources are unchanged
+                    if t and t.get("kernels_sha16") == kernels_sha16() and not gen_over:
                         roof["traffic"] = t["hbm_bytes_per_launch"]
                         roof["traffic_source"] = t.get("source")
+                    elif t:
+                        roof["traffic_source"] = "stale: profiles/pmc_traffic.json was taken with other kernel sources (" + str(t.get("kernels_sha16")) + ")"
                 except Exception:
                     pass
         base = None
@@ -321,7 +384,9 @@ def main():
                                    f"(the I-frame that re-seeds the ring every {N_PFRAMES} steps is outside the timed region)",
                        "generator_overrides": gen_over or None, "clips_per_gpu": args.clips, "parallelism": f"clips sharded over {world} GPU(s), no collective",
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
-            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "config4": c4,
+            # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
+            "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
+            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "config4": c4, "single_stream": single,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -105,10 +105,18 @@ int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
  *   mobi_batch_wait:   waits for the OLDEST step in flight and reports what mobi_batch_decode would have: rc[i] per clip,
  *                      offsets_out[i] = Offset after the frame (may be NULL).
  * mobi_batch_decode, mobi_batch_get_planes and the other calls that read results wait for everything enqueued; mobi_batch_decode is
- * refused (MOBI_E_ARG) while steps are in flight.  What it buys: the host gathers and uploads step n + 1 while the GPU parses step
+ * refused (MOBI_E_ARG) while steps are in flight.
+ * WHICH FRAME IS WHERE: mobi_batch_submit turns the ring at once (Y[i] = Y[i-1], MD.cs:102-106, happens at submission, not at
+ * completion).  With steps in flight, ring_idx 0 of mobi_batch_get_planes / get_argb / convert_argb is the NEWEST submitted step's
+ * frame, and the frame of the step mobi_batch_wait has just reported sits at ring_idx = mobi_batch_in_flight(b) (1 while one later
+ * step is in flight).  The getters wait for everything enqueued before they copy, so reading results between submit and wait drains the
+ * pipeline: read after the last wait, or accept the drain.  mobi_batch_quantizer / mobi_batch_yuv_format describe the step last
+ * WAITED for.  If mobi_batch_submit fails after it has started to enqueue (MOBI_E_DEVICE), the batch is drained and refuses all
+ * further steps: destroy it.  What it buys: the host gathers and uploads step n + 1 while the GPU parses step
  * n, and the GPU goes from parse to reconstruction without asking the host for launch sizes. */
 int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets);
 int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc);
+int mobi_batch_in_flight(const mobi_batch *b); /* steps submitted and not yet waited for: 0, 1 or 2 */
 /* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
 float mobi_batch_last_decode_ms(const mobi_batch *b);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);

@@ -259,6 +259,7 @@ struct mobi_batch {
   size_t slot_bytes = 0, clip_bytes = 0;
   int ring_base = 0;
   int frames_started = 0;
+  bool poisoned = false; // an asynchronous submit failed half-way (mobi_batch_submit): nothing further is accepted
   int debug = 0;
   std::vector<std::unique_ptr<MobiStreamParser>> parsers;
   std::vector<ParsedFrame> cur; // per clip, current frame (batch_decode)
@@ -763,6 +764,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (b->frames_started == 0 && b->async_seq == 0) { // an asynchronous batch parses on the GPU from its first frame
     if (b->parse_auto || b->parse_mode == 1) { b->parse_mode = 1; b->parse_auto = false; b->hybrid_host = 0; }
   }
+  if (b->poisoned) return MOBI_E_DEVICE;
   if (b->parse_mode != 1 || b->hybrid_host != 0) return MOBI_E_ARG; // the decoder state of this batch lives in the host parsers
   if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) return MOBI_E_VERSION;
   if (b->g.mbw > 64 || b->async_count >= 2) return MOBI_E_ARG;
@@ -781,6 +783,18 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (int e = S.h_fault.reserve(sizeof(int) * n)) return e;
   S.offs.assign(offsets, offsets + n);
   S.n_dev = n;
+  // Everything that can fail without touching the device is behind us.  From the first enqueue on, a failure leaves work in flight
+  // that reads this slot's pinned memory and (later) a ring that has turned without a step to wait for: the batch is drained and
+  // POISONED -- every later call reports MOBI_E_DEVICE -- rather than left in a state where the next submit reuses the slot.
+  struct Poison {
+    mobi_batch *b; bool armed = true;
+    ~Poison() {
+      if (!armed) return;
+      if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+      (void)hipStreamSynchronize(b->stream);
+      b->poisoned = true;
+    }
+  } poison{b};
   HIP_TRY(hipMemcpyAsync(S.d_bits.p, S.h_stage.p, st.bytes, hipMemcpyHostToDevice, b->stream2)); // beside whatever the step before is doing
   HIP_TRY(hipEventRecord(S.ev_up, b->stream2));
   HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_up, 0));
@@ -798,6 +812,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   HIP_TRY(hipMemcpyAsync(S.h_fault.p, b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   HIP_TRY(hipEventRecord(S.ev_done, b->stream));
+  poison.armed = false;
   b->async_count++;
   b->async_seq++;
   return MOBI_OK;
@@ -805,6 +820,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
 int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   if (!b || !rc) return MOBI_E_ARG;
   HIP_TRY(hipSetDevice(b->device));
+  if (b->poisoned) return MOBI_E_DEVICE;
   if (b->async_count == 0) return MOBI_E_ARG;
   mobi_batch::AsyncSlot &S = b->aslot[b->async_head & 1];
   HIP_TRY(hipEventSynchronize(S.ev_done));
@@ -822,6 +838,8 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   return MOBI_OK;
 }
 
+int mobi_batch_in_flight(const mobi_batch *b) { return b ? b->async_count : 0; }
+
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
   if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
   b->parse_mode = device_parse == 2 ? 2 : device_parse != 0;
@@ -831,6 +849,7 @@ int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
 
 int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
   if (!b || !data || !len || !offsets || !rc) return MOBI_E_ARG;
+  if (b->poisoned) return MOBI_E_DEVICE;
   HIP_TRY(hipSetDevice(b->device));
   struct CallTimer { // wall time of this call, for the end-to-end measurements (tools/exp_dparse.py)
     mobi_batch *b;
@@ -868,6 +887,12 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
+  // From here on the parsers have consumed the frame and the ring has turned (the two must stay in step: a parser's reference
+  // bookkeeping counts frames).  If the call itself fails below, no clip may report MOBI_OK for a frame that was never reconstructed.
+  struct FailAll {
+    int *rc; int n; bool armed = true;
+    ~FailAll() { if (armed) for (int i = 0; i < n; i++) if (rc[i] == MOBI_OK) rc[i] = MOBI_E_DEVICE; }
+  } fail_all{rc, n};
   if (step_payload_words(ok) + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
   LevelPlan plan;
   plan.build(ok, b->g.mbw);
@@ -902,6 +927,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  fail_all.armed = false;
   b->drain_events();
   for (int i = 0; i < n; i++)
     if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP; // bit 1: an intra dependency never arrived

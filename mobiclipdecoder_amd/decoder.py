@@ -53,6 +53,7 @@ _SIGS = {
     "mobi_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_in_flight": (C.c_int, [C.c_void_p]),
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
     "mobi_batch_get_argb": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

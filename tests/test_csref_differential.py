@@ -141,3 +141,72 @@ def test_coverage_suite_streams():
         data, fo = generate_clip(p)
         ok, thrown = _diff(L, p, data, fo)
         assert ok == p.n_frames and thrown == 0
+
+
+def test_unit_statements_random_sweep():
+    """The oracle's unit entry points against BOTH reference statements of each unit (decoder PredictIntra; the encoder's GetCompvals /
+    PredictIntraPlane / IDCT / FrameUtil.GetPBlock copies) on thousands of random inputs -- the committed
+    tests/golden/unit_vectors.npz is a small sample of this sweep that travels to the GPU box."""
+    from tests.oracle_binding import lib as oracle_lib
+    L = _lib()
+    OL = oracle_lib()
+    L.csref_dec_predict.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int]
+    L.csref_enc_compvals.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.csref_enc_plane.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.csref_enc_idct.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.csref_enc_getpblock.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(2024)
+    S, ROWS = 256, 40
+    dec = L.csref_create(256, 192, 2)
+    stated_twice = 0
+    for trial in range(3000):
+        plane = rng.integers(0, 256, S * ROWS, dtype=np.uint8)
+        four = bool(trial & 1)
+        m = int(rng.choice([0, 1, 3, 4, 5, 6, 7, 8])) + (10 if four else 0)
+        n = 4 if four else 8
+        x = int(rng.choice([0, n, 2 * n, 128, 128 + n, 64])); y = int(rng.choice([0, n, 2 * n, 24]))
+        uv = int(x >= 128 or (trial % 5 == 0))
+        off = y * S + x
+        a, b = plane.copy(), plane.copy()
+        ra = OL.mobi_oracle_predict(m, a.ctypes.data, a.size, off, S, uv)
+        rb = L.csref_dec_predict(dec, m, b.ctypes.data, b.size, off, uv)
+        assert (ra != 0) == (rb != 0), (m, x, y, uv)
+        if rb == 0:
+            assert np.array_equal(a, b), (m, x, y, uv)
+            eoff = S // 2 if (uv and x >= S // 2) else 0
+            e, eo = plane.copy(), np.zeros(64, np.uint8)
+            if L.csref_enc_compvals(m, e.ctypes.data, e.size, x - eoff, y, S, eoff, eo.ctypes.data) == 0:
+                assert np.array_equal(eo[: n * n], a.reshape(ROWS, S)[y:y + n, x:x + n].ravel()), ("encoder statement", m, x, y, uv)
+                stated_twice += 1
+        # planes
+        size = int(rng.choice([16, 8, 4])); px = int(rng.choice([size, 2 * size, 48])); py = int(rng.choice([size, 16])); param = int(rng.integers(-40, 41))
+        a, e, eo = plane.copy(), plane.copy(), np.zeros(256, np.uint8)
+        assert OL.mobi_oracle_plane(size, param, a.ctypes.data, a.size, py * S + px, S) == 0
+        assert L.csref_enc_plane(size, e.ctypes.data, e.size, py * S + px, S, param, eo.ctypes.data) == 0
+        assert np.array_equal(a.reshape(ROWS, S)[py:py + size, px:px + size].ravel(), eo[: size * size]), (size, px, py, param)
+        # CopyBlock
+        w, h = int(rng.choice([2, 4, 8, 16])), int(rng.choice([2, 4, 8, 16]))
+        dx, dy = int(rng.integers(-20, 21)), int(rng.integers(-20, 21))
+        dst, eo = np.zeros(S * ROWS, np.uint8), np.zeros(256, np.uint8)
+        base = 12 * S + 32
+        assert OL.mobi_oracle_copyblock(plane.ctypes.data, plane.size, dx, dy, w, h, dst.ctypes.data, dst.size, base, S) == 0
+        assert L.csref_enc_getpblock(plane.ctypes.data, plane.size, dx, dy, w, h, base, S, eo.ctypes.data) == 0
+        assert np.array_equal(dst.reshape(ROWS, S)[12:12 + h, 32:32 + w].ravel(), eo[: w * h]), (w, h, dx, dy)
+        # inverse transforms (encoder statement = the full transform)
+        nn = 16 if four else 64
+        c = np.zeros(nn, np.int32)
+        k = int(rng.integers(1, nn + 1))
+        pos = rng.choice(nn, size=k, replace=False)
+        c[pos] = rng.integers(-60, 61, k) * int(rng.choice([16, 40, 64, 104, 160]))
+        p = rng.integers(0, 256, nn, dtype=np.uint8)
+        eo = np.zeros(nn, np.uint8)
+        re_ = L.csref_enc_idct(nn, c.ctypes.data, p.ctypes.data, eo.ctypes.data)
+        side = 4 if four else 8
+        d = np.zeros(side * 16, np.uint8)
+        d.reshape(side, 16)[:, :side] = p.reshape(side, side)
+        fn = OL.mobi_oracle_idct4 if four else OL.mobi_oracle_idct8
+        ro = fn(c.ctypes.data, nn, d.ctypes.data, d.size, 0, 16)
+        assert (ro != 0) == (re_ != 0)
+        if re_ == 0:
+            assert np.array_equal(d.reshape(side, 16)[:, :side].ravel(), eo)
+    assert stated_twice > 1500
