@@ -132,6 +132,11 @@ int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out);
  * (Delta.X & 0xFF) | (Delta.Y & 0xFF) << 8 | Frame << 16 | score << 20 (Delta in half pels, as the reference stores it;
  * score = 0xFFF when the ring is empty). */
 int mobi_batch_motion_search(mobi_batch *b, const uint8_t *const *src_y, uint32_t *out);
+/* The encoder's forward transforms: MobiEncoder.DCT64 (Encoder/MobiEncoder.cs:962-1010, n = 8) and DCT16
+ * (:1146-1178, n = 4) of n_blocks residual blocks (Block - CompVals, Encoder/MacroBlock.cs:584-588), n*n int32 each, back to back;
+ * out as the reference returns it (the second pass stores transposed).  Integer arithmetic, truncating divisions: bit-exact.
+ * The quantiser behind it (float division + Math.Round, MacroBlock.cs:591-595) is not part of this library. */
+int mobi_forward_dct(int device, int n, const int32_t *in, int32_t *out, size_t n_blocks);
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip);
 uint32_t mobi_batch_yuv_format(const mobi_batch *b, int clip);
 int mobi_batch_stride(const mobi_batch *b);

@@ -1005,6 +1005,24 @@ int mobi_batch_motion_search(mobi_batch *b, const uint8_t *const *src_y, uint32_
   return MOBI_OK;
 }
 
+// ---- encoder-side forward transforms: MobiEncoder.DCT64 / DCT16 over caller buffers ----
+int mobi_forward_dct(int device, int n, const int32_t *in, int32_t *out, size_t n_blocks) {
+  if ((n != 8 && n != 4) || (n_blocks && (!in || !out)) || n_blocks > 0xFFFFFFFFu / 64) return MOBI_E_ARG;
+  if (n_blocks == 0) return MOBI_OK;
+  HIP_TRY(hipSetDevice(device));
+  const size_t bytes = n_blocks * (size_t)(n * n) * 4;
+  int32_t *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_in, bytes));
+  if (hipMalloc((void **)&d_out, bytes) != hipSuccess) { (void)hipFree(d_in); return MOBI_E_DEVICE; }
+  int rc = MOBI_OK;
+  if (hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice) != hipSuccess || mobi_launch_fwd_dct(n, d_in, d_out, (uint32_t)n_blocks, nullptr) != 0 ||
+      hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = MOBI_E_DEVICE;
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) {
   if (!b || clip < 0 || clip >= b->n) return 0;
   if (b->parse_mode) return b->dev_quant.empty() ? 0 : b->dev_quant[clip];

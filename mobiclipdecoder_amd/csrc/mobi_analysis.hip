@@ -87,3 +87,84 @@ extern "C" int mobi_launch_motion_search(const MobiReconArgs *a, const uint8_t *
   hipLaunchKernelGGL(mobi_motion_search_2x2, dim3((unsigned)a->n_clips * (unsigned)a->n_mbs), dim3(64), 0, s, *a, src_dev, out_dev, n_past);
   return (int)hipGetLastError();
 }
+
+// =====================================================================================================
+// Forward transforms of residual blocks: MobiEncoder.DCT64 (Encoder/MobiEncoder.cs:962-1010) and DCT16 (:1146-1178)
+// =====================================================================================================
+// The other compute loop of the reference's encoder (Encoder/MacroBlock.cs:584-590, 612-616: residual = Block - CompVals, DCT, quantise).
+// Pure integer: x64, a fixed integer matrix per pass, a C# integer division (truncating) -- rows, then columns, results of the second
+// pass stored transposed, as the reference does.  One lane = one row (then one column) of a block: 8 lanes per 8x8 block, 4 per 4x4;
+// the transpose between the passes goes through LDS.  512 B (128 B) of traffic per block: HBM-bound.
+// (The quantiser behind it is float division + Math.Round over a float table (MacroBlock.cs:591-595): not reproducible bit for bit
+// outside the CLR that ran it, and not built.)
+namespace {
+__device__ __forceinline__ void dct8_pass(const int (&x)[8], int (&o)[8]) { // x = samples 0..7 of the row / column
+  const int p = x[0], q = x[7], r = x[2], s = x[5], t = x[3], u = x[4], v = x[1], w = x[6];
+  o[0] = (w + v + u + t + s + r + q + p) / 8;
+  o[1] = (-40 * w + 40 * v - 12 * u + 12 * t - 24 * s + 24 * r - 48 * q + 48 * p) / 289;
+  o[2] = (w + v - 2 * u - 2 * t - s - r + 2 * q + 2 * p) / 10;
+  o[3] = (12 * w - 12 * v + 24 * u - 24 * t + 48 * s - 48 * r - 40 * q + 40 * p) / 289;
+  o[4] = (-w - v + u + t - s - r + q + p) / 8;
+  o[5] = (48 * w - 48 * v - 40 * u + 40 * t - 12 * s + 12 * r - 24 * q + 24 * p) / 289;
+  o[6] = (-2 * w - 2 * v - u - t + 2 * s + 2 * r + q + p) / 10;
+  o[7] = (24 * w - 24 * v + 48 * u - 48 * t - 40 * s + 40 * r - 12 * q + 12 * p) / 289;
+}
+__device__ __forceinline__ void dct4_pass(const int (&x)[4], int (&o)[4]) {
+  const int q = x[0], r = x[1], s = x[2], t = x[3];
+  o[0] = (t + s + r + q) / 4;
+  o[1] = (-2 * t - s + r + 2 * q) / 5;
+  o[2] = (t - s - r + q) / 4;
+  o[3] = (-t + 2 * s - 2 * r + q) / 5;
+}
+} // namespace
+
+extern "C" __global__ __launch_bounds__(256) void mobi_fwd_dct8(const int32_t *in, int32_t *out, uint32_t n_blocks) {
+  __shared__ int tile[32][8][9]; // 32 blocks per workgroup; pitch 9: the column reads of eight lanes hit eight banks
+  const uint32_t blk = blockIdx.x * 32u + (threadIdx.x >> 3);
+  const int lb = threadIdx.x >> 3, r = threadIdx.x & 7;
+  const bool on = blk < n_blocks;
+  int x[8], o[8];
+  if (on) {
+    const int4 a = *(const int4 *)(in + (size_t)blk * 64 + r * 8), b = *(const int4 *)(in + (size_t)blk * 64 + r * 8 + 4);
+    x[0] = a.x * 64; x[1] = a.y * 64; x[2] = a.z * 64; x[3] = a.w * 64; x[4] = b.x * 64; x[5] = b.y * 64; x[6] = b.z * 64; x[7] = b.w * 64;
+    dct8_pass(x, o);
+#pragma unroll
+    for (int k = 0; k < 8; k++) tile[lb][r][k] = o[k];
+  }
+  __syncthreads();
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = tile[lb][j][r]; // column r
+    dct8_pass(x, o);
+    *(int4 *)(out + (size_t)blk * 64 + r * 8) = int4{o[0], o[1], o[2], o[3]};
+    *(int4 *)(out + (size_t)blk * 64 + r * 8 + 4) = int4{o[4], o[5], o[6], o[7]};
+  }
+}
+extern "C" __global__ __launch_bounds__(256) void mobi_fwd_dct4(const int32_t *in, int32_t *out, uint32_t n_blocks) {
+  __shared__ int tile[64][4][5];
+  const uint32_t blk = blockIdx.x * 64u + (threadIdx.x >> 2);
+  const int lb = threadIdx.x >> 2, r = threadIdx.x & 3;
+  const bool on = blk < n_blocks;
+  int x[4], o[4];
+  if (on) {
+    const int4 a = *(const int4 *)(in + (size_t)blk * 16 + r * 4);
+    x[0] = a.x * 64; x[1] = a.y * 64; x[2] = a.z * 64; x[3] = a.w * 64;
+    dct4_pass(x, o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) tile[lb][r][k] = o[k];
+  }
+  __syncthreads();
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = tile[lb][j][r];
+    dct4_pass(x, o);
+    *(int4 *)(out + (size_t)blk * 16 + r * 4) = int4{o[0], o[1], o[2], o[3]};
+  }
+}
+extern "C" int mobi_launch_fwd_dct(int n, const int32_t *in_dev, int32_t *out_dev, uint32_t n_blocks, hipStream_t s) {
+  if (n_blocks == 0) return 0;
+  if (n == 8) hipLaunchKernelGGL(mobi_fwd_dct8, dim3((n_blocks + 31) / 32), dim3(256), 0, s, in_dev, out_dev, n_blocks);
+  else if (n == 4) hipLaunchKernelGGL(mobi_fwd_dct4, dim3((n_blocks + 63) / 64), dim3(256), 0, s, in_dev, out_dev, n_blocks);
+  else return (int)hipErrorInvalidValue;
+  return (int)hipGetLastError();
+}

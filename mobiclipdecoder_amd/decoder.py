@@ -54,6 +54,7 @@ _SIGS = {
     "mobi_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_in_flight": (C.c_int, [C.c_void_p]),
+    "mobi_forward_dct": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
     "mobi_batch_get_argb": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -376,3 +377,16 @@ class MobiclipBatch:
             self.close()
         except Exception:
             pass
+
+
+def forward_dct(blocks, device=0):
+    """MobiEncoder.DCT64 / DCT16 (Encoder/MobiEncoder.cs:962, 1146) on the GPU: blocks = int32 array (n_blocks, 64) or (n_blocks, 16)
+    of residuals -> coefficients of the same shape, as the reference returns them."""
+    a = np.ascontiguousarray(blocks, dtype=np.int32)
+    if a.ndim != 2 or a.shape[1] not in (64, 16):
+        raise ValueError("blocks must be (n, 64) or (n, 16)")
+    out = np.empty_like(a)
+    rc = load_library().mobi_forward_dct(device, 8 if a.shape[1] == 64 else 4, a.ctypes.data, out.ctypes.data, a.shape[0])
+    if rc != 0:
+        raise MobiclipError(error_string(rc))
+    return out

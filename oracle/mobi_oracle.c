@@ -1368,3 +1368,38 @@ int mobi_oracle_plane(int size, int param, uint8_t *dst, int dst_len, int offset
   free(d);
   return rc;
 }
+
+/* ---- encoder-side forward transforms: MobiEncoder.DCT64 (Encoder/MobiEncoder.cs:962-1010) and DCT16 (:1146-1178).
+ * Integer arithmetic throughout: the input (a block of residuals, Block - CompVals, Encoder/MacroBlock.cs:584-588) is scaled by 64, each
+ * pass is a fixed integer matrix followed by a C# integer division (truncation toward zero, like C's), rows first, then columns;
+ * note that the second pass writes its results transposed (tmp2[i * 8 + k] is coefficient k of COLUMN i), exactly as the reference does. */
+static void ora_dct8_pass(int p, int q, int r, int s, int t, int u, int v, int w, int32_t *o) { /* o[0..7] */
+  o[0] = (w + v + u + t + s + r + q + p) / 8;
+  o[1] = (-40 * w + 40 * v - 12 * u + 12 * t - 24 * s + 24 * r - 48 * q + 48 * p) / 289;
+  o[2] = (w + v - 2 * u - 2 * t - s - r + 2 * q + 2 * p) / 10;
+  o[3] = (12 * w - 12 * v + 24 * u - 24 * t + 48 * s - 48 * r - 40 * q + 40 * p) / 289;
+  o[4] = (-w - v + u + t - s - r + q + p) / 8;
+  o[5] = (48 * w - 48 * v - 40 * u + 40 * t - 12 * s + 12 * r - 24 * q + 24 * p) / 289;
+  o[6] = (-2 * w - 2 * v - u - t + 2 * s + 2 * r + q + p) / 10;
+  o[7] = (24 * w - 24 * v + 48 * u - 48 * t - 40 * s + 40 * r - 12 * q + 12 * p) / 289;
+}
+void mobi_oracle_dct8(const int32_t *in, int32_t *out) {
+  int32_t px[64], tmp[64];
+  for (int i = 0; i < 64; i++) px[i] = in[i] * 64;                                       /* :964-968 */
+  for (int i = 0; i < 8; i++)                                                            /* :970-988: p,q,r,s,t,u,v,w = columns 0,7,2,5,3,4,1,6 */
+    ora_dct8_pass(px[i * 8 + 0], px[i * 8 + 7], px[i * 8 + 2], px[i * 8 + 5], px[i * 8 + 3], px[i * 8 + 4], px[i * 8 + 1], px[i * 8 + 6], tmp + i * 8);
+  for (int i = 0; i < 8; i++)                                                            /* :990-1008 */
+    ora_dct8_pass(tmp[0 * 8 + i], tmp[7 * 8 + i], tmp[2 * 8 + i], tmp[5 * 8 + i], tmp[3 * 8 + i], tmp[4 * 8 + i], tmp[1 * 8 + i], tmp[6 * 8 + i], out + i * 8);
+}
+static void ora_dct4_pass(int q, int r, int s, int t, int32_t *o) {
+  o[0] = (t + s + r + q) / 4;
+  o[1] = (-2 * t - s + r + 2 * q) / 5;
+  o[2] = (t - s - r + q) / 4;
+  o[3] = (-t + 2 * s - 2 * r + q) / 5;
+}
+void mobi_oracle_dct4(const int32_t *in, int32_t *out) {
+  int32_t px[16], tmp[16];
+  for (int i = 0; i < 16; i++) px[i] = in[i] * 64;                                       /* :1148-1152 */
+  for (int i = 0; i < 4; i++) ora_dct4_pass(px[i * 4 + 0], px[i * 4 + 1], px[i * 4 + 2], px[i * 4 + 3], tmp + i * 4);          /* :1154-1164 */
+  for (int i = 0; i < 4; i++) ora_dct4_pass(tmp[0 * 4 + i], tmp[1 * 4 + i], tmp[2 * 4 + i], tmp[3 * 4 + i], out + i * 4);      /* :1166-1176 */
+}

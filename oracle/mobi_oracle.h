@@ -97,6 +97,10 @@ int mobi_oracle_copyblock(const uint8_t *src, int src_len, int dx, int dy, uint3
  * is_uv selects the `Dst == UV[0]` V-plane fix-up (:1886).  plane modes: param given explicitly. */
 int mobi_oracle_predict(int mode, uint8_t *dst, int dst_len, int offset, int stride, int is_uv);
 int mobi_oracle_plane(int size /*16,8,4*/, int param, uint8_t *dst, int dst_len, int offset, int stride);
+/* encoder-side forward transforms of a residual block: MobiEncoder.DCT64 (Encoder/MobiEncoder.cs:962) and
+ * DCT16 (:1146): in = 64 / 16 residuals (Block - CompVals), out = 64 / 16 coefficients as the reference returns them */
+void mobi_oracle_dct8(const int32_t *in, int32_t *out);
+void mobi_oracle_dct4(const int32_t *in, int32_t *out);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@ from mobiclipdecoder_amd import sharding
 def run(n_clips, device_parse, n_frames=9, distinct=16):
     streams = []
     for i in range(distinct):
-        p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=n_frames)
+        over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("BENCH_GEN", "").split(",") if kv)}  # experiment hook, as in bench.py
+        p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=n_frames, **over)
         streams.append(m.generate_clip(p))
     b = m.MobiclipBatch(n_clips, 640, 480, 2, device_parse=device_parse)
     b.set_kernel_timing(1)
