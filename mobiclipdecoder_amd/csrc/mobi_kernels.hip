@@ -277,6 +277,7 @@ enum {
   P_COEF = 3072,  // 16 tiles of P_TILE words
   P_TILE = 72,
   P_TAB = 7680,   // entry -> area*8 + g (<= 48 bytes)
+  P_INV = 8128,   // area*8 + g -> entry (48 bytes), behind the scales
   P_SC = 7744     // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
 };
 __device__ __forceinline__ int out_y(int g, int R, int c) { return P_OUT_Y + (R & 7) * 256 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
@@ -360,9 +361,10 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   // A window that would run over the end of its plane row continues in the next row (or, chroma, in the other plane's half): the
   // reference's linear offsets mean exactly that (Stride == Width streams; vectors far outside the picture), and only the slow
   // path's per-dword addressing follows it.  Whole rows of chunks would not.
-  const int ncol8 = lr ? 16 : 24;
-  const bool wrapA = (((posA & (S - 1)) & ~7) + ncol8 > S) || (((cposA & (S - 1)) & ~7) + 16 > (S >> 1));
-  const bool wrapB = (((topB & (S - 1)) & ~7) + ncol8 > S) || (((ctopB & (S - 1)) & ~7) + 16 > (S >> 1));
+  // ((col & ~7) + 24 > S is col >= S - 16; + 16: col >= S - 8; chroma (col & ~7) + 16 > S / 2: col >= S / 2 - 8, the V half included)
+  const int ylim = S - (lr ? 8 : 16), clim = (S >> 1) - 8;
+  const bool wrapA = (posA & (S - 1)) >= ylim || (cposA & (S - 1)) >= clim;
+  const bool wrapB = (topB & (S - 1)) >= ylim || (ctopB & (S - 1)) >= clim;
   const bool wrap = leaves && (wrapA || ((tb || lr) && wrapB));
   const bool win = leaves && !wrap;                           // fetched through the LDS windows
   const bool slow = multi || wrap;
@@ -613,8 +615,13 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     {
       const bool hi = lane >= 32;
       const int kk = lane & 31;
-      if (((hi ? m_hi : m_lo) >> kk) & 1) L[P_TAB + slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1)] = (uint8_t)lane;
+      if (((hi ? m_hi : m_lo) >> kk) & 1) {
+        const int slot = slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1);
+        L[P_TAB + slot] = (uint8_t)lane;
+        L[P_INV + lane] = (uint8_t)slot; // ... and area * 8 + g -> entry, for the scatter
+      }
     }
+    wave_sync();
     s16x2 lo = {0, 0}, hi = {0, 0};
     for (int base = 0; base < n_ent; base += 16) {
       {
@@ -627,7 +634,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       auto scatter = [&](uint32_t e) {
         const int t = e & 0x1FF, level = (int32_t)e >> 16, ar = t >> 6, kk = (ar & 3) * 8 + g, p = t & 63;
         const bool chroma = ar >= 4, is8 = ((chroma ? t_hi : t_lo) >> kk) & 1;
-        const int slot = slot_of_entry(kk, chroma, is8) - base;
+        const int slot = (int)L[P_INV + ar * 8 + g] - base;
         const int si = is8 ? p : 64 + (p & 15);
         const int scale = (int)lds32(L, P_SC + si * 4);
         if ((unsigned)slot < 16u) coef[slot * P_TILE + p] = __mul24(scale, level);
@@ -941,8 +948,11 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     coef[t] = __mul24((int)G[IQ_SCALE + si], level);
   };
 #pragma unroll
-  for (int k = 0; k < 8; k++)
-    if ((uint32_t)(l + 16 * k) < ncoef && !(dbg & 4)) scatter(cw[k]);
+  for (int k = 0; k < 8; k++) {
+    const bool mine = (uint32_t)(l + 16 * k) < ncoef && !(dbg & 4);
+    if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break; // (nobody in the wave has that many)
+    if (mine) scatter(cw[k]);
+  }
   for (uint32_t base = 128; __builtin_amdgcn_ballot_w64(base < ncoef) != 0; base += 128) { // dense macroblocks: 128 more per round trip
 #pragma unroll
     for (int k = 0; k < 8; k++) cw[k] = base + (uint32_t)(l + 16 * k) < ncoef ? rec[MOBI_INTRA_RECORDS + base + l + 16 * k] : 0u;
@@ -952,29 +962,56 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   }
   wave_sync();
 
-  // ---- residuals of all coded areas: eight lanes per area, two areas of each macroblock per round.  Pass 1 in place; pass 2 leaves
-  // int16 residuals (saturated: whatever does not fit is a clamp-table fault anyway) of areas 2k, 2k + 1 over the words of area k ----
-#pragma unroll 1
-  for (int rd = 0; rd < ((dbg & 1) ? 0 : 3); rd++) {
-    const int a = 2 * rd + (l >> 3), r = l & 7;
-    const bool act = (w1 >> (8 + a)) & 1, is8a = (t8 >> a) & 1;
-    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0; // this lane's eight residuals, int16 pairs
-    if (__builtin_amdgcn_ballot_w64(act) != 0) {
-      if (act) idct_pass1(coef + 64 * a, coef + 64 * a, is8a, r);
-      wave_sync();
-      const uint4 pk = idct_pass2_pk(coef + 64 * a, is8a, r); // (lanes of uncoded areas transform whatever is there and drop it)
-      wave_sync(); // every lane has read its words: the stores below land on area rd's (round 0: on what areas 0 and 1 have just read)
-      const uint32_t keep = act ? 0xFFFFFFFFu : 0u;
-      q0 = pk.x & keep; q1 = pk.y & keep; q2 = pk.z & keep; q3 = pk.w & keep;
+  // ---- residuals of the coded areas.  Eight lanes per area; the coded areas of all four macroblocks are taken together, eight per
+  // round (a P-frame's intra macroblocks have ~2 of 6 coded: one round instead of the three that "two areas of each macroblock per
+  // round" took; an I-frame's ~3: two).  Pass 1 in place; pass 2 leaves int16 residuals (saturated: whatever does not fit is a
+  // clamp-table fault anyway) in registers until every round has read its coefficients, then over the words of areas 0..2 ----
+  {
+    const uint32_t cb = (I.valid && !(dbg & 1)) ? (w1 >> 8) & 0x3Fu : 0u;
+    const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)cb, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)cb, 16) << 6) |
+                       ((uint32_t)__builtin_amdgcn_readlane((int)cb, 32) << 12) | ((uint32_t)__builtin_amdgcn_readlane((int)cb, 48) << 18); // bit mb * 6 + area
+    const int n_act = __builtin_popcount(M);
+    uint8_t *tab = (uint8_t *)(Lw + IQ_STEP); // k-th coded area -> its bit number (the first macroblock's step list is not in use yet)
+    if (lane < 24 && ((M >> lane) & 1)) tab[__builtin_popcount(M & ((1u << lane) - 1u))] = (uint8_t)lane;
+    wave_sync();
+    const int r = lane & 7;
+    uint4 q[3];
+    int idx[3];
+    bool is8r[3];
+#pragma unroll
+    for (int rd = 0; rd < 3; rd++) {
+      q[rd] = uint4{0, 0, 0, 0};
+      idx[rd] = -1;
+      is8r[rd] = false;
+      if (rd * 8 < n_act) {
+        const int k = rd * 8 + (lane >> 3);
+        const bool act = k < n_act;
+        const int id = act ? tab[k] : 0, mbi = (id * 43) >> 8, a = id - 6 * mbi; // (id / 6 for id < 24)
+        const int t8x = __builtin_amdgcn_ds_bpermute(mbi << 6, t8);               // that macroblock's 8x8 / 4x4 mask
+        const bool is8a = (t8x >> a) & 1;
+        int *cx = (int *)(Lw + mbi * IQ_WORDS) + 64 * a;
+        if (act) idct_pass1(cx, cx, is8a, r);
+        wave_sync();
+        if (act) {
+          q[rd] = idct_pass2_pk(cx, is8a, r);
+          idx[rd] = id;
+          is8r[rd] = is8a;
+        }
+      }
     }
-    {
-      uint8_t *dst = (uint8_t *)G + 128 * a; // the area's int16 [8][8]
-      if (!act || is8a) { // row r (zeros where nothing is coded: the words underneath belonged to another area)
-        *(uint4 *)(dst + 16 * r) = uint4{q0, q1, q2, q3};
-      } else {            // 4x4 blocks: lane r made rows i0, i0 + 1 of block r >> 1
-        const int sb = r >> 1, row0 = (sb >> 1) * 4 + (r & 1) * 2, c0 = (sb & 1) * 4;
-        *(uint2 *)(dst + 16 * row0 + 2 * c0) = uint2{q0, q1};
-        *(uint2 *)(dst + 16 * (row0 + 1) + 2 * c0) = uint2{q2, q3};
+    wave_sync(); // every lane has read its coefficients: the residuals may land on them
+#pragma unroll
+    for (int rd = 0; rd < 3; rd++) {
+      if (rd * 8 < n_act && idx[rd] >= 0) {
+        const int mbi = (idx[rd] * 43) >> 8, a = idx[rd] - 6 * mbi;
+        uint8_t *dst = (uint8_t *)(Lw + mbi * IQ_WORDS) + 128 * a; // the area's int16 [8][8]
+        if (is8r[rd]) {
+          *(uint4 *)(dst + 16 * r) = q[rd];
+        } else { // 4x4 blocks: lane r made rows i0, i0 + 1 of block r >> 1
+          const int sb = r >> 1, row0 = (sb >> 1) * 4 + (r & 1) * 2, c0 = (sb & 1) * 4;
+          *(uint2 *)(dst + 16 * row0 + 2 * c0) = uint2{q[rd].x, q[rd].y};
+          *(uint2 *)(dst + 16 * (row0 + 1) + 2 * c0) = uint2{q[rd].z, q[rd].w};
+        }
       }
     }
     wave_sync();
@@ -1115,6 +1152,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const int po8 = (l >> 1) * TP + (l & 1) * 4, ro8 = (l >> 1) * 8 + (l & 1) * 4;
   const int po4 = (l >> 2) * TP + (l & 3), ro4 = (l >> 2) * 8 + (l & 3);
   int fault = 0;
+  s16x2 flo = {0, 0}, fhi = {0, 0}; // range of prediction + residual over the 8x8 steps (clamp table domain [-64, 319], MobiConst.cs:587)
   // The tap table entries of a directional block do not depend on pixels: they are fetched two steps ahead (a step is shorter than
   // an L2 round trip; with few waves on the chip -- small batches, the tail of an I-frame's levels -- nobody else hides it).
   uint2 d1 = *(const uint2 *)steps, d2 = *(const uint2 *)(steps + 2);
@@ -1174,12 +1212,17 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
         } else if (d.x & SD_KDC) {
           word = (uint32_t)dcv * 0x01010101u;
         }
-        if (d.x & SD_CODED) {
+        if (d.x & SD_CODED) { // two samples per instruction, as in the inter kernel (idct_pass2_q)
           const uint2 rr = *(const uint2 *)(res16 + (d.y & 0x1FF) + ro8);
-          const int4 r = int4{(int)(int16_t)(rr.x & 0xFFFF), (int)rr.x >> 16, (int)(int16_t)(rr.y & 0xFFFF), (int)rr.y >> 16};
-          const uint32_t q0 = (uint32_t)mobi_add_clamp((int)(word & 0xFF), r.x, &fault), q1 = (uint32_t)mobi_add_clamp((int)((word >> 8) & 0xFF), r.y, &fault);
-          const uint32_t q2 = (uint32_t)mobi_add_clamp((int)((word >> 16) & 0xFF), r.z, &fault), q3 = (uint32_t)mobi_add_clamp((int)(word >> 24), r.w, &fault);
-          word = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+          union { s16x2 v; uint32_t u; } p01, p23, r01, r23;
+          p01.u = __builtin_amdgcn_perm(0u, word, 0x0c010c00u);
+          p23.u = __builtin_amdgcn_perm(0u, word, 0x0c030c02u);
+          r01.u = rr.x;
+          r23.u = rr.y;
+          const s16x2 s01 = __builtin_elementwise_add_sat(p01.v, r01.v), s23 = __builtin_elementwise_add_sat(p23.v, r23.v);
+          flo = __builtin_elementwise_min(flo, __builtin_elementwise_min(s01, s23));
+          fhi = __builtin_elementwise_max(fhi, __builtin_elementwise_max(s01, s23));
+          word = __builtin_amdgcn_perm(sat_pk_u8(s23), sat_pk_u8(s01), 0x05040100u);
         }
         *(uint32_t *)px = word;
       }
@@ -1197,6 +1240,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     }
     wave_sync();
   }
+  if (flo.x < -64 || flo.y < -64 || fhi.x > 319 || fhi.y > 319) fault = 1;
   if (fault && I.valid && !dbg) atomicOr(&A.fault[clip], 1);
 
   // ---- store.  Write-through (sc1), drained and followed by the tag only when an intra macroblock of this step may be waiting for
