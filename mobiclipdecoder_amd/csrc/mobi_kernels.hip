@@ -361,10 +361,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   // A window that would run over the end of its plane row continues in the next row (or, chroma, in the other plane's half): the
   // reference's linear offsets mean exactly that (Stride == Width streams; vectors far outside the picture), and only the slow
   // path's per-dword addressing follows it.  Whole rows of chunks would not.
-  // ((col & ~7) + 24 > S is col >= S - 16; + 16: col >= S - 8; chroma (col & ~7) + 16 > S / 2: col >= S / 2 - 8, the V half included)
-  const int ylim = S - (lr ? 8 : 16), clim = (S >> 1) - 8;
-  const bool wrapA = (posA & (S - 1)) >= ylim || (cposA & (S - 1)) >= clim;
-  const bool wrapB = (topB & (S - 1)) >= ylim || (ctopB & (S - 1)) >= clim;
+  // (The test is on the bytes the window NEEDS, not on the fixed shape that is fetched: a quadrant column beyond them may come from
+  // the next row's first bytes -- in bounds, never looked at.  Width == Stride pictures have every right-most macroblock there.)
+  const int wpx = lr ? 8 : 16, cwpx = lr ? 4 : 8;
+  const bool wrapA = (posA & (S - 1)) + wpx + (phA & 1) > S || (cposA & (S - 1)) + cwpx + (cphA & 1) > (S >> 1);
+  const bool wrapB = (topB & (S - 1)) + wpx + (phB & 1) > S || (ctopB & (S - 1)) + cwpx + (cphB & 1) > (S >> 1);
   const bool wrap = leaves && (wrapA || ((tb || lr) && wrapB));
   const bool win = leaves && !wrap;                           // fetched through the LDS windows
   const bool slow = multi || wrap;
