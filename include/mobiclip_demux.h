@@ -66,7 +66,9 @@ typedef struct {
 int mobi_moc5_open(const uint8_t *file, size_t len, mobi_moc5_info *info);
 /* One iteration of the frame loop (:293-318): the block at *offs.  Returns 1 and decode_offset = *offs + 8 (the
  * decoder gets the WHOLE file as Data and this Offset), then advances *offs by 4 + (blocksize & ~1), rounded up to a
- * multiple of 4; returns 0 when *offs >= len (the reference exits). */
+ * multiple of 4 (never past len); returns 0 when *offs >= len (the reference exits).  A last block whose size field claims more
+ * than the file holds is still returned (1): the reference's loop hands it to the decoder too, which reads what is there.  -1 only
+ * for bad arguments, fewer than 4 bytes left for the size field, or a size that would not advance the offset (2^32 wrap). */
 int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_t *decode_offset, uint32_t *block_size);
 
 /* ---- Moflex (3DS) ------------------------------------------------------------------------------ */

@@ -121,8 +121,10 @@ int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_
   if (decode_offset) *decode_offset = (int32_t)(*offs + 8);
   // (64-bit: a block size near 2^32 must not wrap the offset backwards and make the caller loop for ever)
   const uint64_t o = ((uint64_t)*offs + 4 + (bs & ~1u) + 3) & ~(uint64_t)3;
-  if (o <= *offs || o > len + 3) return -1;
-  *offs = (uint32_t)std::min<uint64_t>(o, 0xFFFFFFFFull);
+  if (o <= *offs) return -1; // (the only hard error: the offset would not advance)
+  // A last block that claims more than the file holds is still handed to the decoder, as the reference's loop does (Form1.cs:282-320:
+  // it passes the whole file as Data and the decoder reads what is there); the following call reports the end of the file.
+  *offs = (uint32_t)std::min<uint64_t>(o, (uint64_t)len);
   return 1;
 }
 

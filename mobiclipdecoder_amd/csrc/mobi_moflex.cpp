@@ -33,14 +33,16 @@ namespace {
 
 struct Escape {}; // managed code would have thrown here (read past the byte[] it holds, duplicate dictionary key, Pop(> 64))
 
-// What one ReadPacket() call can see: `n` bytes of the file starting at the reader position.  Indexing past it is the
-// reference's IndexOutOfRangeException.
+// What one ReadPacket() call can see: the packet array of the reference, filled from the reader position.  Indexing past the array is
+// the reference's IndexOutOfRangeException.
+// The reference reads into `new byte[PacketSize == 0 ? 0x1000 : PacketSize]` (MoLiveDemux.cs:71): bytes of that array behind what the
+// file still held are zero, not out of range -- `cap` is the array's length, `n` the bytes actually read.
 struct Window {
   const uint8_t *p = nullptr;
-  size_t n = 0;
+  size_t n = 0, cap = 0;
   uint8_t operator[](size_t i) const {
-    if (i >= n) throw Escape{};
-    return p[i];
+    if (i >= cap) throw Escape{};
+    return i < n ? p[i] : 0;
   }
   uint32_t be16(size_t i) const { return (uint32_t)(*this)[i] << 8 | (*this)[i + 1]; }
   uint32_t be24(size_t i) const { return be16(i) << 8 | (*this)[i + 2]; }
@@ -154,10 +156,10 @@ struct mobi_moflex {
     std::memset(&s, 0, sizeof(s));
     s.chunk_id = type;
     s.stream_index = w[at];
-    if (at + 1 >= w.n) return s;
+    if (at + 1 >= w.cap) return s;
     if (type == 4) { s.associated_stream_index = w[at + 1]; return s; }
     s.codec_id = w[at + 1];
-    const size_t body = at + 2, left = w.n - body;
+    const size_t body = at + 2, left = w.cap - body;
     if (type == 2) {
       if (left < 4) return s;
       s.frequency = w.be24(body) + 1;
@@ -175,7 +177,7 @@ struct mobi_moflex {
       return s;
     }
     s.pel_ratio_rate = w[body + 9]; // MoLiveStreamVideoWithLayout.cs:40-41 stores both bytes into PelRatioRate: the scale stays 0
-    if (body + 10 >= w.n) return s;
+    if (body + 10 >= w.cap) return s;
     s.image_layout = w[body + 10] & 0xF;
     s.image_rotation = w[body + 10] >> 4;
     return s;
@@ -271,6 +273,7 @@ struct mobi_moflex {
     const size_t want = packet_size ? packet_size : kDefaultWindow;
     w.p = file + pos;
     w.n = pos < len ? (want < len - pos ? want : len - pos) : 0;
+    w.cap = want;
     const uint32_t length = (uint32_t)w.n;
     SyncHeader h;
     if (!in_sync) { // look for a header whose check word fits

@@ -220,4 +220,34 @@ def test_damaged_containers_do_not_hang_the_caller():
     offs = C.c_uint32(8)
     L.mobi_moc5_next_block.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
     L.mobi_moc5_next_block.restype = C.c_int
-    assert L.mobi_moc5_next_block(moc.ctypes.data, moc.size, C.byref(offs), None, None) == -1 and offs.value == 8
+    # the oversized block is handed out once (the reference would pass it to the decoder), the offset lands on the end of the file,
+    # and the walk is over: no wrap, no loop
+    assert L.mobi_moc5_next_block(moc.ctypes.data, moc.size, C.byref(offs), None, None) == 1 and offs.value == 64
+    assert L.mobi_moc5_next_block(moc.ctypes.data, moc.size, C.byref(offs), None, None) == 0
+
+
+def test_moc5_truncated_last_block_is_still_handed_out():
+    """Form1.cs:282-320 passes the whole file as Data for every block, the last one included even if the file was cut inside it."""
+    p = default_params("A", BASE_SEED + 77, n_frames=3, width=64, height=48)
+    data, fo = generate_clip(p)
+    frames = [data[fo[f]:fo[f + 1]] for f in range(p.n_frames)]
+    blob, offs = write_moc5(frames, p.width, p.height)
+    cut = blob[: len(blob) - 5]  # inside the last block
+    walked = list(moc5_blocks(cut))
+    assert len(walked) == 3 and [w[0] for w in walked] == [w[0] for w in moc5_blocks(blob)]
+
+
+def test_moflex_file_shorter_than_the_default_window():
+    """The reference reads into a zero-filled byte[0x1000] before it knows the packet size (MoLiveDemux.cs:71): a file shorter than
+    that is parsed against zeros behind its end, not rejected as out of range."""
+    p = default_params("B", BASE_SEED + 78, n_frames=2, width=64, height=48)
+    data, fo = generate_clip(p)
+    frames = [data[fo[f]:fo[f + 1]] for f in range(p.n_frames)]
+    blob = write_moflex(frames, p.width, p.height)[:-0x1000]  # without the 0x1000 zero bytes FinalizeMoflex appends
+    assert len(blob) < 0x1000
+    d = MoLiveDemux(blob)
+    got = d.next_frame()
+    assert got is not None
+    stream, payload = got
+    assert bytes(payload[: len(frames[0])]) == bytes(frames[0])
+    d.close()
