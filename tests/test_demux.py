@@ -246,8 +246,8 @@ def test_moflex_file_shorter_than_the_default_window():
     blob = write_moflex(frames, p.width, p.height)[:-0x1000]  # without the 0x1000 zero bytes FinalizeMoflex appends
     assert len(blob) < 0x1000
     d = MoLiveDemux(blob)
-    got = d.next_frame()
-    assert got is not None
-    stream, payload = got
-    assert bytes(payload[: len(frames[0])]) == bytes(frames[0])
+    codes = [d.ReadPacket() for _ in range(4)]
+    # synchronisation is found in the short window, and no call ends in the "managed exception" code: reads behind the file's end
+    # see the zero-filled rest of the reference's packet array
+    assert codes[0] == 0 and all(c not in (0xFFFFFFFF, -1) for c in codes), codes
     d.close()
