@@ -1,5 +1,7 @@
 // mobi_parse.cpp -- serial bitstream parser -> per-macroblock command list (see mobi_parse.h).
 #include "mobi_parse.h"
+
+unsigned long mobi_refusal_count[MOBI_REFUSE_CLASSES];
 #include "mobi_recon_math.h"
 
 #include <algorithm>
@@ -185,7 +187,7 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
     check_window(off + (long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * g_.height);
     check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
     check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
-    fail(MOBI_E_UNSUPPORTED);
+    refuse(MOBI_REFUSE_MV);
   }
   leaves_[n_leaf_words_++] = mobi_leaf_w0(x, y, wi, hi, ref); // at most 64 leaves: the tree bottoms out at 2x2
   leaves_[n_leaf_words_++] = mobi_leaf_w1(dx, dy);
@@ -235,7 +237,7 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
   const uint32_t *dq = is8 ? dq8_ : dq4_;
   // Below q=12 the dequant word's scale bits leak into its zigzag byte (MD.cs:3907-3911 vs :3426) and
   // the reference result depends on scratch aliasing inside Internal[]; outside the parity domain.
-  if (quant_ < 12) fail(MOBI_E_UNSUPPORTED);
+  if (quant_ < 12) refuse(MOBI_REFUSE_QUANT);
   const uint16_t *A = vlc_table_ == 1 ? mobi_vx2table1_a : mobi_vx2table0_a;
   const uint8_t *B = vlc_table_ == 1 ? mobi_vx2table1_b : mobi_vx2table0_b;
   int p = 0;
@@ -299,7 +301,7 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
       e >>= 15;
     }
     p += skip;
-    if (p >= N) fail(MOBI_E_UNSUPPORTED); // the reference would walk past the dequant words (Internal[] aliasing)
+    if (p >= N) refuse(MOBI_REFUSE_RUN); // the reference would walk past the dequant words (Internal[] aliasing)
     uint32_t word = dq[p++];
     // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the reduced transforms only
     // look at part of the block, but for q >= 12 nothing they skip can be nonzero: scan positions 0, 0..2, 0..9 map inside the
@@ -393,7 +395,7 @@ void MobiStreamParser::intra_chroma(uint32_t cbp) { // loc_116290, MD.cs:1864-18
       bool ok;
       int16_t p = param16(se(), ok);
       check_intra_reads(2, area_offset(area, 0), false);
-      if (!ok) fail(MOBI_E_UNSUPPORTED);
+      if (!ok) refuse(MOBI_REFUSE_PLANE);
       recs_[area * 4] |= mobi_intra_rec(0, 0, 0, 1, p);
     }
   }
@@ -411,7 +413,7 @@ void MobiStreamParser::intra_full() { // DecIntraFullBlockPMode, MD.cs:1759-1786
     bool ok;
     int16_t p = param16(se(), ok);
     check_intra_reads(2, cur_off_, false);
-    if (!ok) fail(MOBI_E_UNSUPPORTED);
+    if (!ok) refuse(MOBI_REFUSE_PLANE);
     w3_ = 1u | ((uint32_t)(uint16_t)p << 16);
   }
   for (int k = 0; k < 4; k++) intra_area_fixed(k, m, (cbp >> k) & 1);
@@ -435,7 +437,7 @@ void MobiStreamParser::intra_sub() { // DecIntraSubBlockPMode, MD.cs:1789-1807
       if (m == 2) { // the predictor itself reads its parameter (MD.cs:1915-1919)
         bool ok;
         p = param16(se(), ok);
-        if (!ok) fail(MOBI_E_UNSUPPORTED);
+        if (!ok) refuse(MOBI_REFUSE_PLANE);
       }
       check_intra_reads(m, area_offset(k, 0), false);
       recs_[k * 4] |= mobi_intra_rec(m, coded, 0, 0, p);
@@ -454,7 +456,7 @@ void MobiStreamParser::intra_sub() { // DecIntraSubBlockPMode, MD.cs:1789-1807
         if (m == 2) {
           bool ok;
           p = param16(se(), ok);
-          if (!ok) fail(MOBI_E_UNSUPPORTED);
+          if (!ok) refuse(MOBI_REFUSE_PLANE);
         }
         check_intra_reads(m, area_offset(k, sub), true);
         int c = (m4 >> sub) & 1;

@@ -49,6 +49,14 @@ void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]);
 // directional intra predictors as four tile offsets per sample (see mobi_parse.cpp); out: MOBI_TAP_ENTRIES x 4 int16; false = self-check failed
 bool mobi_build_intra_taps(int16_t *out, int pitch);
 
+// The four classes of streams the reference decodes and this library refuses (MOBI_E_UNSUPPORTED); process-wide counters, a measuring aid
+enum { MOBI_REFUSE_MV = 0,     // |MV| > MOBI_MV_LIMIT half-pels (the cell map's 14-bit fields)
+       MOBI_REFUSE_QUANT = 1,  // ModsDS quantiser < 12: the dequant rows alias the intra-mode cache inside Internal[] (MD.cs:3907-3911)
+       MOBI_REFUSE_RUN = 2,    // a coefficient run that steps past its block: the write lands in the next block's scratch (MD.cs:3424-3429)
+       MOBI_REFUSE_PLANE = 3,  // a plane-predictor parameter outside int16 (the record's 16-bit field): |se| >= 2^15 needs a code of >= 33 bits
+       MOBI_REFUSE_CLASSES = 4 };
+extern unsigned long mobi_refusal_count[MOBI_REFUSE_CLASSES];
+
 class MobiStreamParser {
  public:
   MobiStreamParser(uint32_t width, uint32_t height, int version);
@@ -65,6 +73,8 @@ class MobiStreamParser {
  private:
   struct Err { int code; };
   [[noreturn]] void fail(int code) const { throw Err{code}; }
+  // MOBI_E_UNSUPPORTED by cause (INTEGRATION.md error table): counted for tools/exp_refusals.py
+  [[noreturn]] void refuse(int cause) const { mobi_refusal_count[cause]++; throw Err{-6 /* MOBI_E_UNSUPPORTED */}; }
   // bit reader
   uint32_t data_u16(long off) const;
   void fill_bits();

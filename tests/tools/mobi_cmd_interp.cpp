@@ -246,6 +246,8 @@ void exec_intra(Interp &I, int mb, const MbDesc &d) {
 } // namespace
 
 extern "C" {
+// how often the parser refused a stream (MOBI_E_UNSUPPORTED) in this process, by cause (mobi_parse.h: MOBI_REFUSE_*); tools/exp_refusals.py
+void mobi_cmdinterp_refusals(unsigned long out[4]) { for (int i = 0; i < MOBI_REFUSE_CLASSES; i++) out[i] = mobi_refusal_count[i]; }
 void *mobi_cmdinterp_create(uint32_t w, uint32_t h, int version) {
   if ((w & 15) || (h & 15) || w == 0 || h == 0 || w > 1024) return nullptr;
   return new Interp(w, h, version);

@@ -31,5 +31,11 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1500):
             both_err += 1
             break
         both_ok += 1
+import ctypes as C
+from tests.interp_binding import lib as interp_lib
+cnt = (C.c_ulong * 4)()
+interp_lib().mobi_cmdinterp_refusals(cnt)
+print("refusals by cause (all refusing frames, whether or not the reference decodes them): |MV| > 8191: %d, ModsDS quantiser < 12: %d, "
+      "run past the block: %d, plane parameter outside int16: %d" % tuple(cnt))
 print(f"{frames} corrupted frames: {both_ok} decoded by both, {both_err} rejected by both, {refused} refused by the product only "
       f"({refused_ref_ok} of them decoded by the reference's restatement = result differences: {100.0 * refused_ref_ok / frames:.2f} % of frames)")
