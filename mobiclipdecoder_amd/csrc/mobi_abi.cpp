@@ -464,7 +464,7 @@ long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *ite
   return (long long)b->last_pay_cap;
 }
 
-const char *mobi_build_info(void) { return "libmobiclip_hip 0.2 (gfx950, HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_intra_cl, mobi_parse_frames, mobi_yuv_to_argb, mobi_motion_search_2x2; no CPU reconstruction path)"; }
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.3 (gfx950, macroblock-tiled planes; HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_intra_cl, mobi_parse_frames, mobi_untile, mobi_yuv_to_argb, mobi_motion_search_2x2, mobi_fwd_dct8, mobi_fwd_dct4; no CPU reconstruction path)"; }
 
 const char *mobi_error_string(int rc) {
   switch (rc) {

@@ -19,7 +19,8 @@ SO = os.path.join(ROOT, "oracle", "_ref", "libmobi_csref.so")
 
 
 def _lib():
-    if not os.path.exists(SO):
+    gen = os.path.join(ROOT, "oracle", "tools", "cs2cpp.py")
+    if not os.path.exists(SO) or (os.path.isdir("/root/reference") and os.path.getmtime(SO) < os.path.getmtime(gen)):
         if not os.path.isdir("/root/reference"):
             pytest.skip("reference tree absent: the transliteration can only be generated in the build container")
         subprocess.check_call([sys.executable, os.path.join(ROOT, "oracle", "tools", "cs2cpp.py")])
