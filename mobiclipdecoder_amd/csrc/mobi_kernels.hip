@@ -274,11 +274,13 @@ enum {
   P_BYTES = 10240,
   P_OUT_Y = 0,    // 2048 B
   P_OUT_C = 2048, // 1024 B
-  P_COEF = 3072,  // 16 tiles of P_TILE words
+  P_COEF = 3072,  // P_ROUND tiles of P_TILE words
   P_TILE = 72,
-  P_TAB = 7680,   // entry -> area*8 + g (<= 48 bytes)
-  P_INV = 8128,   // area*8 + g -> entry (48 bytes), behind the scales
-  P_SC = 7744     // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
+  P_ROUND = 22,   // coded areas per residual round: three half rounds of eight lanes-by-eight (the third one rarely runs: an octet has 14
+                  // coded areas on average in the generator's mix, more than 16 in one octet out of five, more than 22 in one out of a hundred)
+  P_SC = 9728,    // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
+  P_TAB = 10048,  // entry -> area*8 + g (<= 48 bytes)
+  P_INV = 10112   // area*8 + g -> entry (48 bytes)
 };
 __device__ __forceinline__ int out_y(int g, int R, int c) { return P_OUT_Y + (R & 7) * 256 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
 __device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return P_OUT_C + (R & 3) * 256 + (R >> 2) * 128 + ((g ^ (R & 3)) << 4) + pl * 8 + x; }
@@ -624,12 +626,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     }
     wave_sync();
     s16x2 lo = {0, 0}, hi = {0, 0};
-    for (int base = 0; base < n_ent; base += 16) {
+    for (int base = 0; base < n_ent; base += P_ROUND) {
       {
         const uint4 z = uint4{0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; k++) *(uint4 *)(L + P_COEF + k * 1024 + lane * 16) = z;
-        if (lane < (16 * P_TILE * 4 - 4096) / 16) *(uint4 *)(L + P_COEF + 4096 + lane * 16) = z;
+        const int n_tiles = n_ent - base < P_ROUND ? n_ent - base : P_ROUND;          // (wave-uniform: only the tiles in use)
+        for (int o = lane * 16; o < n_tiles * P_TILE * 4; o += 1024) *(uint4 *)(L + P_COEF + o) = z;
       }
       wave_sync();
       auto scatter = [&](uint32_t e) {
@@ -638,7 +639,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         const int slot = (int)L[P_INV + ar * 8 + g] - base;
         const int si = is8 ? p : 64 + (p & 15);
         const int scale = (int)lds32(L, P_SC + si * 4);
-        if ((unsigned)slot < 16u) coef[slot * P_TILE + p] = __mul24(scale, level);
+        if ((unsigned)slot < (unsigned)P_ROUND) coef[slot * P_TILE + p] = __mul24(scale, level);
       };
 #pragma unroll
       for (int k = 0; k < CWR; k++) {
@@ -659,23 +660,23 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       }
       wave_sync();
       const int r = lane & 7;
-      int kx[2];
-      bool actx[2], is8x[2];
+      int kx[3];
+      bool actx[3], is8x[3];
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < 3; h++) {
         const int idx = base + 8 * h + (lane >> 3);
-        actx[h] = idx < n_ent;
+        actx[h] = idx < n_ent && 8 * h + (lane >> 3) < P_ROUND;
         kx[h] = actx[h] ? L[P_TAB + idx] : 0;
         is8x[h] = idx < n8;
       }
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < 3; h++) {
         int *tile = coef + P_TILE * (8 * h + (lane >> 3));
         if (actx[h]) idct_pass1(tile, tile, is8x[h], r);
       }
       wave_sync();
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < 3; h++) {
         if (actx[h]) {
           // the lane's two 4-pixel words: one row of the area (8x8), or rows i0, i0 + 1 of 4x4 block r >> 1
           const int ge = kx[h] & 7, a = kx[h] >> 3;
@@ -706,16 +707,19 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   {
     uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
     uint8_t *ty0 = y0 + mobi_tile_y(mbx0, mby, lgS), *tc0 = y0 + ysz + mobi_tile_c(mbx0, mby, lgS);
+    const bool full = nmb == 8; // (wave-uniform: only a picture's last octet can be short)
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const int i = lane + 64 * it, gq = i >> 4, quad = (i >> 2) & 3, R0 = (quad >> 1) * 8 + 2 * (i & 3), c0 = (quad & 1) * 8;
       const uint2 v0 = *(const uint2 *)(L + out_y(gq, R0, c0)), v1 = *(const uint2 *)(L + out_y(gq, R0 + 1, c0));
-      *(uint4 *)(ty0 + i * 16) = gq < nmb ? uint4{v0.x, v0.y, v1.x, v1.y} : uint4{0, 0, 0, 0};
+      if (full) *(uint4 *)(ty0 + i * 16) = uint4{v0.x, v0.y, v1.x, v1.y};
+      else *(uint4 *)(ty0 + i * 16) = gq < nmb ? uint4{v0.x, v0.y, v1.x, v1.y} : uint4{0, 0, 0, 0};
     }
     {
       const int gq = lane >> 3, R = lane & 7;
       const uint4 vc = *(const uint4 *)(L + out_c(gq, R, 0, 0));
-      *(uint4 *)(tc0 + lane * 16) = gq < nmb ? vc : uint4{0, 0, 0, 0};
+      if (full) *(uint4 *)(tc0 + lane * 16) = vc;
+      else *(uint4 *)(tc0 + lane * 16) = gq < nmb ? vc : uint4{0, 0, 0, 0};
     }
   }
   if (PROF && lane == 0) { // MOBI_DEBUG=9: where a wave's life goes (shader clock): A issue, fetch wait, MC, deep trees, residual, store issue

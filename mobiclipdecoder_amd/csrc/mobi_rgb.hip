@@ -45,16 +45,18 @@ __device__ __forceinline__ uint32_t convert_px(int version, float Y2, float U, f
 }
 } // namespace
 
-// one lane = 4 horizontally adjacent pixels (one 16-byte store); block = 256 lanes = 1024 pixels of one row
-extern "C" __global__ __launch_bounds__(256) void mobi_yuv_to_argb(const uint8_t *planes, uint64_t clip_bytes, uint32_t slot_bytes, int ring_base,
-                                                                  int width, int height, int stride, int version, int clip0, uint32_t *out) {
-  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, clip = blockIdx.z;
-  if (x0 >= width) return;
+// one lane = 4 horizontally adjacent pixels (one 16-byte store); one wave = one macroblock, lane = (row lane >> 2, pixels 4 * (lane & 3)):
+// the planes are macroblock tiles (mobi_tile.h), so a wave reads its 256 luma bytes as four whole 64-byte pieces (r02's "one block =
+// 1024 pixels of a row" would touch 8 bytes of every piece it reads)
+extern "C" __global__ __launch_bounds__(64) void mobi_yuv_to_argb(const uint8_t *planes, uint64_t clip_bytes, uint32_t slot_bytes, int ring_base,
+                                                                 int width, int height, int stride, int version, int clip0, uint32_t *out) {
+  const int mbw = width >> 4, mby = blockIdx.x / mbw, mbx = blockIdx.x - mby * mbw, clip = blockIdx.z;
+  const int lane = threadIdx.x, x0 = mbx * 16 + (lane & 3) * 4, y = mby * 16 + (lane >> 2);
   const uint8_t *Y = planes + (size_t)(clip0 + clip) * clip_bytes + (size_t)ring_base * slot_bytes;
   const uint8_t *UV = Y + (size_t)stride * height;
   const int S = stride, lgS = 31 - __builtin_clz((unsigned)stride);
-  // the planes are tiled (mobi_tile.h): every access names the reference's linear offset and is mapped
-  const uint32_t yw = *(const uint32_t *)(Y + mobi_ty((uint32_t)(y * S + x0), lgS)); // width is a multiple of 16: all four pixels exist
+  // every access names the reference's linear offset and is mapped
+  const uint32_t yw = *(const uint32_t *)(Y + mobi_ty((uint32_t)(y * S + x0), lgS));
   const int c = (y >> 1) * S + (x0 >> 1);
   const bool lastrow = y == height - 1, odd = (y & 1) != 0, vert = odd && !lastrow;
   // chroma samples this lane may touch: columns c .. c+2 of this chroma row and, for odd luma rows, of the next one.
@@ -102,8 +104,8 @@ extern "C" __global__ __launch_bounds__(256) void mobi_yuv_to_argb(const uint8_t
 
 extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, int n_clips, uint32_t *out_dev, hipStream_t s) {
   if (n_clips <= 0) return 0;
-  const dim3 grid((unsigned)((a->width / 4 + 255) / 256), (unsigned)a->height, (unsigned)n_clips);
-  hipLaunchKernelGGL(mobi_yuv_to_argb, grid, dim3(256), 0, s, (const uint8_t *)a->planes, (uint64_t)a->clip_bytes, a->slot_bytes, a->ring_base,
+  const dim3 grid((unsigned)a->n_mbs, 1u, (unsigned)n_clips);
+  hipLaunchKernelGGL(mobi_yuv_to_argb, grid, dim3(64), 0, s, (const uint8_t *)a->planes, (uint64_t)a->clip_bytes, a->slot_bytes, a->ring_base,
                      a->width, a->height, a->stride, version, clip0, out_dev);
   return (int)hipGetLastError();
 }
