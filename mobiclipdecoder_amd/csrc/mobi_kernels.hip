@@ -3,17 +3,17 @@
 //   mobi_recon_inter8  : the inter macroblocks of a frame step, one wavefront per OCTET of eight horizontally adjacent
 //                        macroblocks: half-pel truncating motion compensation from the reference planes (CopyBlock,
 //                        MD.cs:418-456), dequant + 8x8/4x4 integer inverse transforms + clamp-add of the residual
-//                        (MD.cs:3424-3429, :3435-3798), whole-row stores of Y/U/V.
+//                        (MD.cs:3424-3429, :3435-3798), the octet's tiles stored as 2 KB + 1 KB runs.
 //   mobi_recon_intra   : intra macroblocks (I-frames and codes 6/7 inside P-frames), four per wavefront (16 lanes each): halo load
 //   mobi_recon_intra_cl  with raster-order availability masking, predictors (MD.cs:1883-2774, :3017-3327) and
 //                        residuals in decode order inside LDS; all dependency levels of a step in one launch, ordered by
 //                        per-macroblock completion tags.
+//   mobi_untile        : a frame out of the private tiled planes (mobi_tile.h) into the reference's row-major arrays.
 //
-// 8-bit pel work is HBM-bound by nature: no MFMA.  LDS use is per wave (no workgroup barriers): waves never share
-// LDS data, so a wavefront-scope fence (a pure compiler barrier -- LDS executes a wave's instructions in order) is
-// all that separates producer and consumer lanes.
-// (r01 also had a four-macroblocks-per-wave inter kernel, a first octet kernel and a one-launch step kernel; they are gone:
-// nothing used them any more, and every extra kernel had to be kept bit-exact.)
+// The planes are stored as macroblock tiles (mobi_tile.h, r03): every position in the command list is still the reference's linear
+// byte offset; the kernels map it.  8-bit pel work is memory traffic and integer issue: no MFMA.  LDS use is per wave (no workgroup
+// barriers): waves never share LDS data, so a wavefront-scope fence (a pure compiler barrier -- LDS executes a wave's instructions
+// in order) is all that separates producer and consumer lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
 // padded to a whole number of waves with null items (x = ~0).
 //   x = clip << 13 | mb   y = MbDesc.w1   z = MbDesc.payload_off (inside this step's arena)
 //   w = [0] 16x16 plane present  [1] has intra dependencies  [2] has intra dependents  [3] the left neighbour's last column is in the
-//       edge side buffer  [14:5] number of level words  [31:16] plane parameter
+//       (r02: edge side buffer; unused)  [14:5] number of level words  [31:16] plane parameter
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs A, const uint4 *items, int n_items, int dbg) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
   const int lane = threadIdx.x;
