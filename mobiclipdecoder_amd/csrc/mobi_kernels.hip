@@ -1279,8 +1279,8 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
 // Launch list built on the host (mobi_abi.cpp, LevelPlan): 16 bytes per intra macroblock, sorted by dependency level, every level
 // padded to a whole number of waves with null items (x = ~0).
 //   x = clip << 13 | mb   y = MbDesc.w1   z = MbDesc.payload_off (inside this step's arena)
-//   w = [0] 16x16 plane present  [1] has intra dependencies  [2] has intra dependents  [3] the left neighbour's last column is in the
-//       (r02: edge side buffer; unused)  [14:5] number of level words  [31:16] plane parameter
+//   w = [0] 16x16 plane present  [1] has intra dependencies  [2] has intra dependents  [3] unused (r02: the left neighbour's last
+//       column is in the edge side buffer)  [14:5] number of level words  [31:16] plane parameter
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs A, const uint4 *items, int n_items, int dbg) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
   const int lane = threadIdx.x;
