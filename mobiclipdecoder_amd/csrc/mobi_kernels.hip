@@ -431,15 +431,17 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   uint32_t cwr[CWR]; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
 #pragma unroll
   for (int k = 0; k < CWR; k++) asm volatile("" : "=v"(cwr[k])); // (whatever is there: a word is only looked at when it was loaded)
-  if ((uint32_t)j < ncoef) cwr[0] = cw[j];
+  const uint32_t *cwj = cw + j;       // word 8k + j at a constant offset from here
+  const int left = (int)ncoef - j;    // ... exists while 8k < left
+  if (left > 0) cwr[0] = cwj[0];
   if (__builtin_amdgcn_ballot_w64(ncoef > 8) != 0) {
 #pragma unroll
     for (int k = 1; k < 4; k++)
-      if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+      if (left > 8 * k) cwr[k] = cwj[8 * k];
     if (CWR > 4 && __builtin_amdgcn_ballot_w64(ncoef > 32) != 0) {
 #pragma unroll
       for (int k = 4; k < CWR; k++)
-        if ((uint32_t)(8 * k + j) < ncoef) cwr[k] = cw[8 * k + j];
+        if (left > 8 * k) cwr[k] = cwj[8 * k];
     }
   }
   // slow path (deeper trees; wrapping windows): the whole wave works for one such macroblock later: lane = (row lane >> 2, pixels
@@ -621,7 +623,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       if (((hi ? m_hi : m_lo) >> kk) & 1) {
         const int slot = slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1);
         L[P_TAB + slot] = (uint8_t)lane;
-        L[P_INV + lane] = (uint8_t)slot; // ... and area * 8 + g -> entry, for the scatter
+        L[P_INV + lane] = (uint8_t)(slot | (slot < n8 ? 0x80 : 0)); // ... and area * 8 + g -> entry (+ 0x80: an 8x8 transform), for the scatter
       }
     }
     wave_sync();
@@ -634,16 +636,15 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       }
       wave_sync();
       auto scatter = [&](uint32_t e) {
-        const int t = e & 0x1FF, level = (int32_t)e >> 16, ar = t >> 6, kk = (ar & 3) * 8 + g, p = t & 63;
-        const bool chroma = ar >= 4, is8 = ((chroma ? t_hi : t_lo) >> kk) & 1;
-        const int slot = (int)L[P_INV + ar * 8 + g] - base;
-        const int si = is8 ? p : 64 + (p & 15);
+        const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63;
+        const int inv = L[P_INV + (t >> 6) * 8 + g], slot = (inv & 0x7F) - base;
+        const int si = (inv & 0x80) ? p : 64 + (p & 15);
         const int scale = (int)lds32(L, P_SC + si * 4);
         if ((unsigned)slot < (unsigned)P_ROUND) coef[slot * P_TILE + p] = __mul24(scale, level);
       };
 #pragma unroll
       for (int k = 0; k < CWR; k++) {
-        const bool mine = (uint32_t)(8 * k + j) < ncoef;
+        const bool mine = left > 8 * k;
         if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
         uint32_t e = cwr[k];
         asm volatile("" : "+v"(e));
