@@ -60,7 +60,9 @@ def build_hip(force=False, profiling=False):
         objs.append(o)
     # the reconstruction kernels are bound by instruction issue: LLVM's ILP-first scheduling is worth 1.5 % on mobi_recon_inter8
     # (same registers, same occupancy; measured A/B on one box); the other kernels keep the default
-    extra = {"mobi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+    # r03: both kernels are bound by vector instruction issue; loops the source does not ask to unroll stay loops (-fno-unroll-loops:
+    # 2.51 against 2.57 ms per launch of 8192 clips, tools/exp_kernel_flags.sh)
+    extra = {"mobi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-unroll-loops"]}
     for s in srcs[4:]:
         ko = os.path.join(obj, os.path.basename(s) + ".o")
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DMOBI_PROFILING"] if profiling else []) + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
