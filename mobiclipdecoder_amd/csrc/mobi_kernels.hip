@@ -287,25 +287,20 @@ __device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return P_OUT
 // N output rows of 4 pixels from N + 1 window rows (x0[i], x1[i] = the two aligned dwords holding row i's 5 bytes)
 template <int N>
 __device__ __forceinline__ void mc_rows(const uint32_t (&x0)[N + 1], const uint32_t (&x1)[N + 1], uint32_t sh, int phase, uint32_t *out) {
-  const uint32_t selA = 0x03020100u + sh * 0x01010101u;
-  const bool ph0 = phase == 0, ph2 = phase == 2, ph3 = phase == 3;
-  const uint32_t selB = ph0 ? selA : selA + 0x01010101u;
-  const uint32_t Em = ph0 ? 0xFFFFFFFFu : 0xFEFEFEFEu, m2 = ph2 ? 0xFFFFFFFFu : 0u;
-  uint32_t ae[N + 1], be[N + 1], s[N + 1];
+  // CopyBlock (MD.cs:424-452) as two stages that every phase runs: h = (a >> 1) + (b >> 1) per byte with b = a and no masking when the
+  // phase has no horizontal half-pel ((a + a) >> 1 = a), then the same between a row and the row below it (or itself).
+  // (x >> 1) + (y >> 1) per byte = v_lerp_u8(x & 0xFE, y & 0xFE): the byte average of the two, which cannot carry once the low bits are gone.
+  const bool hor = (phase & 1) != 0, ver = (phase & 2) != 0;
+  const uint32_t selA = 0x03020100u + sh * 0x01010101u, selB = hor ? selA + 0x01010101u : selA;
+  const uint32_t Mh = hor ? 0xFEFEFEFEu : 0xFFFFFFFFu, Mv = ver ? 0xFEFEFEFEu : 0xFFFFFFFFu;
+  uint32_t m[N + 1];
 #pragma unroll
   for (int i = 0; i <= N; i++) {
-    ae[i] = __builtin_amdgcn_perm(x1[i], x0[i], selA) & Em;
-    be[i] = __builtin_amdgcn_perm(x1[i], x0[i], selB) & Em;
+    const uint32_t a = __builtin_amdgcn_perm(x1[i], x0[i], selA) & Mh, b = __builtin_amdgcn_perm(x1[i], x0[i], selB) & Mh;
+    m[i] = __builtin_amdgcn_lerp(a, b, 0u) & Mv;
   }
 #pragma unroll
-  for (int i = 0; i < N; i++) s[i] = __builtin_amdgcn_lerp(ae[i], (ae[i + 1] & m2) | (be[i] & ~m2), 0u); // v_bfi_b32 (a select between two
-                                                                                   // array elements would become a select between their addresses)
-  s[N] = __builtin_amdgcn_lerp(ae[N], be[N], 0u); // the horizontal average of the row below: phase 3 only
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    const uint32_t p3 = __builtin_amdgcn_lerp(s[i] & 0xFEFEFEFEu, s[i + 1] & 0xFEFEFEFEu, 0u);
-    out[i] = ph3 ? p3 : s[i];
-  }
+  for (int i = 0; i < N; i++) out[i] = __builtin_amdgcn_lerp(m[i], ver ? m[i + 1] : m[i], 0u);
 }
 } // namespace
 

@@ -9,10 +9,14 @@ run() {
   hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $P/libmobiclip_hip.so || return
   timeout 300 python $REPO/bench.py --clips 8192 --steps 96 --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 | python $REPO/tools/brief.py
 }
-run -O3 -mllvm -amdgpu-sched-strategy=max-ilp
-run -O3
-run -O3 -mllvm -amdgpu-sched-strategy=max-memory-clause
-run -O3 -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-enable-max-ilp-scheduling-strategy=1
-run -O3 -mllvm -amdgpu-sched-strategy=max-ilp -fno-unroll-loops
-run -O2 -mllvm -amdgpu-sched-strategy=max-ilp
+BASE="-O3 -mllvm -amdgpu-sched-strategy=max-ilp -fno-unroll-loops"
+run $BASE
+run $BASE -fno-slp-vectorize
+run $BASE -mllvm -amdgpu-early-ifcvt=1
+run $BASE -mllvm -amdgpu-skip-uniform-regions=1
+run $BASE -mllvm -amdgpu-late-structurize=1
+run $BASE -fno-vectorize -fno-slp-vectorize
+run $BASE -mllvm -amdgpu-scalar-ir-passes=0
+run $BASE -mllvm -amdgpu-enable-pre-ra-optimizations=0
+run -O3 -fno-unroll-loops
 cp /tmp/lib_keep.so $P/libmobiclip_hip.so; cp /tmp/k_keep.o $O/mobi_kernels.hip.o
