@@ -245,7 +245,11 @@ void exec_intra(Interp &I, int mb, const MbDesc &d) {
 
 } // namespace
 
+#include "../../mobiclipdecoder_amd/csrc/mobi_tile.h"
 extern "C" {
+// the private plane layout's address map (mobi_tile.h), for tests/test_tile_layout.py
+uint32_t mobi_test_ty(uint32_t a, int lgS) { return mobi_ty(a, lgS); }
+uint32_t mobi_test_tc(uint32_t a, int lgS) { return mobi_tc(a, lgS); }
 // how often the parser refused a stream (MOBI_E_UNSUPPORTED) in this process, by cause (mobi_parse.h: MOBI_REFUSE_*); tools/exp_refusals.py
 void mobi_cmdinterp_refusals(unsigned long out[4]) { for (int i = 0; i < MOBI_REFUSE_CLASSES; i++) out[i] = mobi_refusal_count[i]; }
 void *mobi_cmdinterp_create(uint32_t w, uint32_t h, int version) {
