@@ -181,6 +181,13 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 // lane i lands at dst + IMM + i*16; dst must be wave-uniform (it travels in M0); IMM = constant byte offset added to BOTH
 // the source address and the LDS address
 #define MOBI_DMA16(src, dst, IMM) __builtin_amdgcn_global_load_lds((gptr_t)(src), (lptr_t)(dst), 16, IMM, 0)
+// the same with the source as a wave-uniform base (an SGPR pair) + a 32-bit per-lane offset: no 64-bit address arithmetic on the vector
+// unit.  lds = the LDS byte address (wave-uniform) lane 0 lands at.  (One wait state between a write of M0 and an LDS DMA.)
+__device__ __forceinline__ void dma16_sv(const uint8_t *base, uint32_t voff, uint32_t lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+#endif
+}
 
 __device__ __forceinline__ uint32_t lds32(const uint8_t *L, int byte_off) { return *(const uint32_t *)(L + byte_off); }
 // pass 2 of one area by lane r, tracking the range of pred+residual instead of testing every sample.  Only the
@@ -280,8 +287,10 @@ enum {
                   // coded areas on average in the generator's mix, more than 16 in one octet out of five, more than 22 in one out of a hundred)
   P_SC = 9728,    // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
   P_TAB = 10048,  // entry -> area*8 + g (<= 48 bytes)
-  P_INV = 10112   // area*8 + g -> entry (48 bytes)
+  P_INV = 9408    // area*8 + g -> uint16: [6:0] entry, [15:7] what selects the dequant scale: 0x0FC (one 8x8 transform: byte offset =
+                  // 4 * position) or 0x13C (4x4 blocks: 256 + 4 * (position & 15)), see the scatter.  Behind the last coefficient tile.
 };
+static_assert(P_COEF + P_ROUND * P_TILE * 4 <= P_INV && P_INV + 96 <= P_SC, "inter LDS map");
 __device__ __forceinline__ int out_y(int g, int R, int c) { return P_OUT_Y + (R & 7) * 256 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
 __device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return P_OUT_C + (R & 3) * 256 + (R >> 2) * 128 + ((g ^ (R & 3)) << 4) + pl * 8 + x; }
 // N output rows of 4 pixels from N + 1 window rows (x0[i], x1[i] = the two aligned dwords holding row i's 5 bytes)
@@ -322,6 +331,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S);
   const uint32_t ysz = (uint32_t)S * (uint32_t)A.height;
   uint8_t *clip_base = A.planes + (size_t)clip * A.clip_bytes;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)L; // the wave's LDS as an LDS address (for M0)
   const int off0 = (int)(mby * 16 * (uint32_t)S + mbx0 * 16); // the octet's first sample as a linear offset (the slow path's currency)
   const int g = lane & 7, j = lane >> 3; // adjacent lanes = adjacent macroblocks: chunk j of the 8 macroblocks lies side by side in LDS
   unsigned long long pa = 0, pb = 0;
@@ -392,8 +402,12 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     const uint32_t base2 = b2 ? bB : bP, v2 = b2 ? vB : vP, base34 = b34 ? bB : bP, v34 = b34 ? vB : vP;
     const uint32_t v4 = (!tb && ph) ? v34 - 1u : v34;         // a whole leaf has no tenth pair: the ninth again
     uint32_t o[5] = {bP + rowpart(vP), bP + rowpart(vP + 2), base2 + rowpart(v2 + 4), base34 + rowpart(v34 + 6), base34 + rowpart(v4 + 8)};
+    // (only the lanes of macroblocks fetched this way ask: one execution mask for all eight rounds; the others' places in LDS keep
+    // whatever they held -- their motion compensation below runs on it and is overwritten or never stored)
+    if (win) {
 #pragma unroll
-    for (int t = 0; t < 5; t++) MOBI_DMA16(clip_base + (win ? o[t] : 0u), L + P_L + t * 1024, 0);
+      for (int t = 0; t < 5; t++) dma16_sv(clip_base, o[t], lds0 + P_L + t * 1024);
+    }
     // chroma rounds: lane (g, j) brings chunk (row 4t + (j >> 1), column j & 1): both planes of that row
     const int cs = j & 1, ch2 = j >> 1;
     auto cchunk0 = [&](int ctop, uint32_t ref, uint32_t &r) {
@@ -411,16 +425,27 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     const uint32_t cbase1 = cb1 ? cB : cA, q1 = cb1 ? qB : qA, cbase2 = tb ? cB : cA;
     const uint32_t q2 = tb ? qB - (ch2 >= 2 ? (uint32_t)ch2 - 1u : 0u) : qA - (uint32_t)ch2;
     const uint32_t co[3] = {cA + crowpart(qA), cbase1 + crowpart(q1 + 4), cbase2 + crowpart(q2 + 8)};
+    if (win) {
 #pragma unroll
-    for (int t = 0; t < 3; t++) MOBI_DMA16(clip_base + (win ? co[t] : 0u), L + P_C + t * 1024, 0);
+      for (int t = 0; t < 3; t++) dma16_sv(clip_base, co[t], lds0 + P_C + t * 1024);
+    }
     if (any_lr) { // the right halves of LEFT/RIGHT pairs: rows 0..8 of leaf B's own window
       const uint32_t q3 = rB + (uint32_t)ch2;
-      const bool on = lr && win;
-      MOBI_DMA16(clip_base + (on ? cB + crowpart(q3) : 0u), L + P_C1, 0);
-      MOBI_DMA16(clip_base + (on ? cB + crowpart(q3 + 4) : 0u), L + P_C1 + 1024, 0);
-      MOBI_DMA16(clip_base + (on ? cB + crowpart(q3 + 8 - (uint32_t)ch2) : 0u), L + P_C1 + 2048, 0);
+      if (lr && win) {
+        dma16_sv(clip_base, cB + crowpart(q3), lds0 + P_C1);
+        dma16_sv(clip_base, cB + crowpart(q3 + 4), lds0 + P_C1 + 1024);
+        dma16_sv(clip_base, cB + crowpart(q3 + 8 - (uint32_t)ch2), lds0 + P_C1 + 2048);
+      }
     }
   }
+#ifdef MOBI_EXP_PAD_A // tools/exp_pad.sh: does the launch follow the instruction count?  (idle vector / scalar instructions behind stage A's requests)
+#pragma unroll
+  for (int k = 0; k < MOBI_EXP_PAD_A; k++) asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
+#endif
+#ifdef MOBI_EXP_PAD_S
+#pragma unroll
+  for (int k = 0; k < MOBI_EXP_PAD_S; k++) asm volatile("s_nop 0");
+#endif
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
   const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
   uint32_t cwr[CWR]; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
@@ -477,12 +502,13 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       D.csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
       const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
       la = ybase + ((dya >> 1) << lgS) + (dxa >> 1); D.pha = (dxa & 1) | ((dya & 1) << 1); sa = slot_off((uint32_t)mobi_cell_ref(yc.x));
-      lb = ybase + ((dyb >> 1) << lgS) + (dxb >> 1); D.phb = (dxb & 1) | ((dyb & 1) << 1); sb = slot_off((uint32_t)mobi_cell_ref(yc.y));
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
+      auto csrc = [&](int k) {
         const int qx = mobi_cell_dx(cell[k]) >> 1, qy = mobi_cell_dy(cell[k]) >> 1;
         lq[k] = cbase + ((qy >> 1) << lgS) + (qx >> 1); D.phq[k] = (qx & 1) | ((qy & 1) << 1); sq[k] = slot_off((uint32_t)mobi_cell_ref(cell[k]));
-      }
+      };
+      csrc(0);
+      if (D.ysplit) { lb = ybase + ((dyb >> 1) << lgS) + (dxb >> 1); D.phb = (dxb & 1) | ((dyb & 1) << 1); sb = slot_off((uint32_t)mobi_cell_ref(yc.y)); }
+      if (D.csplit) { csrc(1); csrc(2); csrc(3); }
     } else { // whole leaves whose windows wrap: the leaf records of lane gm
       const uint32_t w1m = __builtin_amdgcn_readlane(d.y, gm), w2m = __builtin_amdgcn_readlane(d.z, gm);
       const int pAm = (int)__builtin_amdgcn_readlane(d.w, gm), cAm = (int)__builtin_amdgcn_readlane(d2.x, gm);
@@ -491,15 +517,12 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       const bool yBm = k2 == MOBI_DUAL_TB ? yrow >= 8 : k2 == MOBI_DUAL_LR ? yc4 >= 8 : false;
       const bool cBl2 = k2 == MOBI_DUAL_TB ? crow >= 4 : k2 == MOBI_DUAL_LR ? cc4 >= 4 : false;
       D.ysplit = D.csplit = false;
-      la = lb = (yBm ? pBm : pAm) + (yrow << lgS) + yc4;
-      D.pha = D.phb = (w2m >> (yBm ? 20 : 16)) & 3;
-      sa = sb = slot_off((w2m >> (yBm ? 13 : 10)) & 7);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        lq[k] = (cBl2 ? cBm : cAm) + cv * (S >> 1) + (crow << lgS) + cc4;
-        D.phq[k] = (w2m >> (cBl2 ? 22 : 18)) & 3;
-        sq[k] = slot_off((w2m >> (cBl2 ? 13 : 10)) & 7);
-      }
+      la = (yBm ? pBm : pAm) + (yrow << lgS) + yc4;
+      D.pha = (w2m >> (yBm ? 20 : 16)) & 3;
+      sa = slot_off((w2m >> (yBm ? 13 : 10)) & 7);
+      lq[0] = (cBl2 ? cBm : cAm) + cv * (S >> 1) + (crow << lgS) + cc4;
+      D.phq[0] = (w2m >> (cBl2 ? 22 : 18)) & 3;
+      sq[0] = slot_off((w2m >> (cBl2 ? 13 : 10)) & 7);
     }
     // some lane's window within 8 bytes of the end of a plane row (chroma: of a plane's half): every dword is mapped on its own
     bool gen = (((uint32_t)la & (uint32_t)(S - 1)) >= (uint32_t)(S - 8)) || (((uint32_t)lq[0] & (uint32_t)((S >> 1) - 1)) >= (uint32_t)((S >> 1) - 8));
@@ -618,7 +641,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       if (((hi ? m_hi : m_lo) >> kk) & 1) {
         const int slot = slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1);
         L[P_TAB + slot] = (uint8_t)lane;
-        L[P_INV + lane] = (uint8_t)(slot | (slot < n8 ? 0x80 : 0)); // ... and area * 8 + g -> entry (+ 0x80: an 8x8 transform), for the scatter
+        *(uint16_t *)(L + P_INV + 2 * lane) = (uint16_t)(slot | ((slot < n8 ? 0x0FC : 0x13C) << 7)); // ... and area * 8 + g -> entry, for the scatter
       }
     }
     wave_sync();
@@ -632,9 +655,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       wave_sync();
       auto scatter = [&](uint32_t e) {
         const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63;
-        const int inv = L[P_INV + (t >> 6) * 8 + g], slot = (inv & 0x7F) - base;
-        const int si = (inv & 0x80) ? p : 64 + (p & 15);
-        const int scale = (int)lds32(L, P_SC + si * 4);
+        const uint32_t inv = *(const uint16_t *)(L + P_INV + ((t >> 6) * 8 + g) * 2);
+        const int slot = (int)(inv & 0x7F) - base;
+        const int scale = (int)lds32(L, P_SC + (int)((((uint32_t)t << 2) | 0x100u) & (inv >> 7))); // scale8[p] or scale4[p & 15] (80 words: 64 + 16)
         if ((unsigned)slot < (unsigned)P_ROUND) coef[slot * P_TILE + p] = __mul24(scale, level);
       };
 #pragma unroll
@@ -696,6 +719,10 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
   if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt[5] = prof_stamp(); }
 
+#ifdef MOBI_EXP_PAD_D
+#pragma unroll
+  for (int k = 0; k < MOBI_EXP_PAD_D; k++) asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
+#endif
   // ---- stage D: the octet's tiles are contiguous: 2 KB of luma, 1 KB of chroma, whole lines ----
   // Intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them), and behind the picture's last
   // macroblock (848 = 53 macroblocks: the seventh octet holds five) the zeros the padding already holds: HBM turns every store
