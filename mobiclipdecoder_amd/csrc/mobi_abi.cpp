@@ -808,7 +808,9 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
   a.done = b->d_done;
   if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
-  if (mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), n_mbs, b->stream) != 0) return MOBI_E_DEVICE;
+  // the parse has not run yet, so nobody knows how many intra macroblocks the longest list will have: MOBI_ASYNC_INTRA_SLOTS slots are launched
+  // (a P-frame's lists are shorter), and the workgroups of the last one walk through the rest of theirs (an I-frame: every macroblock)
+  if (mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), std::min(n_mbs, MOBI_ASYNC_INTRA_SLOTS), b->stream) != 0) return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(S.h_fault.p, b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   HIP_TRY(hipEventRecord(S.ev_done, b->stream));

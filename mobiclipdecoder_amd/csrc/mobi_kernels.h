@@ -36,7 +36,9 @@ static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);
 // items_dev: n_items launch items of 16 bytes (MOBI_INTRA_ITEM_WORDS words), sorted by dependency level -- see LevelPlan in mobi_abi.cpp
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
-// device-parsed frames: items_dev = [clip][n_mbs] in raster order, n_intra_dev[clip * stride_words] of them valid; K = the largest count
+// device-parsed frames: items_dev = [clip][n_mbs] in raster order, n_intra_dev[clip * stride_words] of them valid; K = the slots launched:
+// the largest count when the host knows it, else MOBI_ASYNC_INTRA_SLOTS (longer lists are walked by the workgroups of slot K - 1)
+#define MOBI_ASYNC_INTRA_SLOTS 160
 extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s);
 // MD.cs:260-323: ring slot 0 of clips [clip0, clip0 + n_clips) -> out_dev[clip][height][width] 0xAARRGGBB words (mobi_rgb.hip)
 extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, int n_clips, uint32_t *out_dev, hipStream_t s);

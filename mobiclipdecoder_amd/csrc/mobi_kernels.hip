@@ -1320,19 +1320,32 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs 
 // a row waits for (raster-earlier, same clip) always sits in an earlier slot, i.e. was dispatched before it.  Nothing here
 // knows who depends on whom before the descriptor has been read: every macroblock looks at its dependency list and publishes its tag.
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconArgs A, const uint32_t *items, const uint32_t *n_intra, uint32_t n_intra_stride,
-                                                                      uint32_t quads, uint32_t magic_quads) {
+                                                                      uint32_t quads, uint32_t magic_quads, uint32_t last_slot) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
   const int lane = threadIdx.x;
   uint32_t cq;
-  const uint32_t slot = fastdiv(blockIdx.x, quads, magic_quads, cq);
+  uint32_t slot = fastdiv(blockIdx.x, quads, magic_quads, cq);
   const uint32_t clip = 4 * cq + (uint32_t)(lane >> 4);
-  const bool valid = clip < (uint32_t)A.n_clips && slot < n_intra[(size_t)(clip < (uint32_t)A.n_clips ? clip : 0) * n_intra_stride];
-  if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
-  const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
-  const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
-  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
-                valid ? desc->w2 & 0x3FFu : 0u, true, true};
-  recon_intra_quad(A, lds, I, lane);
+  const bool inb = clip < (uint32_t)A.n_clips;
+  const uint32_t ni = inb ? n_intra[(size_t)clip * n_intra_stride] : 0u;
+  // The launch covers slots 0..last_slot.  When the host does not know the longest list (a step submitted before its parse has run:
+  // mobi_batch_submit launches MOBI_ASYNC_INTRA_SLOTS of them, not one per macroblock of the picture), the workgroup of the last slot
+  // walks on through whatever its four clips still have: those macroblocks depend on raster-earlier ones of the same clip only --
+  // earlier slots (dispatched before this workgroup) or this workgroup's own earlier rounds -- so the waits still cannot deadlock;
+  // they just run one after the other, which a raster chain that long mostly does anyway.
+  const bool walks = slot == last_slot; // (wave-uniform)
+  for (;;) {
+    const bool valid = slot < ni;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
+    const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
+    const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
+    const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
+                  valid ? desc->w2 & 0x3FFu : 0u, true, true};
+    recon_intra_quad(A, lds, I, lane);
+    if (!walks) return;
+    slot++;
+    wave_sync();
+  }
 }
 
 // =====================================================================================================
@@ -1382,11 +1395,12 @@ extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_d
   hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items / 4), dim3(64), pad, s, *a, (const uint4 *)items_dev, n_items, dbg);
   return (int)hipGetLastError();
 }
+// K slots are launched; lists longer than K are finished by the workgroups of slot K - 1 (see the kernel)
 extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s) {
   if (K <= 0 || a->n_clips <= 0) return 0;
   const uint32_t quads = ((uint32_t)a->n_clips + 3) / 4;
   const uint64_t m = ((uint64_t)1 << 32) / quads;
   hipLaunchKernelGGL(mobi_recon_intra_cl, dim3((unsigned)K * quads), dim3(64), 0, s, *a, items_dev, n_intra_dev, (uint32_t)n_intra_stride_words, quads,
-                     (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m));
+                     (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m), (uint32_t)K - 1u);
   return (int)hipGetLastError();
 }
