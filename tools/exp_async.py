@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 streams = []
 for i in range(16):
-    p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=3 + steps)
+    p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=3 + steps, **({"iframe_interval": 1} if os.environ.get("IFRAMES") else {}))  # IFRAMES=1: every frame an I-frame
     d, fo = m.generate_clip(p)
     streams.append((d, fo))
 b = m.MobiclipBatch(n, 640, 480, p.version, device_parse=True)
