@@ -4,6 +4,7 @@
   libmobi_streamgen.so    synthetic bitstream generator (input source)           (g++)
   oracle/_build/libmobi_oracle.so   CPU oracle = TEST INFRASTRUCTURE             (gcc)
   tests/tools/libmobi_cmdinterp.so  CPU command-list interpreter = TEST TOOL     (g++)
+  tests/tools/libmobi_lsparse_host.so  lock-step parser's lane functions on the CPU = TEST TOOL (g++)
   tests/tools/abi_caller            plain-C caller of the product's C ABI = TEST TOOL (gcc)
 
 hipcc cross-compiles gfx950 without a GPU.  The built .so files are git-ignored but travel to the
@@ -24,6 +25,7 @@ LIB_HIP = os.path.join(PKG, "libmobiclip_hip.so")
 LIB_GEN = os.path.join(PKG, "libmobi_streamgen.so")
 LIB_ORACLE = os.path.join(ROOT, "oracle", "_build", "libmobi_oracle.so")
 LIB_INTERP = os.path.join(ROOT, "tests", "tools", "libmobi_cmdinterp.so")
+LIB_LSHOST = os.path.join(ROOT, "tests", "tools", "libmobi_lsparse_host.so")  # the lock-step parser's lane functions on the CPU (test tool)
 ABI_CALLER = os.path.join(ROOT, "tests", "tools", "abi_caller")  # plain-C caller of the product library (test tool)
 
 
@@ -95,6 +97,14 @@ def build_interp(force=False):
     return LIB_INTERP
 
 
+def build_lshost(force=False):
+    src = os.path.join(ROOT, "tests", "tools", "mobi_lsparse_host.cpp")
+    parse = os.path.join(CSRC, "mobi_parse.cpp")
+    if force or _newer(LIB_LSHOST, [src, parse] + _hdrs(CSRC)):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + CSRC, src, parse, "-o", LIB_LSHOST])
+    return LIB_LSHOST
+
+
 def build_caller(force=False):
     src = os.path.join(ROOT, "tests", "tools", "abi_caller.c")
     if force or _newer(ABI_CALLER, [src, os.path.join(ROOT, "include", "mobiclip_hip.h"), LIB_HIP]):
@@ -103,7 +113,7 @@ def build_caller(force=False):
 
 
 def build_all(force=False):
-    return [build_hip(force), build_gen(force), build_oracle(force), build_interp(force), build_caller(force)]
+    return [build_hip(force), build_gen(force), build_oracle(force), build_interp(force), build_lshost(force), build_caller(force)]
 
 
 if __name__ == "__main__":

@@ -67,6 +67,8 @@ class MobiStreamParser {
   uint32_t quantizer() const { return quant_; }
   uint32_t yuv_format() const { return yuvfmt_; }
   int frames_started() const { return frames_started_; }
+  const uint8_t *mode_cache() const { return mcache_; }                // bytes of Internal[0..9] (40 of them)
+  bool quant_tables_set() const { return (dq8_[1] & 0xFF) != 0; }      // SetupQuantTables ran: the zigzag bytes of Internal[10..] are there
   const MobiGeom &geom() const { return g_; }
   int version() const { return version_; }
 

@@ -1,0 +1,189 @@
+// mobi_lsparse_host.cpp -- TEST TOOL: the lock-step parser's per-lane functions (mobi_lsparse.h) run on the CPU, one clip at a time, against
+// the host parser (mobi_parse.cpp) on the same frames: descriptors, payload, intra list, consumed bytes and persistent state must be equal
+// whenever the lock-step parser does not bail out, and it must bail out whenever the host parser reports anything but MOBI_OK.
+// Built by mobiclipdecoder_amd/build.py into tests/tools/libmobi_lsparse_host.so; used by tests/test_lsparse.py.  Not part of the product.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "mobi_lsparse.h"
+#include "mobi_parse.h"
+
+namespace {
+struct HostStore {
+  int32_t mvc_[2 * (64 + 2)];
+  uint32_t stk_[16];
+  uint32_t rec_[MOBI_INTRA_RECORDS];
+  uint8_t mc_[40];
+  const uint8_t *data;
+  uint32_t len2; // bytes that exist as whole 16-bit words
+  int32_t &mvc(int i) { return mvc_[i]; }
+  uint32_t &stk(int i) { return stk_[i]; }
+  uint32_t &rec(int i) { return rec_[i]; }
+  uint8_t &mc(int i) { return mc_[i]; }
+  uint32_t ring32(uint32_t rd) const {
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++)
+      if (rd + k < len2) v |= (uint32_t)data[rd + k] << (8 * k);
+    return v;
+  }
+};
+struct Clip {
+  int w, h, version;
+  MobiGeom g;
+  std::vector<uint8_t> tables;
+  HostStore m;
+  LsLane s;
+  uint32_t quant = 0, yuvfmt = 0, tables_set = 0;
+  int frames_started = 0;
+  std::vector<MbDesc> desc;
+  std::vector<uint32_t> pay, items;
+  long rounds = 0, rounds_by_state[16] = {0};
+};
+} // namespace
+
+extern "C" {
+void *mobi_lshost_create(uint32_t w, uint32_t h, int version) {
+  if ((w & 15) || (h & 15) || w == 0 || h == 0 || w > 1024) return nullptr;
+  Clip *c = new Clip();
+  c->w = (int)w; c->h = (int)h; c->version = version;
+  MobiStreamParser p(w, h, version);
+  c->g = p.geom();
+  c->tables.resize(MOBI_DT_BYTES);
+  mobi_dparse_build_tables(version, c->tables.data());
+  memset(&c->m, 0, sizeof(c->m));
+  const int n = c->g.mbw * c->g.mbh;
+  c->desc.resize(n);
+  c->items.resize(n);
+  c->pay.resize((size_t)n * 448 + 64);
+  return c;
+}
+void mobi_lshost_destroy(void *p) { delete (Clip *)p; }
+// One frame.  Returns the bail code (0 = parsed); *consumed, *n_intra, *pay_words as MobiDevResult would carry them.
+int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consumed, uint32_t *n_intra, uint32_t *pay_words, uint32_t *frame_type) {
+  Clip &C = *(Clip *)p;
+  LsCtx c;
+  c.T = C.tables.data();
+  c.width = C.w; c.height = C.h; c.stride = C.g.stride; c.lg = C.g.lg; c.mbw = C.g.mbw; c.mbh = C.g.mbh; c.n_mbs = C.g.mbw * C.g.mbh;
+  c.version = C.version;
+  c.pay_cap = (uint32_t)C.pay.size();
+  c.pay = C.pay.data();
+  // work on copies of what survives the frame: a bail-out must leave it as it was
+  HostStore m = C.m;
+  m.data = data;
+  m.len2 = (uint32_t)len & ~1u;
+  LsLane s;
+  memset(&s, 0, sizeof(s));
+  s.quant = C.quant; s.yuvfmt = C.yuvfmt; s.tables_set = C.tables_set; s.frames_started = C.frames_started + 1;
+  s.desc = C.desc.data(); s.pay_base = 0; s.clip = 0; s.items = C.items.data();
+  ls_begin_frame(s, m, c, (uint32_t)len);
+  while (s.st != LS_DONE) {
+    C.rounds++;
+    C.rounds_by_state[s.st & 15]++;
+    ls_step(s, m, c);
+  }
+  if (!s.bail) {
+    const int used = ls_consumed(s.cbits, (uint32_t)len);
+    if (used < 0) s.bail = 16;
+    else *consumed = used;
+  }
+  if (s.bail) return s.bail;
+  const LsGeom g{C.w, C.h, C.g.stride, C.g.lg, C.g.mbw};
+  for (uint32_t i = 0; i < s.n_items; i++)
+    if (!ls_intra_deps(g, C.desc.data(), (int)(C.items[i] & 0x1FFF))) return 17;
+  C.m = m;
+  C.quant = s.quant; C.yuvfmt = s.yuvfmt; C.tables_set = s.tables_set; C.frames_started = s.frames_started;
+  *n_intra = s.n_items;
+  *pay_words = s.pay_pos;
+  *frame_type = (uint32_t)s.iframe;
+  return 0;
+}
+const MbDesc *mobi_lshost_desc(void *p) { return ((Clip *)p)->desc.data(); }
+const uint32_t *mobi_lshost_payload(void *p) { return ((Clip *)p)->pay.data(); }
+const uint32_t *mobi_lshost_items(void *p) { return ((Clip *)p)->items.data(); }
+uint32_t mobi_lshost_quant(void *p) { return ((Clip *)p)->quant; }
+long mobi_lshost_rounds(void *p, long by_state[16]) {
+  Clip &C = *(Clip *)p;
+  if (by_state) for (int i = 0; i < 16; i++) by_state[i] = C.rounds_by_state[i];
+  return C.rounds;
+}
+
+// The whole differential in one call: every frame of a clip through both parsers.  Returns the number of frames that compared equal
+// (all of them: n_frames), or -(frame + 1) at the first difference (what differs goes to stderr).  *bails = frames the lock-step parser
+// left to the other one (allowed only when allow_bail is set or the host parser did not return MOBI_OK).
+int mobi_lshost_compare(uint32_t w, uint32_t h, int version, const uint8_t *data, const uint32_t *frame_off, int n_frames, int allow_bail, int *bails) {
+  Clip *C = (Clip *)mobi_lshost_create(w, h, version);
+  if (!C) return -1000000;
+  MobiStreamParser hp(w, h, version);
+  ParsedFrame pf;
+  int ok = 0;
+  *bails = 0;
+  for (int f = 0; f < n_frames; f++) {
+    const uint8_t *d = data + frame_off[f];
+    const size_t len = frame_off[f + 1] - frame_off[f];
+    int32_t off = 0;
+    const int rc = hp.parse_frame(d, len, &off, pf);
+    int32_t used = 0;
+    uint32_t n_intra = 0, pay_words = 0, ftype = 0;
+    const int bail = mobi_lshost_parse(C, d, len, &used, &n_intra, &pay_words, &ftype);
+    auto adopt = [&]() { // what survives the frame, as the parser that finished it leaves it (mobi_parse_frames on the device)
+      C->quant = hp.quantizer(); C->yuvfmt = hp.yuv_format(); C->frames_started = hp.frames_started(); C->tables_set = hp.quant_tables_set();
+      memcpy(C->m.mc_, hp.mode_cache(), 40);
+    };
+    if (bail) {
+      (*bails)++;
+      if (rc == MOBI_OK && !allow_bail) { fprintf(stderr, "frame %d: bail-out %d on a frame the host parser accepts\n", f, bail); ok = -(f + 1); break; }
+      adopt();
+      ok++;
+      continue;
+    }
+    if (rc != MOBI_OK) { fprintf(stderr, "frame %d: host parser says %d, the lock-step parser went through\n", f, rc); ok = -(f + 1); break; }
+    if (C->yuvfmt != hp.yuv_format() || C->frames_started != hp.frames_started() || C->tables_set != (uint32_t)hp.quant_tables_set() ||
+        memcmp(C->m.mc_, hp.mode_cache(), 40) != 0) {
+      fprintf(stderr, "frame %d: persistent state differs\n", f);
+      ok = -(f + 1);
+      break;
+    }
+    bool same = used == off && pay_words == pf.payload.size() && ftype == pf.hdr.frame_type && n_intra == pf.hdr.n_intra && C->quant == hp.quantizer();
+    if (!same) fprintf(stderr, "frame %d: consumed %d/%d payload %u/%zu type %u/%u intra %u/%u quant %u/%u\n", f, used, off, pay_words, pf.payload.size(), ftype,
+                       pf.hdr.frame_type, n_intra, pf.hdr.n_intra, C->quant, hp.quantizer());
+    for (size_t mb = 0; same && mb < pf.desc.size(); mb++) {
+      const MbDesc &a = C->desc[mb], &b = pf.desc[mb];
+      bool eq = a.payload_off == b.payload_off && a.w1 == b.w1 && a.w2 == b.w2 && a.w3 == b.w3;
+      if ((a.w1 & 1) == MOBI_MB_INTER) eq = eq && a.w4 == b.w4 && a.w5 == b.w5 && a.w6 == b.w6 && a.w7 == b.w7;
+      else { // the same SET of dependencies
+        uint32_t da[8], db[8];
+        for (int k = 0; k < 4; k++) {
+          const uint32_t wa = (&a.w4)[k], wb = (&b.w4)[k];
+          da[2 * k] = wa & 0xFFFF; da[2 * k + 1] = wa >> 16; db[2 * k] = wb & 0xFFFF; db[2 * k + 1] = wb >> 16;
+        }
+        for (int k = 0; k < 8; k++) {
+          bool fa = da[k] == MOBI_DEP_NONE, fb = db[k] == MOBI_DEP_NONE;
+          for (int j = 0; j < 8; j++) { fa = fa || da[k] == db[j]; fb = fb || db[k] == da[j]; }
+          eq = eq && fa && fb;
+        }
+      }
+      if (!eq) {
+        fprintf(stderr, "frame %d mb %zu: desc %08x %08x %08x %08x %08x %08x %08x %08x  vs host %08x %08x %08x %08x %08x %08x %08x %08x\n", f, mb, a.payload_off, a.w1,
+                a.w2, a.w3, a.w4, a.w5, a.w6, a.w7, b.payload_off, b.w1, b.w2, b.w3, b.w4, b.w5, b.w6, b.w7);
+        same = false;
+      }
+    }
+    for (size_t i = 0; same && i < pf.payload.size(); i++)
+      if (C->pay[i] != pf.payload[i]) { fprintf(stderr, "frame %d: payload word %zu %08x vs host %08x\n", f, i, C->pay[i], pf.payload[i]); same = false; }
+    // the intra list: the host's is sorted by level, this one in raster order -- the same set
+    if (same) {
+      std::vector<uint32_t> x(C->items.begin(), C->items.begin() + n_intra), y(pf.intra_mbs.begin(), pf.intra_mbs.end());
+      for (auto &v : x) v &= 0x1FFF;
+      std::sort(x.begin(), x.end());
+      std::sort(y.begin(), y.end());
+      if (x != y) { fprintf(stderr, "frame %d: intra lists differ\n", f); same = false; }
+    }
+    if (!same) { ok = -(f + 1); break; }
+    ok++;
+  }
+  mobi_lshost_destroy(C);
+  return ok;
+}
+}
