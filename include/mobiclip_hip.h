@@ -94,8 +94,15 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * unless the first call hands over far more than a frame per clip -- whole files as Data, MOC5 style -- which the device path
  * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1/2.  2 = hybrid: the GPU parses most clips while the
  * host pool parses a fixed share of them (a fifth, at most 1024; MOBI_HYBRID_HOST_CLIPS) at the same time; one set of
- * reconstruction launches serves both.  Can only be changed before the first frame: the decoder state lives on one side. */
+ * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front (mobi_lsparse.hip: 64 clips per wavefront, one per
+ * lane, all lanes in one instruction stream): it finishes the frames that decode without incident -- identically, word for word -- and
+ * leaves every other clip (anything the reference throws on, refusals, data ending inside a frame) to the one-wavefront-per-clip
+ * parser, which then runs for those alone.  Pays from about 8000 resident clips.  Can only be changed before the first frame: the
+ * decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
+/* Parse mode 3: how many clips of the last finished frame step the lock-step parser finished itself (the rest went to the other one);
+ * -1 in the other modes or before the first step. */
+int mobi_batch_lockstep_finished(const mobi_batch *b);
 /* Asynchronous frame steps, for callers that already hold the next frame of every clip (demuxed Moflex / Mods packets: the Offset
  * to start from does not depend on the previous frame's parse).  The batch must parse on the GPU (the default from 1024 clips;
  * mobi_batch_set_parse_mode(b, 1) otherwise; not the hybrid mode) and at most two steps may be in flight.

@@ -48,7 +48,7 @@ def _hdrs(d):
 def build_hip(force=False, profiling=False):
     """profiling=True (python build.py --profiling, tools/ only): -DMOBI_PROFILING compiles the ablation / occupancy switches
     (MOBI_INTRA_DBG, MOBI_LDS_PAD, MOBI_INTRA_LDS_PAD) in; the default build has none of them."""
-    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip", "mobi_dparse.hip", "mobi_analysis.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip", "mobi_dparse.hip", "mobi_lsparse.hip", "mobi_analysis.hip")]
     deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h"), os.path.join(ROOT, "include", "mobiclip_demux.h")]
     if not force and not profiling and not _newer(LIB_HIP, deps):
         return LIB_HIP

@@ -292,6 +292,9 @@ struct mobi_batch {
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
   DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
   MobiDevState *d_pstate = nullptr;
+  MobiDevState *d_pstate_ls = nullptr; // shadow copy the lock-step parser writes (mobi_lsparse.hip)
+  int ls_finished = -1;                // clips of the last step it finished itself
+  bool lockstep = false;               // mobi_batch_set_parse_mode(b, 3) / MOBI_DEVICE_PARSE=3: mobi_parse_frames_ls in front of mobi_parse_frames
   MobiDevResult *d_pres = nullptr;
   uint8_t *d_ptables = nullptr;
   PinnedBuf h_pres;
@@ -408,6 +411,7 @@ struct mobi_batch {
     if (d_lin) (void)hipFree(d_lin);
     if (d_argb) (void)hipFree(d_argb);
     if (d_pstate) (void)hipFree(d_pstate);
+    if (d_pstate_ls) (void)hipFree(d_pstate_ls);
     if (d_pres) (void)hipFree(d_pres);
     if (d_ptables) (void)hipFree(d_ptables);
     if (stream) (void)hipStreamDestroy(stream);
@@ -528,7 +532,12 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     b->parse_auto = true;
-    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) { b->parse_mode = std::max(0, std::min(2, atoi(dp))); b->parse_auto = false; }
+    if (const char *dp = getenv("MOBI_DEVICE_PARSE")) {
+      const int v = atoi(dp); // 3: on the GPU, the lock-step parser (64 clips per wave) in front
+      b->parse_mode = v == 3 ? 1 : std::max(0, std::min(2, v));
+      b->lockstep = v == 3;
+      b->parse_auto = false;
+    }
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
     b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
@@ -565,12 +574,14 @@ static int dp_init(mobi_batch *b) {
     MobiDevState *st = nullptr;
     HIP_TRY(hipMalloc((void **)&st, sizeof(MobiDevState) * n));
     if (hipMemset(st, 0, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
+    if (hipMalloc((void **)&b->d_pstate_ls, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
     b->d_pstate = st; // last: its presence means "initialised"
     return MOBI_OK;
   };
   if (int e = init()) {
     if (b->d_pres) { (void)hipFree(b->d_pres); b->d_pres = nullptr; }
     if (b->d_ptables) { (void)hipFree(b->d_ptables); b->d_ptables = nullptr; }
+    if (b->d_pstate_ls) { (void)hipFree(b->d_pstate_ls); b->d_pstate_ls = nullptr; }
     return e;
   }
   b->dev_quant.assign(n, 0);
@@ -640,6 +651,8 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   pa.bit_len = (const uint32_t *)(d_bits + (size_t)nd * 8);
   pa.tables = b->d_ptables;
   pa.state = b->d_pstate;
+  pa.state_ls = b->d_pstate_ls;
+  pa.lockstep = b->lockstep ? 1 : 0;
   pa.desc = (MbDesc *)b->d_pdesc.p;
   pa.payload = (uint32_t *)b->d_ppay.p;
   pa.items = (uint32_t *)b->d_pitems.p;
@@ -720,7 +733,9 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   HIP_TRY(hipStreamSynchronize(b->stream)); // the launch sizes below depend on what the parse found
   if (ptime) { float ms = 0; if (hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
   uint32_t K = 0;
+  if (b->lockstep) b->ls_finished = 0;
   for (int i = 0; i < nd; i++) {
+    if (b->lockstep && res[i].pad == 0x4C53u) b->ls_finished++;
     rc[i] = res[i].rc;
     offsets[i] += res[i].consumed;
     b->dev_quant[i] = res[i].quant;
@@ -828,7 +843,9 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   HIP_TRY(hipEventSynchronize(S.ev_done));
   const MobiDevResult *res = (const MobiDevResult *)S.h_pres.p;
   const int *fault = (const int *)S.h_fault.p;
+  if (b->lockstep) b->ls_finished = 0;
   for (int i = 0; i < S.n_dev; i++) {
+    if (b->lockstep && res[i].pad == 0x4C53u) b->ls_finished++;
     rc[i] = res[i].rc;
     if (offsets_out) offsets_out[i] = S.offs[i] + (int32_t)res[i].consumed;
     b->dev_quant[i] = res[i].quant;
@@ -841,10 +858,12 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
 }
 
 int mobi_batch_in_flight(const mobi_batch *b) { return b ? b->async_count : 0; }
+int mobi_batch_lockstep_finished(const mobi_batch *b) { return b && b->lockstep ? b->ls_finished : -1; }
 
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
   if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
   b->parse_mode = device_parse == 2 ? 2 : device_parse != 0;
+  b->lockstep = device_parse == 3;
   b->parse_auto = false;
   return MOBI_OK;
 }

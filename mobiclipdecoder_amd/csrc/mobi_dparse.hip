@@ -687,11 +687,24 @@ struct DP {
 extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves_per_eu(MOBI_PARSE_WAVES, MOBI_PARSE_WAVES))) void mobi_parse_frames(MobiDevParseArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t tab[MOBI_DT_BYTES];
   __shared__ WaveLds wl[PWAVES];
-  for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += 64 * PWAVES) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
-  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int clip = blockIdx.x * PWAVES + wave;
-  if (clip >= A.n_clips) return;
+  bool finished = false; // by the lock-step parser in front (mobi_lsparse.hip): its new decoder state only has to move into place
+  if (A.lockstep) {
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < PWAVES; w++) {
+      const int cw = blockIdx.x * PWAVES + w;
+      const bool f = cw < A.n_clips && A.res[cw].pad == 0x4C53u; // LS_MAGIC
+      all = all && (f || cw >= A.n_clips);
+      if (w == wave) finished = f;
+    }
+    if (finished && lane == 0) A.state[clip] = A.state_ls[clip];
+    if (all) return; // (every thread of the workgroup sees the same four records)
+  }
+  for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += 64 * PWAVES) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
+  __syncthreads();
+  if (clip >= A.n_clips || finished) return;
   const int n_mbs = A.mbw * A.mbh;
   WaveLds *L = &wl[wave];
   int rc_lane = 0;
@@ -764,6 +777,8 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
 extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64) return (int)hipErrorInvalidValue;
+  if (a->lockstep)
+    if (int e = mobi_launch_parse_ls(a, s)) return e;
   hipLaunchKernelGGL(mobi_parse_frames, dim3((unsigned)((a->n_clips + PWAVES - 1) / PWAVES)), dim3(64 * PWAVES), 0, s, *a);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,172 @@
+// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: 64 clips per wave, one per lane (mobi_lsparse.h has the state machine and
+// says why).
+//
+//   mobi_parse_frames_ls   one wave = 64 clips.  Every lane walks its own frame with ls_step(); the wave runs until the last one is done.
+//                          A lane that meets anything out of the ordinary bails out and leaves its clip to mobi_parse_frames.
+//   mobi_ls_deps           one lane per intra macroblock of the clips the first kernel finished: the dependency lists (MbDesc.w4..w7).
+//   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
+//                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
+//
+// LDS per wave: the table blob (18 KB), and per lane the motion-vector row cache (2 (mbw + 2) words), the partition-tree stack (16), the
+// intra records (24), the mode cache (40 bytes), a 64-byte ring of bitstream -- all lane-interleaved (element i of lane l at i * 64 + l), so
+// that 64 lanes reading "their" element i hit 64 different addresses of one row.  57 KB at 640 pixels, 69 KB at 1024.
+//
+// The bitstream reaches the ring through registers, 16 bytes per lane every LS_SERVICE rounds, committed one service later: the load has
+// that long to arrive, nobody waits for it.  A lane whose ring holds less than a round can ask for (16 bytes) sits the round out.
+#include <hip/hip_runtime.h>
+
+#include "mobi_dparse.h"
+#include "mobi_kernels.h"
+#include "mobi_lsparse.h"
+
+namespace {
+enum { LS_SERVICE = 4 };
+
+struct DevStore {
+  int32_t *mvc_;
+  uint32_t *stk_, *rec_, *ring_;
+  uint8_t *mc_;
+  int lane;
+  __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * 64 + lane]; }
+  __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * 64 + lane]; }
+  __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * 64 + lane]; }
+  __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * 64 + lane]; }
+  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & 15) * 64 + lane]; }
+};
+
+// 16 bytes of the stream at byte offset o (a multiple of 16), bytes at and beyond len2 read as zero (the reference never reads a word
+// that is not whole, MD.cs:2978-2990; the staging area carries 32 zero bytes behind every clip, so the load itself stays inside it)
+__device__ __forceinline__ uint4 ls_chunk(const uint8_t *base, uint32_t o, uint32_t len2) {
+  uint4 v = uint4{0, 0, 0, 0};
+  if (o < len2) {
+    v = *(const uint4 *)(base + o);
+    if (o + 16 > len2) {
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int nb = (int)len2 - (int)(o + 4 * j);
+        w[j] = nb >= 4 ? w[j] : nb <= 0 ? 0u : (w[j] & ((1u << (8 * nb)) - 1u));
+      }
+      v = uint4{w[0], w[1], w[2], w[3]};
+    }
+  }
+  return v;
+}
+} // namespace
+
+extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevParseArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int lane = threadIdx.x;
+  const int mvc_words = 2 * (A.mbw + 2);
+  uint8_t *tab = lds;
+  DevStore m;
+  m.mvc_ = (int32_t *)(lds + MOBI_DT_BYTES);
+  m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * 64);
+  m.rec_ = m.stk_ + 16 * 64;
+  m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * 64;
+  m.mc_ = (uint8_t *)(m.ring_ + 16 * 64);
+  m.lane = lane;
+  for (int i = lane; i < MOBI_DT_BYTES / 16; i += 64) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
+  __syncthreads();
+
+  const int clip = blockIdx.x * 64 + lane;
+  const bool live = clip < A.n_clips;
+  const int n_mbs = A.mbw * A.mbh;
+  LsCtx c;
+  c.T = tab;
+  c.width = A.width; c.height = A.height; c.stride = A.stride; c.lg = A.lg; c.mbw = A.mbw; c.mbh = A.mbh; c.n_mbs = n_mbs;
+  c.version = A.version;
+  c.pay_cap = A.pay_cap;
+  c.pay = A.payload;
+
+  LsLane s;
+  const uint8_t *base = A.bits;
+  uint32_t len = 0, len2 = 0, wr = 0;
+  s.st = LS_DONE; s.bail = 0; s.rd = 0; s.cbits = 0; s.n_items = 0; s.pay_pos = 0; s.iframe = 0; s.quant = 0; s.yuvfmt = 0;
+  if (live) {
+    const MobiDevState *st = A.state + clip;
+    s.quant = st->quant; s.yuvfmt = st->yuvfmt; s.tables_set = st->tables_set;
+    s.frames_started = st->frames_started + 1; // the ring turns before anything can throw (MD.cs:102-108)
+    for (int i = 0; i < 40; i++) m.mc(i) = st->mcache[i];
+    s.desc = A.desc + (size_t)clip * n_mbs;
+    s.pay_base = (uint32_t)clip * A.pay_cap;
+    s.items = A.items + (size_t)clip * n_mbs;
+    s.clip = (uint32_t)clip;
+    base = A.bits + A.bit_off[clip];
+    len = A.bit_len[clip];
+    len2 = len & ~1u;
+    // the ring's first 64 bytes
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 v = ls_chunk(base, 16u * k, len2);
+      m.ring_[(4 * k + 0) * 64 + lane] = v.x; m.ring_[(4 * k + 1) * 64 + lane] = v.y;
+      m.ring_[(4 * k + 2) * 64 + lane] = v.z; m.ring_[(4 * k + 3) * 64 + lane] = v.w;
+    }
+    wr = 64;
+    ls_begin_frame(s, m, c, len);
+  }
+  uint4 pend = uint4{0, 0, 0, 0};
+  bool pending = false;
+  for (uint32_t round = 0;; round++) {
+    if ((round & (LS_SERVICE - 1)) == 0) {
+      if (pending) { // what the last service asked for has had LS_SERVICE rounds to arrive
+        const uint32_t k = (wr >> 2) & 15;
+        m.ring_[(k + 0) * 64 + lane] = pend.x; m.ring_[(k + 1) * 64 + lane] = pend.y;
+        m.ring_[(k + 2) * 64 + lane] = pend.z; m.ring_[(k + 3) * 64 + lane] = pend.w;
+        wr += 16;
+        pending = false;
+      }
+      if (s.st != LS_DONE && wr - s.rd <= 48) {
+        pend = ls_chunk(base, wr, len2);
+        pending = true;
+      }
+    }
+    if (s.st != LS_DONE && wr - s.rd >= 16) ls_step(s, m, c);
+    if (__builtin_amdgcn_ballot_w64(s.st != LS_DONE) == 0) break;
+  }
+  if (!live) return;
+  MobiDevResult r;
+  r.rc = 0;
+  r.consumed = 0;
+  r.pad = 0;
+  if (!s.bail) {
+    const int used = ls_consumed(s.cbits, len);
+    if (used < 0) s.bail = 16;
+    else r.consumed = used;
+  }
+  r.n_intra = s.n_items;
+  r.payload_words = s.pay_pos;
+  r.quant = s.quant; r.yuvfmt = s.yuvfmt; r.frame_type = (uint32_t)s.iframe;
+  if (!s.bail) {
+    r.pad = LS_MAGIC;
+    MobiDevState *st = A.state_ls + clip; // the shadow copy: mobi_parse_frames moves it into place (unless mobi_ls_deps objects)
+    st->quant = s.quant; st->yuvfmt = s.yuvfmt; st->tables_set = s.tables_set; st->frames_started = s.frames_started;
+    for (int i = 0; i < 40; i++) st->mcache[i] = m.mc(i);
+  }
+  A.res[clip] = r;
+}
+
+// lane = one intra macroblock of a finished clip: workgroup = clip * chunks + chunk
+extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A, uint32_t chunks) {
+  const uint32_t clip = blockIdx.x / chunks, chunk = blockIdx.x - clip * chunks;
+  if (clip >= (uint32_t)A.n_clips) return;
+  const MobiDevResult *r = A.res + clip;
+  if (r->pad != LS_MAGIC) return;
+  const uint32_t idx = chunk * 64 + threadIdx.x, n_mbs = (uint32_t)(A.mbw * A.mbh);
+  if (idx >= r->n_intra) return;
+  const LsGeom g{A.width, A.height, A.stride, A.lg, A.mbw};
+  const uint32_t mb = A.items[(size_t)clip * n_mbs + idx] & 0x1FFFu;
+  if (!ls_intra_deps(g, A.desc + (size_t)clip * n_mbs, (int)mb)) A.res[clip].pad = 0; // more than eight: mobi_parse_frames refuses the stream; let it
+}
+
+extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
+  if (a->n_clips <= 0) return 0;
+  if (a->mbw > 64 || !a->state_ls) return (int)hipErrorInvalidValue;
+  const size_t lds = MOBI_DT_BYTES + (size_t)64 * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + 4 * 16 + 40);
+  if (lds > 64 * 1024) // (per device; cheap)
+    if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(mobi_parse_frames_ls, dim3((unsigned)((a->n_clips + 63) / 64)), dim3(64), lds, s, *a);
+  const uint32_t chunks = (uint32_t)(a->mbw * a->mbh + 63) / 64;
+  hipLaunchKernelGGL(mobi_ls_deps, dim3((unsigned)a->n_clips * chunks), dim3(64), 0, s, *a, chunks);
+  return (int)hipGetLastError();
+}

@@ -61,6 +61,7 @@ _SIGS = {
     "mobi_batch_quantizer": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_yuv_format": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_set_parse_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "mobi_batch_lockstep_finished": (C.c_int, [C.c_void_p]),
     "mobi_batch_last_decode_ms": (C.c_float, [C.c_void_p]),
     "mobi_batch_motion_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_stride": (C.c_int, [C.c_void_p]),
@@ -215,6 +216,7 @@ class MobiclipBatch:
 
     def __init__(self, n_clips, Width, Height, Version, device=0, device_parse=None):
         """device_parse: True = decode() parses the bitstreams on the GPU (one wavefront per clip, mobi_dparse.hip),
+        "lockstep" = the same with the lock-step parser in front (64 clips per wavefront, mobi_lsparse.hip),
         False = on host threads, "hybrid" = most clips on the GPU and a fixed share (a fifth, at most 1024) on the host pool at the same
         time, None = library default (device parse from 1024 clips; env MOBI_DEVICE_PARSE=0/1/2)."""
         self._lib = load_library()
@@ -224,7 +226,7 @@ class MobiclipBatch:
             raise MobiclipError(f"mobi_batch_create failed: {error_string(-8)}")
         self.Stride = self._lib.mobi_batch_stride(self._h)
         if device_parse is not None:
-            mode = 2 if device_parse == "hybrid" else int(bool(device_parse))
+            mode = 2 if device_parse == "hybrid" else 3 if device_parse == "lockstep" else int(bool(device_parse))
             rc = self._lib.mobi_batch_set_parse_mode(self._h, mode)
             if rc != 0:
                 raise MobiclipError(error_string(rc))
@@ -252,6 +254,10 @@ class MobiclipBatch:
         e = self._lib.mobi_batch_submit(self._h, ptrs, lens, offs)
         if e != 0:
             raise MobiclipError(error_string(e))
+
+    def lockstep_finished(self):
+        """device_parse="lockstep": clips of the last finished step the lock-step parser finished itself (-1 in other modes)."""
+        return self._lib.mobi_batch_lockstep_finished(self._h)
 
     def wait(self):
         """(rc list, new offsets list) of the oldest submitted step, when its reconstruction is done."""

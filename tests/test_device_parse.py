@@ -11,6 +11,8 @@ from tests.oracle_binding import OracleDecoder
 
 pytestmark = pytest.mark.gpu
 
+DEVICE_PARSE = True  # tests/test_lsparse_gpu.py runs this module's tests again with "lockstep"
+
 
 def _lockstep(params_list, whole_file=False, mutate=None):
     """Decode the clips frame by frame on the GPU (device parse) and with the oracle; compare everything."""
@@ -19,7 +21,7 @@ def _lockstep(params_list, whole_file=False, mutate=None):
         clips = [(mutate(i, np.array(d, copy=True)), fo) for i, (d, fo) in enumerate(clips)]
     p0 = params_list[0]
     n = len(clips)
-    b = MobiclipBatch(n, p0.width, p0.height, p0.version, device_parse=True)
+    b = MobiclipBatch(n, p0.width, p0.height, p0.version, device_parse=DEVICE_PARSE)
     oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(n)]
     n_err = 0
     for f in range(p0.n_frames):
@@ -100,7 +102,7 @@ def test_streams_the_reference_throws_on():
     clips = [generate_clip(p) for p in ps]
     clips = [(mutate(i, np.array(d, copy=True)), fo) for i, (d, fo) in enumerate(clips)]
     n = len(clips)
-    b = MobiclipBatch(n, 256, 192, MobiclipVersion.ModsDS, device_parse=True)
+    b = MobiclipBatch(n, 256, 192, MobiclipVersion.ModsDS, device_parse=DEVICE_PARSE)
     hb = MobiclipBatch(n, 256, 192, MobiclipVersion.ModsDS, device_parse=False)
     oras = [OracleDecoder(256, 192, MobiclipVersion.ModsDS) for _ in range(n)]
     refused = [False] * n  # MOBI_E_UNSUPPORTED: the library refuses what the reference decodes through Internal[] aliasing
@@ -165,7 +167,7 @@ def test_fuzzed_streams_device_parse_equals_host_parse(cfg, version, w, h):
             d = d[: int(d.size * rng.uniform(0.3, 0.9))]
         clips.append((d, fo))   # kind 0 and 5 stay intact
     hb = MobiclipBatch(n, w, h, version, device_parse=False)
-    db = MobiclipBatch(n, w, h, version, device_parse=True)
+    db = MobiclipBatch(n, w, h, version, device_parse=DEVICE_PARSE)
     seen = set()
     for f in range(nfr):
         datas = [c[0][min(int(c[1][f]), c[0].size):min(int(c[1][f + 1]), c[0].size)] for c in clips]
@@ -194,7 +196,7 @@ def test_host_and_device_parse_agree_on_a_larger_batch():
         if p.seed not in clips:
             clips[p.seed] = generate_clip(p)
     hb = MobiclipBatch(nclips, 640, 480, MobiclipVersion.Moflex3DS, device_parse=False)
-    db = MobiclipBatch(nclips, 640, 480, MobiclipVersion.Moflex3DS, device_parse=True)
+    db = MobiclipBatch(nclips, 640, 480, MobiclipVersion.Moflex3DS, device_parse=DEVICE_PARSE)
     for f in range(nfr):
         datas = [clips[p.seed][0][clips[p.seed][1][f]:clips[p.seed][1][f + 1]] for p in ps]
         r1, o1 = hb.decode(datas, [0] * nclips)
@@ -279,7 +281,7 @@ def test_parse_mode_cannot_change_after_the_first_frame():
     from mobiclipdecoder_amd.decoder import load_library
     p = default_params("A", BASE_SEED + 1, n_frames=2)
     data, fo = generate_clip(p)
-    b = MobiclipBatch(1, 256, 192, MobiclipVersion.ModsDS, device_parse=True)
+    b = MobiclipBatch(1, 256, 192, MobiclipVersion.ModsDS, device_parse=DEVICE_PARSE)
     b.decode([data[fo[0]:fo[1]]], [0])
     assert load_library().mobi_batch_set_parse_mode(b._h, 0) != 0
     b.close()
@@ -296,7 +298,7 @@ def test_asynchronous_steps_equal_the_oracle(cfg, nclips):
     clips[0] = (clips[0][0].copy(), clips[0][1])
     clips[0][0][int(clips[0][1][4]) + 9] ^= 0x5A  # clip 0 breaks somewhere in frame 4
     p0 = ps[0]
-    b = MobiclipBatch(nclips, p0.width, p0.height, p0.version, device_parse=True)
+    b = MobiclipBatch(nclips, p0.width, p0.height, p0.version, device_parse=DEVICE_PARSE)
     oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(nclips)]
     frames = [[c[0][c[1][f]:c[1][f + 1]] for c in clips] for f in range(nfr)]
     want = []
@@ -341,7 +343,7 @@ def test_asynchronous_steps_every_frame_checked():
     nfr, nclips = 6, 4
     ps = [default_params("A", BASE_SEED + 1600 + i, n_frames=nfr, pm_intra=200) for i in range(nclips)]
     clips = [generate_clip(p) for p in ps]
-    b = MobiclipBatch(nclips, ps[0].width, ps[0].height, ps[0].version, device_parse=True)
+    b = MobiclipBatch(nclips, ps[0].width, ps[0].height, ps[0].version, device_parse=DEVICE_PARSE)
     oras = [OracleDecoder(ps[0].width, ps[0].height, ps[0].version) for _ in range(nclips)]
     for f in range(nfr):
         datas = [c[0][c[1][f]:c[1][f + 1]] for c in clips]

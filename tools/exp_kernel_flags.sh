@@ -2,7 +2,7 @@
 # usage (GPU box): tools/exp_kernel_flags.sh  -- mobi_kernels.hip built with several compiler settings, bench line of each (8192 clips)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; P=$REPO/mobiclipdecoder_amd; O=$P/_obj
 cp $P/libmobiclip_hip.so /tmp/lib_keep.so; cp $O/mobi_kernels.hip.o /tmp/k_keep.o
-OBJS="$O/mobi_abi.cpp.o $O/mobi_parse.cpp.o $O/mobi_demux.cpp.o $O/mobi_moflex.cpp.o $O/mobi_kernels.hip.o $O/mobi_rgb.hip.o $O/mobi_dparse.hip.o $O/mobi_analysis.hip.o"
+OBJS="$O/mobi_abi.cpp.o $O/mobi_parse.cpp.o $O/mobi_demux.cpp.o $O/mobi_moflex.cpp.o $O/mobi_kernels.hip.o $O/mobi_rgb.hip.o $O/mobi_dparse.hip.o $O/mobi_lsparse.hip.o $O/mobi_analysis.hip.o"
 run() {
   echo "== $*"
   hipcc --offload-arch=gfx950 -std=c++17 -fPIC "$@" -c $P/csrc/mobi_kernels.hip -o $O/mobi_kernels.hip.o 2>&1 | grep -E "error" | head -3
