@@ -293,6 +293,7 @@ struct mobi_batch {
   DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
   MobiDevState *d_pstate = nullptr;
   MobiDevState *d_pstate_ls = nullptr; // shadow copy the lock-step parser writes (mobi_lsparse.hip)
+  uint32_t pay_clip_words = 0;         // of the last device-parsed step (MobiReconArgs.pay_clip_words)
   int ls_finished = -1;                // clips of the last step it finished itself
   bool lockstep = false;               // mobi_batch_set_parse_mode(b, 3) / MOBI_DEVICE_PARSE=3: mobi_parse_frames_ls in front of mobi_parse_frames
   MobiDevResult *d_pres = nullptr;
@@ -636,8 +637,15 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   // arena -- gigabytes for thousands of clips -- is not freed and allocated again every few frames)
   if (st.max_len > b->dp_len_hint) b->dp_len_hint = st.max_len + st.max_len / 4;
   size_t cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * b->dp_len_hint) + 448 + 64;
-  if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * st.max_len) + 448 + 64;
-  if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // payload offsets are 32-bit words
+  // Every clip parsed on the GPU: MbDesc.payload_off is relative to the clip's own part of the arena, which may then be as large as HBM
+  // lets it (24576 clips of 640x480 need 13 G words for an I-frame).  Hybrid: the host-parsed clips' payload is packed behind the
+  // others, so the offsets stay relative to the arena and the arena below 2^32 words.
+  const bool local = nd == n;
+  if (!local) {
+    if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * st.max_len) + 448 + 64;
+    if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // payload offsets are 32-bit words
+  }
+  b->pay_clip_words = local ? (uint32_t)cap_words : 0u;
   const size_t want_desc = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), want_pay = align_up((size_t)n * cap_words * 4 + kPaySlack, kAlign),
                want_items = (size_t)n * n_mbs * 4;
   if (busy && (want_desc > b->d_pdesc.cap || want_pay > b->d_ppay.cap || want_items > b->d_pitems.cap)) HIP_TRY(hipStreamSynchronize(b->stream));
@@ -653,6 +661,7 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   pa.state = b->d_pstate;
   pa.state_ls = b->d_pstate_ls;
   pa.lockstep = b->lockstep ? 1 : 0;
+  pa.pay_local = local ? 1 : 0;
   pa.desc = (MbDesc *)b->d_pdesc.p;
   pa.payload = (uint32_t *)b->d_ppay.p;
   pa.items = (uint32_t *)b->d_pitems.p;
@@ -753,6 +762,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   b->argb_all_valid = false;
   b->frames_started++;
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
+  a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
   if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
   if (K && mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), (int)K, b->stream) != 0)
@@ -821,6 +831,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->argb_all_valid = false;
   b->frames_started++;
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
+  a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
   if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
   // the parse has not run yet, so nobody knows how many intra macroblocks the longest list will have: MOBI_ASYNC_INTRA_SLOTS slots are launched

@@ -721,8 +721,8 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
     for (int i = 0; i < 40; i++) L->mcache[i] = st->mcache[i];
     p.vlc = 0; p.predx = p.predy = 0;
     p.desc = A.desc + (size_t)clip * n_mbs;
-    p.pay = A.payload;
-    p.pay_base = (uint32_t)clip * A.pay_cap;
+    p.pay = A.payload + (A.pay_local ? (size_t)clip * A.pay_cap : (size_t)0);
+    p.pay_base = A.pay_local ? 0u : (uint32_t)clip * A.pay_cap;
     p.pay_pos = 0;
     p.pay_cap = A.pay_cap;
     p.items = A.items + (size_t)clip * n_mbs;

@@ -23,7 +23,9 @@ struct MobiReconArgs {
   int ring_base;            // 13
   int width, height;        // 14, 15
   int stride, mbw, n_mbs, n_clips;          // 16-19
-  uint8_t *reserved20;                      // 20-21  (r02: the edge side buffer; the tiled planes made it unnecessary)
+  uint32_t pay_clip_words;                  // 20     0: MbDesc.payload_off indexes the whole arena; else it is relative to the clip's own
+                                            //        part, payload + clip * pay_clip_words (device-parsed steps: arenas beyond 2^32 words)
+  uint32_t reserved21;                      // 21
   uint32_t qpr, qpc, magic_qpr, magic_qpc;  // 22-25  octets (8 adjacent MBs = one wave) per MB row / per clip: filled in by mobi_launch_inter
   uint32_t step_tag;                        // 26     frame-step counter (never 0): done[] == step_tag means "reconstructed in this step"
   uint32_t inter_per_xcd;                   // 27     inter launch: workgroups per XCD (= gridDim.x / 8)

@@ -447,7 +447,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   for (int k = 0; k < MOBI_EXP_PAD_S; k++) asm volatile("s_nop 0");
 #endif
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
-  const uint32_t *cw = A.payload + d.x + (multi ? MOBI_MV_CELLS : 0);
+  const uint32_t *pay = A.payload + (size_t)clip * A.pay_clip_words; // (wave-uniform)
+  const uint32_t *cw = pay + d.x + (multi ? MOBI_MV_CELLS : 0);
   uint32_t cwr[CWR]; // lane (g, j) scatters words j, j+8, j+16, ... of macroblock g; the first 8*CWR of them travel in registers
 #pragma unroll
   for (int k = 0; k < CWR; k++) asm volatile("" : "=v"(cwr[k])); // (whatever is there: a word is only looked at when it was loaded)
@@ -473,7 +474,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   uint4 c4v0 = uint4{0, 0, 0, 0}, c4v1 = uint4{0, 0, 0, 0};
   auto load_cells = [&](int gm, uint2 &yc, uint4 &c4v) {
     if ((multi_mask >> gm) & 1) {
-      const uint32_t *cells = A.payload + __builtin_amdgcn_readlane(d.x, gm);
+      const uint32_t *cells = pay + __builtin_amdgcn_readlane(d.x, gm);
       yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
       c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
     }
@@ -890,7 +891,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S), mbw = A.mbw;
   const uint32_t clip = I.clip, mb = I.mb, w1 = I.w1, w3 = I.w3, ncoef = I.ncoef;
   const int t8 = (w1 >> 14) & 0x3F;
-  const uint32_t *rec = A.payload + I.pay;
+  const uint32_t *rec = A.payload + (size_t)I.clip * A.pay_clip_words + I.pay;
   const int mby = (int)(((float)mb + 0.5f) / (float)mbw), mbx = (int)mb - mby * mbw; // mb < 8192: the quotient is never within rounding of an integer
   const int off = ((mby * 16) << lgS) + mbx * 16;                                       // < 2^20: the macroblock's linear offset (MD.cs:212-217)
   uint8_t *y0 = A.planes + (size_t)clip * A.clip_bytes + (size_t)(A.ring_base % 6) * A.slot_bytes;

@@ -37,12 +37,14 @@
 
 enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END };
 #define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
+enum { LS_TOKEN_ROUNDS = 3,  // ls_token() on its own this many times behind every ls_step(): up to four tokens per round
+       LS_ROUND_BYTES = 24, // what one such round can take from the ring at most (98 bits of the walk + 3 tokens of 28)
+       LS_RING = 128 };      // bytes of bitstream per lane in LDS
 
 struct LsCtx { // wave-uniform
   const uint8_t *T; // the table blob (mobi_dparse_tables.h)
   int width, height, stride, lg, mbw, mbh, n_mbs, version;
   uint32_t pay_cap;
-  uint32_t *pay; // whole arena
 };
 
 struct LsLane {
@@ -50,7 +52,8 @@ struct LsLane {
   uint64_t W;
   int navail;
   uint32_t cbits; // bits consumed since Data[Offset]
-  uint32_t rd;    // stream byte offset of the next four bytes the window takes
+  uint32_t nxt;   // the 32 bits behind the window
+  uint32_t rd;    // stream byte offset of the four bytes behind those
   // state machine
   int st, ret, bail;
   // frame
@@ -72,10 +75,18 @@ struct LsLane {
   int i_k, i_mode, i_sub, i_subkind, i_chroma;
   // where this clip's output goes
   MbDesc *desc;
+  uint32_t *pay;      // the arena, or this clip's part of it (pay_base = 0 then: see MobiDevParseArgs.pay_local)
   uint32_t pay_base, clip;
   uint32_t *items;
 };
 
+// four equal words at a 4-byte aligned address: one store on the device
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#define LS_STORE4(p, v) (*(ls_u32x4 *)(p) = ls_u32x4{(v), (v), (v), (v)})
+#else
+#define LS_STORE4(p, v) ((p)[0] = (p)[1] = (p)[2] = (p)[3] = (v))
+#endif
 LS_FN int ls_clz(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 LS_FN int ls_ctz(uint32_t v) { return __builtin_ctz(v); }
 LS_FN int ls_min(int a, int b) { return a < b ? a : b; }
@@ -93,11 +104,11 @@ LS_FN void ls_take(LsLane &s, int k) { // 0 <= k <= 32
 // more than 32 bits in the window afterwards (the ring always holds what an iteration can ask for: see the kernel's ring service)
 template <class S>
 LS_FN void ls_refill(LsLane &s, S &m) {
-  if (s.navail <= 32) {
-    const uint32_t d = m.ring32(s.rd); // two 16-bit little-endian words, the first one's bits first (MD.cs:2978-2990)
-    const uint32_t x = (d << 16) | (d >> 16);
-    s.W |= (uint64_t)x << (32 - s.navail);
+  if (s.navail <= 32) { // the 32 bits behind the window wait in a register; the ones behind those are asked for now and not looked at before the next refill
+    s.W |= (uint64_t)s.nxt << (32 - s.navail);
     s.navail += 32;
+    const uint32_t d = m.ring32(s.rd); // two 16-bit little-endian words, the first one's bits first (MD.cs:2978-2990)
+    s.nxt = (d << 16) | (d >> 16);
     s.rd += 4;
   }
 }
@@ -144,6 +155,9 @@ LS_FN void ls_begin_frame(LsLane &s, S &m, const LsCtx &c, uint32_t len) {
   s.i_cbp = s.i_m4 = 0; s.i_k = s.i_mode = s.i_sub = s.i_subkind = s.i_chroma = 0;
   s.vlc = 0; s.iframe = 0;
   if (len < 2) { ls_bail(s, 3); return; }
+  s.nxt = 0;
+  ls_refill(s, m); // (primes nxt)
+  s.navail = 0;
   ls_refill(s, m);
   ls_refill(s, m);
   s.iframe = (int)(ls_win(s) >> 31);
@@ -213,14 +227,19 @@ LS_FN void ls_leaf(LsLane &s, S &m, const LsCtx &c, int wi, int hi, int x, int y
   const int hi_c = cpos + S_ / 2 + ((h >> 1) - 1) * S_ + (w >> 1) - 1 + (cdx & 1) + ((cdy & 1) ? S_ : 0);
   if (pos < 0 || hi_y >= ylen || cpos < 0 || hi_c >= ylen / 2) { ls_bail(s, 8); return; }
   const uint32_t w0 = mobi_leaf_w0(x, y, wi, hi, ref), w1 = mobi_leaf_w1(dx, dy);
-  if (s.nleaf == 0) { s.l0a = w0; s.l0b = w1; }
-  if (s.nleaf == 1) { s.l1a = w0; s.l1b = w1; }
+  const bool first = s.nleaf == 0, second = s.nleaf == 1; // (selects, not stores behind a compare: those became an indexed store into scratch)
+  s.l0a = first ? w0 : s.l0a; s.l0b = first ? w1 : s.l0b;
+  s.l1a = second ? w0 : s.l1a; s.l1b = second ? w1 : s.l1b;
   s.nleaf++;
-  if (wi | hi) {
-    uint32_t *cells = c.pay + s.pay_base + s.mb_pay;
+  if (wi | hi) { // (a row of the leaf at a time: 8, 4, 2 or 1 cells; the lanes of a wave run as many rows as the tallest leaf has)
+    uint32_t *cells = s.pay + s.pay_base + s.mb_pay + (y >> 1) * 8 + (x >> 1);
     const uint32_t cell = mobi_cell(dx, dy, ref);
-    for (int cy = y >> 1; cy < (y + h) >> 1; cy++)
-      for (int cx = x >> 1; cx < (x + w) >> 1; cx++) cells[cy * 8 + cx] = cell;
+    for (int r = 0; r < (h >> 1); r++, cells += 8) {
+      if (w == 16) { LS_STORE4(cells, cell); LS_STORE4(cells + 4, cell); }
+      else if (w == 8) LS_STORE4(cells, cell);
+      else if (w == 4) { cells[0] = cell; cells[1] = cell; }
+      else cells[0] = cell;
+    }
   }
 }
 LS_FN int ls_classify(const LsLane &s) {
@@ -229,6 +248,62 @@ LS_FN int ls_classify(const LsLane &s) {
   if (a == (0u | (1u << 10)) && b == ((4u << 4) | (1u << 10))) return MOBI_DUAL_TB;
   if (a == (0u | (1u << 8)) && b == (4u | (1u << 8))) return MOBI_DUAL_LR;
   return MOBI_DUAL_NONE;
+}
+
+// ---- one residual token (MD.cs:3330-3432).  Also called on its own (ls_token_rounds): tokens are half of all syntax elements, and a round of
+// the whole walk costs the wave twenty times what this region does ----
+template <class S>
+LS_FN void ls_token(LsLane &s, S &m, const LsCtx &c) {
+  const uint8_t *T = c.T;
+  if (s.st == LS_TOKEN) {
+    ls_refill(s, m);
+    const uint16_t *A = (const uint16_t *)(T + ((s.blk_flags & 2) ? MOBI_DT_A1 : MOBI_DT_A0));
+    const uint8_t *B = T + ((s.blk_flags & 2) ? MOBI_DT_B1 : MOBI_DT_B0);
+    int skip = 0, value = 0, len = 0;
+    uint32_t e = 0, last = 0;
+    bool raw = false;
+    uint32_t w = ls_win(s);
+    int esc = 0; // 0: plain, 1: "0" level escape, 2: "10" run escape
+    if ((w >> 25) == 3) {
+      if (!((w >> 24) & 1)) { esc = 1; ls_take(s, 8); }
+      else if (!((w >> 23) & 1)) { esc = 2; ls_take(s, 9); }
+      else { raw = true; ls_take(s, 9); }
+      w = ls_win(s);
+    }
+    if (raw) { // last(1) run(6) level(s12)
+      last = w >> 31;
+      skip = (int)((w >> 25) & 0x3F);
+      value = (int32_t)(w << 7) >> 20;
+      ls_take(s, 19);
+    } else {
+      e = A[w >> 20];
+      len = (int)(e & 0xF);
+      value = (int)((e >> 4) & 0x1F);
+      skip = (int)((e >> 9) & 0x3F);
+      last = e >> 15;
+      if (esc == 1) value += B[e >> 9];
+      if (esc == 2) skip += B[0x80 + value + ((e >> 15) << 6)];
+      if (len == 0) ls_bail(s, 14);
+      else {
+        if ((w >> (32 - len)) & 1) value = -value;
+        ls_take(s, len);
+      }
+    }
+    if (!s.bail) {
+      s.blk_p += skip;
+      if (s.blk_p >= s.blk_n) ls_bail(s, 15);
+      else {
+        const int idx = (s.blk_flags & 4) ? T[((s.blk_flags & 1) ? MOBI_DT_ZZ8 : MOBI_DT_ZZ4) + s.blk_p] : 0;
+        s.blk_p++;
+        if (value != 0) s.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
+        if (last & 1) {
+          s.st = s.ret;
+          if (s.st == LS_NEXT && !s.sub_mask && !s.area_mask) s.st = LS_MB_END;
+        }
+      }
+    }
+  }
+  if (s.bail) s.st = LS_DONE;
 }
 
 // ---------------------------------------------------------------- one round of the walk
@@ -512,55 +587,7 @@ LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
       } else if (!s.area_mask) s.st = LS_MB_END;
     }
   }
-  // ---- one residual token (MD.cs:3330-3432) ----
-  if (s.st == LS_TOKEN) {
-    ls_refill(s, m);
-    const uint16_t *A = (const uint16_t *)(T + ((s.blk_flags & 2) ? MOBI_DT_A1 : MOBI_DT_A0));
-    const uint8_t *B = T + ((s.blk_flags & 2) ? MOBI_DT_B1 : MOBI_DT_B0);
-    int skip = 0, value = 0, len = 0;
-    uint32_t e = 0, last = 0;
-    bool raw = false;
-    uint32_t w = ls_win(s);
-    int esc = 0; // 0: plain, 1: "0" level escape, 2: "10" run escape
-    if ((w >> 25) == 3) {
-      if (!((w >> 24) & 1)) { esc = 1; ls_take(s, 8); }
-      else if (!((w >> 23) & 1)) { esc = 2; ls_take(s, 9); }
-      else { raw = true; ls_take(s, 9); }
-      w = ls_win(s);
-    }
-    if (raw) { // last(1) run(6) level(s12)
-      last = w >> 31;
-      skip = (int)((w >> 25) & 0x3F);
-      value = (int32_t)(w << 7) >> 20;
-      ls_take(s, 19);
-    } else {
-      e = A[w >> 20];
-      len = (int)(e & 0xF);
-      value = (int)((e >> 4) & 0x1F);
-      skip = (int)((e >> 9) & 0x3F);
-      last = e >> 15;
-      if (esc == 1) value += B[e >> 9];
-      if (esc == 2) skip += B[0x80 + value + ((e >> 15) << 6)];
-      if (len == 0) ls_bail(s, 14);
-      else {
-        if ((w >> (32 - len)) & 1) value = -value;
-        ls_take(s, len);
-      }
-    }
-    if (!s.bail) {
-      s.blk_p += skip;
-      if (s.blk_p >= s.blk_n) ls_bail(s, 15);
-      else {
-        const int idx = (s.blk_flags & 4) ? T[((s.blk_flags & 1) ? MOBI_DT_ZZ8 : MOBI_DT_ZZ4) + s.blk_p] : 0;
-        s.blk_p++;
-        if (value != 0) c.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
-        if (last & 1) {
-          s.st = s.ret;
-          if (s.st == LS_NEXT && !s.sub_mask && !s.area_mask) s.st = LS_MB_END;
-        }
-      }
-    }
-  }
+  ls_token(s, m, c);
   // ---- macroblock end: the descriptor (mobi_cmd.h) ----
   if (s.st == LS_MB_END) {
     uint32_t w2 = s.n_coefs, w3 = s.w3, w4 = 0, w5 = 0, w6 = 0, w7 = 0, nl = 0;
@@ -569,22 +596,24 @@ LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
       nl = (uint32_t)s.nleaf;
       dual = ls_classify(s);
       if (nl == 1 || dual) {
+        // leaf records: positions and phases instead of motion vectors (MD.cs:400-416).  (No arrays here: an array indexed by a loop
+        // counter lives in scratch memory on the GPU, and a wave alone on its SIMD waits out every one of those round trips.)
         const int S_ = c.stride;
-        uint32_t pos[4] = {0, 0, 0, 0};
-        for (uint32_t i = 0; i < nl; i++) {
-          const uint32_t a0 = i ? s.l1a : s.l0a, a1 = i ? s.l1b : s.l0b;
+        auto leaf = [&](uint32_t a0, uint32_t a1, int i, uint32_t &py, uint32_t &pc) {
           const int ref = (a0 >> 12) & 7;
           const int dx = (int16_t)(a1 & 0xFFFF), dy = (int16_t)(a1 >> 16), cdx = dx >> 1, cdy = dy >> 1;
-          pos[2 * i] = (uint32_t)(s.cur_off + (dy >> 1) * S_ + (dx >> 1));
-          pos[2 * i + 1] = (uint32_t)(s.cur_off / 2 + (cdy >> 1) * S_ + (cdx >> 1));
+          py = (uint32_t)(s.cur_off + (dy >> 1) * S_ + (dx >> 1));
+          pc = (uint32_t)(s.cur_off / 2 + (cdy >> 1) * S_ + (cdx >> 1));
           w2 |= (uint32_t)ref << (10 + 3 * i);
           w2 |= (uint32_t)((dx & 1) | ((dy & 1) << 1)) << (16 + 4 * i);
           w2 |= (uint32_t)((cdx & 1) | ((cdy & 1) << 1)) << (18 + 4 * i);
-        }
-        w3 = pos[0]; w4 = pos[1]; w5 = pos[2]; w6 = pos[3];
+        };
+        leaf(s.l0a, s.l0b, 0, w3, w4);
+        w5 = w6 = 0;
+        if (nl == 2) leaf(s.l1a, s.l1b, 1, w5, w6);
       }
     } else {
-      uint32_t *rec_out = c.pay + s.pay_base + s.mb_pay;
+      uint32_t *rec_out = s.pay + s.pay_base + s.mb_pay;
       for (int i = 0; i < MOBI_INTRA_RECORDS; i++) rec_out[i] = m.rec(i);
       w4 = w5 = w6 = w7 = MOBI_DEP_NONE | (MOBI_DEP_NONE << 16); // ls_intra_deps fills them in
       s.items[s.n_items++] = (s.clip << 13) | (uint32_t)s.mb;

@@ -8,11 +8,11 @@
 //                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
 //
 // LDS per wave: the table blob (18 KB), and per lane the motion-vector row cache (2 (mbw + 2) words), the partition-tree stack (16), the
-// intra records (24), the mode cache (40 bytes), a 64-byte ring of bitstream -- all lane-interleaved (element i of lane l at i * 64 + l), so
-// that 64 lanes reading "their" element i hit 64 different addresses of one row.  57 KB at 640 pixels, 69 KB at 1024.
+// intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all lane-interleaved (element i of lane l at i * 64 + l), so
+// that 64 lanes reading "their" element i hit 64 different addresses of one row.  61 KB at 640 pixels, 73 KB at 1024.
 //
-// The bitstream reaches the ring through registers, 16 bytes per lane every LS_SERVICE rounds, committed one service later: the load has
-// that long to arrive, nobody waits for it.  A lane whose ring holds less than a round can ask for (16 bytes) sits the round out.
+// The bitstream reaches the ring through registers, 32 bytes per lane every LS_SERVICE rounds, committed one service later: the load has
+// that long to arrive, nobody waits for it.  A lane whose ring holds less than a round can ask for (LS_ROUND_BYTES) sits the round out.
 #include <hip/hip_runtime.h>
 
 #include "mobi_dparse.h"
@@ -20,7 +20,7 @@
 #include "mobi_lsparse.h"
 
 namespace {
-enum { LS_SERVICE = 4 };
+enum { LS_SERVICE = 4, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
 struct DevStore {
   int32_t *mvc_;
@@ -31,7 +31,7 @@ struct DevStore {
   __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * 64 + lane]; }
   __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * 64 + lane]; }
   __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * 64 + lane]; }
-  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & 15) * 64 + lane]; }
+  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & (LS_RING_WORDS - 1)) * 64 + lane]; }
 };
 
 // 16 bytes of the stream at byte offset o (a multiple of 16), bytes at and beyond len2 read as zero (the reference never reads a word
@@ -64,7 +64,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * 64);
   m.rec_ = m.stk_ + 16 * 64;
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * 64;
-  m.mc_ = (uint8_t *)(m.ring_ + 16 * 64);
+  m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * 64);
   m.lane = lane;
   for (int i = lane; i < MOBI_DT_BYTES / 16; i += 64) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
@@ -77,7 +77,6 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   c.width = A.width; c.height = A.height; c.stride = A.stride; c.lg = A.lg; c.mbw = A.mbw; c.mbh = A.mbh; c.n_mbs = n_mbs;
   c.version = A.version;
   c.pay_cap = A.pay_cap;
-  c.pay = A.payload;
 
   LsLane s;
   const uint8_t *base = A.bits;
@@ -89,39 +88,50 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
     s.frames_started = st->frames_started + 1; // the ring turns before anything can throw (MD.cs:102-108)
     for (int i = 0; i < 40; i++) m.mc(i) = st->mcache[i];
     s.desc = A.desc + (size_t)clip * n_mbs;
-    s.pay_base = (uint32_t)clip * A.pay_cap;
+    s.pay = A.payload + (A.pay_local ? (size_t)clip * A.pay_cap : (size_t)0);
+    s.pay_base = A.pay_local ? 0u : (uint32_t)clip * A.pay_cap;
     s.items = A.items + (size_t)clip * n_mbs;
     s.clip = (uint32_t)clip;
     base = A.bits + A.bit_off[clip];
     len = A.bit_len[clip];
     len2 = len & ~1u;
-    // the ring's first 64 bytes
+    // the ring's first LS_RING bytes
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < LS_RING / 16; k++) {
       const uint4 v = ls_chunk(base, 16u * k, len2);
       m.ring_[(4 * k + 0) * 64 + lane] = v.x; m.ring_[(4 * k + 1) * 64 + lane] = v.y;
       m.ring_[(4 * k + 2) * 64 + lane] = v.z; m.ring_[(4 * k + 3) * 64 + lane] = v.w;
     }
-    wr = 64;
+    wr = LS_RING;
     ls_begin_frame(s, m, c, len);
   }
-  uint4 pend = uint4{0, 0, 0, 0};
+  uint4 pend0 = uint4{0, 0, 0, 0}, pend1 = uint4{0, 0, 0, 0};
   bool pending = false;
   for (uint32_t round = 0;; round++) {
     if ((round & (LS_SERVICE - 1)) == 0) {
       if (pending) { // what the last service asked for has had LS_SERVICE rounds to arrive
-        const uint32_t k = (wr >> 2) & 15;
-        m.ring_[(k + 0) * 64 + lane] = pend.x; m.ring_[(k + 1) * 64 + lane] = pend.y;
-        m.ring_[(k + 2) * 64 + lane] = pend.z; m.ring_[(k + 3) * 64 + lane] = pend.w;
-        wr += 16;
+        const uint32_t k = (wr >> 2) & (LS_RING_WORDS - 1); // (a multiple of 8)
+        m.ring_[(k + 0) * 64 + lane] = pend0.x; m.ring_[(k + 1) * 64 + lane] = pend0.y;
+        m.ring_[(k + 2) * 64 + lane] = pend0.z; m.ring_[(k + 3) * 64 + lane] = pend0.w;
+        m.ring_[(k + 4) * 64 + lane] = pend1.x; m.ring_[(k + 5) * 64 + lane] = pend1.y;
+        m.ring_[(k + 6) * 64 + lane] = pend1.z; m.ring_[(k + 7) * 64 + lane] = pend1.w;
+        wr += 32;
         pending = false;
       }
-      if (s.st != LS_DONE && wr - s.rd <= 48) {
-        pend = ls_chunk(base, wr, len2);
+      if (s.st != LS_DONE && wr - s.rd <= LS_RING - 32) {
+        pend0 = ls_chunk(base, wr, len2);
+        pend1 = ls_chunk(base, wr + 16, len2);
         pending = true;
       }
     }
-    if (s.st != LS_DONE && wr - s.rd >= 16) ls_step(s, m, c);
+    if (s.st != LS_DONE && wr - s.rd >= LS_ROUND_BYTES) {
+      ls_step(s, m, c);
+#pragma unroll 1
+      for (int k = 0; k < LS_TOKEN_ROUNDS; k++) {
+        if (s.st != LS_TOKEN) break; // (per lane: the loop runs while any lane still has a token to read)
+        ls_token(s, m, c);
+      }
+    }
     if (__builtin_amdgcn_ballot_w64(s.st != LS_DONE) == 0) break;
   }
   if (!live) return;
@@ -162,7 +172,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A
 extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64 || !a->state_ls) return (int)hipErrorInvalidValue;
-  const size_t lds = MOBI_DT_BYTES + (size_t)64 * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + 4 * 16 + 40);
+  const size_t lds = MOBI_DT_BYTES + (size_t)64 * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
   if (lds > 64 * 1024) // (per device; cheap)
     if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(mobi_parse_frames_ls, dim3((unsigned)((a->n_clips + 63) / 64)), dim3(64), lds, s, *a);

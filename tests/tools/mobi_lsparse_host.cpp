@@ -68,7 +68,6 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
   c.width = C.w; c.height = C.h; c.stride = C.g.stride; c.lg = C.g.lg; c.mbw = C.g.mbw; c.mbh = C.g.mbh; c.n_mbs = C.g.mbw * C.g.mbh;
   c.version = C.version;
   c.pay_cap = (uint32_t)C.pay.size();
-  c.pay = C.pay.data();
   // work on copies of what survives the frame: a bail-out must leave it as it was
   HostStore m = C.m;
   m.data = data;
@@ -76,12 +75,13 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
   LsLane s;
   memset(&s, 0, sizeof(s));
   s.quant = C.quant; s.yuvfmt = C.yuvfmt; s.tables_set = C.tables_set; s.frames_started = C.frames_started + 1;
-  s.desc = C.desc.data(); s.pay_base = 0; s.clip = 0; s.items = C.items.data();
+  s.desc = C.desc.data(); s.pay = C.pay.data(); s.pay_base = 0; s.clip = 0; s.items = C.items.data();
   ls_begin_frame(s, m, c, (uint32_t)len);
   while (s.st != LS_DONE) {
     C.rounds++;
     C.rounds_by_state[s.st & 15]++;
     ls_step(s, m, c);
+    for (int k = 0; k < LS_TOKEN_ROUNDS && s.st == LS_TOKEN; k++) ls_token(s, m, c); // as the kernel does
   }
   if (!s.bail) {
     const int used = ls_consumed(s.cbits, (uint32_t)len);
