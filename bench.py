@@ -73,10 +73,10 @@ def cpu_baseline(params, data, fo, budget_s):
                             "sample": f"{nb} clips including the YUV->ARGB Bitmap of every frame (MD.cs:260-323), {tb:.1f} s"}}
 
 
-def end_to_end(m, streams, W, H, version, device, n_clips, n_steps):
+def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse=True):
     """Bitstreams in host memory -> planes in HBM: mobi_batch_decode with the parse on the GPU (row f3).  Reported next to
     the headline value, never as it: the timed region of `value` starts with the command lists already in HBM."""
-    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=True)
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=device_parse)
     ms = []
     for f in range(2 + n_steps):  # the I-frame, one untimed P-frame (allocations), then n_steps P-frames
         datas = [streams[c % len(streams)][1][streams[c % len(streams)][2][f]:streams[c % len(streams)][2][f + 1]] for c in range(n_clips)]
@@ -87,13 +87,14 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps):
     b.close()
     t = float(np.median(ms))
     out = {"value": round(n_clips * W * H / t / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(t, 3), "clips": n_clips, "steps": n_steps,
-           "parse": "device: mobi_parse_frames, one wavefront per clip",
+           "parse": "device: mobi_parse_frames_ls (64 clips per wavefront, lock step) in front of mobi_parse_frames" if device_parse == "lockstep"
+                    else "device: mobi_parse_frames, one wavefront per clip",
            "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)"}
     # the same frames through mobi_batch_submit / mobi_batch_wait, two steps in flight: wall time per step over the timed P-frames.
     # The pointer arrays are packed beforehand (what a C caller hands over), as the synchronous figure is the time inside the C call.
     import ctypes as C
     import time as _t
-    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=True)
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=device_parse)
     lib, h = b._lib, b._h
     packed = []
     for f in range(3 + n_steps):
@@ -211,6 +212,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
     ap.add_argument("--e2e-steps", type=int, default=12)
+    ap.add_argument("--e2e-large-clips", type=int, default=24576, help="clips of the second end-to-end leg, at the headline batch size with the lock-step parser (64 clips per wavefront); 0 = skip")
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--single-stream", type=int, default=1, help="1: time one clip through mobi_decode / mobi_get_argb (the boundary's own shape); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
@@ -329,11 +331,16 @@ def main():
     n_intra = sum(x[0] for x in stats) / steps
     intra_cmd = sum(x[1] for x in stats) / steps
     b.close()
-    e2e = c4 = single = None
+    e2e = e2e_large = c4 = single = None
     if world == 1 and args.single_stream and args.config == "B":
         single = single_stream_leg(m, streams[0], W, H, p0.version, local)
     if world == 1 and args.e2e_clips > 0 and args.config == "B":
         e2e = end_to_end(m, streams, W, H, p0.version, local, args.e2e_clips, args.e2e_steps)
+    if world == 1 and args.e2e_clips > 0 and min(args.e2e_large_clips, args.clips) >= 8192 and args.config == "B":  # (--e2e-clips 0 skips both legs)
+        try:
+            e2e_large = end_to_end(m, streams, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
+        except m.MobiclipError as e:  # (does not fit beside what the allocator still holds: reported, not fatal)
+            e2e_large = {"error": str(e)}
     if world == 1 and args.config4_clips > 0 and args.config == "B":
         c4 = config4_leg(m, streams, W, H, p0.version, local, args.config4_clips, 24)
 
@@ -386,7 +393,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "config4": c4, "single_stream": single,
+            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -37,8 +37,9 @@
 
 enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END };
 #define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
-enum { LS_TOKEN_ROUNDS = 3,  // ls_token() on its own this many times behind every ls_step(): up to four tokens per round
-       LS_ROUND_BYTES = 24, // what one such round can take from the ring at most (98 bits of the walk + 3 tokens of 28)
+enum { LS_TOKEN_ROUNDS = 4,  // ls_next() + ls_token() on their own this many times behind every ls_step(): block after block, token after
+                             // token, while the expensive rest of the walk waits
+       LS_ROUND_BYTES = 36, // what one such round can take from the ring at most (98 bits of the walk + 4 x (15 + 28))
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
 
 struct LsCtx { // wave-uniform
@@ -306,10 +307,87 @@ LS_FN void ls_token(LsLane &s, S &m, const LsCtx &c) {
   if (s.bail) s.st = LS_DONE;
 }
 
+// ---- inter macroblock: the next coded block (loc_11652C, MD.cs:2909-2929).  Like ls_token() also called on its own ----
+template <class S>
+LS_FN void ls_next(LsLane &s, S &m, const LsCtx &c) {
+  const uint8_t *T = c.T;
+  if (s.st == LS_NEXT) {
+    ls_refill(s, m);
+    if (!s.sub_mask && s.area_mask) {
+      const int a = ls_ctz(s.area_mask);
+      s.area_mask &= s.area_mask - 1;
+      if (ls_win(s) >> 31) {
+        ls_take(s, 1);
+        s.t8mask |= 1u << a;
+        ls_block(s, a, 0, true);
+        s.ret = LS_NEXT;
+        if (!s.bail) s.st = LS_TOKEN;
+      } else {
+        const uint32_t u = ls_ue(s);
+        if (!s.bail) {
+          if (u >= 16) ls_bail(s, 12);
+          else { s.sub_mask = T[MOBI_DT_CBP4_P + u]; s.cur_area = a; }
+        }
+      }
+    }
+    if (s.st == LS_NEXT) {
+      if (s.sub_mask) {
+        const int sub = ls_ctz(s.sub_mask);
+        s.sub_mask &= s.sub_mask - 1;
+        ls_block(s, s.cur_area, sub, false);
+        s.ret = LS_NEXT;
+        if (!s.bail) s.st = LS_TOKEN;
+      } else if (!s.area_mask) s.st = LS_MB_END;
+    }
+  }
+  if (s.bail) s.st = LS_DONE;
+}
+
 // ---------------------------------------------------------------- one round of the walk
 template <class S>
 LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
   const uint8_t *T = c.T;
+  // ---- macroblock end: the descriptor (mobi_cmd.h).  First, so that a lane whose last token came in the extra rounds goes on to
+  // the next macroblock in the same call ----
+  if (s.st == LS_MB_END) {
+    uint32_t w2 = s.n_coefs, w3 = s.w3, w4 = 0, w5 = 0, w6 = 0, w7 = 0, nl = 0;
+    int dual = MOBI_DUAL_NONE;
+    if (s.mb_type == MOBI_MB_INTER) {
+      nl = (uint32_t)s.nleaf;
+      dual = ls_classify(s);
+      if (nl == 1 || dual) {
+        // leaf records: positions and phases instead of motion vectors (MD.cs:400-416).  (No arrays here: an array indexed by a loop
+        // counter lives in scratch memory on the GPU, and a wave alone on its SIMD waits out every one of those round trips.)
+        const int S_ = c.stride;
+        auto leaf = [&](uint32_t a0, uint32_t a1, int i, uint32_t &py, uint32_t &pc) {
+          const int ref = (a0 >> 12) & 7;
+          const int dx = (int16_t)(a1 & 0xFFFF), dy = (int16_t)(a1 >> 16), cdx = dx >> 1, cdy = dy >> 1;
+          py = (uint32_t)(s.cur_off + (dy >> 1) * S_ + (dx >> 1));
+          pc = (uint32_t)(s.cur_off / 2 + (cdy >> 1) * S_ + (cdx >> 1));
+          w2 |= (uint32_t)ref << (10 + 3 * i);
+          w2 |= (uint32_t)((dx & 1) | ((dy & 1) << 1)) << (16 + 4 * i);
+          w2 |= (uint32_t)((cdx & 1) | ((cdy & 1) << 1)) << (18 + 4 * i);
+        };
+        leaf(s.l0a, s.l0b, 0, w3, w4);
+        w5 = w6 = 0;
+        if (nl == 2) leaf(s.l1a, s.l1b, 1, w5, w6);
+      }
+    } else {
+      uint32_t *rec_out = s.pay + s.pay_base + s.mb_pay;
+      for (int i = 0; i < MOBI_INTRA_RECORDS; i++) rec_out[i] = m.rec(i);
+      w4 = w5 = w6 = w7 = MOBI_DEP_NONE | (MOBI_DEP_NONE << 16); // ls_intra_deps fills them in
+      s.items[s.n_items++] = (s.clip << 13) | (uint32_t)s.mb;
+    }
+    MbDesc d;
+    d.payload_off = s.pay_base + s.mb_pay;
+    d.w1 = (uint32_t)s.mb_type | (nl << 1) | (s.cbp6 << 8) | (s.t8mask << 14) | ((s.quant & 63) << 20) | ((uint32_t)dual << 26);
+    d.w2 = w2; d.w3 = w3; d.w4 = w4; d.w5 = w5; d.w6 = w6; d.w7 = w7;
+    s.desc[s.mb] = d;
+    s.pay_pos = s.mb_pay + s.hdr_words + s.n_coefs;
+    s.mb++;
+    if (++s.mx == c.mbw) { s.mx = 0; s.my++; }
+    s.st = LS_MB_BEGIN;
+  }
   // ---- macroblock start (MD.cs:145-222) ----
   if (s.st == LS_MB_BEGIN) {
     if (s.mb >= c.n_mbs) {
@@ -557,77 +635,8 @@ LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
       if (!s.bail) s.st = LS_TOKEN;
     } else s.st = LS_I_FIXED;
   }
-  // ---- inter macroblock: the next coded block (loc_11652C, MD.cs:2909-2929) ----
-  if (s.st == LS_NEXT) {
-    ls_refill(s, m);
-    if (!s.sub_mask && s.area_mask) {
-      const int a = ls_ctz(s.area_mask);
-      s.area_mask &= s.area_mask - 1;
-      if (ls_win(s) >> 31) {
-        ls_take(s, 1);
-        s.t8mask |= 1u << a;
-        ls_block(s, a, 0, true);
-        s.ret = LS_NEXT;
-        if (!s.bail) s.st = LS_TOKEN;
-      } else {
-        const uint32_t u = ls_ue(s);
-        if (!s.bail) {
-          if (u >= 16) ls_bail(s, 12);
-          else { s.sub_mask = T[MOBI_DT_CBP4_P + u]; s.cur_area = a; }
-        }
-      }
-    }
-    if (s.st == LS_NEXT) {
-      if (s.sub_mask) {
-        const int sub = ls_ctz(s.sub_mask);
-        s.sub_mask &= s.sub_mask - 1;
-        ls_block(s, s.cur_area, sub, false);
-        s.ret = LS_NEXT;
-        if (!s.bail) s.st = LS_TOKEN;
-      } else if (!s.area_mask) s.st = LS_MB_END;
-    }
-  }
+  ls_next(s, m, c);
   ls_token(s, m, c);
-  // ---- macroblock end: the descriptor (mobi_cmd.h) ----
-  if (s.st == LS_MB_END) {
-    uint32_t w2 = s.n_coefs, w3 = s.w3, w4 = 0, w5 = 0, w6 = 0, w7 = 0, nl = 0;
-    int dual = MOBI_DUAL_NONE;
-    if (s.mb_type == MOBI_MB_INTER) {
-      nl = (uint32_t)s.nleaf;
-      dual = ls_classify(s);
-      if (nl == 1 || dual) {
-        // leaf records: positions and phases instead of motion vectors (MD.cs:400-416).  (No arrays here: an array indexed by a loop
-        // counter lives in scratch memory on the GPU, and a wave alone on its SIMD waits out every one of those round trips.)
-        const int S_ = c.stride;
-        auto leaf = [&](uint32_t a0, uint32_t a1, int i, uint32_t &py, uint32_t &pc) {
-          const int ref = (a0 >> 12) & 7;
-          const int dx = (int16_t)(a1 & 0xFFFF), dy = (int16_t)(a1 >> 16), cdx = dx >> 1, cdy = dy >> 1;
-          py = (uint32_t)(s.cur_off + (dy >> 1) * S_ + (dx >> 1));
-          pc = (uint32_t)(s.cur_off / 2 + (cdy >> 1) * S_ + (cdx >> 1));
-          w2 |= (uint32_t)ref << (10 + 3 * i);
-          w2 |= (uint32_t)((dx & 1) | ((dy & 1) << 1)) << (16 + 4 * i);
-          w2 |= (uint32_t)((cdx & 1) | ((cdy & 1) << 1)) << (18 + 4 * i);
-        };
-        leaf(s.l0a, s.l0b, 0, w3, w4);
-        w5 = w6 = 0;
-        if (nl == 2) leaf(s.l1a, s.l1b, 1, w5, w6);
-      }
-    } else {
-      uint32_t *rec_out = s.pay + s.pay_base + s.mb_pay;
-      for (int i = 0; i < MOBI_INTRA_RECORDS; i++) rec_out[i] = m.rec(i);
-      w4 = w5 = w6 = w7 = MOBI_DEP_NONE | (MOBI_DEP_NONE << 16); // ls_intra_deps fills them in
-      s.items[s.n_items++] = (s.clip << 13) | (uint32_t)s.mb;
-    }
-    MbDesc d;
-    d.payload_off = s.pay_base + s.mb_pay;
-    d.w1 = (uint32_t)s.mb_type | (nl << 1) | (s.cbp6 << 8) | (s.t8mask << 14) | ((s.quant & 63) << 20) | ((uint32_t)dual << 26);
-    d.w2 = w2; d.w3 = w3; d.w4 = w4; d.w5 = w5; d.w6 = w6; d.w7 = w7;
-    s.desc[s.mb] = d;
-    s.pay_pos = s.mb_pay + s.hdr_words + s.n_coefs;
-    s.mb++;
-    if (++s.mx == c.mbw) { s.mx = 0; s.my++; }
-    s.st = LS_MB_BEGIN;
-  }
   if (s.bail) s.st = LS_DONE; // (a region that bailed out half way may have gone on to set a state)
 }
 

@@ -128,7 +128,8 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
       ls_step(s, m, c);
 #pragma unroll 1
       for (int k = 0; k < LS_TOKEN_ROUNDS; k++) {
-        if (s.st != LS_TOKEN) break; // (per lane: the loop runs while any lane still has a token to read)
+        if (s.st != LS_TOKEN && s.st != LS_NEXT) break; // (per lane: the loop runs while any lane still has a block or a token to read)
+        ls_next(s, m, c);
         ls_token(s, m, c);
       }
     }

@@ -81,7 +81,7 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
     C.rounds++;
     C.rounds_by_state[s.st & 15]++;
     ls_step(s, m, c);
-    for (int k = 0; k < LS_TOKEN_ROUNDS && s.st == LS_TOKEN; k++) ls_token(s, m, c); // as the kernel does
+    for (int k = 0; k < LS_TOKEN_ROUNDS && (s.st == LS_TOKEN || s.st == LS_NEXT); k++) { ls_next(s, m, c); ls_token(s, m, c); } // as the kernel does
   }
   if (!s.bail) {
     const int used = ls_consumed(s.cbits, (uint32_t)len);

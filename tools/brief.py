@@ -6,4 +6,5 @@ for l in sys.stdin:
         d = json.loads(l)
         r = d.get("roofline") or {}
         print("ms_per_step", d["ms_per_step"], "kernel_ms", r.get("avg_launch_ms"), "frac", r.get("frac"), "value", d["value"],
-              "intra_ms", r.get("intra_kernel_ms_per_step"), "e2e", (d.get("end_to_end") or {}).get("value"))
+              "intra_ms", r.get("intra_kernel_ms_per_step"), "e2e", (d.get("end_to_end") or {}).get("value"),
+              "e2e_large", (d.get("end_to_end_large") or {}).get("value"), "async", ((d.get("end_to_end_large") or {}).get("async") or {}).get("value"))
