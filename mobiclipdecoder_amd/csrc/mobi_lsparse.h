@@ -6,7 +6,8 @@
 // end) laid out in the order a macroblock passes through them; every round of the loop each lane executes the regions its state lets it
 // enter, falling through from one to the next, and a region costs the wave its instructions once however many lanes are in it.  The lanes
 // are never synchronised on macroblocks: each walks its own frame; the number of rounds is the longest lane's, and the law of large numbers
-// keeps that close to the mean (a frame is 1200 macroblocks).
+// keeps that close to the mean (a frame is 1200 macroblocks).  Behind every round of the whole walk (ls_step) come LS_TOKEN_ROUNDS cheap ones of
+// "next block" and "one token" only (ls_next, ls_token): those two are most of what a frame consists of.
 //
 // This is the FAST path only.  It produces exactly what mobi_parse_frames produces (descriptors, payload, intra items, result record,
 // persistent state) for streams that decode without incident; at anything else -- every condition under which the reference throws, a

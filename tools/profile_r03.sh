@@ -37,6 +37,8 @@ for N in 64 512 4096; do timeout 200 python $REPO/bench.py --clips $N --cpu-seco
 timeout 200 python $REPO/tools/exp_iframe.py 4096 > "$OUT/iframe.txt" 2>&1
 timeout 200 python $REPO/tools/exp_dparse.py 4096 --device-only > "$OUT/dparse.txt" 2>&1
 $REPO/tools/pmc_dparse.sh $TAG/dparse_pmc 4096 >> "$OUT/dparse.txt" 2>&1
+# the lock-step parser (64 clips per wave) beside the one-wave-per-clip parser, at the batch sizes where each wins; its counters
+{ timeout 600 python $REPO/tools/exp_dparse.py 4096 8192 24576 --device-both; $REPO/tools/pmc_lsparse.sh 4096; } > "$OUT/lsparse.txt" 2>&1
 timeout 300 python $REPO/tools/exp_async.py 4096 12 > "$OUT/async.txt" 2>&1
 timeout 200 python $REPO/tools/exp_rgb.py > "$OUT/rgb.txt" 2>&1
 timeout 200 python $REPO/tools/exp_search.py > "$OUT/search.txt" 2>&1

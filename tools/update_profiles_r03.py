@@ -59,7 +59,7 @@ for cfg in "BAC":
     print(cfg, "value", bench["value"], "ms/step", bench["ms_per_step"], "inter ms", r["avg_launch_ms"], "frac", r["frac"], "whole", r["whole_step_frac"], "traffic", traffic.get(f"{cfg}:{clips}", {}).get("hbm_bytes_per_launch"))
 json.dump(traffic, open(tj, "w"), indent=1)
 with open(os.path.join(dst, "r03_ubench.txt"), "w") as o:
-    for name in ("tilepat", "fetchpat", "pitch", "pwrite", "iframe", "single_stream", "dparse", "async", "rgb", "search", "fuzz"):
+    for name in ("tilepat", "fetchpat", "pitch", "pwrite", "iframe", "single_stream", "dparse", "lsparse", "async", "rgb", "search", "fuzz"):
         p = os.path.join(src, name + ".txt")
         if os.path.exists(p):
             o.write(f"==== {name} ====\n" + open(p).read() + "\n")
