@@ -36,7 +36,8 @@
 #define LS_FN static inline
 #endif
 
-enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END };
+enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END,
+       LS_NEXT_SLOW, LS_TOKEN_SLOW }; // what the cheap rounds leave to the whole walk: a 4x4 area's pattern, an escape token, anything odd
 #define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
 enum { LS_TOKEN_ROUNDS = 4,  // ls_next() + ls_token() on their own this many times behind every ls_step(): block after block, token after
                              // token, while the expensive rest of the walk waits
@@ -257,7 +258,9 @@ LS_FN int ls_classify(const LsLane &s) {
 template <class S>
 LS_FN void ls_token(LsLane &s, S &m, const LsCtx &c) {
   const uint8_t *T = c.T;
-  if (s.st == LS_TOKEN) {
+  const bool mine = s.st == LS_TOKEN_SLOW; // (LS_TOKEN itself belongs to ls_token_fast)
+  if (mine) s.st = LS_TOKEN;
+  if (mine) {
     ls_refill(s, m);
     const uint16_t *A = (const uint16_t *)(T + ((s.blk_flags & 2) ? MOBI_DT_A1 : MOBI_DT_A0));
     const uint8_t *B = T + ((s.blk_flags & 2) ? MOBI_DT_B1 : MOBI_DT_B0);
@@ -312,7 +315,9 @@ LS_FN void ls_token(LsLane &s, S &m, const LsCtx &c) {
 template <class S>
 LS_FN void ls_next(LsLane &s, S &m, const LsCtx &c) {
   const uint8_t *T = c.T;
-  if (s.st == LS_NEXT) {
+  const bool mine = s.st == LS_NEXT_SLOW; // (LS_NEXT itself belongs to ls_next_fast)
+  if (mine) s.st = LS_NEXT;
+  if (mine) {
     ls_refill(s, m);
     if (!s.sub_mask && s.area_mask) {
       const int a = ls_ctz(s.area_mask);
@@ -344,9 +349,99 @@ LS_FN void ls_next(LsLane &s, S &m, const LsCtx &c) {
   if (s.bail) s.st = LS_DONE;
 }
 
-// ---------------------------------------------------------------- one round of the walk
+// ---- the cheap rounds: the two regions again, for the common case only and without a branch inside -- the next block when it is a 4x4
+// block of a pattern already read or an area coded as one 8x8 transform, a plain table token -- and everything else handed to the whole
+// walk (LS_NEXT_SLOW, LS_TOKEN_SLOW: ls_next / ls_token above, called from ls_step_main).  The general forms cost 240 vector + 175 scalar
+// instructions per round in the compiler's hands (every `if` a compare, a saved mask, a branch); these are what a round is made of. ----
 template <class S>
-LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
+LS_FN void ls_next_fast(LsLane &s, S &m, const LsCtx &c) {
+  if (s.st == LS_NEXT) {
+    ls_refill(s, m);
+    bool slow = s.quant < 12, got = false, is8 = false;
+    int tile = 0;
+    if (!s.sub_mask && s.area_mask && !slow) {
+      const int a = ls_ctz(s.area_mask);
+      const uint32_t w = ls_win(s);
+      if (w >> 31) { // one 8x8 transform
+        s.area_mask &= s.area_mask - 1;
+        ls_take(s, 1);
+        s.t8mask |= 1u << a;
+        tile = a * 64;
+        got = is8 = true;
+      } else { // which of its 4x4 blocks are coded (MD.cs:2917-2927)
+        const int z = ls_clz(w);
+        const uint32_t u = (z ? ((w << (z + 1)) >> (32 - z)) : 0u) + (1u << z) - 1u;
+        if (z >= 8 || u >= 16) slow = true;
+        else {
+          s.area_mask &= s.area_mask - 1;
+          ls_take(s, 2 * z + 1);
+          s.sub_mask = c.T[MOBI_DT_CBP4_P + u];
+          s.cur_area = a;
+        }
+      }
+    }
+    if (!got && !slow && s.sub_mask) {
+      const int sub = ls_ctz(s.sub_mask);
+      s.sub_mask &= s.sub_mask - 1;
+      tile = s.cur_area * 64 + sub * 16;
+      got = true;
+    }
+    if (got) {
+      s.blk_p = 0;
+      s.blk_n = is8 ? 64 : 16;
+      s.blk_tile = tile;
+      s.blk_flags = (is8 ? 1u : 0u) | (s.vlc == 1 ? 2u : 0u) | (s.tables_set ? 4u : 0u);
+      s.ret = LS_NEXT;
+      s.st = LS_TOKEN;
+    } else if (slow) s.st = LS_NEXT_SLOW;
+    else if (!s.area_mask) s.st = LS_MB_END;
+  }
+}
+template <class S>
+LS_FN void ls_token_fast(LsLane &s, S &m, const LsCtx &c) {
+  if (s.st == LS_TOKEN) {
+    const uint8_t *T = c.T;
+    ls_refill(s, m); // (more than 32 bits: the longest token, prefix included, has 28)
+    const uint32_t w0 = ls_win(s);
+    // 0: a table code; 1, 2: the escape prefix 0000011 + "0" / "10", a table code whose level / run grows by a second table's entry;
+    // 3: prefix + "11", last(1) run(6) level(s12) spelled out (MD.cs:3346-3420)
+    const int kind = (w0 >> 25) != 3 ? 0 : !((w0 >> 24) & 1) ? 1 : !((w0 >> 23) & 1) ? 2 : 3;
+    const int pre = kind == 0 ? 0 : kind == 1 ? 8 : 9;
+    const uint32_t w = (uint32_t)((s.W << pre) >> 32);
+    const uint32_t e = ((const uint16_t *)(T + ((s.blk_flags & 2) ? MOBI_DT_A1 : MOBI_DT_A0)))[w >> 20];
+    int len = (int)(e & 0xF), skip = (int)((e >> 9) & 0x3F), value = (int)((e >> 4) & 0x1F);
+    uint32_t last = e >> 15;
+    if (kind == 1 || kind == 2) { // (one look-up for both: the index differs)
+      const int add = (T + ((s.blk_flags & 2) ? MOBI_DT_B1 : MOBI_DT_B0))[kind == 1 ? (int)(e >> 9) : 0x80 + value + (int)((e >> 15) << 6)];
+      value += kind == 1 ? add : 0;
+      skip += kind == 2 ? add : 0;
+    }
+    bool neg = len ? ((w >> (32 - len)) & 1) != 0 : false;
+    if (kind == 3) {
+      last = w >> 31;
+      skip = (int)((w >> 25) & 0x3F);
+      value = (int32_t)(w << 7) >> 20;
+      neg = false;
+      len = 19;
+    }
+    const int p = s.blk_p + skip;
+    if (len == 0 || p >= s.blk_n) s.st = LS_TOKEN_SLOW; // what the whole walk bails out on
+    else {
+      value = neg ? -value : value;
+      ls_take(s, pre + len);
+      const int idx = (s.blk_flags & 4) ? T[((s.blk_flags & 1) ? MOBI_DT_ZZ8 : MOBI_DT_ZZ4) + p] : 0;
+      s.blk_p = p + 1;
+      if (value != 0) s.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
+      if (last & 1) s.st = (s.ret == LS_NEXT && !s.sub_mask && !s.area_mask) ? LS_MB_END : s.ret;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- one round of the walk, in three parts the kernel schedules separately:
+// ls_step_main (macroblock end / start, partition node, inter CBP), ls_step_intra (the intra regions: half of the walk's instructions for
+// one macroblock in twenty of a P-frame), and ls_next + ls_token above
+template <class S>
+LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
   const uint8_t *T = c.T;
   // ---- macroblock end: the descriptor (mobi_cmd.h).  First, so that a lane whose last token came in the extra rounds goes on to
   // the next macroblock in the same call ----
@@ -471,6 +566,13 @@ LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
       }
     }
   }
+  ls_next(s, m, c);  // (LS_NEXT_SLOW only: the cheap rounds take LS_NEXT / LS_TOKEN themselves)
+  ls_token(s, m, c); // (LS_TOKEN_SLOW only)
+  if (s.bail) s.st = LS_DONE;
+}
+template <class S>
+LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
+  const uint8_t *T = c.T;
   // ---- intra macroblock header: CBP, then the luma mode of a "full" one (MD.cs:1759-1807) ----
   if (s.st == LS_I_HDR) {
     ls_refill(s, m);
@@ -636,9 +738,15 @@ LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) {
       if (!s.bail) s.st = LS_TOKEN;
     } else s.st = LS_I_FIXED;
   }
-  ls_next(s, m, c);
-  ls_token(s, m, c);
   if (s.bail) s.st = LS_DONE; // (a region that bailed out half way may have gone on to set a state)
+}
+LS_FN bool ls_in_intra(const LsLane &s) { return s.st >= LS_I_HDR && s.st <= LS_I_FSUB; }
+template <class S>
+LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) { // everything once, in the order of the walk
+  ls_step_main(s, m, c);
+  ls_step_intra(s, m, c);
+  ls_next_fast(s, m, c);
+  ls_token_fast(s, m, c);
 }
 
 // What the reference's reader would report as consumed after c bits of a stream of len bytes (see the header); -1: it would have thrown

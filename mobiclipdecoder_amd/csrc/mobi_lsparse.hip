@@ -129,8 +129,8 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
 #pragma unroll 1
       for (int k = 0; k < LS_TOKEN_ROUNDS; k++) {
         if (s.st != LS_TOKEN && s.st != LS_NEXT) break; // (per lane: the loop runs while any lane still has a block or a token to read)
-        ls_next(s, m, c);
-        ls_token(s, m, c);
+        ls_next_fast(s, m, c);
+        ls_token_fast(s, m, c);
       }
     }
     if (__builtin_amdgcn_ballot_w64(s.st != LS_DONE) == 0) break;

@@ -81,7 +81,7 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
     C.rounds++;
     C.rounds_by_state[s.st & 15]++;
     ls_step(s, m, c);
-    for (int k = 0; k < LS_TOKEN_ROUNDS && (s.st == LS_TOKEN || s.st == LS_NEXT); k++) { ls_next(s, m, c); ls_token(s, m, c); } // as the kernel does
+    for (int k = 0; k < LS_TOKEN_ROUNDS && (s.st == LS_TOKEN || s.st == LS_NEXT); k++) { ls_next_fast(s, m, c); ls_token_fast(s, m, c); } // as the kernel does
   }
   if (!s.bail) {
     const int used = ls_consumed(s.cbits, (uint32_t)len);
@@ -107,6 +107,58 @@ long mobi_lshost_rounds(void *p, long by_state[16]) {
   Clip &C = *(Clip *)p;
   if (by_state) for (int i = 0; i < 16; i++) by_state[i] = C.rounds_by_state[i];
   return C.rounds;
+}
+
+// Scheduling experiment (tools/exp_lssched.py): 64 clips as the 64 lanes of one wave, frame f of each, under a schedule of the three parts of
+// the walk: every round ls_step_main; every `period`-th round `burst` times (ls_step_intra + `kb` cheap rounds); then `k` cheap rounds.
+// counts[0..3] = rounds, and how many times each part ran with at least one lane in it (main, intra, cheap).  Returns 0, or a bail code.
+int mobi_lshost_wave_sim(void *const *clips, const uint8_t *const *data, const size_t *len, int n_lanes, int k, int period, int burst, int kb, long counts[4]) {
+  struct Lane { Clip *C; HostStore m; LsLane s; LsCtx c; };
+  std::vector<Lane> L(n_lanes);
+  for (int i = 0; i < n_lanes; i++) {
+    Clip &C = *(Clip *)clips[i];
+    Lane &l = L[i];
+    l.C = &C;
+    l.c.T = C.tables.data();
+    l.c.width = C.w; l.c.height = C.h; l.c.stride = C.g.stride; l.c.lg = C.g.lg; l.c.mbw = C.g.mbw; l.c.mbh = C.g.mbh; l.c.n_mbs = C.g.mbw * C.g.mbh;
+    l.c.version = C.version;
+    l.c.pay_cap = (uint32_t)C.pay.size();
+    l.m = C.m;
+    l.m.data = data[i];
+    l.m.len2 = (uint32_t)len[i] & ~1u;
+    memset(&l.s, 0, sizeof(l.s));
+    l.s.quant = C.quant; l.s.yuvfmt = C.yuvfmt; l.s.tables_set = C.tables_set; l.s.frames_started = C.frames_started + 1;
+    l.s.desc = C.desc.data(); l.s.pay = C.pay.data(); l.s.pay_base = 0; l.s.clip = 0; l.s.items = C.items.data();
+    ls_begin_frame(l.s, l.m, l.c, (uint32_t)len[i]);
+  }
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  auto any = [&](auto pred) { for (auto &l : L) if (pred(l.s)) return true; return false; };
+  auto cheap = [&](int n) {
+    for (int j = 0; j < n; j++) {
+      if (!any([](const LsLane &s) { return s.st == LS_NEXT || s.st == LS_TOKEN; })) break;
+      counts[3]++;
+      for (auto &l : L) { ls_next_fast(l.s, l.m, l.c); ls_token_fast(l.s, l.m, l.c); }
+    }
+  };
+  for (long round = 0; any([](const LsLane &s) { return s.st != LS_DONE; }); round++) {
+    counts[0]++;
+    if (any([](const LsLane &s) { return s.st == LS_MB_END || s.st == LS_MB_BEGIN || s.st == LS_NODE || s.st == LS_P_CBP || s.st == LS_NEXT_SLOW || s.st == LS_TOKEN_SLOW; })) counts[1]++;
+    for (auto &l : L) ls_step_main(l.s, l.m, l.c);
+    if (round % period == 0)
+      for (int b = 0; b < burst; b++) {
+        if (!any([](const LsLane &s) { return ls_in_intra(s); })) break;
+        counts[2]++;
+        for (auto &l : L) ls_step_intra(l.s, l.m, l.c);
+        cheap(kb);
+      }
+    cheap(k);
+  }
+  for (auto &l : L) {
+    if (l.s.bail) return l.s.bail;
+    l.C->m = l.m;
+    l.C->quant = l.s.quant; l.C->yuvfmt = l.s.yuvfmt; l.C->tables_set = l.s.tables_set; l.C->frames_started = l.s.frames_started;
+  }
+  return 0;
 }
 
 // The whole differential in one call: every frame of a clip through both parsers.  Returns the number of frames that compared equal

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Scheduling of the lock-step parser's three parts (CPU, tests/tools/mobi_lsparse_host.cpp): 64 clips as the lanes of one wave, one P-frame and one
+I-frame, how often each part runs under a schedule, and what that costs at the clocks measured for them on the GPU.
+python tools/exp_lssched.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import mobiclipdecoder_amd as m
+from mobiclipdecoder_amd import sharding, build
+L = C.CDLL(build.build_lshost())
+L.mobi_lshost_create.restype = C.c_void_p; L.mobi_lshost_create.argtypes = [C.c_uint, C.c_uint, C.c_int]
+L.mobi_lshost_destroy.argtypes = [C.c_void_p]
+L.mobi_lshost_wave_sim.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+COST = dict(main=float(os.environ.get("C_MAIN", 5.5)), intra=float(os.environ.get("C_INTRA", 5.5)), cheap=float(os.environ.get("C_CHEAP", 1.6)))  # k clocks per run
+streams = [m.generate_clip(m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=4)) for i in range(16)]
+def run(k, period, burst, kb, lanes=64):
+    clips = [L.mobi_lshost_create(640, 480, 2) for _ in range(lanes)]
+    out = []
+    for f in range(3):
+        bufs = [np.ascontiguousarray(streams[i % 16][0][streams[i % 16][1][f]:streams[i % 16][1][f + 1]]) for i in range(lanes)]
+        cp = (C.c_void_p * lanes)(*clips); dp = (C.c_void_p * lanes)(*[b.ctypes.data for b in bufs]); lp = (C.c_size_t * lanes)(*[b.size for b in bufs])
+        cnt = (C.c_long * 4)()
+        rc = L.mobi_lshost_wave_sim(cp, dp, lp, lanes, k, period, burst, kb, cnt)
+        assert rc == 0, rc
+        out.append(list(cnt))
+    for c in clips: L.mobi_lshost_destroy(c)
+    def ms(c): return (c[1] * COST["main"] + c[2] * COST["intra"] + c[3] * COST["cheap"]) * 1e3 / 2.4e9 * 1e3
+    i, p = out[0], out[2]
+    print(f"k={k} intra every {period} x{burst} (+{kb} cheap): P-frame rounds {p[0]} main {p[1]} intra {p[2]} cheap {p[3]} -> {ms(p):5.1f} ms | I-frame rounds {i[0]} intra {i[2]} cheap {i[3]} -> {ms(i):5.1f} ms", flush=True)
+if __name__ == "__main__":
+    run(4, 1, 1, 0)
+    for period, burst, kb in [(2, 1, 0), (2, 2, 2), (3, 2, 2), (4, 3, 2), (4, 4, 4), (6, 4, 4), (8, 6, 4), (8, 8, 4)]:
+        run(4, period, burst, kb)
