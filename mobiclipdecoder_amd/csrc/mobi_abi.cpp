@@ -305,11 +305,15 @@ struct mobi_batch {
   struct AsyncSlot {
     PinnedBuf h_stage, h_pres, h_fault;
     DevBuf d_bits;
-    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    // what the parse of this step leaves in HBM: owned by the slot, so that the parse of step n + 1 (on stream_p) may run under the
+    // reconstruction of step n (on stream), which still reads step n's
+    DevBuf d_pdesc, d_ppay, d_pitems, d_pres;
+    hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_parsed = nullptr;
     std::vector<int32_t> offs; // Offset of every clip at submission
     int n_dev = 0;
   };
   AsyncSlot aslot[2];
+  hipStream_t stream_p = nullptr;      // asynchronous steps: the parse kernels (upload on stream2, reconstruction on stream)
   int async_head = 0, async_count = 0; // oldest step in flight, number of steps in flight (<= 2)
   size_t dp_len_hint = 0;              // longest frame seen so far (+ 25 %): sizes the payload arena of the device-side parser
   uint64_t async_seq = 0;
@@ -391,6 +395,7 @@ struct mobi_batch {
   }
   ~mobi_batch() {
     if (stream2) (void)hipStreamSynchronize(stream2); // an upload of a submitted step may still be reading pinned memory we are about to free
+    if (stream_p) (void)hipStreamSynchronize(stream_p);
     if (stream) (void)hipStreamSynchronize(stream);
     drain_events();
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -398,8 +403,10 @@ struct mobi_batch {
     for (auto &sl : aslot) {
       if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
       if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+      if (sl.ev_parsed) (void)hipEventDestroy(sl.ev_parsed);
     }
     if (stream2) (void)hipStreamDestroy(stream2);
+    if (stream_p) (void)hipStreamDestroy(stream_p);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -632,7 +639,8 @@ static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const siz
 }
 // output buffers + the parse launch.  A clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level
 // per bit read.  `busy`: earlier steps may still be using the buffers (asynchronous steps): drain the stream before growing one.
-static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged &st, bool busy) {
+struct DpOut { DevBuf *desc, *pay, *items; MobiDevResult *res; hipStream_t stream; };
+static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged &st, bool busy, const DpOut &o) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
   // (the longest frame of a step varies from step to step: the bound follows it upwards in steps of a quarter, so that the payload
   // arena -- gigabytes for thousands of clips -- is not freed and allocated again every few frames)
@@ -649,10 +657,10 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   b->pay_clip_words = local ? (uint32_t)cap_words : 0u;
   const size_t want_desc = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), want_pay = align_up((size_t)n * cap_words * 4 + kPaySlack, kAlign),
                want_items = (size_t)n * n_mbs * 4;
-  if (busy && (want_desc > b->d_pdesc.cap || want_pay > b->d_ppay.cap || want_items > b->d_pitems.cap)) HIP_TRY(hipStreamSynchronize(b->stream));
-  if (int e = b->d_pdesc.reserve(want_desc)) return e;
-  if (int e = b->d_ppay.reserve(want_pay)) return e;
-  if (int e = b->d_pitems.reserve(want_items)) return e;
+  if (busy && (want_desc > (*o.desc).cap || want_pay > (*o.pay).cap || want_items > (*o.items).cap)) HIP_TRY(hipStreamSynchronize(o.stream));
+  if (int e = (*o.desc).reserve(want_desc)) return e;
+  if (int e = (*o.pay).reserve(want_pay)) return e;
+  if (int e = (*o.items).reserve(want_items)) return e;
   MobiDevParseArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.bits = d_bits + st.hdr_bytes;
@@ -663,19 +671,19 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   pa.state_ls = b->d_pstate_ls;
   pa.lockstep = b->lockstep ? 1 : 0;
   pa.pay_local = local ? 1 : 0;
-  pa.desc = (MbDesc *)b->d_pdesc.p;
-  pa.payload = (uint32_t *)b->d_ppay.p;
-  pa.items = (uint32_t *)b->d_pitems.p;
-  pa.res = b->d_pres;
+  pa.desc = (MbDesc *)(*o.desc).p;
+  pa.payload = (uint32_t *)(*o.pay).p;
+  pa.items = (uint32_t *)(*o.items).p;
+  pa.res = o.res;
   pa.pay_cap = (uint32_t)cap_words;
   b->last_pay_cap = cap_words;
   pa.n_clips = nd; pa.version = b->version;
   pa.width = b->g.width; pa.height = b->g.height; pa.stride = b->g.stride; pa.lg = b->g.lg; pa.mbw = b->g.mbw; pa.mbh = b->g.mbh;
   if (b->ktiming && !b->ev_p0) { (void)hipEventCreate(&b->ev_p0); (void)hipEventCreate(&b->ev_p1); }
   const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
-  if (ptime) (void)hipEventRecord(b->ev_p0, b->stream);
-  if (mobi_launch_parse(&pa, b->stream) != 0) return MOBI_E_DEVICE;
-  if (ptime) (void)hipEventRecord(b->ev_p1, b->stream);
+  if (ptime) (void)hipEventRecord(b->ev_p0, o.stream);
+  if (mobi_launch_parse(&pa, o.stream) != 0) return MOBI_E_DEVICE;
+  if (ptime) (void)hipEventRecord(b->ev_p1, o.stream);
   return MOBI_OK;
 }
 
@@ -692,7 +700,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   if (int e = dp_stage(b, nd, data, len, offsets, b->h_stage, st)) return e;
   if (int e = b->d_bits.reserve(st.bytes)) return e;
   HIP_TRY(hipMemcpyAsync(b->d_bits.p, b->h_stage.p, st.bytes, hipMemcpyHostToDevice, b->stream));
-  if (int e = dp_parse(b, nd, b->d_bits.p, st, false)) return e;
+  if (int e = dp_parse(b, nd, b->d_bits.p, st, false, DpOut{&b->d_pdesc, &b->d_ppay, &b->d_pitems, b->d_pres, b->stream})) return e;
   const size_t cap_words = b->last_pay_cap;
   const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
   MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
@@ -800,9 +808,12 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
     HIP_TRY(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming));
   }
+  if (!S.ev_parsed) HIP_TRY(hipEventCreateWithFlags(&S.ev_parsed, hipEventDisableTiming));
   if (!b->stream2) HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+  if (!b->stream_p) HIP_TRY(hipStreamCreateWithFlags(&b->stream_p, hipStreamNonBlocking));
   DpStaged st;
   if (int e = dp_stage(b, n, data, len, offsets, S.h_stage, st)) return e; // (this slot's previous step was waited for: its upload is done)
+  if (int e = S.d_pres.reserve(sizeof(MobiDevResult) * n)) return e;
   if (st.bytes > S.d_bits.cap) // growing frees and allocates (a device-wide stall): leave room for the longer frames to come
     if (int e = S.d_bits.reserve(st.bytes + st.bytes / 4)) return e;
   if (int e = S.h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
@@ -817,27 +828,35 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
     ~Poison() {
       if (!armed) return;
       if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+      if (b->stream_p) (void)hipStreamSynchronize(b->stream_p);
       (void)hipStreamSynchronize(b->stream);
       b->poisoned = true;
     }
   } poison{b};
   HIP_TRY(hipMemcpyAsync(S.d_bits.p, S.h_stage.p, st.bytes, hipMemcpyHostToDevice, b->stream2)); // beside whatever the step before is doing
   HIP_TRY(hipEventRecord(S.ev_up, b->stream2));
-  HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_up, 0));
-  if (int e = dp_parse(b, n, S.d_bits.p, st, b->async_count > 0)) return e;
-  HIP_TRY(hipMemcpyAsync(S.h_pres.p, b->d_pres, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream));
+  // Three streams: the upload (stream2), the parse (stream_p: after the upload; the decoder state goes from parse to parse in its order)
+  // and the reconstruction (stream: after this step's parse; the ring goes from step to step in its order).  The parse of this step
+  // runs under the reconstruction of the one before -- the lock-step parser leaves most of the chip idle -- because what it writes
+  // (descriptors, payload, intra lists, results) belongs to the slot, whose previous step has been waited for.
+  HIP_TRY(hipStreamWaitEvent(b->stream_p, S.ev_up, 0));
+  MobiDevResult *d_res = (MobiDevResult *)S.d_pres.p;
+  if (int e = dp_parse(b, n, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, b->stream_p})) return e;
+  HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream_p));
+  HIP_TRY(hipEventRecord(S.ev_parsed, b->stream_p));
+  HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
   // reconstruction straight from what the parse leaves in HBM (failed clips: blank descriptors, no items)
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse throws
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
-  MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
+  MobiReconArgs a = b->args(S.d_pdesc.p, S.d_ppay.p);
   a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
   if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
   // the parse has not run yet, so nobody knows how many intra macroblocks the longest list will have: MOBI_ASYNC_INTRA_SLOTS slots are launched
   // (a P-frame's lists are shorter), and the workgroups of the last one walk through the rest of theirs (an I-frame: every macroblock)
-  if (mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), std::min(n_mbs, MOBI_ASYNC_INTRA_SLOTS), b->stream) != 0) return MOBI_E_DEVICE;
+  if (mobi_launch_intra_cl(&a, (const uint32_t *)S.d_pitems.p, &d_res[0].n_intra, (int)(sizeof(MobiDevResult) / 4), std::min(n_mbs, MOBI_ASYNC_INTRA_SLOTS), b->stream) != 0) return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(S.h_fault.p, b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   HIP_TRY(hipEventRecord(S.ev_done, b->stream));

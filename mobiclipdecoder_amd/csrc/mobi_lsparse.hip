@@ -56,6 +56,9 @@ __device__ __forceinline__ uint4 ls_chunk(const uint8_t *base, uint32_t o, uint3
 
 extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevParseArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  // A wave of this kernel is one long chain of dependent instructions and the launch is as long as that chain.  When the reconstruction of
+  // the step before runs beside it (asynchronous steps: four of its waves on the same SIMD), the chain must not queue behind them.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int mvc_words = 2 * (A.mbw + 2);
   uint8_t *tab = lds;

@@ -14,7 +14,7 @@ for i in range(16):
     p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=3 + steps, **({"iframe_interval": 1} if os.environ.get("IFRAMES") else {}))  # IFRAMES=1: every frame an I-frame
     d, fo = m.generate_clip(p)
     streams.append((d, fo))
-b = m.MobiclipBatch(n, 640, 480, p.version, device_parse=True)
+b = m.MobiclipBatch(n, 640, 480, p.version, device_parse="lockstep" if os.environ.get("LOCKSTEP") else True)  # LOCKSTEP=1: the lock-step parser in front
 lib, h = b._lib, b._h
 # ctypes arrays built once per frame, outside the timed calls: what a C caller would hand over
 def pack(f):
@@ -44,7 +44,7 @@ t = (time.perf_counter() - t0) * 1e3 / steps
 print("asynchronous: %.2f ms per step of %d clips = %.1f Gpixels/s" % (t, n, n * 640 * 480 / t / 1e6))
 # synchronous, same frames again is not possible (decoder state moved on): a fresh batch
 b.close()
-b = m.MobiclipBatch(n, 640, 480, p.version, device_parse=True)
+b = m.MobiclipBatch(n, 640, 480, p.version, device_parse="lockstep" if os.environ.get("LOCKSTEP") else True)  # LOCKSTEP=1: the lock-step parser in front
 lib, h = b._lib, b._h
 for f in range(2):
     assert lib.mobi_batch_decode(h, packed[f][1], packed[f][2], offs, rcs) == 0
