@@ -41,7 +41,8 @@ enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I
 #define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
 enum { LS_TOKEN_ROUNDS = 4,  // ls_next() + ls_token() on their own this many times behind every ls_step(): block after block, token after
                              // token, while the expensive rest of the walk waits
-       LS_ROUND_BYTES = 36, // what one such round can take from the ring at most (98 bits of the walk + 4 x (15 + 28))
+       LS_ROUND_BYTES = 64, // what one such round can take from the ring at most (an intra macroblock's header and every area's mode in one visit:
+                            // ~310 bits, + 4 x (15 + 28) of the cheap rounds)
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
 
 struct LsCtx { // wave-uniform
@@ -432,7 +433,7 @@ LS_FN void ls_token_fast(LsLane &s, S &m, const LsCtx &c) {
       const int idx = (s.blk_flags & 4) ? T[((s.blk_flags & 1) ? MOBI_DT_ZZ8 : MOBI_DT_ZZ4) + p] : 0;
       s.blk_p = p + 1;
       if (value != 0) s.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
-      if (last & 1) s.st = (s.ret == LS_NEXT && !s.sub_mask && !s.area_mask) ? LS_MB_END : s.ret;
+      if (last & 1) s.st = (s.ret == LS_NEXT && !s.sub_mask && !s.area_mask) ? LS_MB_END : (s.ret == LS_I_FSUB && !s.sub_mask) ? LS_I_FIXED : s.ret;
     }
   }
 }
@@ -605,7 +606,7 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
     }
   }
   // ---- "sub" intra macroblock, one luma area (DecIntraSubBlockPMode, MD.cs:1789-1807, :2776) ----
-  if (s.st == LS_I_SUBAREA) {
+  for (int it = 0; it < 5 && s.st == LS_I_SUBAREA; it++) {
     if (s.i_k == 4) s.st = LS_I_CHROMA;
     else {
       const int k = s.i_k, cik = 9 + (k & 1) * 2 + (k >> 1) * 0x10;
@@ -643,7 +644,7 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
       }
     }
   }
-  if (s.st == LS_I_SUB4) {
+  for (int it = 0; it < 5 && s.st == LS_I_SUB4; it++) {
     if (s.i_sub == 4) { s.i_k++; s.st = LS_I_SUBAREA; }
     else {
       const int k = s.i_k, sub = s.i_sub, cik = 9 + (k & 1) * 2 + (k >> 1) * 0x10;
@@ -668,7 +669,7 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
     }
   }
   // ---- chroma mode of an intra macroblock (loc_116290, MD.cs:1864-1880) ----
-  if (s.st == LS_I_CHROMA) {
+  auto chroma_mode = [&]() {
     ls_refill(s, m);
     int md = (int)(ls_win(s) >> 29);
     ls_take(s, 3);
@@ -685,11 +686,15 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
     s.i_mode = md;
     s.i_k = 4;
     s.i_chroma = 1;
+  };
+  if (s.st == LS_I_CHROMA) {
+    chroma_mode();
     if (!s.bail) s.st = LS_I_FIXED;
   }
   // ---- one area whose mode is known (sub_116508, MD.cs:2869-2896) ----
-  if (s.st == LS_I_FIXED) {
-    if (s.i_k == 4 && !s.i_chroma) s.st = LS_I_CHROMA;
+  // (area after area in one visit while they are not coded: a visit costs the wave a round of the whole walk)
+  for (int it = 0; it < 8 && s.st == LS_I_FIXED; it++) {
+    if (s.i_k == 4 && !s.i_chroma) chroma_mode();
     else if (s.i_k == 6) s.st = LS_MB_END;
     else {
       const int k = s.i_k, md = s.i_mode;
