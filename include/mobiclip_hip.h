@@ -109,8 +109,9 @@ int mobi_batch_lockstep_finished(const mobi_batch *b);
  * mobi_batch_set_parse_mode(b, 1) otherwise; not the hybrid mode) and at most two steps may be in flight.
  *   mobi_batch_submit: copies the bytes data[i][offsets[i] .. len[i]) of every clip into pinned memory and enqueues upload, parse and
  *                      reconstruction of one frame step behind the step before; returns without waiting for the GPU.  The caller's
- *                      buffers may be reused as soon as it returns.  Upload, parse and reconstruction have a stream each: the parse of
- *                      step n + 1 runs under the reconstruction of step n (its output buffers belong to the step).
+ *                      buffers may be reused as soon as it returns.  The upload has a stream of its own, and so has the lock-step parser
+ *                      (parse mode 3): the parse of step n + 1 then runs under the reconstruction of step n (its output buffers
+ *                      belong to the step).
  *   mobi_batch_wait:   waits for the OLDEST step in flight and reports what mobi_batch_decode would have: rc[i] per clip,
  *                      offsets_out[i] = Offset after the frame (may be NULL).
  * mobi_batch_decode, mobi_batch_get_planes and the other calls that read results wait for everything enqueued; mobi_batch_decode is

@@ -839,12 +839,17 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // and the reconstruction (stream: after this step's parse; the ring goes from step to step in its order).  The parse of this step
   // runs under the reconstruction of the one before -- the lock-step parser leaves most of the chip idle -- because what it writes
   // (descriptors, payload, intra lists, results) belongs to the slot, whose previous step has been waited for.
-  HIP_TRY(hipStreamWaitEvent(b->stream_p, S.ev_up, 0));
+  // (Only the lock-step parser gets the stream of its own: the one-wave-per-clip parser fills every wave slot of the chip with 122-register
+  // waves, and a reconstruction launched beside it waits for them to leave anyway -- 20.5 instead of 13.2 ms per step of 4096 clips.)
+  hipStream_t ps = b->lockstep ? b->stream_p : b->stream;
+  HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
   MobiDevResult *d_res = (MobiDevResult *)S.d_pres.p;
-  if (int e = dp_parse(b, n, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, b->stream_p})) return e;
-  HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream_p));
-  HIP_TRY(hipEventRecord(S.ev_parsed, b->stream_p));
-  HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
+  if (int e = dp_parse(b, n, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps})) return e;
+  HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, ps));
+  if (ps != b->stream) {
+    HIP_TRY(hipEventRecord(S.ev_parsed, ps));
+    HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
+  }
   // reconstruction straight from what the parse leaves in HBM (failed clips: blank descriptors, no items)
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse throws
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;

@@ -24,6 +24,7 @@ def row(name, d, clips, key, r02):
             f"{T[key]['hbm_bytes_per_launch'] / r['algorithmic_bytes_per_launch']:.2f} | {r['intra_kernel_ms_per_step']:.2f} ms | {r['whole_step_frac']:.3f} | {r02} |")
 
 ss, e2e, c4, cb = B["single_stream"], B["end_to_end"], B["config4"], B["cpu_baseline"]
+e2l = B.get("end_to_end_large") or {"value": 0, "ms_per_step": 0, "clips": 0, "async": {"value": 0, "ms_per_step": 0}}
 s = open("DESIGN.md").read()
 a, b = s.index("Results, MI355X, r03 build"), s.index("Profiles: `profiles/r03_*`")
 text = f'''Results, MI355X, r03 build (`profiles/r03_{{A,B,C}}_bench.json`; the rocprofv3 kernel-trace average of the same command,
@@ -61,8 +62,10 @@ the Bitmap conversion {cb['with_bitmap']['value']:.0f} Mpixels/s (`with_bitmap`)
 
 End to end (`mobi_batch_decode`: bitstream bytes in host memory → planes in HBM; staging, H2D, device parse, reconstruction,
 read-back of 32 B per clip, synchronisation): {e2e['ms_per_step']:.1f} ms per step of 4096 clips = {e2e['value'] / 1e3:.0f} Gpixels/s (`end_to_end`), 10 × below the
-reconstruction kernels; `mobi_batch_submit` / `mobi_batch_wait` with two steps in flight: {e2e['async']['ms_per_step']:.1f} ms = {e2e['async']['value'] / 1e3:.0f} Gpixels/s (`end_to_end.async`). Of
-these the parse kernel is 10.9 ms (unchanged in r03: § "Next rows", f3), reconstruction 1.5 ms. PCIe-inclusive rate of the
+reconstruction kernels; `mobi_batch_submit` / `mobi_batch_wait` with two steps in flight: {e2e['async']['ms_per_step']:.1f} ms = {e2e['async']['value'] / 1e3:.0f} Gpixels/s (`end_to_end.async`).
+At the headline batch with the lock-step parser in front (`end_to_end_large`, {e2l['clips']} clips, f3): {e2l['ms_per_step']:.1f} ms per step = **{e2l['value'] / 1e3:.0f} Gpixels/s**,
+asynchronous {e2l['async']['ms_per_step']:.1f} ms = **{e2l['async']['value'] / 1e3:.0f} Gpixels/s** (r02: a batch of that size could not be parsed on the GPU at all). Of
+the 4096-clip step the parse kernel is 10.9 ms (one wave per clip, unchanged in r03: § "Next rows", f3), reconstruction 1.5 ms. PCIe-inclusive rate of the
 *reconstruction* path fed with host-parsed command lists: ≈90 KB of commands per 640×480 frame, 10 % of the pixel bytes, 20 Gpixels/s with
 32 parse threads (the parse, not PCIe, limits).
 
@@ -75,7 +78,7 @@ def gb(d, key):
 def n(v):
     return format(v, ",.0f").replace(",", " ")
 rows = [f"| A 256×192 Mods P-stream | 1 | 24576 | {n(A['value'])} | {gb(A, 'A:24576'):.0f} | {A['roofline']['frac'] * 100:.1f} / {A['roofline']['whole_step_frac'] * 100:.1f} | — | {A['cpu_baseline']['value']:.0f} / — | yes |",
-        f"| B 640×480 Moflex P-stream | 1 | 24576 | {n(B['value'])} | {gb(B, 'B:24576'):.0f} | {B['roofline']['frac'] * 100:.1f} / {B['roofline']['whole_step_frac'] * 100:.1f} | {n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous) (4096 clips, device parse) | {cb['value']:.0f} / {cb['all_cpus']['value']:.0f} (N = {cb['all_cpus']['cores']}) | yes |",
+        f"| B 640×480 Moflex P-stream | 1 | 24576 | {n(B['value'])} | {gb(B, 'B:24576'):.0f} | {B['roofline']['frac'] * 100:.1f} / {B['roofline']['whole_step_frac'] * 100:.1f} | {n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous) (4096 clips, device parse); {n(e2l['value'])} ({n(e2l['async']['value'])}) at {e2l['clips']} clips, lock-step parse | {cb['value']:.0f} / {cb['all_cpus']['value']:.0f} (N = {cb['all_cpus']['cores']}) | yes |",
         f"| C 848×480 Moflex P-stream | 1 | 6144 | {n(C['value'])} | {gb(C, 'C:6144'):.0f} | {C['roofline']['frac'] * 100:.1f} / {C['roofline']['whole_step_frac'] * 100:.1f} | — | {C['cpu_baseline']['value']:.0f} / — | yes |",
         f"| B ×8 clips (64 over 8 GPUs) | 1 | 8 | {n(c4['value'])} | — | — | — | | yes |"]
 for x in small:
@@ -93,7 +96,8 @@ a, b = s.index("Measured on one MI355X (round 3"), s.index("| read | for |")
 s = s[:a] + f'''Measured on one MI355X (round 3, `python bench.py`, 640×480 Moflex3DS P-frames in stream order, 24576 resident clips, 1.7 s
 timed): {B['value'] / 1e3:.0f} Gpixels/s of reconstruction (command lists resident in HBM), the dominant kernel at {B['roofline']['frac'] * 100:.0f} % of the 8 TB/s HBM
 roofline counting only its own macroblocks' bytes, the whole step at {B['roofline']['whole_step_frac'] * 100:.0f} %, HBM traffic {ratio:.2f} × the algorithmic bytes, bit-exact;
-{e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight); one
+{e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight) at 4096
+clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser; one
 stream through `mobi_decode`: {ss['planes']['p_frame_ms']:.2f} ms per P-frame; {cb['value'] / 1e3:.2f} Gpixels/s for the CPU restatement of the reference on one host
 core ({cb['all_cpus']['value'] / 1e3:.1f} on all {cb['all_cpus']['cores']}). Since round 3 the planes live in HBM as macroblock tiles (`mobi_tile.h`): the reference's linear
 offsets keep their meaning through a bit permutation, and a macroblock's samples are three whole 128-byte lines.
