@@ -137,6 +137,14 @@ LS_FN int ls_se(LsLane &s) {
   return v;
 }
 
+// The partition-code table of this parser's copy of the blob: entry = code | code length << 4, or 0xFF where the reference throws (a code the
+// shape does not have) -- one look-up instead of three behind one another.  i = 0 .. 1023, every entry on its own (any order, any thread).
+LS_FN void ls_prepare_tables(uint8_t *T, int i) {
+  const uint32_t code = T[MOBI_DT_PLUT + i], sh = (uint32_t)i >> 6;
+  const bool ok = code < T[MOBI_DT_PNB + sh] && code <= 9;
+  T[MOBI_DT_PLUT + i] = ok ? (uint8_t)(code | (T[MOBI_DT_PBITS + sh * 12 + (ok ? code : 0)] << 4)) : (uint8_t)0xFF;
+}
+
 // ---------------------------------------------------------------- frame header (MD.cs:113-143, :224-236)
 template <class S>
 LS_FN void ls_setup_quant(LsLane &s, S &m, const LsCtx &c, uint32_t q) { // MD.cs:3884-3925
@@ -521,10 +529,10 @@ LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
     const uint32_t it = m.stk(--s.sp);
     const int wi = it & 3, hi = (it >> 2) & 3, x = ((it >> 4) & 15) * 2, y = ((it >> 8) & 15) * 2;
     const int sh = wi * 4 + hi, w = 16 >> wi, h = 16 >> hi;
-    const uint32_t code = T[MOBI_DT_PLUT + sh * 64 + (ls_win(s) >> T[MOBI_DT_PSHIFT + sh])];
-    if (code >= T[MOBI_DT_PNB + sh] || code > 9) ls_bail(s, 10);
+    const uint32_t pe = T[MOBI_DT_PLUT + sh * 64 + (ls_win(s) >> T[MOBI_DT_PSHIFT + sh])], code = pe & 15; // (ls_prepare_tables: code | length << 4)
+    if (pe == 0xFF) ls_bail(s, 10);
     else {
-      ls_take(s, T[MOBI_DT_PBITS + sh * 12 + code]);
+      ls_take(s, (int)(pe >> 4));
       if (code <= 5) {
         int dx = s.predx, dy = s.predy;
         if (code) {

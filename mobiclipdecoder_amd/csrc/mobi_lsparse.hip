@@ -71,6 +71,8 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   m.lane = lane;
   for (int i = lane; i < MOBI_DT_BYTES / 16; i += 64) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
+  for (int i = lane; i < 1024; i += 64) ls_prepare_tables(tab, i);
+  __syncthreads();
 
   const int clip = blockIdx.x * 64 + lane;
   const bool live = clip < A.n_clips;

@@ -52,6 +52,7 @@ void *mobi_lshost_create(uint32_t w, uint32_t h, int version) {
   c->g = p.geom();
   c->tables.resize(MOBI_DT_BYTES);
   mobi_dparse_build_tables(version, c->tables.data());
+  for (int i = 0; i < 1024; i++) ls_prepare_tables(c->tables.data(), i); // (this copy is the lock-step parser's own, as on the device)
   memset(&c->m, 0, sizeof(c->m));
   const int n = c->g.mbw * c->g.mbh;
   c->desc.resize(n);
