@@ -20,6 +20,9 @@
 #include "mobi_lsparse.h"
 
 namespace {
+#ifndef LS_CLIPS
+#define LS_CLIPS 64 // clips per wave (lanes in use); tools/exp_lsclips.sh tries fewer
+#endif
 enum { LS_SERVICE = 4, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
 struct DevStore {
@@ -74,8 +77,8 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   for (int i = lane; i < 1024; i += 64) ls_prepare_tables(tab, i);
   __syncthreads();
 
-  const int clip = blockIdx.x * 64 + lane;
-  const bool live = clip < A.n_clips;
+  const int clip = blockIdx.x * LS_CLIPS + lane;
+  const bool live = lane < LS_CLIPS && clip < A.n_clips;
   const int n_mbs = A.mbw * A.mbh;
   LsCtx c;
   c.T = tab;
@@ -181,7 +184,7 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   const size_t lds = MOBI_DT_BYTES + (size_t)64 * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
   if (lds > 64 * 1024) // (per device; cheap)
     if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
-  hipLaunchKernelGGL(mobi_parse_frames_ls, dim3((unsigned)((a->n_clips + 63) / 64)), dim3(64), lds, s, *a);
+  hipLaunchKernelGGL(mobi_parse_frames_ls, dim3((unsigned)((a->n_clips + LS_CLIPS - 1) / LS_CLIPS)), dim3(64), lds, s, *a);
   const uint32_t chunks = (uint32_t)(a->mbw * a->mbh + 63) / 64;
   hipLaunchKernelGGL(mobi_ls_deps, dim3((unsigned)a->n_clips * chunks), dim3(64), 0, s, *a, chunks);
   return (int)hipGetLastError();

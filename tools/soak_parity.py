@@ -1,6 +1,6 @@
 """Soak: N clips (private copies of 16 generated streams) replayed for a whole 33-frame clip, twice, on a loaded chip; EVERY clip's
 planes are compared with the oracle's at the I-frame, in the middle and at the end.  Looks for rare hand-off races (completion tags,
-write-through stores) that a handful of clips would never show.  python tools/soak_parity.py [clips] [config] [dparse]
+write-through stores) that a handful of clips would never show.  python tools/soak_parity.py [clips] [config] [dparse | lockstep]
 "dparse": the same through mobi_batch_decode with the parse on the GPU (mobi_recon_intra_cl: items per clip in raster order), 12 frames."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,12 +11,13 @@ from tests.oracle_binding import OracleDecoder
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
-dparse = len(sys.argv) > 3 and sys.argv[3] == "dparse"
+dparse = len(sys.argv) > 3 and sys.argv[3] in ("dparse", "lockstep")
+lockstep = dparse and sys.argv[3] == "lockstep"  # the lock-step parser in front (64 clips per wave)
 distinct, nfr = 16, (12 if dparse else 33)
 ps = [m.default_params(cfg, sharding.stream_seed(cfg, 0, i), n_frames=nfr, pm_intra=120 if i & 1 else 50, iframe_interval=11 if i % 5 == 0 else 0) for i in range(distinct)]
 clips = [m.generate_clip(p) for p in ps]
 W, H, ver = ps[0].width, ps[0].height, ps[0].version
-b = m.MobiclipBatch(n, W, H, ver, device_parse=True if dparse else None)
+b = m.MobiclipBatch(n, W, H, ver, device_parse=("lockstep" if lockstep else True) if dparse else None)
 if not dparse:
     for i in range(distinct):
         assert all(r == 0 for r in b.preload(i, clips[i][0], clips[i][1]))
