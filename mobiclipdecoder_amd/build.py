@@ -64,7 +64,9 @@ def build_hip(force=False, profiling=False):
     # (same registers, same occupancy; measured A/B on one box); the other kernels keep the default
     # r03: both kernels are bound by vector instruction issue; loops the source does not ask to unroll stay loops (-fno-unroll-loops:
     # 2.51 against 2.57 ms per launch of 8192 clips, tools/exp_kernel_flags.sh)
-    extra = {"mobi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-unroll-loops"]}
+    extra = {"mobi_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fno-unroll-loops"],
+             # the lock-step parser is one long dependent chain per wave: 24.8 against 25.6 ms per P-frame step (tools/exp_lsflags.sh)
+             "mobi_lsparse.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     for s in srcs[4:]:
         ko = os.path.join(obj, os.path.basename(s) + ".o")
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DMOBI_PROFILING"] if profiling else []) + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
