@@ -339,8 +339,8 @@ def main():
     if world == 1 and args.e2e_clips > 0 and min(args.e2e_large_clips, args.clips) >= 8192 and args.config == "B":  # (--e2e-clips 0 skips both legs)
         try:
             e2e_large = end_to_end(m, streams, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
-        except m.MobiclipError as e:  # (does not fit beside what the allocator still holds: reported, not fatal)
-            e2e_large = {"error": str(e)}
+        except Exception as e:  # (e.g. does not fit beside what the allocator still holds: reported beside the headline value, not fatal to it)
+            e2e_large = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and args.config4_clips > 0 and args.config == "B":
         c4 = config4_leg(m, streams, W, H, p0.version, local, args.config4_clips, 24)
 

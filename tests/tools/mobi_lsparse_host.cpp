@@ -162,6 +162,55 @@ int mobi_lshost_wave_sim(void *const *clips, const uint8_t *const *data, const s
   return 0;
 }
 
+// The same for any order of the parts within a round: sched = a string of M (ls_step_main), I (ls_step_intra), N (ls_next_fast), T (ls_token_fast).
+// counts[0] = rounds, counts[1..4] = how often M, I, N, T ran with at least one lane in them.
+int mobi_lshost_wave_sched(void *const *clips, const uint8_t *const *data, const size_t *len, int n_lanes, const char *sched, long counts[5]) {
+  struct Lane { Clip *C; HostStore m; LsLane s; LsCtx c; };
+  std::vector<Lane> L(n_lanes);
+  for (int i = 0; i < n_lanes; i++) {
+    Clip &C = *(Clip *)clips[i];
+    Lane &l = L[i];
+    l.C = &C;
+    l.c.T = C.tables.data();
+    l.c.width = C.w; l.c.height = C.h; l.c.stride = C.g.stride; l.c.lg = C.g.lg; l.c.mbw = C.g.mbw; l.c.mbh = C.g.mbh; l.c.n_mbs = C.g.mbw * C.g.mbh;
+    l.c.version = C.version;
+    l.c.pay_cap = (uint32_t)C.pay.size();
+    l.m = C.m;
+    l.m.data = data[i];
+    l.m.len2 = (uint32_t)len[i] & ~1u;
+    memset(&l.s, 0, sizeof(l.s));
+    l.s.quant = C.quant; l.s.yuvfmt = C.yuvfmt; l.s.tables_set = C.tables_set; l.s.frames_started = C.frames_started + 1;
+    l.s.desc = C.desc.data(); l.s.pay = C.pay.data(); l.s.pay_base = 0; l.s.clip = 0; l.s.items = C.items.data();
+    ls_begin_frame(l.s, l.m, l.c, (uint32_t)len[i]);
+  }
+  for (int k = 0; k < 5; k++) counts[k] = 0;
+  auto any = [&](auto pred) { for (auto &l : L) if (pred(l.s)) return true; return false; };
+  while (any([](const LsLane &s) { return s.st != LS_DONE; })) {
+    counts[0]++;
+    for (const char *p = sched; *p; p++) {
+      if (*p == 'M') {
+        if (any([](const LsLane &s) { return s.st == LS_MB_END || s.st == LS_MB_BEGIN || s.st == LS_NODE || s.st == LS_P_CBP || s.st == LS_NEXT_SLOW || s.st == LS_TOKEN_SLOW; })) counts[1]++;
+        for (auto &l : L) ls_step_main(l.s, l.m, l.c);
+      } else if (*p == 'I') {
+        if (any([](const LsLane &s) { return ls_in_intra(s); })) counts[2]++;
+        for (auto &l : L) ls_step_intra(l.s, l.m, l.c);
+      } else if (*p == 'N') {
+        if (any([](const LsLane &s) { return s.st == LS_NEXT; })) counts[3]++;
+        for (auto &l : L) ls_next_fast(l.s, l.m, l.c);
+      } else if (*p == 'T') {
+        if (any([](const LsLane &s) { return s.st == LS_TOKEN; })) counts[4]++;
+        for (auto &l : L) ls_token_fast(l.s, l.m, l.c);
+      }
+    }
+  }
+  for (auto &l : L) {
+    if (l.s.bail) return l.s.bail;
+    l.C->m = l.m;
+    l.C->quant = l.s.quant; l.C->yuvfmt = l.s.yuvfmt; l.C->tables_set = l.s.tables_set; l.C->frames_started = l.s.frames_started;
+  }
+  return 0;
+}
+
 // The whole differential in one call: every frame of a clip through both parsers.  Returns the number of frames that compared equal
 // (all of them: n_frames), or -(frame + 1) at the first difference (what differs goes to stderr).  *bails = frames the lock-step parser
 // left to the other one (allowed only when allow_bail is set or the host parser did not return MOBI_OK).

@@ -27,6 +27,26 @@ def run(k, period, burst, kb, lanes=64):
     def ms(c): return (c[1] * COST["main"] + c[2] * COST["intra"] + c[3] * COST["cheap"]) * 1e3 / 2.4e9 * 1e3
     i, p = out[0], out[2]
     print(f"k={k} intra every {period} x{burst} (+{kb} cheap): P-frame rounds {p[0]} main {p[1]} intra {p[2]} cheap {p[3]} -> {ms(p):5.1f} ms | I-frame rounds {i[0]} intra {i[2]} cheap {i[3]} -> {ms(i):5.1f} ms", flush=True)
+L.mobi_lshost_wave_sched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+W = dict(M=float(os.environ.get("W_M", 1150)), I=float(os.environ.get("W_I", 900)), N=float(os.environ.get("W_N", 130)), T=float(os.environ.get("W_T", 150)))  # instructions per run
+def sched(order, lanes=64):
+    """any order of the four parts within a round; cost = instructions (vector + scalar) of the parts that ran with a lane in them"""
+    clips = [L.mobi_lshost_create(640, 480, 2) for _ in range(lanes)]
+    out = []
+    for f in range(3):
+        bufs = [np.ascontiguousarray(streams[i % 16][0][streams[i % 16][1][f]:streams[i % 16][1][f + 1]]) for i in range(lanes)]
+        cp = (C.c_void_p * lanes)(*clips); dp = (C.c_void_p * lanes)(*[b.ctypes.data for b in bufs]); lp = (C.c_size_t * lanes)(*[b.size for b in bufs])
+        cnt = (C.c_long * 5)()
+        assert L.mobi_lshost_wave_sched(cp, dp, lp, lanes, order.encode(), cnt) == 0
+        out.append(list(cnt))
+    for c in clips: L.mobi_lshost_destroy(c)
+    def mi(c): return (c[1] * W["M"] + c[2] * W["I"] + c[3] * W["N"] + c[4] * W["T"]) / 1e6
+    i, p = out[0], out[2]
+    print(f"{order:28s} P: rounds {p[0]:5d} M {p[1]:5d} I {p[2]:5d} N {p[3]:5d} T {p[4]:5d} -> {mi(p):5.2f} M instr | I-frame: rounds {i[0]:5d} I {i[2]:5d} N {i[3]:5d} T {i[4]:5d} -> {mi(i):5.2f} M", flush=True)
+if __name__ == "__main__" and "--orders" in sys.argv:
+    for o in ["MINTNTNTNTNT", "MINTTTNTTT", "MINTTNTTNTT", "MINTTTTNTTTT", "MINTTTTTT", "MINTNTTTNTTT", "MNTINTNTTNTT", "MINTTNTTTNTTT", "MINTTTNTTTNTTT"]:
+        sched(o)
+    sys.exit(0)
 if __name__ == "__main__":
     run(4, 1, 1, 0)
     for period, burst, kb in [(2, 1, 0), (2, 2, 2), (3, 2, 2), (4, 3, 2), (4, 4, 4), (6, 4, 4), (8, 6, 4), (8, 8, 4)]:
