@@ -6,8 +6,8 @@
 // end) laid out in the order a macroblock passes through them; every round of the loop each lane executes the regions its state lets it
 // enter, falling through from one to the next, and a region costs the wave its instructions once however many lanes are in it.  The lanes
 // are never synchronised on macroblocks: each walks its own frame; the number of rounds is the longest lane's, and the law of large numbers
-// keeps that close to the mean (a frame is 1200 macroblocks).  Behind every round of the whole walk (ls_step) come LS_TOKEN_ROUNDS cheap ones of
-// "next block" and "one token" only (ls_next, ls_token): those two are most of what a frame consists of.
+// keeps that close to the mean (a frame is 1200 macroblocks).  Behind every round of the whole walk come cheap ones of "next block" and "one token"
+// only (ls_round: ls_next_fast, ls_token_fast): those two are most of what a frame consists of.
 //
 // This is the FAST path only.  It produces exactly what mobi_parse_frames produces (descriptors, payload, intra items, result record,
 // persistent state) for streams that decode without incident; at anything else -- every condition under which the reference throws, a
@@ -39,10 +39,9 @@
 enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END,
        LS_NEXT_SLOW, LS_TOKEN_SLOW }; // what the cheap rounds leave to the whole walk: a 4x4 area's pattern, an escape token, anything odd
 #define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
-enum { LS_TOKEN_ROUNDS = 4,  // ls_next() + ls_token() on their own this many times behind every ls_step(): block after block, token after
-                             // token, while the expensive rest of the walk waits
+enum { LS_TOKEN_ROUNDS = 4,  // ls_next_fast() + ls_token_fast() on their own this many times behind every round of the whole walk
        LS_ROUND_BYTES = 64, // what one such round can take from the ring at most (an intra macroblock's header and every area's mode in one visit:
-                            // ~310 bits, + 4 x (15 + 28) of the cheap rounds)
+                            // ~310 bits, + 5 x (15 + 28) of the cheap rounds)
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
 
 struct LsCtx { // wave-uniform
@@ -754,12 +753,22 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
   if (s.bail) s.st = LS_DONE; // (a region that bailed out half way may have gone on to set a state)
 }
 LS_FN bool ls_in_intra(const LsLane &s) { return s.st >= LS_I_HDR && s.st <= LS_I_FSUB; }
+// One round as the kernel runs it: the whole walk once, then the cheap rounds (per lane here; on the GPU each part runs while any lane of the
+// wave is in it)
 template <class S>
-LS_FN void ls_step(LsLane &s, S &m, const LsCtx &c) { // everything once, in the order of the walk
+LS_FN void ls_round(LsLane &s, S &m, const LsCtx &c) {
   ls_step_main(s, m, c);
   ls_step_intra(s, m, c);
   ls_next_fast(s, m, c);
   ls_token_fast(s, m, c);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int k = 0; k < LS_TOKEN_ROUNDS; k++) { // (next and tokens in separate inner loops, so that a token round does not pay for the other
+    if (s.st != LS_TOKEN && s.st != LS_NEXT) break; // region, measured slower: 26.2 against 24.8 ms -- two more levels of masks and branches)
+    ls_next_fast(s, m, c);
+    ls_token_fast(s, m, c);
+  }
 }
 
 // What the reference's reader would report as consumed after c bits of a stream of len bytes (see the header); -1: it would have thrown

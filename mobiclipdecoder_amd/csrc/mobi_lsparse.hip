@@ -1,7 +1,7 @@
 // mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: 64 clips per wave, one per lane (mobi_lsparse.h has the state machine and
 // says why).
 //
-//   mobi_parse_frames_ls   one wave = 64 clips.  Every lane walks its own frame with ls_step(); the wave runs until the last one is done.
+//   mobi_parse_frames_ls   one wave = 64 clips.  Every lane walks its own frame with ls_round(); the wave runs until the last one is done.
 //                          A lane that meets anything out of the ordinary bails out and leaves its clip to mobi_parse_frames.
 //   mobi_ls_deps           one lane per intra macroblock of the clips the first kernel finished: the dependency lists (MbDesc.w4..w7).
 //   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
@@ -133,13 +133,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
       }
     }
     if (s.st != LS_DONE && wr - s.rd >= LS_ROUND_BYTES) {
-      ls_step(s, m, c);
-#pragma unroll 1
-      for (int k = 0; k < LS_TOKEN_ROUNDS; k++) {
-        if (s.st != LS_TOKEN && s.st != LS_NEXT) break; // (per lane: the loop runs while any lane still has a block or a token to read)
-        ls_next_fast(s, m, c);
-        ls_token_fast(s, m, c);
-      }
+      ls_round(s, m, c);
     }
     if (__builtin_amdgcn_ballot_w64(s.st != LS_DONE) == 0) break;
   }

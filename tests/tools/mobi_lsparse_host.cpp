@@ -81,8 +81,7 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
   while (s.st != LS_DONE) {
     C.rounds++;
     C.rounds_by_state[s.st & 15]++;
-    ls_step(s, m, c);
-    for (int k = 0; k < LS_TOKEN_ROUNDS && (s.st == LS_TOKEN || s.st == LS_NEXT); k++) { ls_next_fast(s, m, c); ls_token_fast(s, m, c); } // as the kernel does
+    ls_round(s, m, c); // as the kernel does
   }
   if (!s.bail) {
     const int used = ls_consumed(s.cbits, (uint32_t)len);
