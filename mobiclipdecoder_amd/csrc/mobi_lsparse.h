@@ -39,7 +39,10 @@
 enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END,
        LS_NEXT_SLOW, LS_TOKEN_SLOW }; // what the cheap rounds leave to the whole walk: a 4x4 area's pattern, an escape token, anything odd
 #define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
-enum { LS_TOKEN_ROUNDS = 4,  // ls_next_fast() + ls_token_fast() on their own this many times behind every round of the whole walk
+#ifndef LS_K
+#define LS_K 3 // A/B on one box (tools/exp_lsab.sh): 1: 25.4, 2: 23.9, 3: 23.8, 4: 24.2, 5: 25.2, 6: 26.2 ms per P-frame step
+#endif
+enum { LS_TOKEN_ROUNDS = LS_K,  // ls_next_fast() + ls_token_fast() on their own this many times behind every round of the whole walk
        LS_ROUND_BYTES = 64, // what one such round can take from the ring at most (an intra macroblock's header and every area's mode in one visit:
                             // ~310 bits, + 5 x (15 + 28) of the cheap rounds)
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
@@ -89,6 +92,17 @@ typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 #define LS_STORE4(p, v) (*(ls_u32x4 *)(p) = ls_u32x4{(v), (v), (v), (v)})
 #else
 #define LS_STORE4(p, v) ((p)[0] = (p)[1] = (p)[2] = (p)[3] = (v))
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LS_INTRA_NOUNROLL)
+#define LS_INTRA_LOOP_PRAGMA _Pragma("unroll 1")
+#else
+#define LS_INTRA_LOOP_PRAGMA
+#endif
+// "some lane of the wave" (on the CPU: this lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LS_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#else
+#define LS_ANY(cond) (cond)
 #endif
 LS_FN int ls_clz(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 LS_FN int ls_ctz(uint32_t v) { return __builtin_ctz(v); }
@@ -613,6 +627,7 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
     }
   }
   // ---- "sub" intra macroblock, one luma area (DecIntraSubBlockPMode, MD.cs:1789-1807, :2776) ----
+  LS_INTRA_LOOP_PRAGMA
   for (int it = 0; it < 5 && s.st == LS_I_SUBAREA; it++) {
     if (s.i_k == 4) s.st = LS_I_CHROMA;
     else {
@@ -651,6 +666,7 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
       }
     }
   }
+  LS_INTRA_LOOP_PRAGMA
   for (int it = 0; it < 5 && s.st == LS_I_SUB4; it++) {
     if (s.i_sub == 4) { s.i_k++; s.st = LS_I_SUBAREA; }
     else {
@@ -700,6 +716,7 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
   }
   // ---- one area whose mode is known (sub_116508, MD.cs:2869-2896) ----
   // (area after area in one visit while they are not coded: a visit costs the wave a round of the whole walk)
+  LS_INTRA_LOOP_PRAGMA
   for (int it = 0; it < 8 && s.st == LS_I_FIXED; it++) {
     if (s.i_k == 4 && !s.i_chroma) chroma_mode();
     else if (s.i_k == 6) s.st = LS_MB_END;
@@ -761,11 +778,15 @@ LS_FN void ls_round(LsLane &s, S &m, const LsCtx &c) {
   ls_step_intra(s, m, c);
   ls_next_fast(s, m, c);
   ls_token_fast(s, m, c);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LS_CHEAP_LOOP)
+#pragma unroll // (unrolled: as a loop it began and ended with 32 register copies, the lane state carried round it)
+#elif defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int k = 0; k < LS_TOKEN_ROUNDS; k++) { // (next and tokens in separate inner loops, so that a token round does not pay for the other
-    if (s.st != LS_TOKEN && s.st != LS_NEXT) break; // region, measured slower: 26.2 against 24.8 ms -- two more levels of masks and branches)
+  for (int k = 0; k < LS_TOKEN_ROUNDS; k++) {
+    // The exit is the WAVE's (no lane has a block or a token to read), not the lane's: a lane leaving a loop on its own makes every piece of
+    // its state a value that has to be kept apart from the others' -- a third of the loop's vector instructions were register copies.
+    if (!LS_ANY(s.st == LS_TOKEN || s.st == LS_NEXT)) break;
     ls_next_fast(s, m, c);
     ls_token_fast(s, m, c);
   }

@@ -23,7 +23,10 @@ namespace {
 #ifndef LS_CLIPS
 #define LS_CLIPS 64 // clips per wave (lanes in use); tools/exp_lsclips.sh tries fewer
 #endif
-enum { LS_SERVICE = 4, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
+#ifndef LS_SERVICE_N
+#define LS_SERVICE_N 4
+#endif
+enum { LS_SERVICE = LS_SERVICE_N, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
 struct DevStore {
   int32_t *mvc_;
