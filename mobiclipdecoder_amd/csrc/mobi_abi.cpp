@@ -540,7 +540,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
     b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
     b->parse_auto = true;
-    b->lockstep = n_clips >= 12288; // ... and from there on the lock-step parser in front (64 clips per wave: 26 ms per P-frame step whatever the batch)
+    b->lockstep = n_clips >= 12288; // ... and from there on the lock-step parser in front (64 clips per wave: 24 ms per P-frame step whatever the batch)
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) {
       const int v = atoi(dp); // 3: on the GPU, the lock-step parser (64 clips per wave) in front
       b->parse_mode = v == 3 ? 1 : std::max(0, std::min(2, v));

@@ -66,6 +66,8 @@
 #define A_MAD64(i) { unsigned long long t_; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "=v"(t_) : "v"(r[i]), "v"(y) : "vcc"); r[i] ^= (uint32_t)t_; }
 #define A_MULU24(i) asm volatile("v_mul_u32_u24_e32 %0, %1, %0" : "+v"(r[i]) : "v"(y));
 #define A_LSHLADD64(i) { unsigned long long t_ = m; asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(t_) : "v"(m)); r[i] ^= (uint32_t)t_; }
+#define A_LSHL64(i) { unsigned long long t_ = ((unsigned long long)r[i] << 32) | y; asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(t_) : "v"(z)); r[i] = (uint32_t)(t_ >> 32); }
+#define A_FFBH(i) asm volatile("v_ffbh_u32_e32 %0, %0" : "+v"(r[i]));
 #define A_SALU(i) asm volatile("s_add_u32 %0, %0, 3" : "+s"(seed));
 #define A_RDLANE(i) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(seed) : "v"(r[i]));
 
@@ -76,6 +78,7 @@ KERNEL(k_bfe, A_BFE) KERNEL(k_bfi, A_BFI) KERNEL(k_sdwa, A_SDWA) KERNEL(k_sdwad,
 KERNEL(k_pkadd, A_PKADD) KERNEL(k_pkashr, A_PKASHR) KERNEL(k_pkmax, A_PKMAX) KERNEL(k_subrev, A_SUBREV) KERNEL(k_xor, A_XOR) KERNEL(k_bcnt, A_BCNT)
 KERNEL(k_mbcnt, A_MBCNT) KERNEL(k_dpp, A_DPP) KERNEL(k_adddpp, A_ADDDPP) KERNEL(k_sad, A_SAD) KERNEL(k_cvtpk, A_CVTPK) KERNEL(k_pack, A_PACK)
 KERNEL(k_mullo, A_MULLO) KERNEL(k_mulhi, A_MULHI) KERNEL(k_mulu24, A_MULU24)
+KERNEL(k_lshl64, A_LSHL64) KERNEL(k_ffbh, A_FFBH)
 KERNEL(k_lshlor, A_LSHLOR) KERNEL(k_cmp, A_CMP) KERNEL(k_cmp64, A_CMP64) KERNEL(k_salu, A_SALU) KERNEL(k_rdlane, A_RDLANE)
 
 typedef void (*kern_t)(uint32_t *, int, uint32_t);
@@ -103,6 +106,7 @@ int main(int argc, char **argv) {
   R("v_add_u32_sdwa src byte", k_sdwa) R("v_max_i32_sdwa dst byte preserve", k_sdwad) R("v_mov_b32_dpp quad_perm", k_dpp) R("v_add_u32_dpp row_shr", k_adddpp)
   R("v_pk_add_i16", k_pkadd) R("v_pk_ashrrev_i16", k_pkashr) R("v_pk_max_i16", k_pkmax)
   R("v_mul_lo_u32", k_mullo) R("v_mul_hi_u32", k_mulhi) R("v_mul_u32_u24_e32", k_mulu24)
+  R("v_lshlrev_b64 (+ 2 moves packing the operand)", k_lshl64) R("v_ffbh_u32", k_ffbh)
   R("v_cmp_lt_i32_e32 (vcc)", k_cmp) R("v_cmp_lt_i32_e64 (sgpr)", k_cmp64) R("s_add_u32", k_salu) R("v_readlane_b32", k_rdlane)
   return 0;
 }
