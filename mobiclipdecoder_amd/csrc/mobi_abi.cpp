@@ -753,7 +753,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   uint32_t K = 0;
   if (b->lockstep) b->ls_finished = 0;
   for (int i = 0; i < nd; i++) {
-    if (b->lockstep && res[i].pad == 0x4C53u) b->ls_finished++;
+    if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
     rc[i] = res[i].rc;
     offsets[i] += res[i].consumed;
     b->dev_quant[i] = res[i].quant;
@@ -881,7 +881,7 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   const int *fault = (const int *)S.h_fault.p;
   if (b->lockstep) b->ls_finished = 0;
   for (int i = 0; i < S.n_dev; i++) {
-    if (b->lockstep && res[i].pad == 0x4C53u) b->ls_finished++;
+    if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
     rc[i] = res[i].rc;
     if (offsets_out) offsets_out[i] = S.offs[i] + (int32_t)res[i].consumed;
     b->dev_quant[i] = res[i].quant;

@@ -695,7 +695,7 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
 #pragma unroll
     for (int w = 0; w < PWAVES; w++) {
       const int cw = blockIdx.x * PWAVES + w;
-      const bool f = cw < A.n_clips && A.res[cw].pad == 0x4C53u; // LS_MAGIC
+      const bool f = cw < A.n_clips && A.res[cw].pad == MOBI_LS_MAGIC;
       all = all && (f || cw >= A.n_clips);
       if (w == wave) finished = f;
     }

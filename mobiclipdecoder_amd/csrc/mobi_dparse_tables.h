@@ -21,6 +21,7 @@ enum {
   MOBI_DT_ZZ4 = 18384,     // uint8[16]
   MOBI_DT_BYTES = 18400
 };
+#define MOBI_LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser (mobi_lsparse.hip) finished itself */
 void mobi_dparse_build_tables(int version, uint8_t out[MOBI_DT_BYTES]); // mobi_parse.cpp (owns the tables)
 
 #endif

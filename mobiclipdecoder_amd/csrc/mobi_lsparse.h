@@ -38,7 +38,7 @@
 
 enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I_SUB4, LS_I_CHROMA, LS_I_FIXED, LS_I_FSUB, LS_NEXT, LS_TOKEN, LS_MB_END,
        LS_NEXT_SLOW, LS_TOKEN_SLOW }; // what the cheap rounds leave to the whole walk: a 4x4 area's pattern, an escape token, anything odd
-#define LS_MAGIC 0x4C53u /* MobiDevResult.pad of a clip the lock-step parser finished */
+#define LS_MAGIC MOBI_LS_MAGIC
 #ifndef LS_K
 #define LS_K 3 // A/B on one box (tools/exp_lsab.sh): 1: 25.4, 2: 23.9, 3: 23.8, 4: 24.2, 5: 25.2, 6: 26.2 ms per P-frame step
 #endif
