@@ -108,3 +108,23 @@ def test_damaged_streams_bail_out_or_parse_identically(lib, cfg):
         total_bails += bails
         finished += n - bails
     assert total_bails > 50 and finished > 300, (total_bails, finished)  # both outcomes were exercised
+
+
+def test_random_generator_mixes(lib):
+    """48 random points of the generator's parameter space (macroblock mix, motion range, residual density and shape, escapes, both VLC tables,
+    quantiser deltas, I-frame intervals, both versions, several geometries): intact streams are never handed over and always identical."""
+    rng = np.random.default_rng(0x4C53)
+    for trial in range(48):
+        w, h = [(64, 48), (128, 96), (256, 192), (320, 240), (512, 32), (16, 144)][trial % 6]
+        kw = dict(width=w, height=h, version=1 + trial % 2, n_frames=int(rng.integers(3, 9)), quantizer=int(rng.integers(12, 53)),
+                  pm_skip=int(rng.integers(0, 400)), pm_split1=int(rng.integers(0, 300)), pm_deep=int(rng.integers(0, 250)), pm_intra=int(rng.integers(0, 300)),
+                  pm_multiref=int(rng.integers(0, 500)), mv_range=int(rng.integers(0, 40)), cbp_prob=int(rng.integers(0, 1000)), t8_prob=int(rng.integers(0, 1000)),
+                  dense_prob=int(rng.integers(0, 400)), max_coefs=int(rng.integers(1, 12)), scan_span=int(rng.integers(1, 64)),
+                  intra_sub_prob=int(rng.integers(0, 1000)), plane_prob=int(rng.integers(0, 700)), escape_prob=int(rng.integers(0, 400)),
+                  qdelta_prob=int(rng.integers(0, 600)), table1_prob=int(rng.integers(0, 1000)), iframe_interval=int(rng.integers(0, 5)))
+        if kw["pm_skip"] + kw["pm_split1"] + kw["pm_deep"] + kw["pm_intra"] > 1000:
+            kw["pm_skip"] = 0
+        p = default_params("A", BASE_SEED + 8000 + trial, **kw)
+        d, fo = generate_clip(p)
+        r, bails, n = compare(lib, p, d, fo, 0)
+        assert r == n and bails == 0, (trial, kw, r, bails)
