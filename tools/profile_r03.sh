@@ -42,5 +42,5 @@ $REPO/tools/pmc_dparse.sh $TAG/dparse_pmc 4096 >> "$OUT/dparse.txt" 2>&1
 timeout 300 python $REPO/tools/exp_async.py 4096 12 > "$OUT/async.txt" 2>&1
 timeout 200 python $REPO/tools/exp_rgb.py > "$OUT/rgb.txt" 2>&1
 timeout 200 python $REPO/tools/exp_search.py > "$OUT/search.txt" 2>&1
-{ timeout 600 python $REPO/tools/fuzz_intra_gpu.py 2000 100; timeout 600 python $REPO/tools/fuzz_inter_gpu.py 1500 100; timeout 900 python $REPO/tools/soak_parity.py 4096 B; timeout 900 python $REPO/tools/soak_parity.py 4096 B lockstep; } > "$OUT/fuzz.txt" 2>&1
+{ timeout 600 python $REPO/tools/fuzz_intra_gpu.py 2000 100; timeout 600 python $REPO/tools/fuzz_inter_gpu.py 1500 100; timeout 900 python $REPO/tools/soak_parity.py 4096 B; timeout 900 python $REPO/tools/soak_parity.py 8192 B lockstep; } > "$OUT/fuzz.txt" 2>&1
 ls "$OUT" > /dev/null
