@@ -175,6 +175,9 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
   return q;
 }
 
+#ifdef MOBI_NO_PRIO // tools/exp_prio.sh
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#endif
 namespace {
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
@@ -337,6 +340,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   unsigned long long pa = 0, pb = 0;
   if (PROF) { asm volatile("" : : "s"(off0), "s"(clip)); pa = prof_stamp(); }
 
+  // A wave asks for its descriptors, windows and level words ahead of its neighbours' arithmetic: the sooner its requests are out, the
+  // shorter it holds its place (A/B on one box, tools/exp_prio.sh: 7.31 -> 7.20 ms per launch; the stores at the end as well: -0.3 %)
+  __builtin_amdgcn_s_setprio(3);
   // ---- stage A: descriptor, then every global read of the octet ----
   const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last octet
   const uint4 d = dp[0], d2 = dp[1];
@@ -556,6 +562,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   Deep D0;
   if (slow_mask) deep_fetch(D0, __builtin_ctz(slow_mask), yc0, c4v0);
 
+#ifdef MOBI_PRIO_MC // tools/exp_prio.sh
+  __builtin_amdgcn_s_setprio(MOBI_PRIO_MC);
+#else
+  __builtin_amdgcn_s_setprio(0); // (behind the deep trees' requests too: 7.17 -> 7.10 ms)
+#endif
   // ---- stage B: motion compensation.  Lane (g, rr = j >> 2, q = j & 3) = luma rows 8rr..8rr+7, pixels 4q..4q+3; lane (g, pl = j >> 2,
   // ch = (j >> 1) & 1, qc = j & 1) = plane pl, chroma rows 4ch..4ch+3, samples 4qc..4qc+3: either lies inside one leaf whatever the split ----
   uint32_t mcv[12];
@@ -621,6 +632,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   }
   if (PROF) pt[4] = prof_stamp();
 
+#ifdef MOBI_PRIO_MC
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // ---- stage C: residual ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the scales
   wave_sync();
@@ -724,6 +738,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 #pragma unroll
   for (int k = 0; k < MOBI_EXP_PAD_D; k++) asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
 #endif
+  __builtin_amdgcn_s_setprio(3);
   // ---- stage D: the octet's tiles are contiguous: 2 KB of luma, 1 KB of chroma, whole lines ----
   // Intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them), and behind the picture's last
   // macroblock (848 = 53 macroblocks: the seventh octet holds five) the zeros the padding already holds: HBM turns every store
@@ -899,6 +914,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   uint8_t *ty = y0 + mobi_tile_y((uint32_t)mbx, (uint32_t)mby, lgS), *tc = uv0 + mobi_tile_c((uint32_t)mbx, (uint32_t)mby, lgS); // its tiles (mobi_tile.h)
   const uint2 *taps = (const uint2 *)(A.scale + MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE); // 4480 B every wave reads: they stay in the L1
 
+  __builtin_amdgcn_s_setprio(3); // (as in the inter kernel: requests first; 1.173 -> 1.162 ms)
   // ---- everything that can be asked for at once: block records, dequant scales, the first 64 level words, the halo ----
   const uint32_t recA = I.valid ? rec[l] : 0u, recB = I.valid && l < MOBI_INTRA_RECORDS - 16 ? rec[16 + l] : 0u;
   const uint4 *sc_g = (const uint4 *)(A.scale + ((w1 >> 20) & 63) * MOBI_SCALE_STRIDE);
@@ -932,6 +948,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   uint32_t b0_early = 0, b1_early = 0;
   if (!(dbg & 16)) { w_early = *(const uint2 *)wp; b0_early = *b0p; b1_early = *b1p; }
 
+  __builtin_amdgcn_s_setprio(0);
   { // zero the coefficients; dequant scales behind them
     uint4 *G4 = (uint4 *)G;
     const uint4 z = uint4{0, 0, 0, 0};
