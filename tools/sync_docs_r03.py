@@ -36,7 +36,7 @@ text = f'''Results, MI355X, r03 build (`profiles/r03_{{A,B,C}}_bench.json`; the 
 {row("B 640×480 Moflex3DS", B, 24576, "B:24576", "9.74 ms / 0.379 / 1.36 / 0.319")}
 {row("C 848×480 Moflex3DS", C, 6144, "C:6144", "4.23 ms / 0.307 / 1.35 / 0.274")}
 
-Box-to-box spread of the same build is ±0.5 % with an occasional slow box (five boxes, the final build: 8.48, 8.48, 8.49, 8.53 and once 8.83 ms per step of B). What the
+Box-to-box spread of the same build is ±1 % with an occasional slow box (before the wave priorities, five boxes: 8.48, 8.48, 8.49, 8.53 and once 8.83 ms per step of B; with them, four boxes: 8.26–8.43). What the
 counters say about B (`profiles/r03_B_pmc_summary.txt`): per octet {valu} VALU + {salu} SALU instructions, {float(vmem):.0f} vector-memory and {lds} LDS
 instructions, {rreq} read + {wreq} write requests L1→L2 (r02: 125 + 48), HBM read {rd_gb:.1f} GB + write {wr_gb:.1f} GB per launch = {ratio:.2f} × the
 {B['roofline']['algorithmic_bytes_per_launch'] / 1e9:.1f} GB of algorithmic bytes (r02: 1.36 ×; the rest is 128-byte lines of windows no neighbour shares),
