@@ -7,7 +7,7 @@ for ROUND in 1 2; do
   for F in ${VARIANTS:-"-DMOBI_NO_PRIO" "-DMOBI_AS_IS"}; do
     hipcc --offload-arch=gfx950 -std=c++17 -fPIC -O3 -mllvm -amdgpu-sched-strategy=max-ilp -fno-unroll-loops $F -c $P/csrc/mobi_kernels.hip -o $O/mobi_kernels.hip.o 2>&1 | grep -E " error" | head -3
     hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $P/libmobiclip_hip.so || exit 1
-    echo "[$F] $(timeout 300 python $REPO/bench.py --steps 96 --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 | python $REPO/tools/brief.py | cut -c1-90)"
+    echo "[$F] $(timeout 200 python $REPO/tools/exp_iframe.py 4096 2>&1 | tail -1 | cut -c1-60) | $(timeout 300 python $REPO/bench.py --steps 96 --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 | python $REPO/tools/brief.py | cut -c1-90)"
   done
 done
 cp /tmp/lib_keep.so $P/libmobiclip_hip.so; cp /tmp/k_keep.o $O/mobi_kernels.hip.o
