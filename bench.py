@@ -10,7 +10,9 @@ object of the output line times the whole DecodeFrame path, bitstream in).  Work
 more efficient on this part than many short ones: DESIGN.md has the same measurement from 512 to 24576 clips.
 
   python bench.py                      # 1 GPU, defaults finish in about a minute
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
+  python bench.py --gpus N             # N GPUs of this node: spawns one rank per GPU itself (LOCAL_RANK = GPU index)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # the same under an external launcher
+  python bench.py --gpus 2 --dry-run   # the rank plumbing only (streams, sharding, barrier, reduction, the one line): no HIP call
 
 Clips shard across ranks with no data-path collective (decoder instances share nothing,
 MobiclipDecoder.cs:15-39); torch.distributed (a gloo group: nothing travels over RCCL) is used only for the barrier /
@@ -84,12 +86,14 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
         assert all(r == 0 for r in rcs), "stream error in the end-to-end leg"
         if f >= 2:
             ms.append(b.last_decode_ms())
+    verified = verify_clips(b, streams, len(streams), n_clips, 1 + n_steps, W, H)
     b.close()
     t = float(np.median(ms))
     out = {"value": round(n_clips * W * H / t / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(t, 3), "clips": n_clips, "steps": n_steps,
            "parse": "device: mobi_parse_frames_ls (64 clips per wavefront, lock step) in front of mobi_parse_frames" if device_parse == "lockstep"
                     else "device: mobi_parse_frames, one wavefront per clip",
-           "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)"}
+           "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)",
+           "verified": verified}
     # the same frames through mobi_batch_submit / mobi_batch_wait, two steps in flight: wall time per step over the timed P-frames.
     # The pointer arrays are packed beforehand (what a C caller hands over), as the synchronous figure is the time inside the C call.
     import ctypes as C
@@ -110,9 +114,11 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
         assert not any(rcs), "stream error in the asynchronous end-to-end leg"
     assert lib.mobi_batch_wait(h, outo, rcs) == 0 and not any(rcs)
     ta = (_t.perf_counter() - t0) * 1e3 / n_steps
+    verified_async = verify_clips(b, streams, len(streams), n_clips, 2 + n_steps, W, H)
     b.close()
     out["async"] = {"value": round(n_clips * W * H / ta / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(ta, 3),
-                    "how": "mobi_batch_submit / mobi_batch_wait, two steps in flight; wall time per step over the same P-frames"}
+                    "how": "mobi_batch_submit / mobi_batch_wait, two steps in flight; wall time per step over the same P-frames",
+                    "verified": verified_async}
     return out
 
 
@@ -201,6 +207,78 @@ def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
             "note": "two launches per step (inter: 1200 octet waves; intra: ~480 waves, one macroblock each at this size): launch latency and two or three dependency levels, not bandwidth"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without an external launcher: start one worker per GPU (LOCAL_RANK = GPU index), each a copy of
+    this command with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- exactly the environment `torch.distributed.run` would give
+    them -- and wait for all.  Rank 0 prints the one JSON line on the stdout this process hands down.  There is no reference
+    analogue beyond "independent decoder instances, one thread per open file" (MobiclipDecoder/Form1.cs:199-215)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed: {bad}")
+
+
+def verify_clips(b, streams, distinct, clips, frame, W, H):
+    """After the timed region: the planes of three clips (first, middle, last) as they sit in HBM against the oracle's frame at that
+    stream position -- the bench line says whether the pixels it counted were the right ones.  (The checker, used as the checker.)"""
+    from tests.oracle_binding import OracleDecoder
+    picked = sorted({0, clips // 2, clips - 1})
+    ok, ref = True, {}
+    for c in picked:
+        sidx = c % distinct
+        if sidx not in ref:
+            p, data, fo = streams[sidx]
+            o = OracleDecoder(W, H, p.version)
+            for f in range(frame + 1):
+                o.Data, o.Offset = data[fo[f]:fo[f + 1]], 0
+                assert o.DecodeFrame() is not None
+            ref[sidx] = (o.y(0), o.uv(0))
+            o.close()
+        got = b.planes(c)
+        ok = ok and got is not None and np.array_equal(got[0][:, :W], ref[sidx][0][:, :W]) and np.array_equal(got[1], ref[sidx][1])
+    return {"clips": len(picked), "which": picked, "frame": int(frame), "ok": bool(ok), "against": "CPU oracle, Y and UV planes of ring slot 0"}
+
+
+def dry_run(args, rank, world):
+    """The N-rank plumbing with no HIP call: generate this rank's streams, build the process group, barrier, MAX-reduce a made-up
+    time, gather the seeds, print the one line.  What can be wrong without a GPU is exactly this (tests/test_bench_launcher.py)."""
+    import torch.distributed as dist
+    import mobiclipdecoder_amd as m
+    from mobiclipdecoder_amd import sharding
+    seeds = [sharding.stream_seed(args.config, rank, i) for i in range(max(1, min(args.distinct, 2)))]
+    sizes = []
+    for sd in seeds:
+        p = m.default_params(args.config, sd, n_frames=2, width=64, height=48)
+        sizes.append(int(m.generate_clip(p)[0].size))
+    group = world > 1
+    if group:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    elapsed = sharding.max_over_ranks(dist if group else None, 1.0 + rank)
+    gathered = [{"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes}]
+    if group:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes})
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "decoded Mpixels/s @ 640x480 P-frames", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "elapsed_max_s": elapsed, "ranks": gathered, "scaling": "weak",
+                          "note": "no HIP call was made: rank plumbing only"}), flush=True)
+    if group:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,11 +294,24 @@ def main():
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--single-stream", type=int, default=1, help="1: time one clip through mobi_decode / mobi_get_argb (the boundary's own shape); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: streams, sharding, barrier, reduction, the one line; no HIP call")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: be one (the driver's 1-GPU command is `python3 bench.py --gpus 1 ...`; its N-GPU one may have that shape too)
+        if not args.dry_run:
+            import torch
+            if torch.cuda.device_count() < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} HIP device(s)")
+        launch_ranks(args.gpus, sys.argv[1:])
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, and the line reports n_gpus = ranks")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
     dist = None
     if world > 1:
@@ -231,6 +322,8 @@ def main():
         dist.init_process_group("gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU reconstruction path to time")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} (LOCAL_RANK {local}) has no GPU: {torch.cuda.device_count()} HIP device(s) visible")
 
     import mobiclipdecoder_amd as m
     from mobiclipdecoder_amd import sharding
@@ -324,8 +417,14 @@ def main():
         assert b.sync() == 0, "clamp-domain fault in the timed region"
     km = acc
 
+    my_elapsed = elapsed
     elapsed = sharding.max_over_ranks(dist, elapsed)
+    per_rank = [my_elapsed]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, my_elapsed)
     steps = args.steps
+    verified = verify_clips(b, streams, distinct, args.clips, timed_frames[-1], W, H) if rank == 0 and timed_frames else None
     cmd_bytes = sum(b.cmd_bytes(f) for f in timed_frames) / steps          # per step, all clips of this GPU
     stats = [b.intra_stats(f) for f in timed_frames]
     n_intra = sum(x[0] for x in stats) / steps
@@ -377,13 +476,15 @@ def main():
                 except Exception:
                     pass
         base = None
-        if world == 1 and args.cpu_seconds > 0:
+        if args.cpu_seconds > 0:  # rank 0, after the timed region's last barrier (the other ranks are done and idle)
             base = cpu_baseline(*streams[0], args.cpu_seconds)
         out = {
             "metric": "decoded Mpixels/s @ 640x480 P-frames" if args.config == "B" else f"decoded Mpixels/s P-frames (config {args.config})",
             "value": round(sharding.whole_job_mpix_per_s(world, args.clips, steps, W, H, elapsed), 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed * 1e3 / steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed * 1e3 / steps, 4),
+            "ms_per_step_ranks": {"min": round(min(per_rank) * 1e3 / steps, 4), "max": round(max(per_rank) * 1e3 / steps, 4)},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} {'Moflex3DS' if p0.version == 2 else 'ModsDS'} P-frame reconstruction "
                                    f"(SURVEY 8d generator mix), {args.clips} independent clips per GPU, "
@@ -393,7 +494,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single,
+            "verified": verified, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
