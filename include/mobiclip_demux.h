@@ -17,6 +17,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations are all it exports */
+#endif
 
 /* ---- Mods --------------------------------------------------------------------------------------- */
 typedef struct mobi_mods mobi_mods;
@@ -102,6 +105,9 @@ int mobi_moflex_pop_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint
  * regain synchronisation on the same bytes without ever advancing -- the reference's callers would spin there). */
 int mobi_moflex_next_frame(mobi_moflex *m, mobi_moflex_stream *stream, const uint8_t **data, size_t *len);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations are all it exports */
+#endif
 
 /* MobiclipDecoder.MobiclipVersion, MD.cs:32-37 */
 #define MOBI_VERSION_VXDS 0      /* unimplemented stub in the reference too (MD.cs:63-95) */
@@ -189,6 +192,9 @@ const char *mobi_error_string(int rc);
 /* library self-description: "libmobiclip_hip <ver> gfx950 ..." */
 const char *mobi_build_info(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

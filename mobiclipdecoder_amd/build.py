@@ -1,6 +1,7 @@
 """Build every native artefact in-tree (no JIT cache, no pip install).
 
   libmobiclip_hip.so      product: host parser + C ABI + gfx950 kernels          (hipcc)
+  libmobiclip_hip_prof.so the same sources with -DMOBI_PROFILING (debug hooks, ablation switches): tools/ and two tests only
   libmobi_streamgen.so    synthetic bitstream generator (input source)           (g++)
   oracle/_build/libmobi_oracle.so   CPU oracle = TEST INFRASTRUCTURE             (gcc)
   tests/tools/libmobi_cmdinterp.so  CPU command-list interpreter = TEST TOOL     (g++)
@@ -22,6 +23,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
 
 LIB_HIP = os.path.join(PKG, "libmobiclip_hip.so")
+LIB_HIP_PROF = os.path.join(PKG, "libmobiclip_hip_prof.so")  # -DMOBI_PROFILING twin: tools/ and the tests that inject planes
 LIB_GEN = os.path.join(PKG, "libmobi_streamgen.so")
 LIB_ORACLE = os.path.join(ROOT, "oracle", "_build", "libmobi_oracle.so")
 LIB_INTERP = os.path.join(ROOT, "tests", "tools", "libmobi_cmdinterp.so")
@@ -45,16 +47,30 @@ def _hdrs(d):
     return [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
 
 
+def header_symbols():
+    """every function include/*.h declares (the C ABI)"""
+    import re
+    names = []
+    for h in ("mobiclip_hip.h", "mobiclip_demux.h"):
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", h)).read(), flags=re.S)
+        names += re.findall(r"\b(mobi_\w+)\s*\(", text)
+    return sorted(set(names))
+
+
 def build_hip(force=False, profiling=False):
-    """profiling=True (python build.py --profiling, tools/ only): -DMOBI_PROFILING compiles the ablation / occupancy switches
-    (MOBI_INTRA_DBG, MOBI_LDS_PAD, MOBI_INTRA_LDS_PAD) in; the default build has none of them."""
+    """profiling=True (python -m mobiclipdecoder_amd.build --profiling, tools/ only): a SECOND library, libmobiclip_hip_prof.so, with
+    -DMOBI_PROFILING: the ablation / occupancy / stage-stop switches (MOBI_INTRA_DBG, MOBI_LDS_PAD, MOBI_INTRA_LDS_PAD, MOBI_STOP_STAGE,
+    MOBI_DEBUG=9) and the mobi_debug_* test hooks.  The product library has none of them; tools select the other one with MOBI_LIB."""
     srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip", "mobi_dparse.hip", "mobi_lsparse.hip", "mobi_analysis.hip")]
-    deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h"), os.path.join(ROOT, "include", "mobiclip_demux.h")]
-    if not force and not profiling and not _newer(LIB_HIP, deps):
-        return LIB_HIP
-    obj = os.path.join(PKG, "_obj")
+    deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h"), os.path.join(ROOT, "include", "mobiclip_demux.h"), os.path.abspath(__file__)]
+    lib = LIB_HIP_PROF if profiling else LIB_HIP
+    if not force and not _newer(lib, deps):
+        return lib
+    obj = os.path.join(PKG, "_obj_prof" if profiling else "_obj")
     os.makedirs(obj, exist_ok=True)
-    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
+    prof = ["-DMOBI_PROFILING"] if profiling else []
+    # only the entry points include/*.h declare leave the library (MOBI_API); everything else is hidden
+    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")] + prof
     objs = []
     for s in srcs[:4]:
         o = os.path.join(obj, os.path.basename(s) + ".o")
@@ -69,10 +85,15 @@ def build_hip(force=False, profiling=False):
              "mobi_lsparse.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     for s in srcs[4:]:
         ko = os.path.join(obj, os.path.basename(s) + ".o")
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DMOBI_PROFILING"] if profiling else []) + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + prof + extra.get(os.path.basename(s), []) + ["-c", s, "-o", ko])
         objs.append(ko)
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_HIP])
-    return LIB_HIP
+    # What leaves the library is exactly what include/*.h declares (the profiling twin adds its mobi_debug_* hooks): a linker version
+    # script written from the headers -- no C++ symbols, no template instantiations, no kernel stubs.
+    vs = os.path.join(obj, "exports.map")
+    with open(vs, "w") as f:
+        f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in header_symbols()) + ("    mobi_debug_*;\n" if profiling else "") + "  local: *;\n};\n")
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs] + objs + ["-o", lib])
+    return lib
 
 
 def build_gen(force=False):
@@ -115,12 +136,12 @@ def build_caller(force=False):
 
 
 def build_all(force=False):
-    return [build_hip(force), build_gen(force), build_oracle(force), build_interp(force), build_lshost(force), build_caller(force)]
+    return [build_hip(force), build_hip(force, profiling=True), build_gen(force), build_oracle(force), build_interp(force), build_lshost(force), build_caller(force)]
 
 
 if __name__ == "__main__":
     if "--profiling" in sys.argv:
-        build_hip(force=True, profiling=True)
+        build_hip(force="--force" in sys.argv, profiling=True)
     else:
         build_all(force="--force" in sys.argv)
     print("ok")

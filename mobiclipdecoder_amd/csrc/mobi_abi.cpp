@@ -430,6 +430,10 @@ struct mobi_dec { mobi_batch *b; };
 
 extern "C" {
 
+// ---- test and profiling hooks: only in the -DMOBI_PROFILING twin of the library (libmobiclip_hip_prof.so); the product library has none
+// of them (mobi_debug_write_planes lets any caller overwrite reference frames) ----
+#if defined(MOBI_PROFILING)
+#pragma GCC visibility push(default)
 // profiling aid, not part of the public header: copy out the MOBI_DEBUG=9 per-wave cycle records
 // (uint32 x 4 per macroblock: descriptor, pixels+MC, residual, store drain) of the last inter launch
 int mobi_debug_read_prof(mobi_batch *b, uint32_t *out, size_t n_words) {
@@ -475,6 +479,8 @@ long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *ite
   if (payload_out) HIP_TRY(hipMemcpy(payload_out, b->d_ppay.p, std::min(payload_words * 4, b->d_ppay.cap), hipMemcpyDeviceToHost));
   return (long long)b->last_pay_cap;
 }
+#pragma GCC visibility pop
+#endif // MOBI_PROFILING
 
 const char *mobi_build_info(void) { return "libmobiclip_hip 0.3 (gfx950, macroblock-tiled planes; HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_intra_cl, mobi_parse_frames, mobi_untile, mobi_yuv_to_argb, mobi_motion_search_2x2, mobi_fwd_dct8, mobi_fwd_dct4; no CPU reconstruction path)"; }
 
@@ -505,7 +511,9 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   auto b = std::make_unique<mobi_batch>();
   b->n = n_clips;
-  if (const char *dbg = getenv("MOBI_DEBUG")) b->debug = atoi(dbg); // kernel ablation switch for profiling only
+#if defined(MOBI_PROFILING)
+  if (const char *dbg = getenv("MOBI_DEBUG")) b->debug = atoi(dbg); // 9: the octet kernel with in-kernel cycle records (tools/exp_prof8.py)
+#endif
   b->device = device;
   b->version = version;
   for (int i = 0; i < n_clips; i++) b->parsers.emplace_back(new MobiStreamParser(width, height, version));
@@ -515,7 +523,6 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   b->cur.resize(n_clips);
   b->h_fault.assign(n_clips, 0);
   size_t arena_clips = (size_t)n_clips;
-  if (const char *ac = getenv("MOBI_ARENA_CLIPS")) arena_clips = std::max(arena_clips, (size_t)atoll(ac)); // experiment: allocation size vs speed
   size_t total = kGuard * 2 + b->clip_bytes * arena_clips;
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipMalloc((void **)&b->arena, total) != hipSuccess) return nullptr;

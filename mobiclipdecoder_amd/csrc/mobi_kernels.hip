@@ -175,8 +175,13 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
   return q;
 }
 
-#ifdef MOBI_NO_PRIO // tools/exp_prio.sh
-#define __builtin_amdgcn_s_setprio(x) ((void)0)
+// Stage-by-stage instruction counts (tools/exp_stages.sh): a --profiling build leaves the octet kernel after stage n when the launch
+// asks for it (MobiReconArgs.reserved21, from MOBI_STOP_STAGE), decided at run time so that no code is optimised away.  Wrong pictures,
+// on purpose; the default build has none of it.
+#if defined(MOBI_PROFILING)
+#define MOBI_STOP(n) do { if (A.reserved21 == (n)) return; } while (0)
+#else
+#define MOBI_STOP(n) do { } while (0)
 #endif
 namespace {
 typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -444,14 +449,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       }
     }
   }
-#ifdef MOBI_EXP_PAD_A // tools/exp_pad.sh: does the launch follow the instruction count?  (idle vector / scalar instructions behind stage A's requests)
-#pragma unroll
-  for (int k = 0; k < MOBI_EXP_PAD_A; k++) asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
-#endif
-#ifdef MOBI_EXP_PAD_S
-#pragma unroll
-  for (int k = 0; k < MOBI_EXP_PAD_S; k++) asm volatile("s_nop 0");
-#endif
+  MOBI_STOP(1);
   const int quant = __builtin_amdgcn_readfirstlane((int)((d.y >> 20) & 63));
   const uint32_t *pay = A.payload + (size_t)clip * A.pay_clip_words; // (wave-uniform)
   const uint32_t *cw = pay + d.x + (multi ? MOBI_MV_CELLS : 0);
@@ -491,6 +489,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     if (m2) load_cells(__builtin_ctz(m2), yc1, c4v1);
   }
   if (PROF) pt[1] = prof_stamp();
+  MOBI_STOP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wave_sync();
   if (PROF) pt[2] = prof_stamp();
@@ -562,11 +561,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   Deep D0;
   if (slow_mask) deep_fetch(D0, __builtin_ctz(slow_mask), yc0, c4v0);
 
-#ifdef MOBI_PRIO_MC // tools/exp_prio.sh
-  __builtin_amdgcn_s_setprio(MOBI_PRIO_MC);
-#else
-  __builtin_amdgcn_s_setprio(0); // (behind the deep trees' requests too: 7.17 -> 7.10 ms)
-#endif
+  __builtin_amdgcn_s_setprio(0); // (behind the deep trees' requests too: 7.17 -> 7.10 ms; priority during the motion compensation costs: 7.27)
+  MOBI_STOP(3);
   // ---- stage B: motion compensation.  Lane (g, rr = j >> 2, q = j & 3) = luma rows 8rr..8rr+7, pixels 4q..4q+3; lane (g, pl = j >> 2,
   // ch = (j >> 1) & 1, qc = j & 1) = plane pl, chroma rows 4ch..4ch+3, samples 4qc..4qc+3: either lies inside one leaf whatever the split ----
   uint32_t mcv[12];
@@ -584,6 +580,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     for (int k = 0; k < 5; k++) { x0[k] = lds32(L, a0 + k * 256); x1[k] = lds32(L, a1 + k * 256); }
     mc_rows<4>(x0, x1, (uint32_t)cxo & 3u, cph, mcv + 8);
   }
+  MOBI_STOP(4);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane < MOBI_SCALE_STRIDE / 4) MOBI_DMA16((const uint8_t *)(A.scale + quant * MOBI_SCALE_STRIDE) + lane * 16, L + P_SC, 0);
   {
@@ -604,6 +601,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     }
     mc_rows<8>(x0, x1, (uint32_t)xo & 3u, yph, mcv);
   }
+  MOBI_STOP(5);
   wave_sync();
   {
 #pragma unroll
@@ -612,6 +610,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     for (int k = 0; k < 4; k++) *(uint32_t *)(L + out_c(g, 4 * ch + k, pl, 4 * qc)) = mcv[8 + k];
   }
   if (PROF) pt[3] = prof_stamp();
+  MOBI_STOP(6);
   if (slow_mask) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the scales too)
     deep_finish(__builtin_ctz(slow_mask), D0);
@@ -631,10 +630,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     }
   }
   if (PROF) pt[4] = prof_stamp();
+  MOBI_STOP(7);
 
-#ifdef MOBI_PRIO_MC
-  __builtin_amdgcn_s_setprio(0);
-#endif
   // ---- stage C: residual ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the scales
   wave_sync();
@@ -661,6 +658,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     }
     wave_sync();
     s16x2 lo = {0, 0}, hi = {0, 0};
+    MOBI_STOP(8);
     for (int base = 0; base < n_ent; base += P_ROUND) {
       {
         const uint4 z = uint4{0, 0, 0, 0};
@@ -692,6 +690,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         for (int k = 0; k < 8; k++)
           if (i + 8u * k < ncoef) scatter(tw[k]);
       }
+      MOBI_STOP(9);
       wave_sync();
       const int r = lane & 7;
       int kx[3];
@@ -708,6 +707,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         int *tile = coef + P_TILE * (8 * h + (lane >> 3));
         if (actx[h]) idct_pass1(tile, tile, is8x[h], r);
       }
+      MOBI_STOP(10);
       wave_sync();
 #pragma unroll
       for (int h = 0; h < 3; h++) {
@@ -729,15 +729,13 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         }
       }
       wave_sync();
+      MOBI_STOP(11);
     }
     if (lo.x < -64 || lo.y < -64 || hi.x > 319 || hi.y > 319) atomicOr(&A.fault[clip], 1); // clamp table domain (MobiConst.cs:587)
   }
   if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pt[5] = prof_stamp(); }
 
-#ifdef MOBI_EXP_PAD_D
-#pragma unroll
-  for (int k = 0; k < MOBI_EXP_PAD_D; k++) asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
-#endif
+  MOBI_STOP(12);
   __builtin_amdgcn_s_setprio(3);
   // ---- stage D: the octet's tiles are contiguous: 2 KB of luma, 1 KB of chroma, whole lines ----
   // Intra macroblocks' places too (whatever LDS holds there; mobi_recon_intra overwrites them), and behind the picture's last
@@ -1394,6 +1392,8 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue; // 24-bit multiply in the kernel
   MobiReconArgs b = *a;
   static const int lds_pad = prof_env("MOBI_LDS_PAD");
+  static const int stop_stage = prof_env("MOBI_STOP_STAGE"); // (--profiling builds only: tools/exp_stages.sh)
+  b.reserved21 = (uint32_t)stop_stage;
   b.qpr = ((uint32_t)b.mbw + 7) / 8;                    // octets per macroblock row
   b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);          // ... per clip
   auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };

@@ -1,7 +1,5 @@
 // mobi_parse.cpp -- serial bitstream parser -> per-macroblock command list (see mobi_parse.h).
 #include "mobi_parse.h"
-
-unsigned long mobi_refusal_count[MOBI_REFUSE_CLASSES];
 #include "mobi_recon_math.h"
 
 #include <algorithm>
@@ -11,6 +9,8 @@ unsigned long mobi_refusal_count[MOBI_REFUSE_CLASSES];
 #include "../../include/mobiclip_hip.h"
 #include "mobi_dparse_tables.h"
 #include "mobi_tables.h"
+
+std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES]; // (parse-pool threads count concurrently: relaxed adds)
 
 namespace {
 inline uint32_t shl(uint32_t x, int n) { return x << (n & 31); } // C# masks shift counts to 5 bits

@@ -7,6 +7,7 @@
 // (:3884-3925).  It writes no pixels: every reconstruction step becomes a command (mobi_cmd.h).
 #ifndef MOBI_PARSE_H
 #define MOBI_PARSE_H
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
@@ -55,7 +56,7 @@ enum { MOBI_REFUSE_MV = 0,     // |MV| > MOBI_MV_LIMIT half-pels (the cell map's
        MOBI_REFUSE_RUN = 2,    // a coefficient run that steps past its block: the write lands in the next block's scratch (MD.cs:3424-3429)
        MOBI_REFUSE_PLANE = 3,  // a plane-predictor parameter outside int16 (the record's 16-bit field): |se| >= 2^15 needs a code of >= 33 bits
        MOBI_REFUSE_CLASSES = 4 };
-extern unsigned long mobi_refusal_count[MOBI_REFUSE_CLASSES];
+extern std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES];
 
 class MobiStreamParser {
  public:
@@ -76,7 +77,7 @@ class MobiStreamParser {
   struct Err { int code; };
   [[noreturn]] void fail(int code) const { throw Err{code}; }
   // MOBI_E_UNSUPPORTED by cause (INTEGRATION.md error table): counted for tools/exp_refusals.py
-  [[noreturn]] void refuse(int cause) const { mobi_refusal_count[cause]++; throw Err{-6 /* MOBI_E_UNSUPPORTED */}; }
+  [[noreturn]] void refuse(int cause) const { mobi_refusal_count[cause].fetch_add(1, std::memory_order_relaxed); throw Err{-6 /* MOBI_E_UNSUPPORTED */}; }
   // bit reader
   uint32_t data_u16(long off) const;
   void fill_bits();

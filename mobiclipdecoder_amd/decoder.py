@@ -84,6 +84,16 @@ _SIGS = {
 LIB_PATH = os.environ.get("MOBI_LIB") or os.path.join(_HERE, "libmobiclip_hip.so")  # MOBI_LIB: A/B-test another build of the library
 
 
+def bind_library(path):
+    """dlopen one build of the library and bind every entry point of include/mobiclip_hip.h"""
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load_library():
     """dlopen libmobiclip_hip.so and bind every entry point.  Raises if it was not built: the HIP
     library is the only implementation, there is nothing to fall back to."""
@@ -91,12 +101,7 @@ def load_library():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} missing: run `python -m mobiclipdecoder_amd.build` (or __graft_entry__.build())")
-        lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        _LIB = lib
+        _LIB = bind_library(LIB_PATH)
     return _LIB
 
 

@@ -19,3 +19,13 @@ def _native_built():
     from mobiclipdecoder_amd import build
     build.build_all()
     yield
+
+
+@pytest.fixture
+def profiling_library(monkeypatch):
+    """The -DMOBI_PROFILING twin of the product library (libmobiclip_hip_prof.so: same sources plus the mobi_debug_* test hooks, which the
+    product library does not export) as the library behind MobiclipDecoder / MobiclipBatch for the duration of one test."""
+    from mobiclipdecoder_amd import build, decoder
+    lib = decoder.bind_library(build.build_hip(profiling=True))
+    monkeypatch.setattr(decoder, "_LIB", lib)
+    yield lib

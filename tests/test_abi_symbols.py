@@ -27,6 +27,18 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert set(decoder._SIGS) <= set(names)
 
 
+def test_nothing_but_the_headers_leaves_the_library():
+    """-fvisibility=hidden + a version script written from include/*.h: no C++ symbols, no kernel stubs, no debug hooks"""
+    from mobiclipdecoder_amd import build
+    path = os.path.join(ROOT, "mobiclipdecoder_amd", "libmobiclip_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == set(build.header_symbols()), exported ^ set(build.header_symbols())
+    assert not any("debug" in n for n in exported)
+    prof = subprocess.run(["nm", "-D", "--defined-only", build.LIB_HIP_PROF], capture_output=True, text=True, check=True).stdout
+    assert "mobi_debug_write_planes" in prof  # the test hooks live in the profiling twin only
+
+
 def test_demux_header_symbols_are_exported_and_bound():
     from mobiclipdecoder_amd import decoder, demux
     lib = decoder.load_library()

@@ -242,13 +242,12 @@ def test_hybrid_parse_matches_the_oracle(monkeypatch):
     b.close()
 
 
-def test_default_parse_side_follows_batch_size_and_packet_shape(monkeypatch):
+def test_default_parse_side_follows_batch_size_and_packet_shape(monkeypatch, profiling_library):
     """No explicit choice: 1024 clips and more parse on the GPU when Data looks like packets, on the host when Data is a whole
     file (MOC5 style; the device path would have to upload megabytes per clip and frame).  Same planes either way."""
     import ctypes as C
-    from mobiclipdecoder_amd.decoder import load_library
     monkeypatch.delenv("MOBI_DEVICE_PARSE", raising=False)  # the suite may be run with the parse side forced
-    lib = load_library()
+    lib = profiling_library  # (mobi_debug_read_parse is a hook of the profiling twin only)
     lib.mobi_debug_read_parse.restype = C.c_longlong
     lib.mobi_debug_read_parse.argtypes = [C.c_void_p] * 5 + [C.c_size_t]
     p = default_params("A", BASE_SEED + 77, n_frames=3, width=64, height=48)

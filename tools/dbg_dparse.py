@@ -1,3 +1,4 @@
+import _prof  # noqa: F401  (the profiling twin of the library)
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

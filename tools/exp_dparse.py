@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end DecodeFrame throughput (bitstream in, planes in HBM): host parse vs device parse at several batch sizes."""
+import _prof  # noqa: F401  (the profiling twin of the library)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """mobi_batch_decode with the parse on host threads: time inside the C call per P-frame step (MOBI_PARSE_THREADS sets the pool)."""
+import _prof  # noqa: F401  (the profiling twin of the library)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

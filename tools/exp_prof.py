@@ -1,3 +1,4 @@
+import _prof  # noqa: F401  (the profiling twin of the library)
 import os, sys, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MOBI_DEBUG"] = "9"
 import mobiclipdecoder_amd as m

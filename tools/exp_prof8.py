@@ -1,4 +1,5 @@
 """MOBI_DEBUG=9: where an octet wave's life goes in mobi_recon_inter8 (shader-clock stamps accumulated by the _prof twin of the kernel)."""
+import _prof  # noqa: F401  (the profiling twin of the library)
 import os, sys, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MOBI_DEBUG"] = "9"
 import numpy as np
