@@ -248,6 +248,102 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
 }
 } // namespace
 
+// ---- 16-bit packed transforms (r04): one lane carries the same row of TWO coded areas, one in each half of a dword ----
+// The octet kernel is bound by vector instruction issue, and 44 % of its instructions were the residual stage: two passes of the 8-point
+// butterfly per area row, eight lanes per area, sixteen areas in two half rounds.  v_pk_add_i16 / v_pk_sub_i16 / v_pk_ashrrev_i16 do two of
+// them per instruction.  Exactness: the reference computes in int32 (MD.cs:3435-3798); 16-bit wrapping arithmetic gives the same bits as
+// long as no intermediate leaves int16, and every intermediate of a pass is a sum of inputs with coefficients of magnitude <= 3/2 (plus
+// the truncation of at most a handful of shifts), so after both passes |x| <= 9/4 * (sum of |coefficient| of the area + 32) + 104.  The
+// scatter adds up |coefficient| per area (P_SUM); an octet with an area above MOBI_PK_LIMIT takes the 32-bit rounds instead (wave-uniform).
+#define MOBI_PK_LIMIT 14000 /* 9/4 * (14000 + 32) + 104 = 31676 < 32768 */
+namespace {
+__device__ __forceinline__ void bfly8_pk(const s16x2 in[8], s16x2 out[8]) { // mobi_bfly8, two at a time
+  const s16x2 a0 = in[0] + in[4], a1 = in[0] - in[4];
+  const s16x2 a2 = in[2] + (in[6] >> (short)1), a3 = (in[2] >> (short)1) - in[6];
+  const s16x2 e0 = a0 + a2, e1 = a1 + a3, e2 = a1 - a3, e3 = a0 - a2;
+  const s16x2 b0 = in[1] + in[7] - in[3] - (in[3] >> (short)1);
+  const s16x2 b1 = in[7] - in[1] + in[5] + (in[5] >> (short)1);
+  const s16x2 b2 = in[5] - (in[7] + (in[7] >> (short)1)) - in[3];
+  const s16x2 b3 = in[3] + in[5] + in[1] + (in[1] >> (short)1);
+  const s16x2 o0 = b2 + (b3 >> (short)2), o3 = b3 - (b2 >> (short)2);
+  const s16x2 o1 = b0 + (b1 >> (short)2), o2 = (b0 >> (short)2) - b1;
+  out[0] = e0 + o3; out[7] = e0 - o3;
+  out[1] = e1 + o2; out[6] = e1 - o2;
+  out[2] = e2 + o1; out[5] = e2 - o1;
+  out[3] = e3 + o0; out[4] = e3 - o0;
+}
+__device__ __forceinline__ void bfly4_pk(const s16x2 in[4], s16x2 out[4]) { // mobi_bfly4, two at a time
+  const s16x2 a = in[0] + in[2], b = in[0] - in[2];
+  const s16x2 c = (in[1] >> (short)1) - in[3], d = in[1] + (in[3] >> (short)1);
+  out[0] = a + d; out[3] = a - d; out[1] = b + c; out[2] = b - c;
+}
+union PkRow { uint4 q[2]; s16x2 v[8]; };
+// A pair tile = 64 dwords, dword i = coefficient i of area A (low half) and of area B (high half).  Lane r reads dwords 8r .. 8r + 7 in both
+// passes and for both kinds: an 8x8 transform's group r, or groups k0, k0 + 1 of 4x4 block r >> 1 (16 * (r >> 1) + 4 * k0 = 8r).
+__device__ __forceinline__ void idct_pass1_pk(uint32_t *c, bool is8, int r) {
+  PkRow in;
+  s16x2 out[8];
+  in.q[0] = *(const uint4 *)(c + 8 * r);
+  in.q[1] = *(const uint4 *)(c + 8 * r + 4);
+  const s16x2 rnd = {32, 32};
+  if (is8) {
+    if (r == 0) in.v[0] += rnd;
+    bfly8_pk(in.v, out);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) *(s16x2 *)(c + 8 * m + r) = out[m];
+  } else {
+    const int s = r >> 1, k0 = (r & 1) * 2;
+    if (k0 == 0) in.v[0] += rnd;
+    bfly4_pk(in.v, out);
+    bfly4_pk(in.v + 4, out + 4);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < 4; m++) *(uint2 *)(c + 16 * s + 4 * m + k0) = uint2{__builtin_bit_cast(uint32_t, out[m]), __builtin_bit_cast(uint32_t, out[4 + m])};
+  }
+}
+// pass 2 and the pixel update of both areas: out[k] = residual k of the lane's row in area A (low half) and area B (high half); words wa
+// hold samples 0..3, wb samples 4..7 (8x8: one row; 4x4: rows i0, i0 + 1 of block r >> 1).  The range of prediction + residual is tracked
+// per half (the clamp table's domain, MobiConst.cs:587) instead of testing every sample.
+__device__ __forceinline__ void idct_pass2_pk(const uint32_t *t, bool is8, int r, uint8_t *waA, uint8_t *wbA, uint8_t *waB, uint8_t *wbB, bool actB,
+                                              s16x2 &lo, s16x2 &hi) {
+  PkRow in;
+  s16x2 out[8];
+  in.q[0] = *(const uint4 *)(t + 8 * r);
+  in.q[1] = *(const uint4 *)(t + 8 * r + 4);
+  if (is8) {
+    bfly8_pk(in.v, out);
+  } else {
+    bfly4_pk(in.v, out);
+    bfly4_pk(in.v + 4, out + 4);
+  }
+  const uint32_t pA[2] = {*(const uint32_t *)waA, *(const uint32_t *)wbA}, pB[2] = {*(const uint32_t *)waB, *(const uint32_t *)wbB};
+  uint32_t resA[2], resB[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    uint32_t sat[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // sample k of both words as two uint16: byte k of A's word below, byte k of B's word above
+      const s16x2 pp = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(pB[h], pA[h], 0x0c040c00u + (uint32_t)k * 0x00010001u));
+      const s16x2 sum = __builtin_elementwise_add_sat(pp, out[4 * h + k] >> (short)6);
+      lo = __builtin_elementwise_min(lo, sum);
+      hi = __builtin_elementwise_max(hi, sum);
+      sat[k] = sat_pk_u8(sum); // byte 0: A's sample, byte 1: B's
+    }
+    const uint32_t m01 = __builtin_amdgcn_perm(sat[1], sat[0], 0x05010400u), m23 = __builtin_amdgcn_perm(sat[3], sat[2], 0x05010400u); // A k, A k+1, B k, B k+1
+    resA[h] = __builtin_amdgcn_perm(m23, m01, 0x05040100u);
+    resB[h] = __builtin_amdgcn_perm(m23, m01, 0x07060302u);
+  }
+  *(uint32_t *)waA = resA[0];
+  *(uint32_t *)wbA = resA[1];
+  if (actB) {
+    *(uint32_t *)waB = resB[0];
+    *(uint32_t *)wbB = resB[1];
+  }
+}
+} // namespace
+
 // =====================================================================================================
 // mobi_recon_inter8 (r02): one wavefront per octet, second generation
 // =====================================================================================================
@@ -278,29 +374,32 @@ namespace {
 //         both planes of a leaf share one window.  TOP/BOTTOM: leaf A rows 0..4, leaf B rows 5..9.
 //   P_C1  the same for the right half of a LEFT/RIGHT pair.
 // After motion compensation (the windows are dead):
-//   P_OUT_Y  luma sample (row R, column c) of macroblock g at (R & 7) * 256 + (R >> 3) * 128 + (((g ^ (R & 7)) * 16) + c): a row's eight
-//            macroblocks are rotated by the row number, so that the 64 lanes of a motion-compensation store, the eight lanes that add
-//            one area's residual (one row each) and the 16-byte reads of the final copy all spread over the banks.
-//   P_OUT_C  chroma (row R, plane pl, sample x) at (R & 3) * 256 + (R >> 2) * 128 + ((g ^ (R & 3)) * 16) + pl * 8 + x.
+//   P_OUT  the octet's output samples, luma rows R = 0..15 and chroma rows as R = 16..23 (column = plane * 8 + sample) in ONE formula:
+//          (row R, column c) of macroblock g at (R & 7) * 384 + (R >> 3) * 128 + ((g ^ (R & 7)) * 16) + c.  A row's eight macroblocks are
+//          rotated by the row number, so that the 64 lanes of a motion-compensation store, the eight lanes that add one area's residual
+//          (one row each) and the 16-byte reads of the final copy all spread over the banks; and a coded area's place is one constant
+//          K = (area < 4 ? area >> 1 : 2) * 128 + (area & 1) * 8 whatever the plane (r03 kept chroma in a layout of its own: the residual
+//          add spent 30 instructions per half round choosing between the two).
 enum {
   P_L = 0,
   P_C = 5120,
   P_C1 = 7680,
   P_BYTES = 10240,
-  P_OUT_Y = 0,    // 2048 B
-  P_OUT_C = 2048, // 1024 B
-  P_COEF = 3072,  // P_ROUND tiles of P_TILE words
+  P_OUT = 0,      // 3072 B
+  P_COEF = 3072,  // coefficient tiles of P_TILE words: 8 tiles of int16 PAIRS (two areas each) per packed round, or P_ROUND tiles of int32
   P_TILE = 72,
-  P_ROUND = 22,   // coded areas per residual round: three half rounds of eight lanes-by-eight (the third one rarely runs: an octet has 14
-                  // coded areas on average in the generator's mix, more than 16 in one octet out of five, more than 22 in one out of a hundred)
+  P_PAIRS = 8,    // packed round: 16 coded areas (an octet has 14 on average in the generator's mix, more than 16 in one out of five)
+  P_ROUND = 22,   // 32-bit rounds (the fall-back when some area's coefficients are too large for 16-bit butterflies): three half rounds of eight
+  P_SUM = P_COEF + P_PAIRS * P_TILE * 4, // sum of |coefficient| per coded area (48 words), behind the packed tiles; dead before a 32-bit round
   P_SC = 9728,    // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
-  P_TAB = 10048,  // entry -> area*8 + g (<= 48 bytes)
-  P_INV = 9408    // area*8 + g -> uint16: [6:0] entry, [15:7] what selects the dequant scale: 0x0FC (one 8x8 transform: byte offset =
+  P_TAB = 10048,  // slot -> uint32: [6:4] g, [15:8] area * 8 + g, [31:16] K (above): 48 words
+  P_INV = 9408    // area*8 + g -> uint16: [6:0] slot, [15:7] what selects the dequant scale: 0x0FC (one 8x8 transform: byte offset =
                   // 4 * position) or 0x13C (4x4 blocks: 256 + 4 * (position & 15)), see the scatter.  Behind the last coefficient tile.
 };
-static_assert(P_COEF + P_ROUND * P_TILE * 4 <= P_INV && P_INV + 96 <= P_SC, "inter LDS map");
-__device__ __forceinline__ int out_y(int g, int R, int c) { return P_OUT_Y + (R & 7) * 256 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
-__device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return P_OUT_C + (R & 3) * 256 + (R >> 2) * 128 + ((g ^ (R & 3)) << 4) + pl * 8 + x; }
+static_assert(P_COEF + P_ROUND * P_TILE * 4 <= P_INV && P_INV + 96 <= P_SC && P_TAB + 192 <= P_BYTES && P_SUM + 192 <= P_INV, "inter LDS map");
+__device__ __forceinline__ int out_px(int g, int R, int c) { return P_OUT + (R & 7) * 384 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
+__device__ __forceinline__ int out_y(int g, int R, int c) { return out_px(g, R, c); }
+__device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return out_px(g, 16 + R, pl * 8 + x); }
 // N output rows of 4 pixels from N + 1 window rows (x0[i], x1[i] = the two aligned dwords holding row i's 5 bytes)
 template <int N>
 __device__ __forceinline__ void mc_rows(const uint32_t (&x0)[N + 1], const uint32_t (&x1)[N + 1], uint32_t sh, int phase, uint32_t *out) {
@@ -636,42 +735,50 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the scales
   wave_sync();
   if (m_lo | m_hi) {
-    // entries: 8x8 areas first, then the areas made of 4x4 blocks; inside a kind by area, then macroblock
+    // slots: the 8x8 areas first, then -- from an even slot, so that the two areas of a packed pair are of one kind -- the areas made of
+    // 4x4 blocks; inside a kind by area, then macroblock.  (n8 odd: slot n8 stays empty.)
     const uint32_t m8_lo = m_lo & t_lo, m8_hi = m_hi & t_hi, m4_lo = m_lo & ~t_lo, m4_hi = m_hi & ~t_hi;
     const int n8_lo = __builtin_popcount(m8_lo), n8 = n8_lo + __builtin_popcount(m8_hi);
-    const int n4_lo = __builtin_popcount(m4_lo), n_ent = n8 + n4_lo + __builtin_popcount(m4_hi);
-    auto slot_of_entry = [=](int kk, bool chroma, bool is8) { // kk = (area & 3) * 8 + g.  (By value, and masks by arithmetic: a select between
-      const uint32_t flip = is8 ? 0u : 0xFFFFFFFFu;          // captured variables turns into a select between their addresses, i.e. scratch.)
-      const uint32_t mask = chroma ? m_hi & (t_hi ^ flip) : m_lo & (t_lo ^ flip);
-      const int first = (is8 ? 0 : n8) + (chroma ? (is8 ? n8_lo : n4_lo) : 0);
-      return first + __builtin_popcount(mask & ((1u << kk) - 1u));
-    };
-    int *coef = (int *)(L + P_COEF);
+    const int n4_lo = __builtin_popcount(m4_lo), first4 = (n8 + 1) & ~1, n_slots = first4 + n4_lo + __builtin_popcount(m4_hi);
     {
       const bool hi = lane >= 32;
       const int kk = lane & 31;
       if (((hi ? m_hi : m_lo) >> kk) & 1) {
-        const int slot = slot_of_entry(kk, hi, ((hi ? t_hi : t_lo) >> kk) & 1);
-        L[P_TAB + slot] = (uint8_t)lane;
-        *(uint16_t *)(L + P_INV + 2 * lane) = (uint16_t)(slot | ((slot < n8 ? 0x0FC : 0x13C) << 7)); // ... and area * 8 + g -> entry, for the scatter
+        const bool is8 = ((hi ? t_hi : t_lo) >> kk) & 1;
+        const uint32_t flip = is8 ? 0u : 0xFFFFFFFFu;
+        const uint32_t mask = hi ? m_hi & (t_hi ^ flip) : m_lo & (t_lo ^ flip);
+        const int first = (is8 ? 0 : first4) + (hi ? (is8 ? n8_lo : n4_lo) : 0);
+        const int slot = first + __builtin_popcount(mask & ((1u << kk) - 1u));
+        const int a = lane >> 3;
+        const uint32_t K = (uint32_t)((a < 4 ? a >> 1 : 2) * 128 + (a & 1) * 8);
+        *(uint32_t *)(L + P_TAB + 4 * slot) = ((uint32_t)(lane & 7) << 4) | ((uint32_t)lane << 8) | (K << 16);
+        *(uint16_t *)(L + P_INV + 2 * lane) = (uint16_t)(slot | ((is8 ? 0x0FC : 0x13C) << 7)); // area * 8 + g -> slot, for the scatter
       }
+      if (lane < 48) *(uint32_t *)(L + P_SUM + 4 * lane) = 0u;
     }
     wave_sync();
-    s16x2 lo = {0, 0}, hi = {0, 0};
     MOBI_STOP(8);
-    for (int base = 0; base < n_ent; base += P_ROUND) {
-      {
-        const uint4 z = uint4{0, 0, 0, 0};
-        const int n_tiles = n_ent - base < P_ROUND ? n_ent - base : P_ROUND;          // (wave-uniform: only the tiles in use)
-        for (int o = lane * 16; o < n_tiles * P_TILE * 4; o += 1024) *(uint4 *)(L + P_COEF + o) = z;
-      }
-      wave_sync();
+    s16x2 lo = {0, 0}, hi = {0, 0};
+    const int r = lane & 7, grp = lane >> 3;
+    // one pass over the macroblock's level words: PK = into the int16 pair tiles of slots [base, base + 16) (and, in the first round, the
+    // per-area sums of |coefficient|), else into the int32 tiles of slots [base, base + P_ROUND)
+    auto scatter_all = [&](auto pk, int base) {
+      constexpr bool PK = decltype(pk)::value;
       auto scatter = [&](uint32_t e) {
-        const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63;
-        const uint32_t inv = *(const uint16_t *)(L + P_INV + ((t >> 6) * 8 + g) * 2);
+        const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63, kk = (t >> 6) * 8 + g;
+        const uint32_t inv = *(const uint16_t *)(L + P_INV + kk * 2);
         const int slot = (int)(inv & 0x7F) - base;
         const int scale = (int)lds32(L, P_SC + (int)((((uint32_t)t << 2) | 0x100u) & (inv >> 7))); // scale8[p] or scale4[p & 15] (80 words: 64 + 16)
-        if ((unsigned)slot < (unsigned)P_ROUND) coef[slot * P_TILE + p] = __mul24(scale, level);
+        const int v = __mul24(scale, level);
+        if (PK) {
+          if ((unsigned)slot < 2u * P_PAIRS) *(int16_t *)(L + P_COEF + (slot >> 1) * (P_TILE * 4) + p * 4 + (slot & 1) * 2) = (int16_t)v;
+          if (base == 0) { // (a word is looked at once per round; the sums are complete after the first)
+            const int av = v < 0 ? -v : v;
+            __hip_atomic_fetch_add((uint32_t *)(L + P_SUM + kk * 4), (uint32_t)(av > 0xFFFF ? 0xFFFF : av), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+        } else {
+          if ((unsigned)slot < (unsigned)P_ROUND) *(int *)(L + P_COEF + slot * (P_TILE * 4) + p * 4) = v;
+        }
       };
 #pragma unroll
       for (int k = 0; k < CWR; k++) {
@@ -690,46 +797,77 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         for (int k = 0; k < 8; k++)
           if (i + 8u * k < ncoef) scatter(tw[k]);
       }
+    };
+    auto zero_tiles = [&](int n_tiles) { // (wave-uniform: only the tiles in use)
+      const uint4 z = uint4{0, 0, 0, 0};
+      for (int o = lane * 16; o < n_tiles * P_TILE * 4; o += 1024) *(uint4 *)(L + P_COEF + o) = z;
+    };
+    // where the lane's two words of an area are: 8x8 -> row r, samples 0..3 and 4..7; 4x4 -> rows i0, i0 + 1 of block r >> 1.
+    // address = C + ((g ^ x) << 4) + K(area) in the layout of out_px
+    const int s4 = r >> 1, rowa4 = (s4 >> 1) * 4 + (r & 1) * 2, cola4 = (s4 & 1) * 4;
+    const int Ca8 = P_OUT + r * 384, Cb8 = Ca8 + 4, x8 = r << 4;
+    const int Ca4 = P_OUT + rowa4 * 384 + cola4, Cb4 = P_OUT + (rowa4 + 1) * 384 + cola4, xa4 = rowa4 << 4, xb4 = (rowa4 + 1) << 4;
+    bool wide = false; // (wave-uniform) some area's coefficients are too large for the 16-bit butterflies
+    for (int base = 0; base < n_slots; base += 2 * P_PAIRS) {
+      zero_tiles(n_slots - base < 2 * P_PAIRS ? (n_slots - base + 1) >> 1 : P_PAIRS);
+      wave_sync();
+      scatter_all(std::true_type{}, base);
+      wave_sync();
+      if (base == 0) {
+        const uint32_t sm = lane < 48 ? lds32(L, P_SUM + 4 * lane) : 0u;
+        if (__builtin_amdgcn_ballot_w64(sm > (uint32_t)MOBI_PK_LIMIT) != 0) { wide = true; break; }
+      }
       MOBI_STOP(9);
+      const int slot0 = base + 2 * grp;           // the group's pair: slots slot0 (A), slot0 + 1 (B)
+      const bool act = slot0 < n_slots, is8g = slot0 < first4;
+      const bool actB = slot0 + 1 < n_slots && slot0 + 1 != n8;
+      uint32_t *tile = (uint32_t *)(L + P_COEF) + P_TILE * grp;
+      if (act) idct_pass1_pk(tile, is8g, r);
       wave_sync();
-      const int r = lane & 7;
-      int kx[3];
-      bool actx[3], is8x[3];
-#pragma unroll
-      for (int h = 0; h < 3; h++) {
-        const int idx = base + 8 * h + (lane >> 3);
-        actx[h] = idx < n_ent && 8 * h + (lane >> 3) < P_ROUND;
-        kx[h] = actx[h] ? L[P_TAB + idx] : 0;
-        is8x[h] = idx < n8;
-      }
-#pragma unroll
-      for (int h = 0; h < 3; h++) {
-        int *tile = coef + P_TILE * (8 * h + (lane >> 3));
-        if (actx[h]) idct_pass1(tile, tile, is8x[h], r);
-      }
       MOBI_STOP(10);
-      wave_sync();
-#pragma unroll
-      for (int h = 0; h < 3; h++) {
-        if (actx[h]) {
-          // the lane's two 4-pixel words: one row of the area (8x8), or rows i0, i0 + 1 of 4x4 block r >> 1
-          const int ge = kx[h] & 7, a = kx[h] >> 3;
-          const bool is8 = is8x[h];
-          const int s4 = r >> 1, rowa = is8 ? r : (s4 >> 1) * 4 + (r & 1) * 2, cola = is8 ? 0 : (s4 & 1) * 4;
-          const int rowb = is8 ? r : rowa + 1, colb = is8 ? 4 : cola;
-          uint8_t *wa, *wb;
-          if (a < 4) {
-            wa = L + out_y(ge, (a >> 1) * 8 + rowa, (a & 1) * 8 + cola);
-            wb = L + out_y(ge, (a >> 1) * 8 + rowb, (a & 1) * 8 + colb);
-          } else {
-            wa = L + out_c(ge, rowa, a - 4, cola);
-            wb = L + out_c(ge, rowb, a - 4, colb);
-          }
-          idct_pass2_q(coef + P_TILE * (8 * h + (lane >> 3)), is8, r, wa, wb, lo, hi);
-        }
+      if (act) {
+        const uint32_t recA = lds32(L, P_TAB + 4 * slot0), recB = actB ? lds32(L, P_TAB + 4 * slot0 + 4) : recA;
+        const int Ca = is8g ? Ca8 : Ca4, Cb = is8g ? Cb8 : Cb4, xa = is8g ? x8 : xa4, xb = is8g ? x8 : xb4;
+        const int gA = (int)(recA & 0x70u), KA = (int)(recA >> 16), gB = (int)(recB & 0x70u), KB = (int)(recB >> 16);
+        idct_pass2_pk(tile, is8g, r, L + (Ca + (gA ^ xa) + KA), L + (Cb + (gA ^ xb) + KA), L + (Ca + (gB ^ xa) + KB), L + (Cb + (gB ^ xb) + KB), actB, lo, hi);
       }
       wave_sync();
       MOBI_STOP(11);
+    }
+    if (wide) { // the same in int32, eight lanes per area, P_ROUND areas per round (r03's residual stage)
+      const int hole = (n8 & 1) ? n8 : -1; // (n8 odd: slot n8 is empty)
+      for (int base = 0; base < n_slots; base += P_ROUND) {
+        zero_tiles(n_slots - base < P_ROUND ? n_slots - base : P_ROUND);
+        wave_sync();
+        scatter_all(std::false_type{}, base);
+        wave_sync();
+        int *coef = (int *)(L + P_COEF);
+        uint32_t recx[3];
+        bool actx[3], is8x[3];
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+          const int idx = base + 8 * h + grp;
+          actx[h] = idx < n_slots && idx != hole && 8 * h + grp < P_ROUND;
+          recx[h] = actx[h] ? lds32(L, P_TAB + 4 * idx) : 0u;
+          is8x[h] = idx < n8;
+        }
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+          int *tile = coef + P_TILE * (8 * h + grp);
+          if (actx[h]) idct_pass1(tile, tile, is8x[h], r);
+        }
+        wave_sync();
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+          if (actx[h]) {
+            const bool is8 = is8x[h];
+            const int Ca = is8 ? Ca8 : Ca4, Cb = is8 ? Cb8 : Cb4, xa = is8 ? x8 : xa4, xb = is8 ? x8 : xb4;
+            const int gg = (int)(recx[h] & 0x70u), KK = (int)(recx[h] >> 16);
+            idct_pass2_q(coef + P_TILE * (8 * h + grp), is8, r, L + (Ca + (gg ^ xa) + KK), L + (Cb + (gg ^ xb) + KK), lo, hi);
+          }
+        }
+        wave_sync();
+      }
     }
     if (lo.x < -64 || lo.y < -64 || hi.x > 319 || hi.y > 319) atomicOr(&A.fault[clip], 1); // clamp table domain (MobiConst.cs:587)
   }
