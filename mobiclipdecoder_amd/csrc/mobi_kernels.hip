@@ -180,8 +180,11 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, uint32_t d, uint32_t mag
 // on purpose; the default build has none of it.
 #if defined(MOBI_PROFILING)
 #define MOBI_STOP(n) do { if (A.reserved21 == (n)) return; } while (0)
+/* the same for mobi_recon_intra (MOBI_INTRA_DBG = n << 8); the tag is still published: whoever waits for this macroblock must not spin */
+#define MOBI_ISTOP(n) do { if ((dbg >> 8) == (n)) { if (I.valid && I.publish && l == 0) __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + mb, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; } } while (0)
 #else
 #define MOBI_STOP(n) do { } while (0)
+#define MOBI_ISTOP(n) do { } while (0)
 #endif
 namespace {
 typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -393,10 +396,11 @@ enum {
   P_SUM = P_COEF + P_PAIRS * P_TILE * 4, // sum of |coefficient| per coded area (48 words), behind the packed tiles; dead before a 32-bit round
   P_SC = 9728,    // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
   P_TAB = 10048,  // slot -> uint32: [6:4] g, [15:8] area * 8 + g, [31:16] K (above): 48 words
-  P_INV = 9408    // area*8 + g -> uint16: [6:0] slot, [15:7] what selects the dequant scale: 0x0FC (one 8x8 transform: byte offset =
-                  // 4 * position) or 0x13C (4x4 blocks: 256 + 4 * (position & 15)), see the scatter.  Behind the last coefficient tile.
+  P_INV = 9408    // area*8 + g -> uint32: [12:0] where the slot's coefficients start in the packed tiles (byte offset from P_COEF: pair tile
+                  // slot >> 1, half slot & 1), [19:13] slot, [31:23] what selects the dequant scale: 0x0FC (one 8x8 transform: byte offset =
+                  // 4 * position) or 0x13C (4x4 blocks: 256 + 4 * (position & 15)), see the scatter.  48 words behind the last coefficient tile.
 };
-static_assert(P_COEF + P_ROUND * P_TILE * 4 <= P_INV && P_INV + 96 <= P_SC && P_TAB + 192 <= P_BYTES && P_SUM + 192 <= P_INV, "inter LDS map");
+static_assert(P_COEF + P_ROUND * P_TILE * 4 <= P_INV && P_INV + 192 <= P_SC && P_TAB + 192 <= P_BYTES && P_SUM + 192 <= P_INV, "inter LDS map");
 __device__ __forceinline__ int out_px(int g, int R, int c) { return P_OUT + (R & 7) * 384 + (R >> 3) * 128 + ((g ^ (R & 7)) << 4) + c; }
 __device__ __forceinline__ int out_y(int g, int R, int c) { return out_px(g, R, c); }
 __device__ __forceinline__ int out_c(int g, int R, int pl, int x) { return out_px(g, 16 + R, pl * 8 + x); }
@@ -703,10 +707,12 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   MOBI_STOP(5);
   wave_sync();
   {
+    // out_px with the row's low bits constant: (g ^ k) << 4 = (g << 4) ^ (k << 4), and nothing else of the address lives in bits 4..6
+    const int by = P_OUT + rr * 128 + (g << 4) + 4 * q, bc = P_OUT + 256 + ch * (4 * 384) + ((g << 4) ^ (ch << 6)) + pl * 8 + 4 * qc;
 #pragma unroll
-    for (int k = 0; k < 8; k++) *(uint32_t *)(L + out_y(g, 8 * rr + k, 4 * q)) = mcv[k];
+    for (int k = 0; k < 8; k++) *(uint32_t *)(L + ((by ^ (k << 4)) + k * 384)) = mcv[k];            // = out_y(g, 8 * rr + k, 4 * q)
 #pragma unroll
-    for (int k = 0; k < 4; k++) *(uint32_t *)(L + out_c(g, 4 * ch + k, pl, 4 * qc)) = mcv[8 + k];
+    for (int k = 0; k < 4; k++) *(uint32_t *)(L + ((bc ^ (k << 4)) + k * 384)) = mcv[8 + k];        // = out_c(g, 4 * ch + k, pl, 4 * qc)
   }
   if (PROF) pt[3] = prof_stamp();
   MOBI_STOP(6);
@@ -752,7 +758,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         const int a = lane >> 3;
         const uint32_t K = (uint32_t)((a < 4 ? a >> 1 : 2) * 128 + (a & 1) * 8);
         *(uint32_t *)(L + P_TAB + 4 * slot) = ((uint32_t)(lane & 7) << 4) | ((uint32_t)lane << 8) | (K << 16);
-        *(uint16_t *)(L + P_INV + 2 * lane) = (uint16_t)(slot | ((is8 ? 0x0FC : 0x13C) << 7)); // area * 8 + g -> slot, for the scatter
+        *(uint32_t *)(L + P_INV + 4 * lane) = (uint32_t)((slot >> 1) * (P_TILE * 4) + (slot & 1) * 2) | ((uint32_t)slot << 13) | ((is8 ? 0x0FCu : 0x13Cu) << 23); // area * 8 + g -> slot, for the scatter
       }
       if (lane < 48) *(uint32_t *)(L + P_SUM + 4 * lane) = 0u;
     }
@@ -764,20 +770,23 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     // per-area sums of |coefficient|), else into the int32 tiles of slots [base, base + P_ROUND)
     auto scatter_all = [&](auto pk, int base) {
       constexpr bool PK = decltype(pk)::value;
+      const int base_off = PK ? (base >> 1) * (P_TILE * 4) : 0; // (wave-uniform)
       auto scatter = [&](uint32_t e) {
-        const int t = e & 0x1FF, level = (int32_t)e >> 16, p = t & 63, kk = (t >> 6) * 8 + g;
-        const uint32_t inv = *(const uint16_t *)(L + P_INV + kk * 2);
-        const int slot = (int)(inv & 0x7F) - base;
-        const int scale = (int)lds32(L, P_SC + (int)((((uint32_t)t << 2) | 0x100u) & (inv >> 7))); // scale8[p] or scale4[p & 15] (80 words: 64 + 16)
+        const uint32_t t = e & 0x1FF, t4 = t << 2, p4 = t4 & 0xFCu, kk4 = ((t >> 6) * 8 + (uint32_t)g) << 2;
+        const int level = (int32_t)e >> 16;
+        const uint32_t inv = lds32(L, P_INV + (int)kk4);
+        const int scale = (int)lds32(L, P_SC + (int)((t4 | 0x100u) & (inv >> 23))); // scale8[p] or scale4[p & 15] (80 words: 64 + 16)
         const int v = __mul24(scale, level);
         if (PK) {
-          if ((unsigned)slot < 2u * P_PAIRS) *(int16_t *)(L + P_COEF + (slot >> 1) * (P_TILE * 4) + p * 4 + (slot & 1) * 2) = (int16_t)v;
+          const uint32_t off = (inv & 0x1FFFu) - (uint32_t)base_off;
+          if (off < (uint32_t)(P_PAIRS * P_TILE * 4)) *(int16_t *)(L + P_COEF + off + p4) = (int16_t)v;
           if (base == 0) { // (a word is looked at once per round; the sums are complete after the first)
             const int av = v < 0 ? -v : v;
-            __hip_atomic_fetch_add((uint32_t *)(L + P_SUM + kk * 4), (uint32_t)(av > 0xFFFF ? 0xFFFF : av), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add((uint32_t *)(L + P_SUM + kk4), (uint32_t)(av > 0xFFFF ? 0xFFFF : av), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           }
         } else {
-          if ((unsigned)slot < (unsigned)P_ROUND) *(int *)(L + P_COEF + slot * (P_TILE * 4) + p * 4) = v;
+          const int slot = (int)((inv >> 13) & 0x7Fu) - base;
+          if ((unsigned)slot < (unsigned)P_ROUND) *(int *)(L + P_COEF + slot * (P_TILE * 4) + p4) = v;
         }
       };
 #pragma unroll
@@ -1064,16 +1073,26 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   // 8-byte loads (luma columns -4..23, U and V -4..15 each; the tiles keep column c at byte 4 + c).  Left column: two bytes per lane out
   // of the left neighbour's right quadrants (2 lines) and its chroma tile (1 line) -- in the reference's linear planes they were 32
   // different lines, which is what r02's edge side buffer was for.
-  const bool interior = I.valid && mbx >= 1 && mbx + 1 < mbw && mby >= 1;
+  // At the picture's edges too, as long as the planes have padding columns (Width < Stride: every stream but 256- and 512-wide ones):
+  // what lies outside the picture is then the padding's zeros or a negative offset -- nobody's, so it reads as the fresh plane's 0 --
+  // and the pieces a macroblock does have are where they are for an interior one.  (Width == Stride: the reference's linear offsets
+  // wrap into the neighbouring rows' pixels; those macroblocks ask for every halo sample who owns its address, below.)
+  const bool interior = I.valid && ((mbx >= 1 && mbx + 1 < mbw && mby >= 1) || A.width < S);
+  const bool hasW = mby >= 1 && (l == 0 || l == 4 || l == 5 ? mbx >= 1 : l == 3 || l == 8 || l == 9 ? mbx + 1 < mbw : true); // the lane's piece of the row above exists
+  const bool hasL = mbx >= 1;
   const uint8_t *wp = ty, *b0p = ty, *b1p = ty; // lanes with nothing to fetch read the macroblock's own first sample and drop it
   if (interior) {
     const int up = S << 4;                                 // a tile row of luma tiles in bytes (S / 16 tiles of 256 B); chroma: half
-    if (l == 0) wp = ty - up - 256 + 192 + 56;             // above-left, BR quadrant, row 7: columns -8..-1
-    else if (l < 3) wp = ty - up + (l == 1 ? 128 : 192) + 56; // above, BL / BR, row 7
-    else if (l == 3) wp = ty - up + 256 + 128 + 56;        // above-right, BL, row 7
-    else if (l < 10) wp = tc - (up >> 1) + ((l - 4) >> 1) * 128 - 128 + 112 + (l & 1) * 8; // chroma row 7 of above-left / above / above-right: U, V
-    b0p = ty - 256 + (1 + 2 * (l >> 3)) * 64 + (l & 7) * 8 + 7;
-    b1p = tc - 128 + (l & 7) * 16 + (l >> 3) * 8 + 7;
+    if (hasW) {
+      if (l == 0) wp = ty - up - 256 + 192 + 56;             // above-left, BR quadrant, row 7: columns -8..-1
+      else if (l < 3) wp = ty - up + (l == 1 ? 128 : 192) + 56; // above, BL / BR, row 7
+      else if (l == 3) wp = ty - up + 256 + 128 + 56;        // above-right, BL, row 7
+      else if (l < 10) wp = tc - (up >> 1) + ((l - 4) >> 1) * 128 - 128 + 112 + (l & 1) * 8; // chroma row 7 of above-left / above / above-right: U, V
+    }
+    if (hasL) {
+      b0p = ty - 256 + (1 + 2 * (l >> 3)) * 64 + (l & 7) * 8 + 7;
+      b1p = tc - 128 + (l & 7) * 16 + (l >> 3) * 8 + 7;
+    }
   }
   // where the 8 bytes go: column c at byte 4 + c of tile row 0; the above-left pieces keep their last four columns only
   const int wdst = l < 4 ? (l == 0 ? 0 : 8 * l - 4) : ((l & 1) ? IQ_TCV : IQ_TCU) + (l < 6 ? 0 : l < 8 ? 4 : 12);
@@ -1121,6 +1140,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     vm_wait(wl, c0, c1);
     if (waits) { wv = wl; b0 = c0; b1 = c1; }
   }
+  MOBI_ISTOP(1);
 
   // ---- dequantise and scatter the level words ----
   wave_sync();
@@ -1143,6 +1163,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
       if (base + (uint32_t)(l + 16 * k) < ncoef) scatter(cw[k]);
   }
   wave_sync();
+  MOBI_ISTOP(2);
 
   // ---- residuals of the coded areas.  Eight lanes per area; the coded areas of all four macroblocks are taken together, eight per
   // round (a P-frame's intra macroblocks have ~2 of 6 coded: one round instead of the three that "two areas of each macroblock per
@@ -1198,6 +1219,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     }
     wave_sync();
   }
+  MOBI_ISTOP(3);
 
   // ---- tiles: zero (what nobody owns yet reads 0, as the reference's fresh plane does), then the halo ----
   {
@@ -1209,12 +1231,14 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   }
   wave_sync();
   if (interior) {
-    if (l < 10) {
+    if (l < 10 && hasW) {
       if (!whalf) *(uint32_t *)(tile + wdst) = wv.x;
       *(uint32_t *)(tile + wdst + (whalf ? 0 : 4)) = wv.y;
     }
-    tile[b0dst] = (uint8_t)b0;
-    tile[b1dst] = (uint8_t)b1;
+    if (hasL) {
+      tile[b0dst] = (uint8_t)b0;
+      tile[b1dst] = (uint8_t)b1;
+    }
   }
   // At the picture's edges the linear offsets of the reference wrap into the previous / next row or fall into the padding: every
   // halo sample asks who owns its address (217 luma + 178 chroma samples, 7 per lane and round).  One macroblock in twelve; the
@@ -1262,6 +1286,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     }
   }
   wave_sync();
+  MOBI_ISTOP(4);
 
   // ---- the schedule: one step per unsplit area, four per split one, in decode order.  Lane 4a + s of the row owns the candidate
   // (area a, block s); its place in the list follows from how many areas before a are split. ----
@@ -1314,6 +1339,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     if (l < 8 && posB >= 0) *(uint2 *)(steps + 2 * posB) = dB;
   }
   wave_sync();
+  MOBI_ISTOP(5);
 
   // ---- 16x16 plane (MD.cs:3017-3166): 64 words, four per lane ----
   if (__builtin_amdgcn_ballot_w64((w3 & 1) != 0) != 0) {
@@ -1348,6 +1374,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     eb2 = *(const uint4_a4 *)(tp + 2);
   }
   if (dbg & 2) n_iter = 0;
+  MOBI_ISTOP(6);
 #pragma unroll 1
   for (int t = 0; t < n_iter; t++) {
     const uint2 d = d1;
@@ -1423,6 +1450,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     wave_sync();
   }
   if (flo.x < -64 || flo.y < -64 || fhi.x > 319 || fhi.y > 319) fault = 1;
+  MOBI_ISTOP(7);
   if (fault && I.valid && !dbg) atomicOr(&A.fault[clip], 1);
 
   // ---- store.  Write-through (sc1), drained and followed by the tag only when an intra macroblock of this step may be waiting for

@@ -22,7 +22,7 @@ for it in range(rounds):
     kw = dict(width=w, height=h, version=ver, n_frames=nfr, pm_intra=int(rng.choice([0, 50, 200])), pm_deep=int(rng.choice([0, 100, 400])), pm_multiref=int(rng.choice([0, 200, 600])), pm_skip=int(rng.choice([0, 150, 500])), pm_split1=int(rng.choice([100, 400])), intra_sub_prob=int(rng.choice([100, 500, 900])),
               plane_prob=int(rng.choice([0, 300, 700])), iframe_interval=int(rng.choice([0, 0, 4])), mv_range=int(rng.choice([2, 12, 40, 90])),
               cbp_prob=int(rng.choice([100, 300, 700])), dense_prob=int(rng.choice([0, 200])), qdelta_prob=int(rng.choice([0, 300])),
-              table1_prob=int(rng.choice([0, 500])), escape_prob=int(rng.choice([0, 80])), quantizer=int(rng.choice([12, 25, 40, 52])),
+              table1_prob=int(rng.choice([0, 500])), escape_prob=int(rng.choice([0, 80])), quantizer=int(rng.choice([12, 18, 25, 29, 33, 36, 40, 46, 52])),
               intra_dc_only=int(rng.choice([0, 0, 1])), edge_mode=int(rng.choice([0, 1])))
     ps = [m.default_params("A", BASE_SEED + 100000 + 1000 * (seed0 + it) + i, **kw) for i in range(nclips)]
     clips = [m.generate_clip(p) for p in ps]
