@@ -80,7 +80,22 @@ def main():
                                   "frame_off": [int(x) for x in fo], "bytes": int(data.size), "frames": frames})
         print(name, data.size, "bytes", p.n_frames, "frames")
     json.dump(manifest, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
+    write_text_manifest(manifest)
+
+
+def write_text_manifest(manifest):
+    """the same manifest as plain lines, for tests/golden/verify/VerifyGolden.cs (a C# program against the unmodified reference: no JSON
+    parser needed under mono)"""
+    with open(os.path.join(HERE, "golden_manifest.txt"), "w") as f:
+        f.write("# written by tests/golden/make_golden.py from golden.json; read by tests/golden/verify/VerifyGolden.cs\n")
+        for c in manifest["cases"]:
+            f.write(f"case {c['name']} {c['width']} {c['height']} {c['version']} {len(c['frames'])}\n")
+            for i, fr in enumerate(c["frames"]):
+                f.write(f"frame {c['frame_off'][i]} {c['frame_off'][i + 1]} {fr['y_sha256']} {fr['uv_sha256']} {fr['offset_after']} {fr['quantizer']}\n")
 
 
 if __name__ == "__main__":
-    main()
+    if "--text-only" in sys.argv:  # golden_manifest.txt from the committed golden.json, nothing regenerated
+        write_text_manifest(json.load(open(os.path.join(HERE, "golden.json"))))
+    else:
+        main()

@@ -44,3 +44,18 @@ def test_hip_reproduces_golden(case):
     assert d.Stride == case["stride"]
     _run(case, d)
     d.close()
+
+
+def test_text_manifest_for_the_reference_side_check_matches_golden_json():
+    """tests/golden/verify/VerifyGolden.cs (a C# program against the unmodified reference; it cannot run here) reads golden_manifest.txt:
+    the same content as golden.json, line by line."""
+    g = MAN
+    lines = [ln.split() for ln in open(os.path.join(HERE, "golden_manifest.txt")) if not ln.startswith("#")]
+    it = iter(lines)
+    for c in g["cases"]:
+        assert next(it) == ["case", c["name"], str(c["width"]), str(c["height"]), str(c["version"]), str(len(c["frames"]))]
+        for i, fr in enumerate(c["frames"]):
+            assert next(it) == ["frame", str(c["frame_off"][i]), str(c["frame_off"][i + 1]), fr["y_sha256"], fr["uv_sha256"], str(fr["offset_after"]), str(fr["quantizer"])]
+    assert next(it, None) is None
+    src = open(os.path.join(HERE, "verify", "VerifyGolden.cs")).read()
+    assert "new MobiclipDecoder(" in src and "DecodeFrame()" in src and "golden_manifest.txt" in src
