@@ -250,6 +250,59 @@ def verify_clips(b, streams, distinct, clips, frame, W, H):
     return {"clips": len(picked), "which": picked, "frame": int(frame), "ok": bool(ok), "against": "CPU oracle, Y and UV planes of ring slot 0"}
 
 
+def content_leg(m, sharding, config, rank, local, clips, distinct, overrides, chains=2):
+    """The same batch on OTHER content: generator overrides (e.g. lowfreq_prob=700: 70 % of the coded blocks carry one or two levels within
+    the three lowest scan positions -- what DC-dominated video looks like, and what the reference's IDCT1P / IDCT3P classes take,
+    MD.cs:2939-2940; the headline mix, 1..6 levels uniformly over 16 positions, is the transforms' worst case).  Reported BESIDE the
+    headline value, never as it: `chains` x 32 P-frames in stream order, the I-frames outside the timed region."""
+    streams = []
+    for i in range(distinct):
+        p = m.default_params(config, sharding.stream_seed(config, rank, i), n_frames=1 + N_PFRAMES, **overrides)
+        streams.append((p,) + m.generate_clip(p))
+    p0 = streams[0][0]
+    W, H = p0.width, p0.height
+    b = m.MobiclipBatch(clips, W, H, p0.version, device=local)
+    for i, (p, data, fo) in enumerate(streams):
+        assert all(r == 0 for r in b.preload(i, data, fo))
+    for c in range(distinct, clips):
+        b.preload_clone(c, c % distinct)
+    b.commit()
+    b.set_kernel_timing(0)
+    b.replay(0)
+    for f in range(1, 9):  # warm-up
+        b.replay(f)
+    assert b.sync() == 0
+    stream_ms, acc = 0.0, {"inter_ms": 0.0, "intra_ms": 0.0, "inter_launches": 0, "intra_launches": 0}
+    for _ in range(chains):
+        b.set_kernel_timing(0)
+        b.replay(0)
+        assert b.sync() == 0
+        b.set_kernel_timing(2)
+        b.time_begin()
+        for f in range(1, 1 + N_PFRAMES):
+            b.replay(f)
+        stream_ms += b.time_end()
+        km = b.kernel_ms()
+        for k in acc:
+            acc[k] += km[k]
+        assert b.sync() == 0
+    steps = chains * N_PFRAMES
+    frames = list(range(1, 1 + N_PFRAMES))
+    cmd = sum(b.cmd_bytes(f) for f in frames) / N_PFRAMES
+    st = [b.intra_stats(f) for f in frames]
+    n_intra, intra_cmd = sum(x[0] for x in st) / N_PFRAMES, sum(x[1] for x in st) / N_PFRAMES
+    verified = verify_clips(b, streams, distinct, clips, N_PFRAMES, W, H)
+    b.close()
+    n_mbs = (W // 16) * (H // 16)
+    step_ms, inter_ms = stream_ms / steps, acc["inter_ms"] / max(1, acc["inter_launches"])
+    algo = (clips * n_mbs - n_intra) * 768.0 + (cmd - intra_cmd)
+    return {"generator_overrides": overrides, "clips": clips, "steps": steps, "ms_per_step": round(step_ms, 4),
+            "value": round(clips * W * H / step_ms / 1e3, 1), "unit": "Mpixels/s",
+            "inter_kernel_ms": round(inter_ms, 4), "inter_frac": round(algo / (inter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_step_frac": round((clips * 3.0 * W * H + cmd) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "command_bytes_per_frame": round(cmd / clips, 1), "timed_region_s": round(stream_ms * 1e-3, 3), "verified": verified}
+
+
 def dry_run(args, rank, world):
     """The N-rank plumbing with no HIP call: generate this rank's streams, build the process group, barrier, MAX-reduce a made-up
     time, gather the seeds, print the one line.  What can be wrong without a GPU is exactly this (tests/test_bench_launcher.py)."""
@@ -294,6 +347,7 @@ def main():
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--single-stream", type=int, default=1, help="1: time one clip through mobi_decode / mobi_get_argb (the boundary's own shape); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
+    ap.add_argument("--content-lowfreq", type=int, default=700, help="second content profile beside the headline: per mille of coded blocks that carry only 1..2 levels in the three lowest scan positions; 0 = skip")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: streams, sharding, barrier, reduction, the one line; no HIP call")
     args = ap.parse_args()
 
@@ -442,6 +496,12 @@ def main():
             e2e_large = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and args.config4_clips > 0 and args.config == "B":
         c4 = config4_leg(m, streams, W, H, p0.version, local, args.config4_clips, 24)
+    content = None
+    if world == 1 and args.content_lowfreq > 0 and not gen_over:
+        try:
+            content = content_leg(m, sharding, args.config, rank, local, args.clips, distinct, {"lowfreq_prob": args.content_lowfreq})
+        except Exception as e:
+            content = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         n_mbs = (W // 16) * (H // 16)
@@ -494,7 +554,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "verified": verified, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single,
+            "verified": verified, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single, "content_lowfreq": content,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -572,24 +572,23 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         if (left > 8 * k) cwr[k] = cwj[8 * k];
     }
   }
-  // slow path (deeper trees; wrapping windows): the whole wave works for one such macroblock later: lane = (row lane >> 2, pixels
-  // 4 * (lane & 3)) for luma, lanes 0..31 = (plane, row, 4 samples) for chroma.  The MV cells of the first two deep trees travel with
-  // everything else (6 % of the octets have two): one of their two round trips.
+  // slow path (deeper trees; wrapping windows): the whole wave works for one such macroblock later.  A deeper tree is fetched cell by cell
+  // (r04): lane = one cell of the 8 x 8 MV cell map = 2 x 2 luma samples and one sample of each chroma plane, one motion vector, one window
+  // of 3 x 3 luma and 2 x 2 chroma bytes -- whatever the tree looks like (r03's lanes owned 4 x 1 samples: up to two luma and four chroma
+  // windows each when the leaves were narrower than that, 300 instructions per such macroblock against 160 now).  A whole leaf whose
+  // window wraps keeps the 4 x 1 lanes: lane = (row lane >> 2, pixels 4 * (lane & 3)) for luma, lanes 0..31 = (plane, row, 4 samples)
+  // for chroma, vectors from the leaf records.  The cells of the first two deep trees travel with everything else (6 % of the octets
+  // have two): one of their two round trips.
   const int yrow = lane >> 2, yc4 = (lane & 3) * 4;
   const int cv = (lane >> 4) & 1, crow = (lane & 15) >> 1, cc4 = (lane & 1) * 4;
-  uint2 yc0 = uint2{0, 0}, yc1 = uint2{0, 0};
-  uint4 c4v0 = uint4{0, 0, 0, 0}, c4v1 = uint4{0, 0, 0, 0};
-  auto load_cells = [&](int gm, uint2 &yc, uint4 &c4v) {
-    if ((multi_mask >> gm) & 1) {
-      const uint32_t *cells = pay + __builtin_amdgcn_readlane(d.x, gm);
-      yc = *(const uint2_a4 *)(cells + (yrow >> 1) * 8 + (yc4 >> 1));
-      c4v = *(const uint4_a4 *)(cells + crow * 8 + cc4);
-    }
+  uint32_t cell0 = 0, cell1 = 0;
+  auto load_cell = [&](int gm, uint32_t &c) {
+    if ((multi_mask >> gm) & 1) c = (pay + __builtin_amdgcn_readlane(d.x, gm))[lane];
   };
   if (slow_mask) {
-    load_cells(__builtin_ctz(slow_mask), yc0, c4v0);
+    load_cell(__builtin_ctz(slow_mask), cell0);
     const uint32_t m2 = slow_mask & (slow_mask - 1);
-    if (m2) load_cells(__builtin_ctz(m2), yc1, c4v1);
+    if (m2) load_cell(__builtin_ctz(m2), cell1);
   }
   if (PROF) pt[1] = prof_stamp();
   MOBI_STOP(2);
@@ -598,26 +597,64 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   if (PROF) pt[2] = prof_stamp();
 
   // slow path: issue the first one's pixel fetches now, consume them after the others' motion compensation
-  struct Deep { Win wa, wb, wq[4]; int pha, phb, phq[4]; bool ysplit, csplit; };
-  auto deep_fetch = [&](Deep &D, int gm, uint2 yc, uint4 c4v) {
+  struct Deep { // both kinds: `cells` says which
+    bool cells;
+    // a cell: rows r, r + 1, r + 2 of luma (two aligned dwords each), rows r, r + 1 of U and of V; byte shifts and CopyBlock phases
+    uint2 yr[3], ur[2], vr[2];
+    uint32_t ysh, csh;
+    int yph, cph;
+    // a wrapping leaf: one luma, one chroma window per lane
+    Win wa, wq;
+    int pha, phq;
+  };
+  auto deep_fetch = [&](Deep &D, int gm, uint32_t cell) {
     const int offm = off0 + gm * 16;
-    uint32_t sa, sb, sq[4];
-    int la, lb, lq[4];
-    if ((multi_mask >> gm) & 1) {
-      // a lane's 4 luma pixels sit under two cells, its 4 chroma samples under four; for the common splits they are the same cell
-      const uint32_t cell[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
-      const int ybase = offm + (yrow << lgS) + yc4, cbase = (offm >> 1) + cv * (S >> 1) + (crow << lgS) + cc4;
-      D.ysplit = __builtin_amdgcn_ballot_w64(yc.x != yc.y) != 0;
-      D.csplit = __builtin_amdgcn_ballot_w64(lane < 32 && (cell[0] != cell[1] || cell[0] != cell[2] || cell[0] != cell[3])) != 0;
-      const int dxa = mobi_cell_dx(yc.x), dya = mobi_cell_dy(yc.x), dxb = mobi_cell_dx(yc.y), dyb = mobi_cell_dy(yc.y);
-      la = ybase + ((dya >> 1) << lgS) + (dxa >> 1); D.pha = (dxa & 1) | ((dya & 1) << 1); sa = slot_off((uint32_t)mobi_cell_ref(yc.x));
-      auto csrc = [&](int k) {
-        const int qx = mobi_cell_dx(cell[k]) >> 1, qy = mobi_cell_dy(cell[k]) >> 1;
-        lq[k] = cbase + ((qy >> 1) << lgS) + (qx >> 1); D.phq[k] = (qx & 1) | ((qy & 1) << 1); sq[k] = slot_off((uint32_t)mobi_cell_ref(cell[k]));
-      };
-      csrc(0);
-      if (D.ysplit) { lb = ybase + ((dyb >> 1) << lgS) + (dxb >> 1); D.phb = (dxb & 1) | ((dyb & 1) << 1); sb = slot_off((uint32_t)mobi_cell_ref(yc.y)); }
-      if (D.csplit) { csrc(1); csrc(2); csrc(3); }
+    D.cells = (multi_mask >> gm) & 1;
+    if (D.cells) {
+      const int cy = lane >> 3, cx = lane & 7;
+      const int dx = mobi_cell_dx(cell), dy = mobi_cell_dy(cell), qx = dx >> 1, qy = dy >> 1;
+      const uint32_t sl = slot_off((uint32_t)mobi_cell_ref(cell));
+      const int lo = offm + ((2 * cy + (dy >> 1)) << lgS) + 2 * cx + (dx >> 1);                // the cell's first source sample (MD.cs:400-416)
+      const int co = (offm >> 1) + ((cy + (qy >> 1)) << lgS) + cx + (qx >> 1);                 // ... in U; V = + Stride / 2 (+ 8 in a tile row)
+      D.yph = (dx & 1) | ((dy & 1) << 1);
+      D.cph = (qx & 1) | ((qy & 1) << 1);
+      D.ysh = (uint32_t)lo & 3;
+      D.csh = (uint32_t)co & 3;
+      const uint32_t l4 = (uint32_t)lo & ~3u, c4 = (uint32_t)co & ~3u;
+      // some lane's window within 8 bytes of the end of a plane row, or its U window not inside the U half (a vector far to the left
+      // wraps into the previous row's V half, and "V = U + 8 in the tile row" only holds in the U half): every dword is mapped on its own
+      const bool gen = (l4 & (uint32_t)(S - 1)) >= (uint32_t)(S - 8) || (c4 & (uint32_t)(S - 1)) >= (uint32_t)((S >> 1) - 8);
+      if (__builtin_amdgcn_ballot_w64(gen) != 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          D.yr[k].x = *(const uint32_t *)(clip_base + (sl + mobi_ty(l4 + (uint32_t)(k << lgS), lgS)));
+          D.yr[k].y = *(const uint32_t *)(clip_base + (sl + mobi_ty(l4 + (uint32_t)(k << lgS) + 4, lgS)));
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint32_t a0 = sl + ysz + mobi_tc(c4 + (uint32_t)(k << lgS), lgS), a1 = sl + ysz + mobi_tc(c4 + (uint32_t)(k << lgS) + 4, lgS);
+          const uint32_t b0 = sl + ysz + mobi_tc(c4 + (uint32_t)(k << lgS) + (uint32_t)(S >> 1), lgS), b1 = sl + ysz + mobi_tc(c4 + (uint32_t)(k << lgS) + (uint32_t)(S >> 1) + 4, lgS);
+          D.ur[k] = uint2{*(const uint32_t *)(clip_base + a0), *(const uint32_t *)(clip_base + a1)};
+          D.vr[k] = uint2{*(const uint32_t *)(clip_base + b0), *(const uint32_t *)(clip_base + b1)};
+        }
+      } else {
+        // luma: the next dword is + 4 inside a quadrant row, else the next quadrant column's first; the row below + 8 inside a quadrant,
+        // + 72 into the quadrant below, or the tile below's first row (as fetch_win_y)
+        const uint32_t t = sl + mobi_ty(l4, lgS), row = l4 >> lgS;
+        const uint32_t dc = (l4 & 4u) ? ((l4 & 8u) ? 188u : 60u) : 4u;
+        auto down = [&](uint32_t r) { return (r & 7u) != 7u ? 8u : (r & 8u) ? ((16u << lgS) - 184u) : 72u; };
+        const uint32_t t1 = t + down(row), t2 = t1 + down(row + 1);
+        D.yr[0] = uint2{*(const uint32_t *)(clip_base + t), *(const uint32_t *)(clip_base + (t + dc))};
+        D.yr[1] = uint2{*(const uint32_t *)(clip_base + t1), *(const uint32_t *)(clip_base + (t1 + dc))};
+        D.yr[2] = uint2{*(const uint32_t *)(clip_base + t2), *(const uint32_t *)(clip_base + (t2 + dc))};
+        // chroma: U and V of a sample are 8 bytes apart in the tile row; next dword + 4, or the next tile's (+ 124); row below + 16 or the tile below
+        const uint32_t u = sl + ysz + mobi_tc(c4, lgS), crow0 = c4 >> lgS;
+        const uint32_t cdc = (c4 & 4u) ? 124u : 4u, cdr = (crow0 & 7u) != 7u ? 16u : (8u << lgS) - 112u;
+        D.ur[0] = uint2{*(const uint32_t *)(clip_base + u), *(const uint32_t *)(clip_base + (u + cdc))};
+        D.vr[0] = uint2{*(const uint32_t *)(clip_base + (u + 8)), *(const uint32_t *)(clip_base + (u + cdc + 8))};
+        D.ur[1] = uint2{*(const uint32_t *)(clip_base + (u + cdr)), *(const uint32_t *)(clip_base + (u + cdr + cdc))};
+        D.vr[1] = uint2{*(const uint32_t *)(clip_base + (u + cdr + 8)), *(const uint32_t *)(clip_base + (u + cdr + cdc + 8))};
+      }
     } else { // whole leaves whose windows wrap: the leaf records of lane gm
       const uint32_t w1m = __builtin_amdgcn_readlane(d.y, gm), w2m = __builtin_amdgcn_readlane(d.z, gm);
       const int pAm = (int)__builtin_amdgcn_readlane(d.w, gm), cAm = (int)__builtin_amdgcn_readlane(d2.x, gm);
@@ -625,44 +662,57 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       const int k2 = (w1m >> 26) & 3;
       const bool yBm = k2 == MOBI_DUAL_TB ? yrow >= 8 : k2 == MOBI_DUAL_LR ? yc4 >= 8 : false;
       const bool cBl2 = k2 == MOBI_DUAL_TB ? crow >= 4 : k2 == MOBI_DUAL_LR ? cc4 >= 4 : false;
-      D.ysplit = D.csplit = false;
-      la = (yBm ? pBm : pAm) + (yrow << lgS) + yc4;
+      const int la = (yBm ? pBm : pAm) + (yrow << lgS) + yc4;
       D.pha = (w2m >> (yBm ? 20 : 16)) & 3;
-      sa = slot_off((w2m >> (yBm ? 13 : 10)) & 7);
-      lq[0] = (cBl2 ? cBm : cAm) + cv * (S >> 1) + (crow << lgS) + cc4;
-      D.phq[0] = (w2m >> (cBl2 ? 22 : 18)) & 3;
-      sq[0] = slot_off((w2m >> (cBl2 ? 13 : 10)) & 7);
-    }
-    // some lane's window within 8 bytes of the end of a plane row (chroma: of a plane's half): every dword is mapped on its own
-    bool gen = (((uint32_t)la & (uint32_t)(S - 1)) >= (uint32_t)(S - 8)) || (((uint32_t)lq[0] & (uint32_t)((S >> 1) - 1)) >= (uint32_t)((S >> 1) - 8));
-    if (D.ysplit) gen = gen || (((uint32_t)lb & (uint32_t)(S - 1)) >= (uint32_t)(S - 8));
-    if (D.csplit) {
-#pragma unroll
-      for (int k = 1; k < 4; k++) gen = gen || (((uint32_t)lq[k] & (uint32_t)((S >> 1) - 1)) >= (uint32_t)((S >> 1) - 8));
-    }
-    const bool general = __builtin_amdgcn_ballot_w64(gen) != 0;
-    D.wa = fetch_win_y(clip_base, sa, la, S, lgS, general);
-    if (D.ysplit) D.wb = fetch_win_y(clip_base, sb, lb, S, lgS, general);
-    D.wq[0] = fetch_win_c(clip_base, sq[0] + ysz, lq[0], S, lgS, general);
-    if (D.csplit) {
-#pragma unroll
-      for (int k = 1; k < 4; k++) D.wq[k] = fetch_win_c(clip_base, sq[k] + ysz, lq[k], S, lgS, general);
+      const uint32_t sa = slot_off((w2m >> (yBm ? 13 : 10)) & 7);
+      const int lq = (cBl2 ? cBm : cAm) + cv * (S >> 1) + (crow << lgS) + cc4;
+      D.phq = (w2m >> (cBl2 ? 22 : 18)) & 3;
+      const uint32_t sq = slot_off((w2m >> (cBl2 ? 13 : 10)) & 7);
+      // some lane's window within 8 bytes of the end of a plane row (chroma: of a plane's half): every dword is mapped on its own
+      const bool gen = (((uint32_t)la & (uint32_t)(S - 1)) >= (uint32_t)(S - 8)) || (((uint32_t)lq & (uint32_t)((S >> 1) - 1)) >= (uint32_t)((S >> 1) - 8));
+      const bool general = __builtin_amdgcn_ballot_w64(gen) != 0;
+      D.wa = fetch_win_y(clip_base, sa, la, S, lgS, general);
+      D.wq = fetch_win_c(clip_base, sq + ysz, lq, S, lgS, general);
     }
   };
   auto deep_finish = [&](int gm, const Deep &D) {
-    const uint32_t va = mc4_select(D.wa, D.pha);
-    const uint32_t vb = D.ysplit ? mc4_select(D.wb, D.phb) : va;
-    uint32_t cpred = mc4_select(D.wq[0], D.phq[0]);
-    if (D.csplit) {
-      cpred &= 0xFFu;
+    if (D.cells) {
+      const int cy = lane >> 3, cx = lane & 7;
+      const uint32_t M = 0x7F7F7F7Fu;
+      // luma: bytes x, x + 1 (a) and x + 1, x + 2 (b) of three rows; CopyBlock (MD.cs:424-452) for rows 0, 1 of the cell: two samples each
+      uint32_t a[3], h[3];
 #pragma unroll
-      for (int k = 1; k < 4; k++) cpred |= mc4_select(D.wq[k], D.phq[k]) & (0xFFu << (8 * k));
+      for (int k = 0; k < 3; k++) {
+        a[k] = cut(D.yr[k], D.ysh);
+        const uint32_t b = cut1(D.yr[k], D.ysh);
+        h[k] = ((a[k] >> 1) & M) + ((b >> 1) & M);
+      }
+      uint32_t yo[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint32_t v = ((a[k] >> 1) & M) + ((a[k + 1] >> 1) & M), p3 = ((h[k] >> 1) & M) + ((h[k + 1] >> 1) & M);
+        yo[k] = D.yph == 0 ? a[k] : D.yph == 1 ? h[k] : D.yph == 2 ? v : p3;
+      }
+      *(uint16_t *)(L + out_y(gm, 2 * cy, 2 * cx)) = (uint16_t)yo[0];
+      *(uint16_t *)(L + out_y(gm, 2 * cy + 1, 2 * cx)) = (uint16_t)yo[1];
+      // chroma: the U sample in byte 0, the V sample in byte 1 of every operand
+      const uint32_t au = cut(D.ur[0], D.csh), bu = cut1(D.ur[0], D.csh), cu = cut(D.ur[1], D.csh), du = cut1(D.ur[1], D.csh);
+      const uint32_t av = cut(D.vr[0], D.csh), bv = cut1(D.vr[0], D.csh), cvv = cut(D.vr[1], D.csh), dv = cut1(D.vr[1], D.csh);
+      const uint32_t ca = __builtin_amdgcn_perm(av, au, 0x0c0c0400u), cb = __builtin_amdgcn_perm(bv, bu, 0x0c0c0400u);
+      const uint32_t cc = __builtin_amdgcn_perm(cvv, cu, 0x0c0c0400u), cd = __builtin_amdgcn_perm(dv, du, 0x0c0c0400u);
+      const uint32_t hca = (ca >> 1) & M, hcb = (cb >> 1) & M, hcc = (cc >> 1) & M, hcd = (cd >> 1) & M;
+      const uint32_t c1 = hca + hcb, c2 = hca + hcc, c3 = ((c1 >> 1) & M) + (((hcc + hcd) >> 1) & M);
+      const uint32_t uvp = D.cph == 0 ? ca : D.cph == 1 ? c1 : D.cph == 2 ? c2 : c3;
+      L[out_c(gm, cy, 0, cx)] = (uint8_t)uvp;
+      L[out_c(gm, cy, 1, cx)] = (uint8_t)(uvp >> 8);
+    } else {
+      const uint32_t va = mc4_select(D.wa, D.pha), cpred = mc4_select(D.wq, D.phq);
+      *(uint32_t *)(L + out_y(gm, yrow, yc4)) = va;
+      if (lane < 32) *(uint32_t *)(L + out_c(gm, crow, cv, cc4)) = cpred;
     }
-    *(uint32_t *)(L + out_y(gm, yrow, yc4)) = (va & 0x0000FFFFu) | (vb & 0xFFFF0000u);
-    if (lane < 32) *(uint32_t *)(L + out_c(gm, crow, cv, cc4)) = cpred;
   };
   Deep D0;
-  if (slow_mask) deep_fetch(D0, __builtin_ctz(slow_mask), yc0, c4v0);
+  if (slow_mask) deep_fetch(D0, __builtin_ctz(slow_mask), cell0);
 
   __builtin_amdgcn_s_setprio(0); // (behind the deep trees' requests too: 7.17 -> 7.10 ms; priority during the motion compensation costs: 7.27)
   MOBI_STOP(3);
@@ -724,12 +774,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     while (mm) { // a second, third ... such macroblock in the same octet: exposed round trips (rare)
       const int gm = __builtin_ctz(mm);
       mm &= mm - 1;
-      uint2 yc = yc1;
-      uint4 c4v = c4v1;
-      if (!second) load_cells(gm, yc, c4v);
+      uint32_t cell = cell1;
+      if (!second) load_cell(gm, cell);
       second = false;
       Deep Dn;
-      deep_fetch(Dn, gm, yc, c4v);
+      deep_fetch(Dn, gm, cell);
       asm volatile("" ::: "memory");
       deep_finish(gm, Dn);
     }

@@ -238,9 +238,10 @@ struct Gen {
     for (int attempt = 0;; attempt++) {
       memset(lev, 0, sizeof(lev));
       bool dense = (n == 8) && rng.chance(P.dense_prob) && attempt < 4;
-      int span = dense ? 64 : (P.scan_span < N ? P.scan_span : N);
+      const bool lowfreq = !dense && P.lowfreq_prob > 0 && rng.chance(P.lowfreq_prob); // DC / three lowest positions only
+      int span = dense ? 64 : lowfreq ? 3 : (P.scan_span < N ? P.scan_span : N);
       if (span < 1) span = 1;
-      int cnt = dense ? 64 : rng.range(1, P.max_coefs < span ? P.max_coefs : span);
+      int cnt = dense ? 64 : rng.range(1, lowfreq ? 2 : P.max_coefs < span ? P.max_coefs : span);
       if (attempt >= 6) cnt = 1;
       for (int k = 0; k < cnt; k++) {
         int pos = dense ? k : (int)rng.below((uint32_t)span);

@@ -44,6 +44,8 @@ typedef struct mobi_gen_params {
   int32_t escape_prob;    /* per coefficient: force one of the three escape forms, per mille */
   int32_t qdelta_prob;    /* per P-frame: non-zero quantizer delta, per mille */
   int32_t table1_prob;    /* per I-frame: select residual VLC table 1, per mille */
+  int32_t lowfreq_prob;   /* per coded block: 1..2 levels within the first 3 scan positions (what the reference's IDCT1P / IDCT3P classes take,
+                             MD.cs:2939-2940) instead of the draw above, per mille; 0 = never (and no random number is drawn for it) */
 } mobi_gen_params;
 
 /* Fill `p` with the SURVEY.md 8(d) distribution for config 'A' (256x192 ModsDS),

@@ -21,6 +21,7 @@ class GenParams(C.Structure):
         ("dense_prob", C.c_int32), ("max_coefs", C.c_int32), ("scan_span", C.c_int32),
         ("intra_sub_prob", C.c_int32), ("plane_prob", C.c_int32), ("intra_dc_only", C.c_int32),
         ("edge_mode", C.c_int32), ("escape_prob", C.c_int32), ("qdelta_prob", C.c_int32), ("table1_prob", C.c_int32),
+        ("lowfreq_prob", C.c_int32),
     ]
 
 
