@@ -1034,6 +1034,21 @@ __device__ __forceinline__ uint32_t ldg_u8_sc1(const uint8_t *p) { // past this 
 #endif
   return v;
 }
+// LDS address + a signed 16-bit half of a tap-table word, in one instruction (SDWA: the operand selects the half and sign-extends it):
+// the directional predictors read four neighbour samples per predicted sample at tile offsets that come as int16 pairs
+__device__ __forceinline__ uint32_t tap_addr(uint32_t base, uint32_t packed, int hi) {
+  uint32_t d = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (hi) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(base), "v"(packed));
+  else asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(base), "v"(packed));
+#endif
+  return d;
+}
+typedef const uint8_t __attribute__((address_space(3))) *lds_u8p;
+__device__ __forceinline__ uint32_t tap4(uint32_t base, uint32_t w0, uint32_t w1) { // (t0 + t1 + t2 + t3 + 2) >> 2 over the four taps of two table words
+  const uint32_t a = *(lds_u8p)tap_addr(base, w0, 0), b = *(lds_u8p)tap_addr(base, w0, 1), c = *(lds_u8p)tap_addr(base, w1, 0), d = *(lds_u8p)tap_addr(base, w1, 1);
+  return (a + b + (c + d + 2u)) >> 2;
+}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 ldg_x2_sc1(const uint8_t *p) {
   u32x2 v = {0, 0};
@@ -1406,35 +1421,20 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
 
   // ---- the steps.  An 8x8 block is one step, four samples per lane (its predictors read only samples outside the block); a 4x4
   // block one sample per lane ----
+  const uint32_t tile_lds = (uint32_t)(size_t)(lptr_t)tile; // the tile as an LDS address
   const int po8 = (l >> 1) * TP + (l & 1) * 4, ro8 = (l >> 1) * 8 + (l & 1) * 4;
   const int po4 = (l >> 2) * TP + (l & 3), ro4 = (l >> 2) * 8 + (l & 3);
   int fault = 0;
   s16x2 flo = {0, 0}, fhi = {0, 0}; // range of prediction + residual over the 8x8 steps (clamp table domain [-64, 319], MobiConst.cs:587)
-  // The tap table entries of a directional block do not depend on pixels: they are fetched two steps ahead (a step is shorter than
-  // an L2 round trip; with few waves on the chip -- small batches, the tail of an I-frame's levels -- nobody else hides it).
-  uint2 d1 = *(const uint2 *)steps, d2 = *(const uint2 *)(steps + 2);
-  uint4 ea1, eb1, ea2, eb2;
-  {
-    const uint2 *tp = taps + (((d1.x >> SD_TAP) & 0x3FF) + ((d1.x & SD_IS4) ? l : 4 * l));
-    ea1 = *(const uint4_a4 *)tp;
-    eb1 = *(const uint4_a4 *)(tp + 2);
-    tp = taps + (((d2.x >> SD_TAP) & 0x3FF) + ((d2.x & SD_IS4) ? l : 4 * l));
-    ea2 = *(const uint4_a4 *)tp;
-    eb2 = *(const uint4_a4 *)(tp + 2);
-  }
-  if (dbg & 2) n_iter = 0;
-  MOBI_ISTOP(6);
-#pragma unroll 1
-  for (int t = 0; t < n_iter; t++) {
-    const uint2 d = d1;
-    const uint4 ea = ea1, eb = eb1;
-    d1 = d2; ea1 = ea2; eb1 = eb2;
-    if (t + 2 < n_iter) {
-      d2 = *(const uint2 *)(steps + 2 * (t + 2));
-      const uint2 *tp = taps + (((d2.x >> SD_TAP) & 0x3FF) + ((d2.x & SD_IS4) ? l : 4 * l));
-      ea2 = *(const uint4_a4 *)tp;
-      eb2 = *(const uint4_a4 *)(tp + 2);
-    }
+  // The tap table entries of a directional block do not depend on pixels: they are asked for one step ahead (two register sets taken in
+  // turn: r03 rotated three sets through eleven 64-bit moves per step).
+  auto load_step = [&](int t, uint2 &d, uint4 &ea, uint4 &eb) {
+    d = *(const uint2 *)(steps + 2 * t);
+    const uint2 *tp = taps + (((d.x >> SD_TAP) & 0x3FF) + ((d.x & SD_IS4) ? l : 4 * l));
+    ea = *(const uint4_a4 *)tp;
+    eb = *(const uint4_a4 *)(tp + 2);
+  };
+  auto do_step = [&](const uint2 d, const uint4 ea, const uint4 eb) {
     const int o = (int)(d.x & 0x7FF);
     const bool is4 = (d.x & SD_IS4) != 0;
     if (__builtin_amdgcn_ballot_w64((d.x & SD_KPLANE) != 0) != 0) { // plane with delta, 8x8 (MD.cs:3168-3251) or 4x4 (:3253-3327): a lane makes a word of four samples
@@ -1461,11 +1461,8 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
         uint8_t *px = tile + o + po8;
         uint32_t word = *(const uint32_t *)px;
         if (d.x & SD_KTAP) { // the directional predictors: four neighbour samples per predicted sample, named by the tap table
-          const uint8_t *tb = tile + o;
-          const uint32_t t0 = (tb[(int16_t)(ea.x & 0xFFFF)] + tb[(int16_t)(ea.x >> 16)] + tb[(int16_t)(ea.y & 0xFFFF)] + tb[(int16_t)(ea.y >> 16)] + 2) >> 2;
-          const uint32_t t1 = (tb[(int16_t)(ea.z & 0xFFFF)] + tb[(int16_t)(ea.z >> 16)] + tb[(int16_t)(ea.w & 0xFFFF)] + tb[(int16_t)(ea.w >> 16)] + 2) >> 2;
-          const uint32_t t2 = (tb[(int16_t)(eb.x & 0xFFFF)] + tb[(int16_t)(eb.x >> 16)] + tb[(int16_t)(eb.y & 0xFFFF)] + tb[(int16_t)(eb.y >> 16)] + 2) >> 2;
-          const uint32_t t3 = (tb[(int16_t)(eb.z & 0xFFFF)] + tb[(int16_t)(eb.z >> 16)] + tb[(int16_t)(eb.w & 0xFFFF)] + tb[(int16_t)(eb.w >> 16)] + 2) >> 2;
+          const uint32_t tb = tile_lds + (uint32_t)o;
+          const uint32_t t0 = tap4(tb, ea.x, ea.y), t1 = tap4(tb, ea.z, ea.w), t2 = tap4(tb, eb.x, eb.y), t3 = tap4(tb, eb.z, eb.w);
           word = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);
         } else if (d.x & SD_KDC) {
           word = (uint32_t)dcv * 0x01010101u;
@@ -1488,15 +1485,27 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     if (__builtin_amdgcn_ballot_w64(w4) != 0) {
       if (w4) {
         uint8_t *px = tile + o + po4;
-        const uint8_t *tb = tile + o;
         int p = *px;
-        if (d.x & SD_KTAP) p = (tb[(int16_t)(ea.x & 0xFFFF)] + tb[(int16_t)(ea.x >> 16)] + tb[(int16_t)(ea.y & 0xFFFF)] + tb[(int16_t)(ea.y >> 16)] + 2) >> 2;
+        if (d.x & SD_KTAP) p = (int)tap4(tile_lds + (uint32_t)o, ea.x, ea.y);
         else if (d.x & SD_KDC) p = dcv;
         if (d.x & SD_CODED) p = mobi_add_clamp(p, (int)res16[(d.y & 0x1FF) + ro4], &fault);
         *px = (uint8_t)p;
       }
     }
     wave_sync();
+  };
+  if (dbg & 2) n_iter = 0;
+  MOBI_ISTOP(6);
+  uint2 dA, dB = uint2{0, 0};
+  uint4 eaA, ebA, eaB = uint4{0, 0, 0, 0}, ebB = uint4{0, 0, 0, 0};
+  load_step(0, dA, eaA, ebA);
+#pragma unroll 1
+  for (int t = 0; t < n_iter; t += 2) {
+    if (t + 1 < n_iter) load_step(t + 1, dB, eaB, ebB);
+    do_step(dA, eaA, ebA);
+    if (t + 1 >= n_iter) break;
+    if (t + 2 < n_iter) load_step(t + 2, dA, eaA, ebA);
+    do_step(dB, eaB, ebB);
   }
   if (flo.x < -64 || flo.y < -64 || fhi.x > 319 || fhi.y > 319) fault = 1;
   MOBI_ISTOP(7);
