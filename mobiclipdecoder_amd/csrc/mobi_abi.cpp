@@ -694,6 +694,13 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   return MOBI_OK;
 }
 
+// Once the parsers have consumed a frame and the ring has turned, a call that fails before its reconstruction is complete must not leave
+// any clip reporting MOBI_OK for a frame that was never reconstructed (host-parsed and device-parsed steps alike: ADVICE r03)
+struct FailAll {
+  int *rc; int n; bool armed = true;
+  ~FailAll() { if (armed) for (int i = 0; i < n; i++) if (rc[i] == MOBI_OK) rc[i] = MOBI_E_DEVICE; }
+};
+
 static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
   const int nd = n - b->hybrid_host, nh = b->hybrid_host; // clips [0, nd): parsed on the GPU; [nd, n): by the host pool meanwhile
@@ -777,6 +784,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
+  FailAll fail_all{rc, n}; // rc[], Offset, the ring and the device-side decoder state have advanced: the launches below must complete
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
   a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
@@ -786,6 +794,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  fail_all.armed = false;
   for (int i = 0; i < n; i++)
     if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
   return MOBI_OK;
@@ -953,10 +962,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->frames_started++;
   // From here on the parsers have consumed the frame and the ring has turned (the two must stay in step: a parser's reference
   // bookkeeping counts frames).  If the call itself fails below, no clip may report MOBI_OK for a frame that was never reconstructed.
-  struct FailAll {
-    int *rc; int n; bool armed = true;
-    ~FailAll() { if (armed) for (int i = 0; i < n; i++) if (rc[i] == MOBI_OK) rc[i] = MOBI_E_DEVICE; }
-  } fail_all{rc, n};
+  FailAll fail_all{rc, n};
   if (step_payload_words(ok) + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
   LevelPlan plan;
   plan.build(ok, b->g.mbw);

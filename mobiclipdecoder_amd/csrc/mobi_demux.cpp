@@ -124,7 +124,9 @@ int mobi_moc5_next_block(const uint8_t *file, size_t len, uint32_t *offs, int32_
   if (o <= *offs) return -1; // (the only hard error: the offset would not advance)
   // A last block that claims more than the file holds is still handed to the decoder, as the reference's loop does (Form1.cs:282-320:
   // it passes the whole file as Data and the decoder reads what is there); the following call reports the end of the file.
-  *offs = (uint32_t)std::min<uint64_t>(o, (uint64_t)len);
+  const uint64_t next = std::min<uint64_t>(o, (uint64_t)len);
+  if (next > 0xFFFFFFFFull || next <= *offs) return -1; // (files beyond 4 GB: the 32-bit offset cannot follow; never backwards -- ADVICE r03)
+  *offs = (uint32_t)next;
   return 1;
 }
 

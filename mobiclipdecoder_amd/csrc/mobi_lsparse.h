@@ -46,6 +46,10 @@ enum { LS_TOKEN_ROUNDS = LS_K,  // ls_next_fast() + ls_token_fast() on their own
        LS_ROUND_BYTES = 64, // what one such round can take from the ring at most (an intra macroblock's header and every area's mode in one visit:
                             // ~310 bits, + 5 x (15 + 28) of the cheap rounds)
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
+// ls_refill() reads the ring without looking at the write pointer: a round must not be able to take more than LS_ROUND_BYTES from it.
+// The walk's worst case is ~310 bits, a cheap round's 15 + 28: beyond LS_K = 4 the sum passes 512 bits and a mis-tuned build would parse
+// stale ring bytes and still call the clip finished -- so such a build does not compile.
+static_assert(310 + LS_K * 43 <= LS_ROUND_BYTES * 8, "LS_K: the cheap rounds could outrun the bitstream ring");
 
 struct LsCtx { // wave-uniform
   const uint8_t *T; // the table blob (mobi_dparse_tables.h)

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for CFG in B A C; do
   D=$OUT/$CFG; mkdir -p "$D"
   # A: 1.3 ms per step, C: 12 ms (24576 clips, halved by bench.py if they do not fit): >= 1 s of timed region for each
-  EXTRA=""; [ "$CFG" = "A" ] && EXTRA="--steps 1024"; [ "$CFG" = "C" ] && EXTRA="--steps 128"
+  EXTRA=""; [ "$CFG" = "A" ] && EXTRA="--steps 1024"; [ "$CFG" = "C" ] && EXTRA="--steps 400"
   timeout -k 5 900 python $REPO/bench.py --config $CFG $EXTRA > "$D/bench.json" 2> "$D/bench.err"
   BENCH="python $REPO/bench.py --config $CFG --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0"
   timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o t -- $BENCH --steps 64 > "$D/trace.log" 2>&1 || echo "trace failed" >> "$D/errors.log"
