@@ -1177,33 +1177,11 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     if (l < 4) G4[IQ_SCALE / 4 + 16 + l] = sc1;
   }
 
-  // All dependency levels of a frame step run in ONE launch: items are sorted by level, workgroups are dispatched in order, and a
-  // row waits here until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this step's tag.  Hand-off across CUs: the
-  // producer stores pixels write-through (sc1), drains them, then publishes its tag; the consumer polls the tag with agent-scope
-  // loads and reads the halo with sc1 loads, so neither a stale L1 line nor a dirty L2 line can sit in between.
-  u32x2 wv = {w_early.x, w_early.y};
-  uint32_t b0 = b0_early, b1 = b1_early;
+  // (the dependency list is asked for with everything else; the wait for the producers themselves comes as late as it can: below,
+  // in front of the halo's placement)
   const bool waits = I.valid && I.has_deps;
-  if (__builtin_amdgcn_ballot_w64(waits) != 0) {
-    if (waits && l < MOBI_INTRA_DEPS) {
-      const MbDesc *desc = A.desc + (size_t)clip * A.n_mbs + mb;
-      const uint32_t wd = (&desc->w4)[l >> 1];
-      const uint32_t dep = (wd >> (16 * (l & 1))) & 0xFFFFu;
-      if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) { // inter macroblocks ran in the launch before this one
-        const uint32_t *f = A.done + (size_t)clip * A.n_mbs + (dep & 0x1FFFu);
-        int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.step_tag) {
-          __builtin_amdgcn_s_sleep(4);
-          if (++spins > (1 << 21)) { atomicOr(&A.fault[clip], 2); break; } // a producer that never ran: report, do not hang
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    u32x2 wl = ldg_x2_sc1(wp);
-    uint32_t c0 = ldg_u8_sc1(b0p), c1 = ldg_u8_sc1(b1p);
-    vm_wait(wl, c0, c1);
-    if (waits) { wv = wl; b0 = c0; b1 = c1; }
-  }
+  uint32_t wd = 0;
+  if (waits && l < MOBI_INTRA_DEPS) wd = (&(A.desc + (size_t)clip * A.n_mbs + mb)->w4)[l >> 1];
   MOBI_ISTOP(1);
 
   // ---- dequantise and scatter the level words ----
@@ -1294,6 +1272,87 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     if (l < (IQ_TCV + 9 * TP) / 16 - 64) T4[64 + l] = z;
   }
   wave_sync();
+  MOBI_ISTOP(4);
+
+  // ---- the schedule: one step per unsplit area, four per split one, in decode order.  Lane 4a + s of the row owns the candidate
+  // (area a, block s); its place in the list follows from how many areas before a are split. ----
+  int n_iter;
+  {
+    const uint64_t balA = __builtin_amdgcn_ballot_w64(((recA >> 5) & 1) != 0 && (l & 3) == 0);          // areas 0..3: lanes 0, 4, 8, 12 of the row
+    const uint64_t balB = __builtin_amdgcn_ballot_w64(((recB >> 5) & 1) != 0 && (l & 3) == 0 && l < 8); // areas 4, 5: lanes 0, 4
+    const uint32_t mA = (uint32_t)(balA >> (lane & 48)) & 0x1111u, mB = (uint32_t)(balB >> (lane & 48)) & 0x11u;
+    const uint32_t splits = (mA & 1) | ((mA >> 3) & 2) | ((mA >> 6) & 4) | ((mA >> 9) & 8) | ((mB & 1) << 4) | ((mB >> 4) << 5);
+    const int nst = 6 + 3 * __builtin_popcount(splits);
+    n_iter = max(max(__builtin_amdgcn_readlane(nst, 0), __builtin_amdgcn_readlane(nst, 16)), max(__builtin_amdgcn_readlane(nst, 32), __builtin_amdgcn_readlane(nst, 48)));
+    // rows with fewer steps than the longest of the four idle through the rest: a descriptor that does nothing
+    const uint2 idle = uint2{(uint32_t)(TP + 4), 0u};
+    *(uint2 *)(steps + 2 * l) = idle;
+    if (l < 8) *(uint2 *)(steps + 2 * (16 + l)) = idle;
+    wave_sync();
+    auto build = [=](int t, uint32_t rown, uint32_t r0, int &pos) -> uint2 {
+      const int a = t >> 2, s = t & 3;
+      const bool split = (r0 >> 5) & 1, pre = (r0 >> 6) & 1;
+      pos = (s == 0 || split) ? a + 3 * __builtin_popcount(splits & ((1u << a) - 1u)) + s : -1;
+      const uint32_t rs = split ? rown : r0;
+      const int mode = (int)(rs & 15);
+      const bool coded = (rs >> 4) & 1, luma = a < 4;
+      const int by = (luma ? (a >> 1) * 8 : 0) + (split ? (s >> 1) * 4 : 0), bx = (luma ? (a & 1) * 8 : 0) + (split ? (s & 1) * 4 : 0);
+      const int o_blk = (luma ? 0 : a == 4 ? IQ_TCU : IQ_TCV) + (by + 1) * TP + 4 + bx;
+      const bool k_dc = mode == 3, k_tap = mode < 2 || (mode >= 4 && mode <= 8);
+      const bool plane_blk = mode == 2, plane_pre = pre && s == 0;
+      const uint32_t param = plane_blk ? rs >> 16 : r0 >> 16;
+      const int mi = !k_tap ? 0 : mode < 2 ? mode : mode - 2;
+      const int tapbase = split ? MOBI_TAP_4X4 + mi * 16 : mi * 64;
+      const int boff = (luma ? off : (off >> 1) + (a - 4) * (S >> 1)) + by * S + bx;
+      const bool vfix = !luma && (boff & (S - 1)) >= (S >> 1);                                              // MD.cs:1886
+      const bool la = ((boff - (vfix ? (S >> 1) : 0)) & (S - 1)) != 0, ta = boff >= S;                      // :1923-1924
+      const int ri = a * 64 + (split ? (s >> 1) * 32 + (s & 1) * 4 : 0);
+      uint32_t d0 = (uint32_t)o_blk | ((uint32_t)tapbase << SD_TAP);
+      if (split) d0 |= SD_IS4;
+      if (coded) d0 |= SD_CODED;
+      if (k_tap) d0 |= SD_KTAP;
+      if (k_dc) d0 |= SD_KDC;
+      if (plane_blk || plane_pre) d0 |= SD_KPLANE;
+      if (ta) d0 |= SD_TA;
+      if (la) d0 |= SD_LA;
+      if (plane_blk && split) d0 |= SD_P4;
+      return uint2{d0, (uint32_t)ri | (param << 16)};
+    };
+    int posA, posB;
+    const uint2 dA = build(l, recA, quad_first(recA), posA);
+    const uint2 dB = build(16 + (l & 7), recB, quad_first(recB), posB);
+    if (posA >= 0) *(uint2 *)(steps + 2 * posA) = dA;
+    if (l < 8 && posB >= 0) *(uint2 *)(steps + 2 * posB) = dB;
+  }
+  wave_sync();
+  MOBI_ISTOP(5);
+
+  // All dependency levels of a frame step run in ONE launch: items are sorted by level, workgroups are dispatched in order, and a
+  // row waits HERE until the intra macroblocks its halo reads (MbDesc.w4..w7) carry this step's tag -- with its level words scattered,
+  // its residuals transformed and its step list built (r04: the wait stood in front of all that; in a raster chain -- an I-frame, a
+  // small batch -- every link then started its own work only when its producer was done).  Hand-off across CUs: the
+  // producer stores pixels write-through (sc1), drains them, then publishes its tag; the consumer polls the tag with agent-scope
+  // loads and reads the halo with sc1 loads, so neither a stale L1 line nor a dirty L2 line can sit in between.
+  u32x2 wv = {w_early.x, w_early.y};
+  uint32_t b0 = b0_early, b1 = b1_early;
+  if (__builtin_amdgcn_ballot_w64(waits) != 0) {
+    if (waits && l < MOBI_INTRA_DEPS) {
+      const uint32_t dep = (wd >> (16 * (l & 1))) & 0xFFFFu;
+      if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) { // inter macroblocks ran in the launch before this one
+        const uint32_t *f = A.done + (size_t)clip * A.n_mbs + (dep & 0x1FFFu);
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.step_tag) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 21)) { atomicOr(&A.fault[clip], 2); break; } // a producer that never ran: report, do not hang
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32x2 wl = ldg_x2_sc1(wp);
+    uint32_t c0 = ldg_u8_sc1(b0p), c1 = ldg_u8_sc1(b1p);
+    vm_wait(wl, c0, c1);
+    if (waits) { wv = wl; b0 = c0; b1 = c1; }
+  }
   if (interior) {
     if (l < 10 && hasW) {
       if (!whalf) *(uint32_t *)(tile + wdst) = wv.x;
@@ -1350,60 +1409,6 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     }
   }
   wave_sync();
-  MOBI_ISTOP(4);
-
-  // ---- the schedule: one step per unsplit area, four per split one, in decode order.  Lane 4a + s of the row owns the candidate
-  // (area a, block s); its place in the list follows from how many areas before a are split. ----
-  int n_iter;
-  {
-    const uint64_t balA = __builtin_amdgcn_ballot_w64(((recA >> 5) & 1) != 0 && (l & 3) == 0);          // areas 0..3: lanes 0, 4, 8, 12 of the row
-    const uint64_t balB = __builtin_amdgcn_ballot_w64(((recB >> 5) & 1) != 0 && (l & 3) == 0 && l < 8); // areas 4, 5: lanes 0, 4
-    const uint32_t mA = (uint32_t)(balA >> (lane & 48)) & 0x1111u, mB = (uint32_t)(balB >> (lane & 48)) & 0x11u;
-    const uint32_t splits = (mA & 1) | ((mA >> 3) & 2) | ((mA >> 6) & 4) | ((mA >> 9) & 8) | ((mB & 1) << 4) | ((mB >> 4) << 5);
-    const int nst = 6 + 3 * __builtin_popcount(splits);
-    n_iter = max(max(__builtin_amdgcn_readlane(nst, 0), __builtin_amdgcn_readlane(nst, 16)), max(__builtin_amdgcn_readlane(nst, 32), __builtin_amdgcn_readlane(nst, 48)));
-    // rows with fewer steps than the longest of the four idle through the rest: a descriptor that does nothing
-    const uint2 idle = uint2{(uint32_t)(TP + 4), 0u};
-    *(uint2 *)(steps + 2 * l) = idle;
-    if (l < 8) *(uint2 *)(steps + 2 * (16 + l)) = idle;
-    wave_sync();
-    auto build = [=](int t, uint32_t rown, uint32_t r0, int &pos) -> uint2 {
-      const int a = t >> 2, s = t & 3;
-      const bool split = (r0 >> 5) & 1, pre = (r0 >> 6) & 1;
-      pos = (s == 0 || split) ? a + 3 * __builtin_popcount(splits & ((1u << a) - 1u)) + s : -1;
-      const uint32_t rs = split ? rown : r0;
-      const int mode = (int)(rs & 15);
-      const bool coded = (rs >> 4) & 1, luma = a < 4;
-      const int by = (luma ? (a >> 1) * 8 : 0) + (split ? (s >> 1) * 4 : 0), bx = (luma ? (a & 1) * 8 : 0) + (split ? (s & 1) * 4 : 0);
-      const int o_blk = (luma ? 0 : a == 4 ? IQ_TCU : IQ_TCV) + (by + 1) * TP + 4 + bx;
-      const bool k_dc = mode == 3, k_tap = mode < 2 || (mode >= 4 && mode <= 8);
-      const bool plane_blk = mode == 2, plane_pre = pre && s == 0;
-      const uint32_t param = plane_blk ? rs >> 16 : r0 >> 16;
-      const int mi = !k_tap ? 0 : mode < 2 ? mode : mode - 2;
-      const int tapbase = split ? MOBI_TAP_4X4 + mi * 16 : mi * 64;
-      const int boff = (luma ? off : (off >> 1) + (a - 4) * (S >> 1)) + by * S + bx;
-      const bool vfix = !luma && (boff & (S - 1)) >= (S >> 1);                                              // MD.cs:1886
-      const bool la = ((boff - (vfix ? (S >> 1) : 0)) & (S - 1)) != 0, ta = boff >= S;                      // :1923-1924
-      const int ri = a * 64 + (split ? (s >> 1) * 32 + (s & 1) * 4 : 0);
-      uint32_t d0 = (uint32_t)o_blk | ((uint32_t)tapbase << SD_TAP);
-      if (split) d0 |= SD_IS4;
-      if (coded) d0 |= SD_CODED;
-      if (k_tap) d0 |= SD_KTAP;
-      if (k_dc) d0 |= SD_KDC;
-      if (plane_blk || plane_pre) d0 |= SD_KPLANE;
-      if (ta) d0 |= SD_TA;
-      if (la) d0 |= SD_LA;
-      if (plane_blk && split) d0 |= SD_P4;
-      return uint2{d0, (uint32_t)ri | (param << 16)};
-    };
-    int posA, posB;
-    const uint2 dA = build(l, recA, quad_first(recA), posA);
-    const uint2 dB = build(16 + (l & 7), recB, quad_first(recB), posB);
-    if (posA >= 0) *(uint2 *)(steps + 2 * posA) = dA;
-    if (l < 8 && posB >= 0) *(uint2 *)(steps + 2 * posB) = dB;
-  }
-  wave_sync();
-  MOBI_ISTOP(5);
 
   // ---- 16x16 plane (MD.cs:3017-3166): 64 words, four per lane ----
   if (__builtin_amdgcn_ballot_w64((w3 & 1) != 0) != 0) {
