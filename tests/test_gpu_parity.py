@@ -275,3 +275,26 @@ def test_intra_rows_of_four_padding_and_picture_edges(w, h, ver, nclips):
     b.close()
     for o in oras:
         o.close()
+
+
+@pytest.mark.parametrize("q", [12, 22, 27, 31, 34, 37, 41, 46, 52])
+def test_residual_rounds_16_bit_and_32_bit_by_quantizer(q):
+    """The octet kernel transforms on packed int16 while every area's sum of |coefficient| stays below MOBI_PK_LIMIT and in int32
+    otherwise (mobi_kernels.hip, stage C).  Coefficients grow with the quantiser (x 2 every 6 steps), so a sweep through it with many
+    coded areas, dense blocks and raw-level escapes crosses that limit inside frames, inside octets and between them; both paths, and
+    octets with more than sixteen coded areas (a second packed round), must give the reference's pixels."""
+    for ver_cfg, w, h in (("A", 256, 48), ("B", 640, 32)):
+        p = default_params(ver_cfg, BASE_SEED + 900 + q, n_frames=5, width=w, height=h, quantizer=q, cbp_prob=800, t8_prob=700, dense_prob=150,
+                           escape_prob=60, max_coefs=10, scan_span=40, pm_intra=20, qdelta_prob=300)
+        _run_stream(p)
+
+
+@pytest.mark.parametrize("w,h,ver", [(64, 48, 1), (256, 32, 1), (512, 32, 2), (640, 48, 2), (848, 32, 2), (1024, 32, 2)])
+def test_deeper_trees_cell_by_cell(w, h, ver):
+    """Every macroblock a deeper partition tree (the octet kernel's cell path: one lane = one 2x2 cell, r04), vectors that leave the picture,
+    read the stride padding, wrap around plane rows (Width == Stride: 256, 512, 1024) and into the other chroma plane's half; older
+    reference frames; with and without residuals."""
+    for cbp in (0, 400):
+        p = default_params("A" if ver == 1 else "B", BASE_SEED + 950 + w + cbp, n_frames=7, width=w, height=h, pm_deep=900, pm_split1=50, pm_skip=20,
+                           pm_intra=10, pm_multiref=500, mv_range=70, edge_mode=1, cbp_prob=cbp)
+        _run_stream(p)
