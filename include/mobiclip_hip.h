@@ -42,8 +42,11 @@ extern "C" {
 #define MOBI_E_VERSION (-4)      /* VxDS / unknown version */
 #define MOBI_E_CLAMP (-5)        /* residual add left the clamp table domain (MobiConst.cs:587; MD.cs:3551);
                                     detected on the GPU, so the parser state has already advanced */
-#define MOBI_E_UNSUPPORTED (-6)  /* stream relies on scratch-array aliasing inside `Internal`
-                                    (coefficient run past the block, ModsDS quantizer < 12); see DESIGN.md */
+#define MOBI_E_UNSUPPORTED (-6)  /* the reference decodes this frame to something and this library refuses: a coefficient run
+                                    that reads the transforms' scratch inside `Internal`, a motion vector beyond +-8191 half-pels
+                                    in a deeper partition tree, a plane parameter outside int16; and, when the parse runs on the
+                                    GPU, every run past its block and every ModsDS quantiser < 12 (the host parser decodes those
+                                    since r04: INTEGRATION.md, error table) */
 #define MOBI_E_ARG (-7)          /* bad argument / dimensions not a multiple of 16 (the reference cannot
                                     decode those either: MD.cs:216-217) */
 #define MOBI_E_DEVICE (-8)       /* HIP error (no device, allocation, launch) */

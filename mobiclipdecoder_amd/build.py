@@ -70,7 +70,7 @@ def build_hip(force=False, profiling=False):
     os.makedirs(obj, exist_ok=True)
     prof = ["-DMOBI_PROFILING"] if profiling else []
     # only the entry points include/*.h declare leave the library (MOBI_API); everything else is hidden
-    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")] + prof
+    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-fwrapv", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")] + prof
     objs = []
     for s in srcs[:4]:
         o = os.path.join(obj, os.path.basename(s) + ".o")
@@ -116,7 +116,7 @@ def build_interp(force=False):
     src = os.path.join(ROOT, "tests", "tools", "mobi_cmd_interp.cpp")
     parse = os.path.join(CSRC, "mobi_parse.cpp")
     if force or _newer(LIB_INTERP, [src, parse] + _hdrs(CSRC)):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, parse, "-o", LIB_INTERP])
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fwrapv", src, parse, "-o", LIB_INTERP])
     return LIB_INTERP
 
 
@@ -124,7 +124,7 @@ def build_lshost(force=False):
     src = os.path.join(ROOT, "tests", "tools", "mobi_lsparse_host.cpp")
     parse = os.path.join(CSRC, "mobi_parse.cpp")
     if force or _newer(LIB_LSHOST, [src, parse] + _hdrs(CSRC)):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + CSRC, src, parse, "-o", LIB_LSHOST])
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fwrapv", "-I" + CSRC, src, parse, "-o", LIB_LSHOST])
     return LIB_LSHOST
 
 

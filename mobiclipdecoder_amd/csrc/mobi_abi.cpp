@@ -534,6 +534,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     // 64 rows: the 6-bit quantizer field of any descriptor stays inside; the intra kernel's tap table rides behind them
     std::vector<int32_t> tab((size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE + MOBI_TAP_ENTRIES * 2 + 8, 0) /* + 8: the kernel fetches four entries at a time */;
     for (int q = 0; q < MOBI_SCALE_QMAX; q++) mobi_build_scale_table(q, &tab[(size_t)q * MOBI_SCALE_STRIDE]);
+    mobi_build_scale_table(MOBI_SCALE_LITERAL, &tab[(size_t)MOBI_SCALE_LITERAL * MOBI_SCALE_STRIDE]); // the row of ones: literal frames (mobi_parse.cpp)
     if (!mobi_build_intra_taps((int16_t *)&tab[(size_t)MOBI_SCALE_ROWS * MOBI_SCALE_STRIDE], MOBI_TAP_PITCH)) {
       snprintf(g_last_hip_error, sizeof(g_last_hip_error), "intra tap table self-check failed");
       return nullptr;

@@ -132,5 +132,7 @@ struct FrameHdr {
 #define MOBI_TAP_ENTRIES (MOBI_TAP_MODES * 80)
 #define MOBI_TAP_PITCH 32 /* the intra kernel's tile pitch */
 #define MOBI_SCALE_ROWS 64
+#define MOBI_SCALE_LITERAL 63 /* the row of ones: MbDesc.w1's quantiser field of a frame whose residual words carry coefficient VALUES
+                                 (the host parser's Internal[] walk, mobi_parse.cpp); no real quantiser reaches 54 (MD.cs:3864-3880) */
 
 #endif

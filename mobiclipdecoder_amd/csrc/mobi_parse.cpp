@@ -11,6 +11,7 @@
 #include "mobi_tables.h"
 
 std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES]; // (parse-pool threads count concurrently: relaxed adds)
+std::atomic<unsigned long> mobi_literal_frame_count;
 
 namespace {
 inline uint32_t shl(uint32_t x, int n) { return x << (n & 31); } // C# masks shift counts to 5 bits
@@ -232,15 +233,44 @@ void MobiStreamParser::pblock(int wi, int hi, int x, int y, int mv_slot) {
 }
 
 // ------------------------------------------------------------------ residual (MD.cs:3330-3432)
+// The reference's coefficient store is  r8 = Internal[r12++]; Internal[90 + (r8 & 0xFF)] = (r8 >> 8) * value  (MD.cs:3424-3429): r12 walks
+// the dequant words (Internal[10..73] / [74..89]) and a run that is too long simply walks on -- into the 4x4 words, the coefficient block
+// itself ([90..153], with whatever earlier blocks and transforms left there), the transforms' scratch, the table select [218], the MV
+// predictors and row cache -- while below quantiser 12 (ModsDS) the words' own low byte carries table bits and the "zigzag index" reaches
+// 255.  r03 refused both.  r04 keeps the words of Internal[] such a walk can touch (all but the scratch) and walks with it: the block's
+// coefficients are then whatever Internal[90..] holds when the transform starts, shipped as LITERAL values (see literal_frame).
+uint32_t MobiStreamParser::internal_read(uint32_t idx) const {
+  if (idx >= 392) fail(MOBI_E_INDEX); // managed array bounds
+  if (idx < 10) fail(MOBI_E_INDEX);   // (never: r12 starts at 10 and only grows)
+  if (idx < 74) return dq8_[idx - 10];
+  if (idx < 90) return dq4_[idx - 74];
+  if (idx < 154) return ib_[idx - 90];
+  if (idx < 218) refuse(MOBI_REFUSE_RUN); // the first pass of the last transform of each variant: not kept
+  if (idx == 218) return i218_;
+  if (idx == 219) return (uint32_t)predx_;
+  if (idx == 220) return (uint32_t)predy_;
+  if (idx - 221 < mvc_.size()) return (uint32_t)mvc_[idx - 221];
+  return itail_[idx];
+}
+void MobiStreamParser::internal_write(uint32_t idx, uint32_t v) { // idx = 90 + a byte: 90..345
+  if (idx < 154) ib_[idx - 90] = v;
+  else if (idx < 218) {} // scratch: every transform writes what it reads there first, and a run that reads it is refused
+  else if (idx == 218) { i218_ = v; vlc_table_ = v == 1; } // (the tables of the block being read were chosen at its start, MD.cs:3332-3333)
+  else if (idx == 219) predx_ = (int)v; // (dead: set again before the next macroblock's first leaf, MD.cs:207-208)
+  else if (idx == 220) predy_ = (int)v;
+  else if (idx - 221 < mvc_.size()) mvc_[idx - 221] = (int)v; // the MV row cache: later macroblocks' predictors see it
+  else itail_[idx] = v;
+}
 void MobiStreamParser::resid_block(int area, int sub, bool is8) {
   const int N = is8 ? 64 : 16;
   const uint32_t *dq = is8 ? dq8_ : dq4_;
-  // Below q=12 the dequant word's scale bits leak into its zigzag byte (MD.cs:3907-3911 vs :3426) and
-  // the reference result depends on scratch aliasing inside Internal[]; outside the parity domain.
-  if (quant_ < 12) refuse(MOBI_REFUSE_QUANT);
+  const uint32_t start = is8 ? 10 : 74;
   const uint16_t *A = vlc_table_ == 1 ? mobi_vx2table1_a : mobi_vx2table0_a;
   const uint8_t *B = vlc_table_ == 1 ? mobi_vx2table1_b : mobi_vx2table0_b;
-  int p = 0;
+  memset(ib_, 0, sizeof(uint32_t) * N); // MD.cs:2933-2936 / 2948-2951, 2960-2963
+  bool odd = quant_ < 12;               // below 12 every dequant word may point anywhere (MD.cs:3907-3911 vs :3426)
+  uint32_t r12 = start;
+  const int n0 = n_coefs_;
   const int tile = is8 ? area * 64 : area * 64 + sub * 16;
   for (;;) {
     int skip, value;
@@ -300,14 +330,74 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
       skip = (int)((e >> 9) & 0x3F);
       e >>= 15;
     }
-    p += skip;
-    if (p >= N) refuse(MOBI_REFUSE_RUN); // the reference would walk past the dequant words (Internal[] aliasing)
-    uint32_t word = dq[p++];
-    // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the reduced transforms only
-    // look at part of the block, but for q >= 12 nothing they skip can be nonzero: scan positions 0, 0..2, 0..9 map inside the
-    // respective regions (tests/test_oracle_identities.py pins that property of the zigzag tables), so every level is kept.
-    if (value != 0) coefs_[n_coefs_++] = (uint32_t)(tile + (int)(word & 0xFF)) | ((uint32_t)(int)(int16_t)value << 16); // = mobi_coef()
+    r12 += (uint32_t)skip;
+    if (!odd && r12 < start + (uint32_t)N) { // the word is the block's own and its low byte a position inside the block
+      const uint32_t word = dq[r12 - start];
+      ib_[word & 0xFF] = (word >> 8) * (uint32_t)value; // (int * int in the reference: the low 32 bits either way)
+      // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the reduced transforms only
+      // look at part of the block, but for q >= 12 nothing they skip can be nonzero: scan positions 0, 0..2, 0..9 map inside the
+      // respective regions (tests/test_oracle_identities.py pins that property of the zigzag tables), so every level is kept.
+      if (value != 0) coefs_[n_coefs_++] = (uint32_t)(tile + (int)(word & 0xFF)) | ((uint32_t)(int)(int16_t)value << 16); // = mobi_coef()
+    } else { // MD.cs:3424-3429 as written
+      odd = true;
+      const uint32_t r8 = internal_read(r12);
+      internal_write(90 + (r8 & 0xFF), (r8 >> 8) * (uint32_t)value);
+    }
+    r12++;
     if (e & 1) break;
+  }
+  // the transform variant the reference runs (by the final index, MD.cs:2939-2942, 2954-2955, 2966-2967) and what it reads
+  enum { V1, V3, V16, VALL };
+  const int variant = is8 ? (r12 <= 11 ? V1 : r12 <= 13 ? V3 : r12 <= 20 ? V16 : VALL) : (r12 <= 75 ? V1 : VALL);
+  if (odd) {
+    // The level words written so far describe the block only if every store went where it should: replace them by the block as the
+    // transform will see it, value by value (positions the variant does not read are not part of it).
+    frame_literal_ = true;
+    n_coefs_ = n0;
+    for (int p = 0; p < N; p++) {
+      const bool read = variant == VALL || p == 0 || (variant == V3 && (p == 1 || p == 8)) || (variant == V16 && (p & 7) < 4 && p < 32);
+      const int32_t v = (int32_t)ib_[p];
+      if (!read || v == 0) continue;
+      if (v != (int16_t)v) refuse(MOBI_REFUSE_RUN); // a literal travels in the level's 16 bits
+      coefs_[n_coefs_++] = (uint32_t)(tile + p) | 0x8000u | ((uint32_t)v << 16); // bit 15: a value, not a level (literal_frame clears it)
+    }
+  }
+  // what the transforms themselves leave in Internal[90..153] (a later run past a block may read it)
+  if (is8 && variant == V3) { // IDCT3Px8 keeps its first pass in Internal[90..97] (MD.cs:3661-3707)
+    const int r8 = (int)ib_[0] + 32, r9 = (int)ib_[1];
+    const int r7 = r9 + (r9 >> 1), r11 = r7 >> 2, r3 = r9 + ((-r9) >> 2), r5 = r9 + (r9 >> 2);
+    ib_[0] = (uint32_t)(r8 + r7); ib_[7] = (uint32_t)(r8 - r7);
+    ib_[1] = (uint32_t)(r8 + r5); ib_[6] = (uint32_t)(r8 - r5);
+    ib_[2] = (uint32_t)(r8 + r3); ib_[5] = (uint32_t)(r8 - r3);
+    ib_[3] = (uint32_t)(r8 + r11); ib_[4] = (uint32_t)(r8 - r11);
+  } else if (!is8 && variant == VALL) { // IDCT16Px4's first pass goes to Internal[106..121] (MD.cs:3728-3784)
+    for (int k = 0; k < 4; k++) {
+      int in[4] = {(int)ib_[4 * k] + (k == 0 ? 0x20 : 0), (int)ib_[4 * k + 1], (int)ib_[4 * k + 2], (int)ib_[4 * k + 3]}, out[4];
+      mobi_bfly4(in, out);
+      for (int m = 0; m < 4; m++) ib_[16 + 4 * m + k] = (uint32_t)out[m];
+    }
+  }
+}
+// A frame in which some block's stores left their place (frame_literal_): every residual of the frame is shipped DEQUANTISED, as the value
+// the transform reads, and the frame's macroblocks name scale row MOBI_SCALE_LITERAL (all ones) instead of their quantiser -- the
+// kernels multiply a "level" by a scale of one and never know.  (Per frame, not per block: the octet kernel takes one scale row for its
+// eight macroblocks.)  A value that does not fit the level's 16 bits is the one thing that cannot travel: refused.
+void MobiStreamParser::literal_frame(ParsedFrame &out) {
+  mobi_literal_frame_count.fetch_add(1, std::memory_order_relaxed);
+  int32_t sc[MOBI_SCALE_STRIDE];
+  mobi_build_scale_table((int)quant_, sc);
+  for (MbDesc &d : out.desc) {
+    const bool intra = (d.w1 & 1) == MOBI_MB_INTRA;
+    const uint32_t nl = (d.w1 >> 1) & 0x7F, dual = (d.w1 >> 26) & 3, t8 = (d.w1 >> 14) & 0x3F;
+    uint32_t *w = out.payload.data() + d.payload_off + (intra ? MOBI_INTRA_RECORDS : (nl > 1 && !dual) ? MOBI_MV_CELLS : 0);
+    for (uint32_t i = 0, n = d.w2 & 0x3FF; i < n; i++) {
+      if (w[i] & 0x8000u) { w[i] &= ~0x8000u; continue; }
+      const int t = (int)(w[i] & 0x1FF), p = t & 63;
+      const int32_t v = sc[((t8 >> (t >> 6)) & 1) ? p : 64 + (p & 15)] * (int32_t)(int16_t)(w[i] >> 16);
+      if (v != (int16_t)v) refuse(MOBI_REFUSE_RUN);
+      w[i] = (uint32_t)t | ((uint32_t)v << 16);
+    }
+    d.w1 = (d.w1 & ~(63u << 20)) | ((uint32_t)MOBI_SCALE_LITERAL << 20);
   }
 }
 void MobiStreamParser::resid_area(int area) { // loc_11652C, MD.cs:2909-2929
@@ -484,6 +574,7 @@ void MobiStreamParser::parse_p(ParsedFrame &out) {
     if (dq != 0) setup_quant(quant_ + (uint32_t)dq);
   }
   vlc_table_ = 0;
+  i218_ = 0;
   std::fill(mvc_.begin(), mvc_.end(), 0);
   out.hdr.frame_type = 0;
   for (int mb = 0; mb < g_.mbw * g_.mbh; mb++) {
@@ -503,6 +594,7 @@ void MobiStreamParser::parse_i(ParsedFrame &out) {
   yuvfmt_ = win_ >> 31;
   win_ += win_;
   vlc_table_ = (int)(win_ >> 31);
+  i218_ = (uint32_t)vlc_table_;
   win_ += win_;
   nbr_ -= 3;
   if (nbr_ < 0) fill_bits();
@@ -606,7 +698,9 @@ int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offs
     win_ <<= 16;
     bool iframe = (win_ >> 31) == 1;
     win_ += win_;
+    frame_literal_ = false;
     if (iframe) parse_i(out); else parse_p(out);
+    if (frame_literal_) literal_frame(out);
     finish_levels(out);
   } catch (const Err &e) {
     rc = e.code;
@@ -619,6 +713,10 @@ int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offs
 // with MbDesc.w1[25:20].  q outside [12,53] is never used by a residual (resid_block rejects it).
 void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]) {
   memset(out, 0, sizeof(int32_t) * MOBI_SCALE_STRIDE);
+  if (q == MOBI_SCALE_LITERAL) { // literal frames (MobiStreamParser::literal_frame): the "levels" are the coefficients themselves
+    for (int i = 0; i < MOBI_SCALE_STRIDE; i++) out[i] = 1;
+    return;
+  }
   if (q < 0 || q >= (int)sizeof(mobi_qdiv6)) return;
   const int sh = mobi_qdiv6[q] + 8, m = mobi_qmod6[q];
   for (int i = 0; i < 64; i++) out[mobi_zz8[i]] = (int32_t)((((uint32_t)mobi_dq8[m * 64 + i]) << (sh - 2)) >> 8);

@@ -52,11 +52,13 @@ bool mobi_build_intra_taps(int16_t *out, int pitch);
 
 // The four classes of streams the reference decodes and this library refuses (MOBI_E_UNSUPPORTED); process-wide counters, a measuring aid
 enum { MOBI_REFUSE_MV = 0,     // |MV| > MOBI_MV_LIMIT half-pels (the cell map's 14-bit fields)
-       MOBI_REFUSE_QUANT = 1,  // ModsDS quantiser < 12: the dequant rows alias the intra-mode cache inside Internal[] (MD.cs:3907-3911)
-       MOBI_REFUSE_RUN = 2,    // a coefficient run that steps past its block: the write lands in the next block's scratch (MD.cs:3424-3429)
+       MOBI_REFUSE_QUANT = 1,  // (r03: ModsDS quantiser < 12; r04 decodes those frames: nothing counts here any more)
+       MOBI_REFUSE_RUN = 2,    // a coefficient run past its block (MD.cs:3424-3429) that reads the transforms' scratch, Internal[154..217], or
+                               // leaves a coefficient outside int16 (r04: the other such runs are decoded, see resid_block)
        MOBI_REFUSE_PLANE = 3,  // a plane-predictor parameter outside int16 (the record's 16-bit field): |se| >= 2^15 needs a code of >= 33 bits
        MOBI_REFUSE_CLASSES = 4 };
 extern std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES];
+extern std::atomic<unsigned long> mobi_literal_frame_count; // frames shipped as literal values (MobiStreamParser::literal_frame): a measuring aid too
 
 class MobiStreamParser {
  public:
@@ -95,6 +97,9 @@ class MobiStreamParser {
   void p_residual();
   void resid_area(int area);
   void resid_block(int area, int sub, bool is8);
+  uint32_t internal_read(uint32_t idx) const;
+  void internal_write(uint32_t idx, uint32_t v);
+  void literal_frame(ParsedFrame &out);
   void intra_full();
   void intra_sub();
   void intra_chroma(uint32_t cbp);
@@ -118,7 +123,15 @@ class MobiStreamParser {
   uint32_t quant_ = 0, yuvfmt_ = 0;
   uint32_t dq8_[64], dq4_[16]; // Internal[10..73], Internal[74..89]
   uint8_t mcache_[40];         // bytes of Internal[0..9]
-  int vlc_table_ = 0;          // Internal[218]
+  int vlc_table_ = 0;          // Internal[218] == 1
+  // r04: the part of Internal[] that a coefficient run past its block, or a ModsDS quantiser below 12, reads and writes (MD.cs:3424-3429):
+  // the coefficient block Internal[90..153] as every residual block and every transform variant leaves it, the table select as a word,
+  // and whatever was written behind the MV row cache.  (Internal[154..217], the transforms' scratch, is not kept: a run that READS it
+  // stays a refusal.)
+  uint32_t ib_[64] = {0};      // Internal[90..153]
+  uint32_t i218_ = 0;          // Internal[218]
+  uint32_t itail_[392] = {0};  // Internal[idx] for indices that are nothing else (behind the MV row cache)
+  bool frame_literal_ = false; // a block of this frame read or wrote Internal[] out of its place: its residuals ship as literal values
   int frames_started_ = 0;
   std::vector<int> mvc_; // MV row cache, Internal[221..]
   int predx_ = 0, predy_ = 0;
