@@ -461,10 +461,15 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   const bool multi = valid && nl > 1 && kind2 == 0;           // deeper tree: MV cell map in the payload
   const bool tb = leaves && kind2 == MOBI_DUAL_TB, lr = leaves && kind2 == MOBI_DUAL_LR;
   const uint32_t cbp6 = valid ? (d.y >> 8) & 0x3F : 0, ncoef = cbp6 ? d.z & 0x3FF : 0;
-  const unsigned long long mb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((cbp6 >> j) & 1));      // bit area*8 + g
-  const unsigned long long tb64 = __builtin_amdgcn_ballot_w64(j < 6 && ((d.y >> (14 + j)) & 1));
+  // (wave masks as ballots of ONE comparison each, combined on the scalar unit: a ballot of a compound condition goes through a 0 / 1
+  // register and a second comparison)
+  const unsigned long long v64 = __builtin_amdgcn_ballot_w64(g < nmb) & __builtin_amdgcn_ballot_w64((d.y & 1) == MOBI_MB_INTER); // = ballot(valid)
+  const unsigned long long six = 0x0000FFFFFFFFFFFFull; // lanes with j < 6
+  const unsigned long long mb64 = __builtin_amdgcn_ballot_w64(((d.y >> (8 + j)) & 1) != 0) & v64 & six;   // bit area*8 + g: the area is coded
+  const unsigned long long tb64 = __builtin_amdgcn_ballot_w64(((d.y >> (14 + j)) & 1) != 0) & six;        // ... with one 8x8 transform
   const uint32_t m_lo = (uint32_t)mb64, m_hi = (uint32_t)(mb64 >> 32), t_lo = (uint32_t)tb64, t_hi = (uint32_t)(tb64 >> 32);
-  const uint32_t inter_mask = (uint32_t)__builtin_amdgcn_ballot_w64(valid) & 0xFFu, multi_mask = (uint32_t)__builtin_amdgcn_ballot_w64(multi) & 0xFFu;
+  const uint32_t inter_mask = (uint32_t)v64 & 0xFFu;
+  const uint32_t multi_mask = (uint32_t)(v64 & __builtin_amdgcn_ballot_w64(nl > 1) & __builtin_amdgcn_ballot_w64(kind2 == 0)) & 0xFFu;
   if (inter_mask == 0) return; // nothing but intra macroblocks here
   auto slot_off = [&](uint32_t ref) {
     int sl = A.ring_base - (int)ref;
@@ -485,9 +490,11 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   // (The test is on the bytes the window NEEDS, not on the fixed shape that is fetched: a quadrant column beyond them may come from
   // the next row's first bytes -- in bounds, never looked at.  Width == Stride pictures have every right-most macroblock there.)
   const int wpx = lr ? 8 : 16, cwpx = lr ? 4 : 8;
-  const bool wrapA = (posA & (S - 1)) + wpx + (phA & 1) > S || (cposA & (S - 1)) + cwpx + (cphA & 1) > (S >> 1);
-  const bool wrapB = (topB & (S - 1)) + wpx + (phB & 1) > S || (ctopB & (S - 1)) + cwpx + (cphB & 1) > (S >> 1);
-  const bool wrap = leaves && (wrapA || ((tb || lr) && wrapB));
+  // (as one number per leaf -- by how many samples its windows run over, luma or chroma -- and one comparison: chains of || and && on
+  // lane conditions compile to 0 / 1 registers and comparisons of those)
+  const int overA = max((posA & (S - 1)) + wpx + (phA & 1) - S, (cposA & (S - 1)) + cwpx + (cphA & 1) - (S >> 1));
+  const int overB = max((topB & (S - 1)) + wpx + (phB & 1) - S, (ctopB & (S - 1)) + cwpx + (cphB & 1) - (S >> 1));
+  const bool wrap = leaves && max(overA, kind2 != 0 ? overB : 0) > 0;
   const bool win = leaves && !wrap;                           // fetched through the LDS windows
   const bool slow = multi || wrap;
   const uint32_t slow_mask = (uint32_t)__builtin_amdgcn_ballot_w64(slow) & 0xFFu;
@@ -840,7 +847,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       };
 #pragma unroll
       for (int k = 0; k < CWR; k++) {
-        const bool mine = left > 8 * k;
+        int lf = left;
+        asm volatile("" : "+v"(lf)); // (compared where it is needed: hoisted, the sixteen comparisons of this unrolled loop become sixteen
+        const bool mine = lf > 8 * k; //  0 / 1 registers in front of it and sixteen more comparisons inside)
         if (k && __builtin_amdgcn_ballot_w64(mine) == 0) break;
         uint32_t e = cwr[k];
         asm volatile("" : "+v"(e));
