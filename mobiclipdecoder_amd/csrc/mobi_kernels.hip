@@ -348,25 +348,20 @@ __device__ __forceinline__ void idct_pass2_pk(const uint32_t *t, bool is8, int r
 } // namespace
 
 // =====================================================================================================
-// mobi_recon_inter8 (r02): one wavefront per octet, second generation
+// mobi_recon_inter8: one wavefront per octet (Kernels; how it got here: HISTORY.md)
 // =====================================================================================================
-// What r01's counters said about the kernel above (profiles/r01_pmc_summary.txt): the texture addresser is busy 80 % of
-// the launch (44 vector-memory instructions per wave, 24 of them the 8-byte register fetches of the two-half macroblocks),
-// every wave waits for two memory round trips in series (descriptor, then windows), and the integer VALU is not one
-// machine: two-operand adds / shifts / logic ops issue in ~2.7 cycles per wave, everything with three operands, byte
-// selects, compares, SDWA and 16-bit packed forms in ~4.3 (tools/ubench/oprate.hip).  Hence:
-//   * ONE fetch path for every macroblock with whole leaves (16x16, two 16x8, two 8x16): the DMA rounds take a per-lane
-//     source address, so the rows of a top/bottom pair and the 16-byte halves of a left/right pair simply come from the
-//     other leaf's position.  Chroma windows start at a 4-byte boundary (not 16): 9 + 3 bytes then fit ONE 16-byte chunk.
-//     19 vector-memory instructions per wave instead of 44.
-//   * a lane owns 8 consecutive luma rows x 4 pixels (4 chroma rows x 4): it lies inside one leaf whatever the split, the
-//     row below of one row is the row of the next (masked bytes and the horizontal average are computed once per row),
-//     and the extra row under a lane's rows (9th / 5th) comes straight into its registers.
-//   * CopyBlock (MD.cs:424-452) by v_perm_b32 (byte window out of two dwords) and v_lerp_u8: (a>>1)+(b>>1) per byte is
-//     the byte average of a & 0xFE and b & 0xFE; phase 0 uses the same instructions with mask 0xFF and b = a.
-//   * macroblocks with deeper trees fetch their MV cells beside the DMA rounds and their pixels under the MC of the others.
-//   * coefficient tiles at a pitch of 72 words (the transposing stores of the 8 lanes of 4 areas hit 32 different banks),
-//     8x8 areas sorted in front of 4x4 ones so that a half round usually runs one kind of butterfly.
+//   A. every lane decodes its macroblock's descriptor; ONE fetch path for every macroblock with whole leaves (16x16, two 16x8, two
+//      8x16): DMA rounds with a per-lane source address (global_load_lds_dwordx4), so the rows of a top/bottom pair and the halves of a
+//      left/right pair simply come from the other leaf's position; level words travel in registers.
+//   B. a lane owns 8 consecutive luma rows x 4 pixels (4 chroma rows x 4): it lies inside one leaf whatever the split.  CopyBlock
+//      (MD.cs:424-452) by v_perm_b32 (byte window out of two dwords) and v_lerp_u8: (a>>1)+(b>>1) per byte is the byte average of
+//      a & 0xFE and b & 0xFE; phase 0 uses the same instructions with mask 0xFF and b = a.
+//      Deeper partition trees: the whole wave for one macroblock, a lane = one 2x2 cell of the MV cell map (r04).
+//   C. residual on packed int16, the same row of TWO coded areas per lane, sixteen areas per round (r04); 32-bit rounds behind a guard.
+//   D. the octet's tiles are contiguous: whole-line stores.
+// The integer VALU is not one machine (tools/ubench/oprate.hip: two-operand adds / shifts / logic ops issue in ~2.7 cycles per wave,
+// everything with three operands, byte selects, compares, SDWA, DPP and 16-bit packed forms in ~4.3), and the kernel is bound by its
+// vector instruction count: tools/exp_stages.sh counts it stage by stage (MOBI_STOP).
 namespace {
 // LDS of one octet (10 KB: sixteen waves per CU).  While the windows are in flight / being interpolated:
 //   P_L   luma windows: chunk (row pair p = 0..9, quadrant column s = 0..3) of macroblock g at p * 512 + s * 128 + g * 16; a chunk =
