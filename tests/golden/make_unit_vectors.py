@@ -164,5 +164,37 @@ def main():
           int((rc != 0).sum()), "throw in the decoder")
 
 
+def write_text(path=os.path.join(ROOT, "tests", "golden", "unit_vectors.txt")):
+    """unit_vectors.npz as plain lines, for tests/golden/verify/VerifyUnits.cs (a C# program against the unmodified reference): byte arrays as
+    hex, int arrays comma-separated.  Needs nothing but the committed .npz."""
+    d = np.load(OUT)
+    hx = lambda a: np.asarray(a, np.uint8).tobytes().hex()
+    cs = lambda a: ",".join(str(int(v)) for v in np.asarray(a).ravel())
+    with open(path, "w") as f:
+        f.write("# written by tests/golden/make_unit_vectors.py --text from unit_vectors.npz; read by tests/golden/verify/VerifyUnits.cs\n")
+        f.write(f"stride {S} rows {ROWS}\n")
+        for k in range(len(d["idct8_rc"])):
+            f.write(f"idct8 {int(d['idct8_rc'][k])} {cs(d['idct8_coef'][k])} {hx(d['idct8_pred'][k])} {hx(d['idct8_out'][k])}\n")
+        for k in range(len(d["idct4_rc"])):
+            f.write(f"idct4 {int(d['idct4_rc'][k])} {cs(d['idct4_coef'][k])} {hx(d['idct4_pred'][k])} {hx(d['idct4_out'][k])}\n")
+        for k in range(len(d["dct8_in"])):
+            f.write(f"dct8 {cs(d['dct8_in'][k])} {cs(d['dct8_out'][k])}\n")
+        for k in range(len(d["dct4_in"])):
+            f.write(f"dct4 {cs(d['dct4_in'][k])} {cs(d['dct4_out'][k])}\n")
+        f.write(f"copysrc {int(d['copy_offset'])} {hx(d['copy_src'])}\n")
+        for (w, h, dx, dy), o in zip(d["copy_cases"], d["copy_out"]):
+            f.write(f"copy {w} {h} {dx} {dy} {hx(o[: w * h])}\n")
+        f.write(f"intraplane {hx(d['intra_plane'])}\n")
+        for (m, x, y, uv), pr, rc in zip(d["intra_cases"], d["intra_pred"], d["intra_rc"]):
+            n = 8 if m < 10 else 4
+            f.write(f"intra {m} {x} {y} {uv} {int(rc)} {hx(pr[: n * n])}\n")
+        for (size, x, y, param), o in zip(d["plane_cases"], d["plane_out"]):
+            f.write(f"plane {size} {x} {y} {param} {hx(o[: size * size])}\n")
+
+
 if __name__ == "__main__":
-    main()
+    if "--text" in sys.argv:
+        write_text()
+    else:
+        main()
+        write_text()
