@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/exp_lsab.sh "<flags A>" "<flags B>" ...  -- mobi_lsparse.hip built with each set of -D flags in turn, twice round, parse time of each
+# (-DLS_K=n: 1..4 only -- beyond that the cheap rounds could outrun the bitstream ring and the build stops at a static_assert)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; P=$REPO/mobiclipdecoder_amd; O=$P/_obj
 cp $P/libmobiclip_hip.so /tmp/lib_keep.so; cp $O/mobi_lsparse.hip.o /tmp/l_keep.o
 OBJS="$O/mobi_abi.cpp.o $O/mobi_parse.cpp.o $O/mobi_demux.cpp.o $O/mobi_moflex.cpp.o $O/mobi_kernels.hip.o $O/mobi_rgb.hip.o $O/mobi_dparse.hip.o $O/mobi_lsparse.hip.o $O/mobi_analysis.hip.o"
