@@ -181,7 +181,7 @@ def kernels_sha16():
 
 def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
     """BASELINE config 4 ("64 clips sharded across 8 GPUs") as seen by ONE GPU: its share of 8 clips, replayed like the big batch.
-    150 octet waves per clip fill a few per cent of the chip, so this is the latency of two short launches per step, not a
+    150 octet waves per clip fill a few per cent of the chip, so this is the latency of one short launch per step (r04: mobi_recon_step), not a
     throughput figure; it is reported next to the headline value, never as it."""
     b = m.MobiclipBatch(n_clips, W, H, version, device=device)
     for c in range(n_clips):
@@ -204,7 +204,7 @@ def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
     return {"workload": f"{n_clips} clips of {W}x{H} on this GPU = the per-GPU share of 64 clips over 8 GPUs", "steps": n_steps,
             "ms_per_step": round(stream_ms / n_steps, 4), "value": round(n_clips * n_steps * W * H / (stream_ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
             "wall_ms_per_step": round(wall * 1e3 / n_steps, 4),
-            "note": "two launches per step (inter: 1200 octet waves; intra: ~480 waves, one macroblock each at this size): launch latency and two or three dependency levels, not bandwidth"}
+            "note": "one launch per step (mobi_recon_step: 1200 octet waves of inter macroblocks and ~480 intra waves, one macroblock each at this size, which wait for the tags of the macroblocks their halo reads): launch latency and two or three dependency levels, not bandwidth"}
 
 
 def launch_ranks(n, argv):

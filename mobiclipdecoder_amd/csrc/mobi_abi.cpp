@@ -30,6 +30,7 @@ constexpr size_t kPaySlack = 2048; // lanes of the inter kernel with nothing to 
 constexpr size_t kGuard = 65536; // slack on both ends of the plane arena: the slow MC path fetches the dwords of the row below a window's last
                                  // row whether its phase needs them or not, and in the tiled planes (mobi_tile.h) that row may be a tile row (<= 16 KB) away
 constexpr size_t kAlign = 16;
+constexpr size_t kFusedStepMbs = (size_t)256 * 1200; // steps of at most this many macroblocks go out as ONE launch (mobi_recon_step); MOBI_FUSED_STEP_MBS overrides, 0 = never
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -296,6 +297,7 @@ struct mobi_batch {
   uint32_t pay_clip_words = 0;         // of the last device-parsed step (MobiReconArgs.pay_clip_words)
   int ls_finished = -1;                // clips of the last step it finished itself
   bool lockstep = false;               // mobi_batch_set_parse_mode(b, 3) / MOBI_DEVICE_PARSE=3: mobi_parse_frames_ls in front of mobi_parse_frames
+  size_t fused_mbs = kFusedStepMbs;     // launch_plan: steps of at most this many macroblocks go out as one launch
   MobiDevResult *d_pres = nullptr;
   uint8_t *d_ptables = nullptr;
   PinnedBuf h_pres;
@@ -370,6 +372,15 @@ struct mobi_batch {
   // one frame step = the inter launch, then ONE intra launch for all dependency levels (items sorted by level, waves wait for
   // the tags of the macroblocks they depend on).  r01 also had a launch per level and a whole-step launch; both were slower.
   int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev) {
+    // Small steps (BASELINE config 4: 8 clips per GPU): one launch carries both kinds of macroblock -- the kernel boundary between the two
+    // launches is a fifth of such a step.  Large ones keep two: the fused kernel has the octet's registers and LDS for the intra fours too.
+    if (plan.any_inter && plan.n_items && (size_t)n * g.mbw * g.mbh <= fused_mbs) {
+      EvPair ep{nullptr, nullptr, 0};
+      if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
+      if (mobi_launch_step(&a, items_dev, (int)plan.n_items, stream) != 0) return MOBI_E_DEVICE;
+      if (ktiming) { (void)hipEventRecord(ep.b, stream); evs.push_back(ep); }
+      return MOBI_OK;
+    }
     if (plan.any_inter) {
       EvPair ep{nullptr, nullptr, 0};
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
@@ -555,6 +566,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
       b->lockstep = v == 3;
       b->parse_auto = false;
     }
+    if (const char *fs = getenv("MOBI_FUSED_STEP_MBS")) b->fused_mbs = (size_t)strtoull(fs, nullptr, 10);
     int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
     if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
     b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));

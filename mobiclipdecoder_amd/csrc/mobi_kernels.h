@@ -38,6 +38,8 @@ static_assert(sizeof(MobiReconArgs) == 128, "kernarg block layout");
 extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s);
 // items_dev: n_items launch items of 16 bytes (MOBI_INTRA_ITEM_WORDS words), sorted by dependency level -- see LevelPlan in mobi_abi.cpp
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
+// small batches: both of the above in one launch (mobi_recon_step: the intra fours wait for the inter macroblocks their halo reads)
+extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
 // device-parsed frames: items_dev = [clip][n_mbs] in raster order, n_intra_dev[clip * stride_words] of them valid; K = the slots launched:
 // the largest count when the host knows it, else MOBI_ASYNC_INTRA_SLOTS (longer lists are walked by the workgroups of slot K - 1)
 #define MOBI_ASYNC_INTRA_SLOTS 160

@@ -55,6 +55,7 @@ struct Geo { // stride is 256/512/1024 (MD.cs:50-52): divide/modulo by shifts
 // v_alignbyte.  All loads of a macroblock are issued before the first one is consumed: no control flow sits between them.
 typedef uint2 __attribute__((aligned(4))) uint2_a4;
 typedef uint4 __attribute__((aligned(4))) uint4_a4;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct Win { uint2 r0, r1; uint32_t sh; }; // row, row below, byte shift 0..3
 // The four dwords of a window (o4, o4 + 4, o4 + S, o4 + S + 4 in linear terms) in tiled terms: the next dword is + 4 inside a
 // quadrant row, else the next quadrant column's first (+ 60, or + 188 into the next tile); the row below is + 8 inside a quadrant,
@@ -427,7 +428,7 @@ __device__ __forceinline__ unsigned long long prof_stamp() { // shader clock, pi
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
-template <int PROF, int CWR>
+template <int PROF, int CWR, int FUSED>
 __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t *L, uint32_t clip, uint32_t mby, uint32_t ox, int lane) {
   unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0};
   if (PROF) pt[0] = prof_stamp();
@@ -945,6 +946,32 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     uint8_t *y0 = clip_base + (uint32_t)A.ring_base * A.slot_bytes;
     uint8_t *ty0 = y0 + mobi_tile_y(mbx0, mby, lgS), *tc0 = y0 + ysz + mobi_tile_c(mbx0, mby, lgS);
     const bool full = nmb == 8; // (wave-uniform: only a picture's last octet can be short)
+    if (FUSED) {
+      // One launch for the whole step (mobi_recon_step, small batches): the intra macroblocks' waves run beside this one.  Nothing is
+      // written over an intra macroblock's place (its wave may be there first); the inter macroblocks' samples go through to memory
+      // (sc1), are drained, and every inter macroblock gets this step's tag, which the intra waves that read it as halo poll.
+      // (An asm store of more than 64 bits needs its own two wait states before a vector instruction may write its data registers: the
+      // compiler pads its own stores, not these -- without the s_nop the next round's moves into the tuple changed the first dword of
+      // the lanes whose data are read last.)
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int i = lane + 64 * it, gq = i >> 4, quad = (i >> 2) & 3, R0 = (quad >> 1) * 8 + 2 * (i & 3), c0 = (quad & 1) * 8;
+        const uint2 v0 = *(const uint2 *)(L + out_y(gq, R0, c0)), v1 = *(const uint2 *)(L + out_y(gq, R0 + 1, c0));
+        const u32x4 v = {v0.x, v0.y, v1.x, v1.y};
+        const uint8_t *dst = ty0 + i * 16;
+        if ((inter_mask >> gq) & 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+      }
+      {
+        const int gq = lane >> 3, R = lane & 7;
+        const uint4 c4 = *(const uint4 *)(L + out_c(gq, R, 0, 0));
+        const u32x4 vc = {c4.x, c4.y, c4.z, c4.w};
+        const uint8_t *dst = tc0 + lane * 16;
+        if ((inter_mask >> gq) & 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(vc) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the samples have left this CU before the tags do
+      if (lane < 8 && ((inter_mask >> lane) & 1))
+        __hip_atomic_store(A.done + (size_t)clip * A.n_mbs + mby * mbw + mbx0 + lane, A.step_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const int i = lane + 64 * it, gq = i >> 4, quad = (i >> 2) & 3, R0 = (quad >> 1) * 8 + 2 * (i & 3), c0 = (quad & 1) * 8;
@@ -957,6 +984,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
       const uint4 vc = *(const uint4 *)(L + out_c(gq, R, 0, 0));
       if (full) *(uint4 *)(tc0 + lane * 16) = vc;
       else *(uint4 *)(tc0 + lane * 16) = gq < nmb ? vc : uint4{0, 0, 0, 0};
+    }
     }
   }
   if (PROF && lane == 0) { // MOBI_DEBUG=9: where a wave's life goes (shader clock): A issue, fetch wait, MC, deep trees, residual, store issue
@@ -986,7 +1014,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     uint32_t rem, ox;                                                                                  \
     const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem); /* qpr / qpc: octets per macroblock row / per clip */ \
     const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);                                         \
-    recon_inter_oct<PROF, NCWR>(A, lds, clip, mby, ox, (int)threadIdx.x);                              \
+    recon_inter_oct<PROF, NCWR, 0>(A, lds, clip, mby, ox, (int)threadIdx.x);                              \
   }
 // 4 waves per SIMD (108 VGPRs, no spills; 5 waves = 96 VGPRs spill 5 registers since the windows became 16-byte aligned and
 // measure the same) with 128 level words per macroblock in registers (96: 848x480 with its dense blocks 8 % slower; 192: no better).
@@ -1030,7 +1058,6 @@ enum { SD_O = 0,           // [10:0]  byte offset of the block's top-left sample
        SD_P4 = 1 << 30 };  // the plane is a 4x4 one
 // word 1: [8:0] index of the step's first residual (+ lane's), [31:16] plane parameter
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t ldg_u8_sc1(const uint8_t *p) { // past this CU's L1; valid after vm_wait*
   uint32_t v = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1109,6 +1136,7 @@ struct QItem {
 };
 } // namespace
 
+template <int FUSED = 0> // FUSED: the step's inter macroblocks run in the same launch (mobi_recon_step): wait for the ones the halo reads as well
 __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_t *Lw, const QItem &I, int lane, int dbg = 0) {
   const int l = lane & 15;
   uint32_t *G = Lw + (lane >> 4) * IQ_WORDS;
@@ -1183,7 +1211,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
 
   // (the dependency list is asked for with everything else; the wait for the producers themselves comes as late as it can: below,
   // in front of the halo's placement)
-  const bool waits = I.valid && I.has_deps;
+  const bool waits = I.valid && (FUSED || I.has_deps);
   uint32_t wd = 0;
   if (waits && l < MOBI_INTRA_DEPS) wd = (&(A.desc + (size_t)clip * A.n_mbs + mb)->w4)[l >> 1];
   MOBI_ISTOP(1);
@@ -1342,7 +1370,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   if (__builtin_amdgcn_ballot_w64(waits) != 0) {
     if (waits && l < MOBI_INTRA_DEPS) {
       const uint32_t dep = (wd >> (16 * (l & 1))) & 0xFFFFu;
-      if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) { // inter macroblocks ran in the launch before this one
+      if (dep != MOBI_DEP_NONE && (FUSED || !(dep & MOBI_DEP_INTER))) { // (two launches: the inter macroblocks ran in the one before)
         const uint32_t *f = A.done + (size_t)clip * A.n_mbs + (dep & 0x1FFFu);
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.step_tag) {
@@ -1534,8 +1562,8 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     const u32x4 vc = {*(const uint32_t *)su, *(const uint32_t *)(su + 4), *(const uint32_t *)sv, *(const uint32_t *)(sv + 4)};
     uint8_t *dstc = tc + (l & 7) * 16;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+    if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
     if (l < 8) {
       if (anyp) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dstc), "v"(vc) : "memory");
       else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dstc), "v"(vc) : "memory");
@@ -1561,6 +1589,30 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs 
   const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
                 (item.w & 2) != 0, (item.w & 4) != 0};
   recon_intra_quad(A, lds, I, lane, dbg);
+}
+
+// Small batches: the whole frame step in ONE launch.  Workgroups [0, n_inter) are octets of inter macroblocks, the rest fours of intra
+// items as above.  Two launches cost a kernel boundary (the second waits until the first has drained, then starts cold) -- at 8 clips per
+// GPU (BASELINE config 4) that boundary is a fifth of the step; here an intra macroblock starts as soon as the inter macroblocks its halo
+// reads carry the step's tag.  Inter workgroups never wait and are dispatched first, so the waits cannot deadlock.
+extern "C" __global__ __launch_bounds__(64, 4) void mobi_recon_step(MobiReconArgs A, const uint4 *items, uint32_t n_inter) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[P_BYTES];
+  static_assert(P_BYTES >= 4 * IQ_WORDS * 4, "the intra fours fit the octet's LDS");
+  if (blockIdx.x < n_inter) {
+    const uint32_t oi = (blockIdx.x & 7) * A.inter_per_xcd + (blockIdx.x >> 3);
+    if (oi >= A.qpc * (uint32_t)A.n_clips) return;
+    uint32_t rem, ox;
+    const uint32_t clip = fastdiv(oi, A.qpc, A.magic_qpc, rem);
+    const uint32_t mby = fastdiv(rem, A.qpr, A.magic_qpr, ox);
+    recon_inter_oct<0, 16, 1>(A, lds, clip, mby, ox, (int)threadIdx.x);
+    return;
+  }
+  const int lane = threadIdx.x;
+  const uint4 item = items[(blockIdx.x - n_inter) * 4 + (lane >> 4)];
+  const bool valid = item.x != 0xFFFFFFFFu;
+  const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
+                (item.w & 2) != 0, (item.w & 4) != 0};
+  recon_intra_quad<1>(A, (uint32_t *)lds, I, lane);
 }
 
 // Items as the device-side parser leaves them (mobi_dparse.hip): per clip, raster order, n_intra[clip] of them at a stride of
@@ -1644,6 +1696,21 @@ extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_d
   static const int dbg = prof_env("MOBI_INTRA_DBG"); // timing ablations only: 1 no transform, 2 no steps, 4 no scatter, 8 no stores, 16 no halo, 32 no levels
   static const int pad = prof_env("MOBI_INTRA_LDS_PAD");
   hipLaunchKernelGGL(mobi_recon_intra, dim3((unsigned)n_items / 4), dim3(64), pad, s, *a, (const uint4 *)items_dev, n_items, dbg);
+  return (int)hipGetLastError();
+}
+extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
+  if (a->n_clips <= 0 || n_items <= 0 || (n_items & 3)) return (int)hipErrorInvalidValue;
+  if (a->slot_bytes >= (1u << 24)) return (int)hipErrorInvalidValue;
+  MobiReconArgs b = *a;
+  b.reserved21 = 0;
+  b.qpr = ((uint32_t)b.mbw + 7) / 8;
+  b.qpc = b.qpr * (uint32_t)(b.n_mbs / b.mbw);
+  auto magic = [](uint32_t d) { uint64_t m = ((uint64_t)1 << 32) / d; return (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m); };
+  b.magic_qpr = magic(b.qpr);
+  b.magic_qpc = magic(b.qpc);
+  const unsigned g8 = (unsigned)(((long)b.qpc * b.n_clips + 7) / 8 * 8);
+  b.inter_per_xcd = g8 / 8;
+  hipLaunchKernelGGL(mobi_recon_step, dim3(g8 + (unsigned)n_items / 4), dim3(64), 0, s, b, (const uint4 *)items_dev, (uint32_t)g8);
   return (int)hipGetLastError();
 }
 // K slots are launched; lists longer than K are finished by the workgroups of slot K - 1 (see the kernel)

@@ -26,6 +26,10 @@ for it in range(rounds):
     ps = [m.default_params("A", BASE_SEED + 100000 + 1000 * (seed0 + it) + i, **kw) for i in range(nclips)]
     clips = [m.generate_clip(p) for p in ps]
     dev = bool(it & 1)
+    if it & 2:  # host-parsed rounds: a small step is ONE launch (mobi_recon_step) unless the limit is 0; both kinds in turn
+        os.environ["MOBI_FUSED_STEP_MBS"] = "0"
+    else:
+        os.environ.pop("MOBI_FUSED_STEP_MBS", None)
     b = m.MobiclipBatch(nclips, w, h, ver, device_parse=dev)
     oras = [OracleDecoder(w, h, ver) for _ in ps]
     for f in range(nfr):
@@ -38,7 +42,7 @@ for it in range(rounds):
                 y, uv = b.planes(i)
                 ok = np.array_equal(y, o[0]) and np.array_equal(uv, o[1])
             if not ok:
-                print("DIFFERENCE round", it, "frame", f, "clip", i, "device_parse", dev, "rc", rcs[i], oras[i].last_error, kw, "seed", ps[i].seed)
+                print("DIFFERENCE round", it, "frame", f, "clip", i, "device_parse", dev, "two_launches", bool(it & 2), "rc", rcs[i], oras[i].last_error, kw, "seed", ps[i].seed)
                 sys.exit(1)
         frames += nclips
         mbs += nclips * (w // 16) * (h // 16)
