@@ -164,7 +164,7 @@ def single_stream_leg(m, stream, W, H, version, device):
         n += 1
     cpu_ms = (time.perf_counter() - t0) * 1e3 / (n * p.n_frames)
     o.close()
-    res.update({"workload": f"one {W}x{H} clip, {p.n_frames} frames, mobi_create / mobi_decode per frame (host parse, upload, two launches, sync)",
+    res.update({"workload": f"one {W}x{H} clip, {p.n_frames} frames, mobi_create / mobi_decode per frame (host parse, upload, one launch for a P-frame's step, sync)",
                 "value": round(W * H / res["planes"]["p_frame_ms"] / 1e3, 1), "unit": "Mpixels/s (P-frames, planes)",
                 "oracle_ms_per_frame_1_thread": round(cpu_ms, 4)})
     return res

@@ -72,7 +72,7 @@ waves: wave latency plus a chain of two or three dependency levels. An I-frame s
 
 **Single stream** (`single_stream`): what the boundary replaces is one `MobiclipDecoder` used by one thread
 (`MobiConverter/Program.cs:57-71`, `Form1.cs:199-215`). One 640×480 clip through `mobi_create` / `mobi_decode` per frame (host parse,
-upload, two launches, synchronise), wall time per call: **P-frame {ss['planes']['p_frame_ms']:.2f} ms, I-frame {ss['planes']['i_frame_ms']:.2f} ms**; with `mobi_get_argb` (the Bitmap `DecodeFrame()`
+upload, launch, synchronise), wall time per call: **P-frame {ss['planes']['p_frame_ms']:.2f} ms, I-frame {ss['planes']['i_frame_ms']:.2f} ms**; with `mobi_get_argb` (the Bitmap `DecodeFrame()`
 returns) {ss['with_bitmap']['p_frame_ms']:.2f} / {ss['with_bitmap']['i_frame_ms']:.2f} ms; the oracle on one host thread: {ss['oracle_ms_per_frame_1_thread']:.2f} ms per frame (planes only). One clip fills 0.3 % of the part: its place is the batch.
 
 `cpu_baseline`: the oracle (a C restatement, expected to be faster than the C# original: no GC, no per-row allocations), same
