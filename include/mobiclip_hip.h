@@ -96,7 +96,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
 /* Where mobi_batch_decode parses the bitstreams.  0: host threads, command lists uploaded per call.  1: on the GPU, one
  * wavefront per clip (mobi_dparse.hip): Data[Offset..) of every clip is uploaded instead and the command lists never leave
  * HBM; same rc / Offset / planes.  The parse of one clip is serial and a GPU lane is slow at it; the GPU wins by running
- * thousands of clips at once, from about 900 resident clips upward.  Default: by batch size (device parse from 1024 clips,
+ * thousands of clips at once, from about 20 resident clips per host parse thread upward.  Default: by batch size (device parse from max(640, 20 x threads) clips,
  * unless the first call hands over far more than a frame per clip -- whole files as Data, MOC5 style -- which the device path
  * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1/2.  2 = hybrid: the GPU parses most clips while the
  * host pool parses a fixed share of them (a fifth, at most 1024; MOBI_HYBRID_HOST_CLIPS) at the same time; one set of
@@ -111,7 +111,7 @@ int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
  * -1 in the other modes or before the first step. */
 int mobi_batch_lockstep_finished(const mobi_batch *b);
 /* Asynchronous frame steps, for callers that already hold the next frame of every clip (demuxed Moflex / Mods packets: the Offset
- * to start from does not depend on the previous frame's parse).  The batch must parse on the GPU (the default from 1024 clips;
+ * to start from does not depend on the previous frame's parse).  The batch must parse on the GPU (the default for large batches, see above;
  * mobi_batch_set_parse_mode(b, 1) otherwise; not the hybrid mode) and at most two steps may be in flight.
  *   mobi_batch_submit: copies the bytes data[i][offsets[i] .. len[i]) of every clip into pinned memory and enqueues upload, parse and
  *                      reconstruction of one frame step behind the step before; returns without waiting for the GPU.  The caller's

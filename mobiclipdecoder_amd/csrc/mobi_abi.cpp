@@ -115,7 +115,7 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
   bool any_inter = false;
   uint64_t cmd_bytes = 0;       // descriptors + payload of every macroblock of the step
   uint64_t intra_cmd_bytes = 0; // ... of the intra ones: descriptor, 24 block records, level words (the inter kernel never reads them)
-  void build(const std::vector<const ParsedFrame *> &frames, int mbw) {
+  void build(const std::vector<const ParsedFrame *> &frames, int /*mbw*/) {
     // Few intra macroblocks (small batches): every one gets a wave of its own (three null items behind it) -- the chip has room for
     // them all at once, and a lone macroblock's wave is shorter than a wave that runs the longest step list of four.  Measured
     // (640x480 P-frames, intra launch): 8 clips 45 -> 33 us, 64 clips 53 -> 41 us, 512 clips 78 -> 110 us: dense from there on.
@@ -138,69 +138,33 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
     std::vector<size_t> base(frames.size() + 1, 0); // where each clip's payload starts in the step's arena (as step_write lays it out)
     for (size_t c = 0; c < frames.size(); c++) base[c + 1] = base[c] + (frames[c] ? frames[c]->payload.size() : 0);
     n_intra = 0;
+    size_t total = 0;
+    for (auto *f : frames)
+      if (f) total += f->intra_items.size();
+    items.reserve((sparse ? 4 : 1) * total + 16 * (size_t)maxl);
+    const uint32_t none[4] = {MOBI_ITEM_NONE, 0, 0, 0};
     for (uint32_t L = 1; L <= maxl; L++) {
-      // two passes per level: macroblocks away from the picture's edges first, the others (whose halo needs the per-sample
-      // ownership test, mobi_recon_intra) behind them, so that few waves of four carry one
-      for (int edge_pass = 0; edge_pass < 2; edge_pass++)
+      // two passes per level: macroblocks away from the picture's edges first, the others (on Width == Stride pictures their halo needs the
+      // per-sample ownership test, mobi_recon_intra) behind them, so that few waves of four carry one.  The parsers wrote the items
+      // (ParsedFrame::intra_items, level by level): this is a concatenation with the clip number and the clip's place in the arena added.
+      for (uint32_t edge_pass = 0; edge_pass < 2; edge_pass++)
         for (size_t c = 0; c < frames.size(); c++) {
           const ParsedFrame *f = frames[c];
           if (!f || L > f->hdr.n_levels) continue;
           for (uint32_t i = f->level_start[L]; i < f->level_start[L + 1]; i++) {
-            const uint32_t mb = f->intra_mbs[i];
-            const uint32_t mbx = mb % (uint32_t)mbw;
-            const bool interior = mbx >= 1 && mbx + 1 < (uint32_t)mbw && mb >= (uint32_t)mbw;
-            if (interior == (edge_pass != 0)) continue;
-            const MbDesc &d = f->desc[mb];
-            uint32_t flags = d.w3 & 0xFFFF0001u;
-            const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
-            for (int k = 0; k < MOBI_INTRA_DEPS; k++) {
-              const uint32_t dep = (deps[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-              if (dep != MOBI_DEP_NONE && !(dep & MOBI_DEP_INTER)) flags |= 2u;
-            }
-            flags |= (d.w2 & 0x3FFu) << 5;
-            intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + (d.w2 & 0x3FFu));
-            items.push_back(MOBI_ITEM(c, mb));
-            items.push_back(d.w1);
-            items.push_back(d.payload_off + (uint32_t)base[c]);
-            items.push_back(flags);
+            const uint32_t *it = &f->intra_items[(size_t)i * 4];
+            if (((it[3] >> 3) & 1u) != edge_pass) continue;
+            intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + ((it[3] >> 5) & 0x3FFu));
+            const uint32_t item[4] = {MOBI_ITEM(c, it[0]), it[1], it[2] + (uint32_t)base[c], it[3] & ~8u};
+            items.insert(items.end(), item, item + 4);
             n_intra++;
-            for (int k = 1; k < 4 && sparse; k++) {
-              items.push_back(MOBI_ITEM_NONE);
-              items.push_back(0);
-              items.push_back(0);
-              items.push_back(0);
-            }
+            for (int k = 1; k < 4 && sparse; k++) items.insert(items.end(), none, none + 4);
           }
         }
       // a wave carries four macroblocks, and a macroblock may wait for one of the level before: levels start on a wave boundary
-      while ((items.size() / MOBI_INTRA_ITEM_WORDS) & 3) {
-        items.push_back(MOBI_ITEM_NONE);
-        items.push_back(0);
-        items.push_back(0);
-        items.push_back(0);
-      }
+      while ((items.size() / MOBI_INTRA_ITEM_WORDS) & 3) items.insert(items.end(), none, none + 4);
     }
     n_items = (uint32_t)(items.size() / MOBI_INTRA_ITEM_WORDS);
-    // second pass: "has dependents".  Index the items by (clip, mb), then mark what the polling ones name.
-    if (n_items) {
-      std::vector<std::vector<std::pair<uint32_t, uint32_t>>> by_clip(frames.size()); // (mb, item index)
-      for (uint32_t i = 0; i < n_items; i++)
-        if (items[4 * i] != MOBI_ITEM_NONE) by_clip[items[4 * i] >> 13].push_back({items[4 * i] & 0x1FFFu, i});
-      for (auto &v : by_clip) std::sort(v.begin(), v.end());
-      for (uint32_t i = 0; i < n_items; i++) {
-        if (items[4 * i] == MOBI_ITEM_NONE || !(items[4 * i + 3] & 2u)) continue;
-        const uint32_t c = items[4 * i] >> 13, mb = items[4 * i] & 0x1FFFu;
-        const MbDesc &d = frames[c]->desc[mb];
-        const uint32_t deps[4] = {d.w4, d.w5, d.w6, d.w7};
-        for (int k = 0; k < MOBI_INTRA_DEPS; k++) {
-          const uint32_t dep = (deps[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-          if (dep == MOBI_DEP_NONE || (dep & MOBI_DEP_INTER)) continue;
-          auto &v = by_clip[c];
-          auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(dep & 0x1FFFu, 0u));
-          if (it != v.end() && it->first == (dep & 0x1FFFu)) items[4 * it->second + 3] |= 4u;
-        }
-      }
-    }
   }
 };
 
@@ -268,6 +232,7 @@ struct mobi_batch {
   std::vector<int> h_fault;
   // per-call staging (batch_decode)
   PinnedBuf h_stage;
+  PinnedBuf h_items;                   // host-parsed steps: the launch list (the staging buffer's chunks are in flight by then)
   DevBuf d_cmd, d_items;
   int32_t *d_scale = nullptr; // [MOBI_SCALE_QMAX][MOBI_SCALE_STRIDE]
   unsigned long long *d_prof = nullptr; // MOBI_DEBUG=9: in-kernel cycle accumulators
@@ -289,6 +254,7 @@ struct mobi_batch {
   size_t last_pay_cap = 0;
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
+  float phase_ms[6] = {0, 0, 0, 0, 0, 0};      // (profiling) host-parsed step: parse loop, plan, stage + upload enqueue, launch enqueue, sync, rest
   float last_hostparse_ms = 0;                 // ... / of its host parse part (host parse mode)
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
   DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
@@ -297,6 +263,7 @@ struct mobi_batch {
   uint32_t pay_clip_words = 0;         // of the last device-parsed step (MobiReconArgs.pay_clip_words)
   int ls_finished = -1;                // clips of the last step it finished itself
   bool lockstep = false;               // mobi_batch_set_parse_mode(b, 3) / MOBI_DEVICE_PARSE=3: mobi_parse_frames_ls in front of mobi_parse_frames
+  int host_chunk = 256;                // host-parsed steps: clips per chunk of the parse / stage / upload pipeline (mobi_batch_decode)
   size_t fused_mbs = kFusedStepMbs;     // launch_plan: steps of at most this many macroblocks go out as one launch
   MobiDevResult *d_pres = nullptr;
   uint8_t *d_ptables = nullptr;
@@ -479,6 +446,7 @@ mobi_batch *mobi_debug_dec_batch(mobi_dec *d) { return d ? d->b : nullptr; }
 float mobi_debug_parse_ms(const mobi_batch *b) { return b ? b->last_parse_ms : 0.f; }
 float mobi_debug_stage_ms(const mobi_batch *b) { return b ? b->last_stage_ms : 0.f; }
 float mobi_debug_hostparse_ms(const mobi_batch *b) { return b ? b->last_hostparse_ms : 0.f; }
+float mobi_debug_phase_ms(const mobi_batch *b, int k) { return b && k >= 0 && k < 6 ? b->phase_ms[k] : 0.f; } // host-parsed step: where the call's time went
 long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *items_out, uint32_t *res_out, uint32_t *payload_out, size_t payload_words) {
   if (!b || !b->d_pres) return MOBI_E_ARG;
   const size_t n = (size_t)b->n, n_mbs = (size_t)b->g.mbw * b->g.mbh;
@@ -557,7 +525,19 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     const size_t dbytes = (size_t)n_clips * b->g.mbw * b->g.mbh * 4;
     if (hipMalloc((void **)&b->d_done, dbytes) != hipSuccess) return nullptr;
     if (hipMemset(b->d_done, 0, dbytes) != hipSuccess) return nullptr;
-    b->parse_mode = n_clips >= 1024; // the break-even against 32 host parse threads is ~900 resident clips
+    if (const char *fs = getenv("MOBI_FUSED_STEP_MBS")) b->fused_mbs = (size_t)strtoull(fs, nullptr, 10);
+    // parse threads: measured on a 2 x 64-core host (tools/exp_hostparse.py, 1024 clips: 16 / 32 / 64 / 128 threads parse a P-frame step in
+    // 20.0 / 10.3 / 5.5 / 4.3 ms): one per two hardware threads, 64 at most
+    const int hw = (int)std::thread::hardware_concurrency();
+    int helpers = std::min({n_clips, std::max(hw / 2, std::min(hw, 8)), 64}) - 1;
+#if defined(MOBI_PROFILING)
+    if (const char *hc = getenv("MOBI_HOST_CHUNK")) b->host_chunk = atoi(hc); // (tools/exp_hostparse.py; 0: no pipeline)
+#endif
+    if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
+    b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
+    // Where the parse runs by default: on the host threads up to ~20 resident clips per thread, on the GPU beyond (640x480, r04: 64 threads
+    // take a step of 1024 / 1536 / 2048 clips in 9.1 / 13.6 / 18.2 ms, parse to planes; mobi_parse_frames in 13.2 / 10.6 / 10.4 ms)
+    b->parse_mode = n_clips >= std::max(640, 20 * (b->pool->size() + 1));
     b->parse_auto = true;
     b->lockstep = n_clips >= 12288; // ... and from there on the lock-step parser in front (64 clips per wave: 24 ms per P-frame step whatever the batch)
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) {
@@ -566,10 +546,6 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
       b->lockstep = v == 3;
       b->parse_auto = false;
     }
-    if (const char *fs = getenv("MOBI_FUSED_STEP_MBS")) b->fused_mbs = (size_t)strtoull(fs, nullptr, 10);
-    int helpers = std::min({n_clips, (int)std::thread::hardware_concurrency(), 32}) - 1;
-    if (const char *pt = getenv("MOBI_PARSE_THREADS")) helpers = atoi(pt) - 1;
-    b->pool.reset(new ParsePool(std::max(0, std::min(helpers, 255))));
   }
   if (b->debug == 9) {
     const size_t pbytes = (size_t)n_clips * (b->g.mbw * b->g.mbh) * 16;
@@ -957,18 +933,76 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   }
   if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;
-  // 1. host: serial VLC parse of one frame per clip -> command lists
+  // 1. host: serial VLC parse of one frame per clip -> command lists.  The clips are taken in chunks: while the pool parses chunk k + 1, the
+  // descriptors and payload of chunk k -- staged by the same threads, still warm in their caches -- are on their way to the GPU (a step of
+  // 1024 clips of 640x480 is 100 MB of commands: as long on the bus as it is in the parsers).  A chunk's place in the payload arena is the
+  // sum of the chunks before it, so nothing has to wait for the whole batch; only the launch list does (levels are sorted over all clips).
+  // The pipelined path needs the step to fit the buffers as they are (they grow in the classic path below, with headroom): the first frame
+  // of a batch, and any frame a quarter larger than every one before it, is staged and uploaded after the parse, as all were before r04.
   std::vector<const ParsedFrame *> ok(n, nullptr);
   bool any_version_error = false;
-  const auto t_parse0 = std::chrono::steady_clock::now();
   static const uint8_t kNoData[2] = {0, 0};
-  b->pool->run(n, [&](int i) { rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); }); // Data == null: nothing readable, as Data.Length == 0
-  b->last_hostparse_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_parse0).count();
-  for (int i = 0; i < n; i++) {
-    if (rc[i] == MOBI_OK) ok[i] = &b->cur[i];
-    if (rc[i] == MOBI_E_VERSION) any_version_error = true;
+  const int n_mbs = b->g.mbw * b->g.mbh;
+  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign); // slack: a wave reads up to 8 descriptors at once
+  const size_t buf_cap = std::min(b->h_stage.cap, b->d_cmd.cap);
+  const size_t cap_words = buf_cap > desc_bytes + kPaySlack + kAlign ? (buf_cap - desc_bytes - kPaySlack - kAlign) / 4 : 0;
+  const int chunk = b->host_chunk;
+  const int chunks = chunk > 0 && n >= 2 * chunk ? (n + chunk - 1) / chunk : 1;
+  bool piped = chunks > 1 && cap_words > 0;
+  int uploaded = 0; // clips [0, uploaded) are staged and on their way
+  std::vector<size_t> base(n + 1, 0); // where each clip's payload starts in the step's arena (words)
+  uint8_t *hs = b->h_stage.p;
+  float parse_ms = 0, stage_ms = 0;
+  auto stage_range = [&](int c0, int c1) {
+    for (int i = c0; i < c1; i++) step_write_clip(ok[i], base[i], n_mbs, (MbDesc *)hs + (size_t)i * n_mbs, (uint32_t *)(hs + desc_bytes));
+  };
+  auto stage_clips = [&](int c0, int c1) { // every clip writes its own descriptors and payload (at most 32 writers: more threads than that
+    const int groups = std::min(c1 - c0, 32); // on the pinned buffer slow each other down -- measured: 34 ms -> 70-90 ms per step of 2048 clips)
+    b->pool->run(groups, [&](int g) { stage_range(c0 + (int)((long)(c1 - c0) * g / groups), c0 + (int)((long)(c1 - c0) * (g + 1) / groups)); });
+  };
+  std::atomic<int> up_err{0};
+  auto upload_clips = [&](int c0, int c1) { // (the copy calls hold their thread for as long as the bus is busy: 2.3 ms per 100 MB, measured)
+    if (hipSetDevice(b->device) != hipSuccess) { up_err = 1; return; }
+    const size_t d0 = (size_t)c0 * n_mbs * sizeof(MbDesc), d1 = (size_t)c1 * n_mbs * sizeof(MbDesc);
+    if (hipMemcpyAsync(b->d_cmd.p + d0, hs + d0, d1 - d0, hipMemcpyHostToDevice, b->stream) != hipSuccess) up_err = 1;
+    if (base[c1] > base[c0] &&
+        hipMemcpyAsync(b->d_cmd.p + desc_bytes + base[c0] * 4, hs + desc_bytes + base[c0] * 4, (base[c1] - base[c0]) * 4, hipMemcpyHostToDevice, b->stream) != hipSuccess)
+      up_err = 1;
+  };
+  // Round k of the pool: the clips of chunk k are parsed; beside them chunk k - 1 (parsed, its place in the arena known) is staged in
+  // eight pieces, and chunk k - 2 (staged) is handed to the copy engine by one thread.
+  int staged = 0;        // clips [0, staged) are in the staging buffer
+  for (int k = 0; k < chunks + 2; k++) {
+    const int c0 = k < chunks ? (int)((long)n * k / chunks) : n, c1 = k < chunks ? (int)((long)n * (k + 1) / chunks) : n;
+    const int s0 = staged, s1 = piped && k >= 1 ? (int)((long)n * std::min(k, chunks) / chunks) : staged;         // to stage now: parsed chunks not staged yet
+    const int u0 = uploaded, u1 = piped ? staged : uploaded;                                                       // to upload now: staged, not uploaded
+    const int n_parse = c1 - c0, n_stage = s1 > s0 ? std::min(8, s1 - s0) : 0, n_up = u1 > u0 ? 1 : 0;
+    if (n_parse + n_stage + n_up == 0) continue;
+    const auto t0 = std::chrono::steady_clock::now();
+    b->pool->run(n_up + n_stage + n_parse, [&](int j) {
+      if (j < n_up) { upload_clips(u0, u1); return; }
+      j -= n_up;
+      if (j < n_stage) { stage_range(s0 + (int)((long)(s1 - s0) * j / n_stage), s0 + (int)((long)(s1 - s0) * (j + 1) / n_stage)); return; }
+      const int i = c0 + (j - n_stage);
+      rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); // Data == null: nothing readable, as Data.Length == 0
+    });
+    parse_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (up_err) return MOBI_E_DEVICE;
+    uploaded = u1;
+    staged = s1;
+    for (int i = c0; i < c1; i++) {
+      if (rc[i] == MOBI_OK) ok[i] = &b->cur[i];
+      if (rc[i] == MOBI_E_VERSION) any_version_error = true;
+      base[i + 1] = base[i] + (ok[i] ? ok[i]->payload.size() : 0);
+    }
+    if (any_version_error || base[c1] > cap_words) piped = false; // (what is staged already still goes up if it was asked to; the rest waits for the classic path)
   }
-  if (any_version_error) return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
+  const auto tp1 = std::chrono::steady_clock::now();
+  b->last_hostparse_ms = parse_ms;
+  if (any_version_error) { // DecodeFrame() returns before touching the ring (MD.cs:56-61)
+    if (uploaded) HIP_TRY(hipStreamSynchronize(b->stream)); // (nothing may still be reading the staging buffer when the next call fills it)
+    return MOBI_OK;
+  }
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
@@ -976,40 +1010,43 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // From here on the parsers have consumed the frame and the ring has turned (the two must stay in step: a parser's reference
   // bookkeeping counts frames).  If the call itself fails below, no clip may report MOBI_OK for a frame that was never reconstructed.
   FailAll fail_all{rc, n};
-  if (step_payload_words(ok) + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
+  if (base[n] + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
   LevelPlan plan;
   plan.build(ok, b->g.mbw);
-  // 2. stage [desc table][payload arena][items] and upload
-  const int n_mbs = b->g.mbw * b->g.mbh;
-  const size_t desc_bytes = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign); // slack: a wave reads up to 8 descriptors at once
-  const size_t pay_bytes = align_up(step_payload_words(ok) * 4 + kPaySlack, kAlign);
+  const auto tp2 = std::chrono::steady_clock::now();
+  // 2. what is not on its way yet: [desc table][payload arena] (all of it, if the step did not go chunk by chunk), and the items
+  const size_t pay_bytes = align_up(base[n] * 4 + kPaySlack, kAlign);
   const size_t item_bytes = align_up(plan.items.size() * 4 + 4, kAlign);
-  if (int e = b->h_stage.reserve(desc_bytes + pay_bytes + item_bytes)) return e;
-  if (int e = b->d_cmd.reserve(desc_bytes + pay_bytes)) return e;
+  if (int e = b->h_items.reserve(item_bytes)) return e;
   if (int e = b->d_items.reserve(item_bytes)) return e;
-  uint8_t *hs = b->h_stage.p;
   const auto t_stage0 = std::chrono::steady_clock::now();
-  { // every clip writes its own descriptors and payload (190 MB per step at 2048 clips of 640x480: too much for one thread)
-    std::vector<size_t> base(n + 1, 0);
-    for (int i = 0; i < n; i++) base[i + 1] = base[i] + (ok[i] ? ok[i]->payload.size() : 0);
-    // at most 32 writers: more threads than that on the pinned buffer slow each other down (measured: 34 ms -> 70-90 ms per step)
-    const int groups = std::min(n, 32);
-    b->pool->run(groups, [&](int g) {
-      for (int i = (int)((long)n * g / groups), e = (int)((long)n * (g + 1) / groups); i < e; i++)
-        step_write_clip(ok[i], base[i], n_mbs, (MbDesc *)hs + (size_t)i * n_mbs, (uint32_t *)(hs + desc_bytes));
-    });
+  if (uploaded < n) {
+    if (uploaded) HIP_TRY(hipStreamSynchronize(b->stream)); // the buffers may move: nothing of the chunks that did go may be in flight
+    const size_t want = desc_bytes + pay_bytes + pay_bytes / 4;  // (headroom: the next steps of this size go chunk by chunk)
+    if (int e = b->h_stage.reserve(want)) return e;
+    if (int e = b->d_cmd.reserve(want)) return e;
+    hs = b->h_stage.p;
+    stage_clips(0, n);
+    HIP_TRY(hipMemcpyAsync(b->d_cmd.p, hs, desc_bytes + pay_bytes, hipMemcpyHostToDevice, b->stream));
   }
-  if (!plan.items.empty()) memcpy(hs + desc_bytes + pay_bytes, plan.items.data(), plan.items.size() * 4);
-  b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
-  HIP_TRY(hipMemcpyAsync(b->d_cmd.p, hs, desc_bytes + pay_bytes, hipMemcpyHostToDevice, b->stream));
-  if (!plan.items.empty())
-    HIP_TRY(hipMemcpyAsync(b->d_items.p, hs + desc_bytes + pay_bytes, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
+  if (!plan.items.empty()) {
+    memcpy(b->h_items.p, plan.items.data(), plan.items.size() * 4);
+    HIP_TRY(hipMemcpyAsync(b->d_items.p, b->h_items.p, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
+  }
+  b->last_stage_ms = stage_ms + std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
+  const auto tp3 = std::chrono::steady_clock::now();
   // 3. device: reconstruction
   MobiReconArgs a = b->args(b->d_cmd.p, b->d_cmd.p + desc_bytes);
   if (int e = b->launch_plan(a, plan, (const uint32_t *)b->d_items.p)) return e;
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+  const auto tp4 = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(b->stream));
+  {
+    const auto tp5 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<float, std::milli>(y - x).count(); };
+    b->phase_ms[0] = ms(call_timer.t0, tp1); b->phase_ms[1] = ms(tp1, tp2); b->phase_ms[2] = ms(tp2, tp3); b->phase_ms[3] = ms(tp3, tp4); b->phase_ms[4] = ms(tp4, tp5);
+  }
   fail_all.armed = false;
   b->drain_events();
   for (int i = 0; i < n; i++)

@@ -24,6 +24,7 @@ void ParsedFrame::clear() {
   desc.clear();
   payload.clear();
   intra_mbs.clear();
+  intra_items.clear();
   level_start.clear();
 }
 
@@ -620,6 +621,7 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
   const int n = (int)out.desc.size();
   const long S = g_.stride;
   std::vector<uint16_t> level(n, 0);
+  std::vector<uint8_t> flag(n, 0); // launch-item flags: 2 = has intra dependencies, 4 = has intra dependents
   int maxl = 0, n_intra = 0;
   for (int mb = 0; mb < n; mb++) {
     if ((out.desc[mb].w1 & 1) != MOBI_MB_INTRA) continue;
@@ -636,6 +638,7 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
         if ((deps[k] & 0x1FFF) == o) return;
       if (n_deps == MOBI_INTRA_DEPS) fail(MOBI_E_UNSUPPORTED); // cannot happen: the halo touches at most 7 macroblocks
       deps[n_deps++] = (uint16_t)(o | (level[o] == 0 ? MOBI_DEP_INTER : 0));
+      if (level[o] != 0) { flag[mb] |= 2; flag[o] |= 4; }
     };
     // The halo is the row above (columns -1 .. +23 luma, -1 .. +15 chroma) and the columns left and right of the macroblock.
     // Its owners change only at 16-pixel (8 for chroma) boundaries and, in the side columns, between the first row and the
@@ -672,8 +675,20 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
   for (int l = 1; l <= maxl + 1 && l < (int)out.level_start.size(); l++) out.level_start[l] += out.level_start[l - 1];
   out.intra_mbs.resize(n_intra);
   std::vector<uint32_t> cursor(out.level_start.begin(), out.level_start.end());
+  out.intra_items.resize((size_t)n_intra * 4);
   for (int mb = 0; mb < n; mb++)
-    if (level[mb]) out.intra_mbs[cursor[level[mb]]++] = (uint32_t)mb;
+    if (level[mb]) {
+      const uint32_t at = cursor[level[mb]]++;
+      out.intra_mbs[at] = (uint32_t)mb;
+      const MbDesc &d = out.desc[mb];
+      const int mbx = mb % g_.mbw;
+      const bool interior = mbx >= 1 && mbx + 1 < g_.mbw && mb >= g_.mbw;
+      uint32_t *it = &out.intra_items[(size_t)at * 4];
+      it[0] = (uint32_t)mb;
+      it[1] = d.w1;
+      it[2] = d.payload_off;
+      it[3] = (d.w3 & 0xFFFF0001u) | flag[mb] | (interior ? 0u : 8u) | ((d.w2 & 0x3FFu) << 5);
+    }
   out.hdr.n_mbs = (uint32_t)n;
   out.hdr.n_intra = (uint32_t)n_intra;
   out.hdr.n_levels = (uint32_t)maxl;

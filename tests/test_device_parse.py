@@ -257,10 +257,12 @@ def test_hybrid_parse_matches_the_oracle(monkeypatch):
 
 
 def test_default_parse_side_follows_batch_size_and_packet_shape(monkeypatch, profiling_library):
-    """No explicit choice: 1024 clips and more parse on the GPU when Data looks like packets, on the host when Data is a whole
-    file (MOC5 style; the device path would have to upload megabytes per clip and frame).  Same planes either way."""
+    """No explicit choice: from 20 resident clips per host parse thread (640 at least) the parse runs on the GPU when Data looks like
+    packets, on the host when Data is a whole file (MOC5 style; the device path would have to upload megabytes per clip and frame).
+    Same planes either way."""
     import ctypes as C
     monkeypatch.delenv("MOBI_DEVICE_PARSE", raising=False)  # the suite may be run with the parse side forced
+    monkeypatch.setenv("MOBI_PARSE_THREADS", "32")  # (the default follows the host's core count)
     lib = profiling_library  # (mobi_debug_read_parse is a hook of the profiling twin only)
     lib.mobi_debug_read_parse.restype = C.c_longlong
     lib.mobi_debug_read_parse.argtypes = [C.c_void_p] * 5 + [C.c_size_t]
@@ -273,7 +275,7 @@ def test_default_parse_side_follows_batch_size_and_packet_shape(monkeypatch, pro
         o = ora.DecodeFrame()
         want.append((o[0].copy(), o[1].copy()))
     whole = np.concatenate([data, np.zeros(300000, np.uint8)])  # a "file" with a long tail behind the three frames
-    for n, style, expect_device in [(1024, "packets", True), (1024, "file", False), (1023, "packets", False)]:
+    for n, style, expect_device in [(640, "packets", True), (640, "file", False), (639, "packets", False)]:
         b = MobiclipBatch(n, 64, 48, p.version)
         for f in range(3):
             if style == "packets":

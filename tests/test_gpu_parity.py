@@ -298,3 +298,44 @@ def test_deeper_trees_cell_by_cell(w, h, ver):
         p = default_params("A" if ver == 1 else "B", BASE_SEED + 950 + w + cbp, n_frames=7, width=w, height=h, pm_deep=900, pm_split1=50, pm_skip=20,
                            pm_intra=10, pm_multiref=500, mv_range=70, edge_mode=1, cbp_prob=cbp)
         _run_stream(p)
+
+
+def test_host_parsed_step_chunk_by_chunk_and_its_fallback():
+    """mobi_batch_decode with the parse on the host takes the clips in chunks of 128 and uploads a chunk's commands while the next is
+    parsed -- when the step fits the buffers as they are; a step larger than every one before it is staged after the parse, as all were
+    before.  288 clips (three chunks) of 16 streams; the second half of the batch hands over nothing at step 0 (an exception, as
+    Data.Length == 0 would be) and starts its stream a step late: step 0 sizes the buffers for half a batch of I-frames, step 1 brings the
+    late half's I-frames beside the first half's P-frames and outgrows them in its second chunk (the fallback, with a chunk already on its
+    way), the steps after that go chunk by chunk.  Every clip against its own oracle, every frame."""
+    n, distinct, nfr, W, H = 288, 16, 5, 160, 112
+    ps = [default_params("A", BASE_SEED + 5200 + i, n_frames=nfr, width=W, height=H, version=2, pm_intra=80, cbp_prob=500) for i in range(distinct)]
+    clips = [generate_clip(p) for p in ps]
+    late = lambda c: c >= n // 2
+    oras = [OracleDecoder(W, H, MobiclipVersion.Moflex3DS) for _ in range(2 * distinct)]  # (stream, on time / late)
+    b = MobiclipBatch(n, W, H, MobiclipVersion.Moflex3DS, device_parse=False)
+    for step in range(nfr + 1):
+        def frame_of(c):
+            f = step - 1 if late(c) else step
+            return f if 0 <= f < nfr else None
+        datas = []
+        for c in range(n):
+            f = frame_of(c)
+            data, fo = clips[c % distinct]
+            datas.append(data[fo[f]:fo[f + 1]] if f is not None else b"")
+        rcs, offs = b.decode(datas, [0] * n)
+        want = {}
+        for k in range(2 * distinct):
+            f = frame_of(k % distinct + (n // 2 if k >= distinct else 0))
+            data, fo = clips[k % distinct]
+            oras[k].Data, oras[k].Offset = (data[fo[f]:fo[f + 1]] if f is not None else b""), 0
+            want[k] = (oras[k].DecodeFrame(), oras[k].Offset, oras[k].last_error)
+        for c in range(n):
+            o, off, err = want[c % distinct + (distinct if late(c) else 0)]
+            if o is None:
+                assert rcs[c] == err != 0, (step, c)
+                continue
+            assert rcs[c] == 0 and offs[c] == off, (step, c)
+            if c % 7 == 0 or step == nfr:
+                y, uv = b.planes(c)
+                assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (step, c)
+    b.close()

@@ -39,7 +39,7 @@ def run(n_clips, device_parse, n_frames=9, distinct=16):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
-    modes = (True,) if "--device-only" in sys.argv else ("hybrid",) if "--hybrid" in sys.argv else ("lockstep",) if "--lockstep" in sys.argv else \
+    modes = (False,) if "--host-only" in sys.argv else (True,) if "--device-only" in sys.argv else ("hybrid",) if "--hybrid" in sys.argv else ("lockstep",) if "--lockstep" in sys.argv else \
             (True, "lockstep") if "--device-both" in sys.argv else (False, True)
     sizes = [int(a) for a in args] or [512, 2048]
     for n in sizes:
