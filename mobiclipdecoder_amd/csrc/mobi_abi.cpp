@@ -987,7 +987,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
       rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); // Data == null: nothing readable, as Data.Length == 0
     });
     parse_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (up_err) return MOBI_E_DEVICE;
+    if (up_err) piped = false; // (reported below, once the ring has turned and every clip's rc can say so: the parsers have consumed their frames)
     uploaded = u1;
     staged = s1;
     for (int i = c0; i < c1; i++) {
@@ -1010,6 +1010,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // From here on the parsers have consumed the frame and the ring has turned (the two must stay in step: a parser's reference
   // bookkeeping counts frames).  If the call itself fails below, no clip may report MOBI_OK for a frame that was never reconstructed.
   FailAll fail_all{rc, n};
+  if (up_err) return MOBI_E_DEVICE;
   if (base[n] + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
   LevelPlan plan;
   plan.build(ok, b->g.mbw);
