@@ -36,6 +36,8 @@ timeout 400 python $REPO/tools/exp_intra_ablate.py 8192 > "$OUT/intra_ablate.txt
 for N in 64 512 4096; do timeout 200 python $REPO/bench.py --clips $N --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --steps 96 2>/dev/null; done > "$OUT/bench_small.jsonl"
 timeout 200 python $REPO/tools/exp_iframe.py 4096 > "$OUT/iframe.txt" 2>&1
 timeout 200 python $REPO/tools/exp_iframe.py 24576 >> "$OUT/iframe.txt" 2>&1
+bash $REPO/tools/exp_fused.sh $TAG/fused_raw > "$OUT/fused.txt" 2>&1
+{ for N in 256 512 1024 2048; do timeout 200 python $REPO/tools/exp_hostparse.py $N | tail -1; done; MOBI_HOST_CHUNK=0 timeout 200 python $REPO/tools/exp_hostparse.py 1024 | tail -1 | sed "s/^/no pipeline: /"; MOBI_PARSE_THREADS=32 timeout 200 python $REPO/tools/exp_hostparse.py 1024 | tail -1; } > "$OUT/hostparse.txt" 2>&1
 { timeout 600 python $REPO/tools/exp_dparse.py 4096 8192 24576 --device-both; } > "$OUT/lsparse.txt" 2>&1
 timeout 300 python $REPO/tools/exp_async.py 4096 12 > "$OUT/async.txt" 2>&1
 { timeout 600 python $REPO/tools/fuzz_intra_gpu.py 2000 100; timeout 600 python $REPO/tools/fuzz_inter_gpu.py 3000 100; timeout 900 python $REPO/tools/soak_parity.py 4096 B; timeout 900 python $REPO/tools/soak_parity.py 8192 B lockstep; } > "$OUT/fuzz.txt" 2>&1
