@@ -20,7 +20,11 @@ def lib():
         L.mobi_cmdinterp_y.argtypes = [C.c_void_p, C.c_int]
         L.mobi_cmdinterp_uv.restype = C.POINTER(C.c_uint8)
         L.mobi_cmdinterp_uv.argtypes = [C.c_void_p, C.c_int]
-        for n in ("stride", "quantizer", "cmd_bytes", "levels"):
+        for n in ("desc", "intra_mbs", "level_start", "intra_items"):
+            f = getattr(L, "mobi_cmdinterp_" + n)
+            f.argtypes = [C.c_void_p]
+            f.restype = C.POINTER(C.c_uint32)
+        for n in ("stride", "quantizer", "cmd_bytes", "levels", "n_mbs", "n_intra"):
             f = getattr(L, "mobi_cmdinterp_" + n)
             f.argtypes = [C.c_void_p]
             f.restype = C.c_uint32
@@ -72,3 +76,11 @@ class InterpDecoder:
             self.close()
         except Exception:
             pass
+
+    def command_list(self):
+        """The last frame's command list as the host parser left it: (desc [n_mbs, 8], intra_mbs [n_intra], level_start [levels + 2],
+        intra_items [n_intra, 4]) -- copies."""
+        n, ni, nl = self.L.mobi_cmdinterp_n_mbs(self.h), self.L.mobi_cmdinterp_n_intra(self.h), self.levels
+        arr = lambda f, shape: np.ctypeslib.as_array(f(self.h), shape).copy() if int(np.prod(shape)) else np.zeros(shape, np.uint32)
+        return (arr(self.L.mobi_cmdinterp_desc, (n, 8)), arr(self.L.mobi_cmdinterp_intra_mbs, (ni,)),
+                arr(self.L.mobi_cmdinterp_level_start, (nl + 2,)), arr(self.L.mobi_cmdinterp_intra_items, (ni, 4)))

@@ -1,0 +1,55 @@
+"""The launch items of intra macroblocks (ParsedFrame::intra_items, mobi_parse.cpp finish_levels) against the descriptors they summarise.
+The step's launch list (LevelPlan, mobi_abi.cpp) is a concatenation of these, so what a wave of mobi_recon_intra is told -- where the
+records are, whether to poll tags, whether to publish its own -- is decided here, in the parser."""
+import numpy as np
+import pytest
+
+from mobiclipdecoder_amd import default_params, generate_clip
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+from tests.interp_binding import InterpDecoder
+
+DEP_NONE, DEP_INTER = 0xFFFF, 0x8000
+
+
+@pytest.mark.parametrize("cfg,kw", [("A", dict(pm_intra=300)), ("A", dict(width=64, height=48, pm_intra=500, plane_prob=500)),
+                                    ("B", dict(pm_intra=120, n_frames=4)), ("A", dict(width=1024, height=32, version=2, pm_intra=400))])
+def test_items_say_what_the_descriptors_say(cfg, kw):
+    p = default_params(cfg, BASE_SEED + 6100, **{"n_frames": 5, **kw})
+    data, fo = generate_clip(p)
+    d = InterpDecoder(p.width, p.height, p.version)
+    mbw = p.width // 16
+    seen_deps = seen_dependents = seen_edge = 0
+    for f in range(p.n_frames):
+        d.Data, d.Offset = data[: fo[f + 1]], int(fo[f])
+        assert d.DecodeFrame() is not None
+        desc, mbs, ls, items = d.command_list()
+        intra = np.nonzero((desc[:, 1] & 1) == 1)[0]  # MOBI_MB_INTRA
+        assert sorted(mbs.tolist()) == intra.tolist() and len(items) == len(mbs)
+        assert ls[0] == 0 and ls[1] == 0 and ls[-1] == len(mbs) and np.all(np.diff(ls.astype(np.int64)) >= 0)
+        named = set()  # intra macroblocks some other intra macroblock's halo reads
+        for mb in mbs:
+            w = desc[mb, 4:8]
+            for dep in np.concatenate([w & 0xFFFF, w >> 16]):
+                if dep != DEP_NONE and not dep & DEP_INTER:
+                    assert (desc[dep & 0x1FFF, 1] & 1) == 1 and (dep & 0x1FFF) < mb
+                    named.add(int(dep & 0x1FFF))
+        level = {}
+        for L in range(1, len(ls) - 1):
+            for i in range(ls[L], ls[L + 1]):
+                level[int(mbs[i])] = L
+        for i, mb in enumerate(mbs):
+            it = items[i]
+            assert it[0] == mb and it[1] == desc[mb, 1] and it[2] == desc[mb, 0]
+            w = desc[mb, 4:8]
+            deps = [int(x) for x in np.concatenate([w & 0xFFFF, w >> 16]) if x != DEP_NONE]
+            intra_deps = [x & 0x1FFF for x in deps if not x & DEP_INTER]
+            flags = int(it[3])
+            assert (flags & 0xFFFF0001) == (int(desc[mb, 3]) & 0xFFFF0001)
+            assert bool(flags & 2) == bool(intra_deps) and bool(flags & 4) == (int(mb) in named)
+            mbx = int(mb) % mbw
+            assert bool(flags & 8) == (not (mbx >= 1 and mbx + 1 < mbw and mb >= mbw))
+            assert (flags >> 5) & 0x3FF == int(desc[mb, 2]) & 0x3FF and not flags & 0x8010
+            # a macroblock's level is one more than the highest level among the intra macroblocks it waits for
+            assert level[int(mb)] == 1 + max([level[x] for x in intra_deps], default=0)
+            seen_deps += bool(flags & 2); seen_dependents += bool(flags & 4); seen_edge += bool(flags & 8)
+    assert seen_deps and seen_dependents and seen_edge

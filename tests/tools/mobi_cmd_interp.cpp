@@ -283,4 +283,12 @@ int mobi_cmdinterp_stride(void *p) { return ((Interp *)p)->g.stride; }
 uint32_t mobi_cmdinterp_quantizer(void *p) { return ((Interp *)p)->parser.quantizer(); }
 uint32_t mobi_cmdinterp_cmd_bytes(void *p) { return ((Interp *)p)->pf.hdr.cmd_bytes; }
 uint32_t mobi_cmdinterp_levels(void *p) { return ((Interp *)p)->pf.hdr.n_levels; }
+// the last frame's command list as the parser left it (tests/test_launch_items.py): descriptors (8 words per macroblock), the intra
+// macroblocks in launch order with the start of every level, and the launch items the parser wrote for them (4 words each)
+uint32_t mobi_cmdinterp_n_mbs(void *p) { return (uint32_t)((Interp *)p)->pf.desc.size(); }
+const uint32_t *mobi_cmdinterp_desc(void *p) { return (const uint32_t *)((Interp *)p)->pf.desc.data(); }
+uint32_t mobi_cmdinterp_n_intra(void *p) { return (uint32_t)((Interp *)p)->pf.intra_mbs.size(); }
+const uint32_t *mobi_cmdinterp_intra_mbs(void *p) { return ((Interp *)p)->pf.intra_mbs.data(); }
+const uint32_t *mobi_cmdinterp_level_start(void *p) { return ((Interp *)p)->pf.level_start.data(); }
+const uint32_t *mobi_cmdinterp_intra_items(void *p) { return ((Interp *)p)->pf.intra_items.data(); }
 }
