@@ -65,7 +65,7 @@ lowest scan positions — DC-dominated content, what the reference's `IDCT1P` / 
 commands per frame against {(B['roofline']['whole_step_bytes'] / B['config']['clips_per_gpu'] - 921600) / 1e3:.0f}.
 
 B at small batches (`profiles/{RND}_small_batches.jsonl`): ''' + "; ".join(
-    f"{x['config']['clips_per_gpu']} clips {x['ms_per_step']:.3f} ms per step = {x['value'] / 1e3:.0f} Gpixels/s (inter frac {x['roofline']['frac']:.2f}, whole step {x['roofline']['whole_step_frac']:.2f})"
+    f"{x['config']['clips_per_gpu']} clips {x['ms_per_step']:.3f} ms per step = {x['value'] / 1e3:.0f} Gpixels/s (" + (f"one launch, whole step {x['roofline']['whole_step_frac']:.3f}" if x['roofline'].get('kernel') == 'mobi_recon_step' else f"inter frac {x['roofline']['frac']:.2f}, whole step {x['roofline']['whole_step_frac']:.2f}") + ")"
     for x in small) + f'''. 8 clips
 (`config4`: BASELINE.json's 64 clips over 8 GPUs = 8 per GPU): {c4['ms_per_step']:.4f} ms per step = {c4['value'] / 1e3:.0f} Gpixels/s — one launch (`mobi_recon_step`) of 1200 octet and ≈480 intra
 waves: wave latency plus a chain of two or three dependency levels. An I-frame step (all macroblocks intra, outside the timed region): ''' + ", ".join(f"{float(ms):.1f} ms at {n} clips" for n, ms in ifr) + f'''.
