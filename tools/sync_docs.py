@@ -84,8 +84,8 @@ read-back of 32 B per clip, synchronisation): {e2e['ms_per_step']:.1f} ms per st
 `mobi_batch_submit` / `mobi_batch_wait` with two steps in flight: {e2e['async']['ms_per_step']:.1f} ms = {e2e['async']['value'] / 1e3:.0f} Gpixels/s (`end_to_end.async`).
 At the headline batch with the lock-step parser in front (`end_to_end_large`, {e2l['clips']} clips): {e2l['ms_per_step']:.1f} ms per step = **{e2l['value'] / 1e3:.0f} Gpixels/s**,
 asynchronous {e2l['async']['ms_per_step']:.1f} ms = **{e2l['async']['value'] / 1e3:.0f} Gpixels/s**. The parse is what such a step waits for (`HISTORY.md`, parsers). PCIe-inclusive rate of the
-*reconstruction* path fed with host-parsed command lists: ≈90 KB of commands per 640×480 frame, 10 % of the pixel bytes, 20 Gpixels/s with
-32 parse threads (the parse, not PCIe, limits).
+*reconstruction* path fed with host-parsed command lists: ≈90 KB of commands per 640×480 frame, 10 % of the pixel bytes, 35 Gpixels/s with
+64 parse threads at 1024 clips (`profiles/{RND}_ubench.txt`, hostparse: parse, staging and upload pipelined; the parse, not PCIe, limits).
 '''
 s = open("DESIGN.md").read()
 a, b = s.index("<!-- results:begin -->") + len("<!-- results:begin -->\n"), s.index("<!-- results:end -->")
