@@ -103,3 +103,40 @@ def test_division_by_239_is_correctly_rounded_for_every_float():
     rounded for arbitrary divisors, so it is checked for this one over all 2^32 bit patterns on the device."""
     from mobiclipdecoder_amd import decoder
     assert decoder.load_library().mobi_selftest_div239(0) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,version", [(16, 16, 2), (48, 32, 1), (848, 48, 2), (1024, 32, 2), (256, 64, 1), (80, 16, 2)])
+def test_hip_bitmap_on_random_planes(w, h, version, profiling_library):
+    """The Bitmap kernel on planes of random bytes (every Y / U / V value beside every other, the extremes included -- decoded pictures
+    are smooth): one wave takes two macroblocks side by side, so widths with an odd number of macroblocks (16, 48, 848, 80), a single
+    macroblock, Width == Stride (1024) and both colour paths are here; the last row and the last column take no chroma mean (MD.cs:269).
+    Checked against the oracle's ARGB (itself pinned to the float32 restatement above)."""
+    import ctypes as C
+    from mobiclipdecoder_amd import MobiclipDecoder
+    from tests.test_unit_vectors import _inject
+    p = default_params("A", BASE_SEED + 43, n_frames=1, width=w, height=h, version=version)
+    data, fo = generate_clip(p)
+    g = MobiclipDecoder(w, h, version)
+    o = OracleDecoder(w, h, version)
+    g.Data = o.Data = data[fo[0]:fo[1]]
+    g.Offset = o.Offset = 0
+    assert g.DecodeFrame() is not None and o.DecodeFrame() is not None
+    rng = np.random.default_rng(w * 131 + h)
+    for trial in range(4):
+        y = np.zeros((h, o.Stride), np.uint8)
+        uv = np.zeros((h // 2, o.Stride), np.uint8)
+        if trial == 3:  # extremes only
+            y[:, :w] = rng.choice(np.array([0, 1, 15, 16, 17, 254, 255], np.uint8), (h, w))
+            uv[:, : w // 2] = rng.choice(np.array([0, 1, 127, 128, 129, 255], np.uint8), (h // 2, w // 2))
+            uv[:, o.Stride // 2: o.Stride // 2 + w // 2] = rng.choice(np.array([0, 1, 127, 128, 129, 255], np.uint8), (h // 2, w // 2))
+        else:
+            y[:, :w] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            uv[:, : w // 2] = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+            uv[:, o.Stride // 2: o.Stride // 2 + w // 2] = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+        _inject(profiling_library, g, o, y, uv)
+        a, b = g.Bitmap(), o.argb()
+        assert np.array_equal(a, b), (trial, np.argwhere(a != b)[:8].tolist())
+        assert np.array_equal(b, _numpy_argb(y, uv, w, h, version))
+    g.close()
+    o.close()
