@@ -207,6 +207,44 @@ def config4_leg(m, streams, W, H, version, device, n_clips, n_steps):
             "note": "one launch per step (mobi_recon_step: 1200 octet waves of inter macroblocks and ~480 intra waves, one macroblock each at this size, which wait for the tags of the macroblocks their halo reads): launch latency and two or three dependency levels, not bandwidth"}
 
 
+def bitmap_leg(m, streams, W, H, version, device, n_clips):
+    """Row f1: the Bitmap DecodeFrame() returns (MD.cs:260-323) for every clip of a resident batch, mobi_yuv_to_argb alone: 1.5 bytes read
+    and 4 written per pixel against the HBM roofline.  Beside the headline, never in it (the headline metric is planes)."""
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device)
+    for c in range(n_clips):
+        if c < len(streams):
+            p, data, fo = streams[c]
+            assert all(r == 0 for r in b.preload(c, data, fo))
+        else:
+            b.preload_clone(c, c % len(streams))
+    b.commit()
+    for f in range(3):
+        b.replay(f)
+    assert b.sync() == 0
+    for _ in range(3):
+        b.convert_argb()
+    assert b.sync() == 0
+    n = 20
+    b.time_begin()
+    for _ in range(n):
+        b.convert_argb()
+    ms = b.time_end() / n
+    got = b.bitmap(n_clips - 1)
+    from tests.oracle_binding import OracleDecoder  # (the checker)
+    p, data, fo = streams[(n_clips - 1) % len(streams)]
+    o = OracleDecoder(W, H, version)
+    for f in range(3):
+        o.Data, o.Offset = data, int(fo[f])
+        assert o.DecodeFrame() is not None
+    ok = bool((got == o.argb()).all())
+    b.close()
+    byts = n_clips * W * H * 5.5
+    return {"kernel": "mobi_yuv_to_argb", "clips": n_clips, "ms": round(ms, 4), "value": round(n_clips * W * H / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+            "roofline": {"bound": "hbm", "achieved": round(byts / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": int(byts)},
+            "verified": {"clip": n_clips - 1, "ok": ok, "against": "CPU oracle's ARGB of the same frame"}}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without an external launcher: start one worker per GPU (LOCAL_RANK = GPU index), each a copy of
     this command with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- exactly the environment `torch.distributed.run` would give
@@ -344,6 +382,7 @@ def main():
     ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
     ap.add_argument("--e2e-steps", type=int, default=12)
     ap.add_argument("--e2e-large-clips", type=int, default=24576, help="clips of the second end-to-end leg, at the headline batch size with the lock-step parser (64 clips per wavefront); 0 = skip")
+    ap.add_argument("--bitmap-clips", type=int, default=512, help="clips of the Bitmap leg (row f1: mobi_yuv_to_argb on a resident batch); 0 = skip")
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--single-stream", type=int, default=1, help="1: time one clip through mobi_decode / mobi_get_argb (the boundary's own shape); 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline becomes null)")
@@ -508,6 +547,12 @@ def main():
             e2e_large = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and args.config4_clips > 0 and args.config == "B":
         c4 = config4_leg(m, streams, W, H, p0.version, local, args.config4_clips, 24)
+    bitmap = None
+    if world == 1 and args.bitmap_clips > 0 and args.config == "B":
+        try:
+            bitmap = bitmap_leg(m, streams, W, H, p0.version, local, args.bitmap_clips)
+        except Exception as e:
+            bitmap = {"error": f"{type(e).__name__}: {e}"}
     content = None
     if world == 1 and args.content_lowfreq > 0 and not gen_over:
         try:
@@ -575,7 +620,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "verified": verified, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single, "content_lowfreq": content,
+            "verified": verified, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

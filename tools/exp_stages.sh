@@ -8,7 +8,7 @@ TAG=${1:-stages}; CLIPS=${2:-4096}; REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/g
 export MOBI_LIB=$REPO/mobiclipdecoder_amd/libmobiclip_hip_prof.so
 cd /tmp && export TMPDIR=/tmp
 for ST in 1 2 3 4 5 6 7 8 9 10 11 12 0; do
-  MOBI_STOP_STAGE=$ST timeout 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d "$OUT/s$ST" -o p -- python $REPO/bench.py --config ${CONFIG:-B} --clips $CLIPS --steps 4 --warmup 1 --cpu-seconds 0 --no-kernel-events --e2e-clips 0 --config4-clips 0 --single-stream 0 > "$OUT/s$ST.log" 2>&1
+  MOBI_STOP_STAGE=$ST timeout 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d "$OUT/s$ST" -o p -- python $REPO/bench.py --config ${CONFIG:-B} --clips $CLIPS --steps 4 --warmup 1 --cpu-seconds 0 --no-kernel-events --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --bitmap-clips 0 > "$OUT/s$ST.log" 2>&1
   python - "$OUT/s$ST" $ST <<'PY'
 import sys, csv, glob, collections
 acc = collections.defaultdict(float)

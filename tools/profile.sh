@@ -11,7 +11,7 @@ for CFG in B A C; do
   # A: 1.3 ms per step, C: 12 ms (24576 clips, halved by bench.py if they do not fit): >= 1 s of timed region for each
   EXTRA=""; [ "$CFG" = "A" ] && EXTRA="--steps 1024"; [ "$CFG" = "C" ] && EXTRA="--steps 400"
   timeout -k 5 900 python $REPO/bench.py --config $CFG $EXTRA > "$D/bench.json" 2> "$D/bench.err"
-  BENCH="python $REPO/bench.py --config $CFG --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0"
+  BENCH="python $REPO/bench.py --config $CFG --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --bitmap-clips 0"
   timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o t -- $BENCH --steps 64 > "$D/trace.log" 2>&1 || echo "trace failed" >> "$D/errors.log"
   i=0
   while read -r PMC; do
@@ -33,7 +33,7 @@ done
 bash $REPO/tools/exp_stages.sh $TAG/stages_inter 4096 > "$OUT/stages_inter.txt" 2>&1
 bash $REPO/tools/exp_istages.sh $TAG/stages_intra 4096 > "$OUT/stages_intra.txt" 2>&1
 timeout 400 python $REPO/tools/exp_intra_ablate.py 8192 > "$OUT/intra_ablate.txt" 2>&1
-for N in 64 512 4096; do timeout 200 python $REPO/bench.py --clips $N --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --steps 96 2>/dev/null; done > "$OUT/bench_small.jsonl"
+for N in 64 512 4096; do timeout 200 python $REPO/bench.py --clips $N --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --bitmap-clips 0 --steps 96 2>/dev/null; done > "$OUT/bench_small.jsonl"
 timeout 200 python $REPO/tools/exp_iframe.py 4096 > "$OUT/iframe.txt" 2>&1
 timeout 200 python $REPO/tools/exp_iframe.py 24576 >> "$OUT/iframe.txt" 2>&1
 bash $REPO/tools/exp_fused.sh $TAG/fused_raw > "$OUT/fused.txt" 2>&1

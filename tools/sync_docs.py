@@ -75,7 +75,10 @@ waves: wave latency plus a chain of two or three dependency levels. An I-frame s
 upload, launch, synchronise), wall time per call: **P-frame {ss['planes']['p_frame_ms']:.2f} ms, I-frame {ss['planes']['i_frame_ms']:.2f} ms**; with `mobi_get_argb` (the Bitmap `DecodeFrame()`
 returns) {ss['with_bitmap']['p_frame_ms']:.2f} / {ss['with_bitmap']['i_frame_ms']:.2f} ms; the oracle on one host thread: {ss['oracle_ms_per_frame_1_thread']:.2f} ms per frame (planes only). One clip fills 0.3 % of the part: its place is the batch.
 
-`cpu_baseline`: the oracle (a C restatement, expected to be faster than the C# original: no GC, no per-row allocations), same
+''' + (f'''**The Bitmap** (`bitmap`, row f1): `mobi_yuv_to_argb` on {B['bitmap']['clips']} resident clips: {B['bitmap']['ms']:.3f} ms = {B['bitmap']['value'] / 1e3:.0f} Gpixels/s,
+{B['bitmap']['roofline']['achieved'] / 1e3:.2f} TB/s of its 5.5 algorithmic bytes per pixel = **{B['bitmap']['roofline']['frac']:.3f}** of the roofline; checked against the oracle's ARGB.
+
+''' if B.get('bitmap') and 'ms' in B['bitmap'] else '') + f'''`cpu_baseline`: the oracle (a C restatement, expected to be faster than the C# original: no GC, no per-row allocations), same
 stream, parse + reconstruction, one C call per clip: one thread {cb['value']:.0f} Mpixels/s on the GPU box's host (`value`); one thread including
 the Bitmap conversion {cb['with_bitmap']['value']:.0f} Mpixels/s (`with_bitmap`); `all_cpus` = one decoder per host cpu ({cb['all_cpus']['cores']}): {cb['all_cpus']['value'] / 1e3:.1f} Gpixels/s.
 
@@ -113,6 +116,8 @@ rows = [f"| A 256×192 Mods P-stream | 1 | {A['config']['clips_per_gpu']} | {n(A
 for x in small:
     k = x["config"]["clips_per_gpu"]
     rows.append(f"| B ×{k} clips | 1 | {k} | {n(x['value'])} | — | {pct(x)} | " + (f"{n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous)" if k == 4096 else "—") + " | | yes |")
+if B.get('bitmap') and 'ms' in B['bitmap']:
+    rows.append(f"| B, the Bitmap of every clip (`bitmap`: `mobi_yuv_to_argb`, {B['bitmap']['clips']} clips) | 1 | {B['bitmap']['clips']} | {n(B['bitmap']['value'])} | — | {B['bitmap']['roofline']['frac'] * 100:.1f} (its own 5.5 B per pixel) | — | {cb['with_bitmap']['value']:.0f} / — (decode + Bitmap) | yes |")
 rows.append(f"| B single stream (`mobi_decode`, one clip) | 1 | 1 | {n(ss['value'])} (P-frame {ss['planes']['p_frame_ms']:.2f} ms, I-frame {ss['planes']['i_frame_ms']:.2f} ms per call; with the Bitmap "
             f"{ss['with_bitmap']['p_frame_ms']:.2f} / {ss['with_bitmap']['i_frame_ms']:.2f} ms) | — | — | = | {307.2 / ss['oracle_ms_per_frame_1_thread']:.0f} / — ({ss['oracle_ms_per_frame_1_thread']:.2f} ms per frame) | yes |")
 s = open("BASELINE.md").read()

@@ -23,7 +23,7 @@ for cfg in "BAC":
         if "mobi" in r["Kernel_Name"]:
             groups[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     with open(os.path.join(dst, f"{RND}_{cfg}_kernel_by_grid.txt"), "w") as o:
-        o.write(f"# rocprofv3 --kernel-trace of: python bench.py --config {cfg} --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --steps 64\n")
+        o.write(f"# rocprofv3 --kernel-trace of: python bench.py --config {cfg} --cpu-seconds 0 --e2e-clips 0 --config4-clips 0 --single-stream 0 --content-lowfreq 0 --bitmap-clips 0 --steps 64\n")
         o.write("# (I-frame at start + 8 warm-up + 64 timed P-frame steps + 2 I-frame re-seeds; grid = work-items = 64 x waves)\n")
         o.write("# kernel                grid_size    launches   avg_ms    min_ms    max_ms\n")
         for (k, g), v in sorted(groups.items()):
