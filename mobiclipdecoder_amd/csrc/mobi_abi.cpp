@@ -778,7 +778,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
   if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
-  if (K && mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), (int)K, b->stream) != 0)
+  if (K && mobi_launch_intra_cl(&a, (const uint32_t *)b->d_pitems.p, &b->d_pres[0].n_intra, (int)(sizeof(MobiDevResult) / 4), (int)K, 0, b->stream) != 0)
     return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
@@ -865,8 +865,8 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   a.done = b->d_done;
   if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
   // the parse has not run yet, so nobody knows how many intra macroblocks the longest list will have: MOBI_ASYNC_INTRA_SLOTS slots are launched
-  // (a P-frame's lists are shorter), and the workgroups of the last one walk through the rest of theirs (an I-frame: every macroblock)
-  if (mobi_launch_intra_cl(&a, (const uint32_t *)S.d_pitems.p, &d_res[0].n_intra, (int)(sizeof(MobiDevResult) / 4), std::min(n_mbs, MOBI_ASYNC_INTRA_SLOTS), b->stream) != 0) return MOBI_E_DEVICE;
+  // (a P-frame's lists are shorter), and a second launch (mobi_recon_intra_walk, one workgroup per four clips) goes through the rest of theirs (an I-frame: every macroblock)
+  if (mobi_launch_intra_cl(&a, (const uint32_t *)S.d_pitems.p, &d_res[0].n_intra, (int)(sizeof(MobiDevResult) / 4), std::min(n_mbs, MOBI_ASYNC_INTRA_SLOTS), 1, b->stream) != 0) return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(S.h_fault.p, b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   HIP_TRY(hipEventRecord(S.ev_done, b->stream));

@@ -41,9 +41,10 @@ extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_d
 // small batches: both of the above in one launch (mobi_recon_step: the intra fours wait for the inter macroblocks their halo reads)
 extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s);
 // device-parsed frames: items_dev = [clip][n_mbs] in raster order, n_intra_dev[clip * stride_words] of them valid; K = the slots launched:
-// the largest count when the host knows it, else MOBI_ASYNC_INTRA_SLOTS (longer lists are walked by the workgroups of slot K - 1)
+// the largest count when the host knows it (walk = 0), else MOBI_ASYNC_INTRA_SLOTS and walk = 1: a second launch, mobi_recon_intra_walk, one
+// workgroup per four clips, goes through what the lists hold beyond K
 #define MOBI_ASYNC_INTRA_SLOTS 160
-extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s);
+extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, int walk, hipStream_t s);
 // MD.cs:260-323: ring slot 0 of clips [clip0, clip0 + n_clips) -> out_dev[clip][height][width] 0xAARRGGBB words (mobi_rgb.hip)
 extern "C" int mobi_launch_argb(const MobiReconArgs *a, int version, int clip0, int n_clips, uint32_t *out_dev, hipStream_t s);
 extern "C" long long mobi_launch_div239_check(hipStream_t s); // mismatches of the RGB kernel's x/239 over all floats, or -1

@@ -1038,16 +1038,21 @@ MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16)
 // record and read back by all 16.  The wave runs as many steps as its longest macroblock has (95 % of the areas are unsplit in the
 // generator's mix); the wave-level branches inside a step ask "does any of the four need a plane / a DC / an 8x8 / a 4x4 now".
 namespace {
-// LDS of one macroblock, 2080 bytes, two lives:
+// LDS of one macroblock, 1888 bytes, two lives:
 //   while the residuals are made    [0, 1536) coefficients, int32 [6][64]               [1536, 1856) dequant scales
-//   from then on                    [0, 768) residuals, int16 [6][64]   [768, 1888) the three tiles   [1888, 2080) step descriptors
+//   from then on                    [0, 768) residuals, int16 [6][64]   [768, 1888) the three tiles, the step descriptors in their slack
 // (pass 2 of the transforms writes the int16 residuals of areas 2k, 2k + 1 over the int32 words of area k, which is done with by then;
 // r02's first version kept all three side by side: 2848 bytes, 14 waves per CU instead of 19, and the launch is latency-bound
 // wherever it is not bound by its stores.)
 enum { IQ_TILE = 768,                                                      // bytes
        IQ_TCU = 17 * TP, IQ_TCV = IQ_TCU + 9 * TP,                         // chroma tiles behind the luma tile (bytes from the tile's start)
-       IQ_SCALE = 1536 / 4, IQ_STEP = (IQ_TILE + IQ_TCV + 9 * TP) / 4, IQ_WORDS = IQ_STEP + 48 }; // words
-static_assert(IQ_STEP * 4 == 1888 && IQ_WORDS * 4 == 2080 && IQ_SCALE * 4 + 320 <= IQ_STEP * 4, "intra LDS map");
+       IQ_SCALE = 1536 / 4, IQ_WORDS = (IQ_TILE + IQ_TCV + 9 * TP) / 4, // words
+       IQ_TAB = 1856 };                                                   // bytes: 32 free ones between the scales and the end, while the residuals are made
+static_assert(IQ_WORDS * 4 == 1888 && IQ_SCALE * 4 + 320 <= IQ_TAB && IQ_TAB + 24 <= IQ_WORDS * 4 && 4 * IQ_WORDS * 4 <= 6 * 1280, "intra LDS map");
+// The step descriptors (two words per step, at most 24 steps) live in the chroma tiles' slack: a chroma tile row holds columns -4..15 in its
+// first 20 bytes and nothing in the other 12 -- three words per row, 54 in the 18 rows.  (r04: they had 192 bytes of their own behind the
+// tiles; without them a wave's LDS is 7552 bytes = six allocation granules of 1280 instead of seven: the LDS would hold 21 waves per CU instead of 18; at 85 registers the SIMDs hold 20.)
+__device__ __forceinline__ int step_word(int k) { const int row = (k * 43) >> 7; return IQ_TILE + IQ_TCU + row * TP + 20 + 4 * (k - 3 * row); } // byte offset of word k < 54
 // step descriptor, word 0
 enum { SD_O = 0,           // [10:0]  byte offset of the block's top-left sample inside the macroblock's tiles
        SD_TAP = 11,        // [20:11] first tap table entry of this step (+ lane)
@@ -1143,7 +1148,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   uint8_t *tile = (uint8_t *)G + IQ_TILE;
   int *coef = (int *)G;
   const int16_t *res16 = (const int16_t *)G;
-  uint32_t *steps = G + IQ_STEP;
+  uint8_t *Gb = (uint8_t *)G;
   const int S = A.stride, lgS = 31 - __builtin_clz((unsigned)S), mbw = A.mbw;
   const uint32_t clip = I.clip, mb = I.mb, w1 = I.w1, w3 = I.w3, ncoef = I.ncoef;
   const int t8 = (w1 >> 14) & 0x3F;
@@ -1248,7 +1253,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)cb, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)cb, 16) << 6) |
                        ((uint32_t)__builtin_amdgcn_readlane((int)cb, 32) << 12) | ((uint32_t)__builtin_amdgcn_readlane((int)cb, 48) << 18); // bit mb * 6 + area
     const int n_act = __builtin_popcount(M);
-    uint8_t *tab = (uint8_t *)(Lw + IQ_STEP); // k-th coded area -> its bit number (the first macroblock's step list is not in use yet)
+    uint8_t *tab = (uint8_t *)Lw + IQ_TAB; // k-th coded area -> its bit number (in the first macroblock's free bytes behind its scales)
     if (lane < 24 && ((M >> lane) & 1)) tab[__builtin_popcount(M & ((1u << lane) - 1u))] = (uint8_t)lane;
     wave_sync();
     const int r = lane & 7;
@@ -1318,8 +1323,12 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     n_iter = max(max(__builtin_amdgcn_readlane(nst, 0), __builtin_amdgcn_readlane(nst, 16)), max(__builtin_amdgcn_readlane(nst, 32), __builtin_amdgcn_readlane(nst, 48)));
     // rows with fewer steps than the longest of the four idle through the rest: a descriptor that does nothing
     const uint2 idle = uint2{(uint32_t)(TP + 4), 0u};
-    *(uint2 *)(steps + 2 * l) = idle;
-    if (l < 8) *(uint2 *)(steps + 2 * (16 + l)) = idle;
+    auto put_step = [&](int t, uint2 d) {
+      *(uint32_t *)(Gb + step_word(2 * t)) = d.x;
+      *(uint32_t *)(Gb + step_word(2 * t + 1)) = d.y;
+    };
+    put_step(l, idle);
+    if (l < 8) put_step(16 + l, idle);
     wave_sync();
     auto build = [=](int t, uint32_t rown, uint32_t r0, int &pos) -> uint2 {
       const int a = t >> 2, s = t & 3;
@@ -1353,8 +1362,8 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
     int posA, posB;
     const uint2 dA = build(l, recA, quad_first(recA), posA);
     const uint2 dB = build(16 + (l & 7), recB, quad_first(recB), posB);
-    if (posA >= 0) *(uint2 *)(steps + 2 * posA) = dA;
-    if (l < 8 && posB >= 0) *(uint2 *)(steps + 2 * posB) = dB;
+    if (posA >= 0) put_step(posA, dA);
+    if (l < 8 && posB >= 0) put_step(posB, dB);
   }
   wave_sync();
   MOBI_ISTOP(5);
@@ -1466,7 +1475,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   // The tap table entries of a directional block do not depend on pixels: they are asked for one step ahead (two register sets taken in
   // turn: r03 rotated three sets through eleven 64-bit moves per step).
   auto load_step = [&](int t, uint2 &d, uint4 &ea, uint4 &eb) {
-    d = *(const uint2 *)(steps + 2 * t);
+    d = uint2{*(const uint32_t *)(Gb + step_word(2 * t)), *(const uint32_t *)(Gb + step_word(2 * t + 1))};
     const uint2 *tp = taps + (((d.x >> SD_TAP) & 0x3FF) + ((d.x & SD_IS4) ? l : 4 * l));
     ea = *(const uint4_a4 *)tp;
     eb = *(const uint4_a4 *)(tp + 2);
@@ -1621,21 +1630,37 @@ extern "C" __global__ __launch_bounds__(64, 4) void mobi_recon_step(MobiReconArg
 // a row waits for (raster-earlier, same clip) always sits in an earlier slot, i.e. was dispatched before it.  Nothing here
 // knows who depends on whom before the descriptor has been read: every macroblock looks at its dependency list and publishes its tag.
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconArgs A, const uint32_t *items, const uint32_t *n_intra, uint32_t n_intra_stride,
-                                                                      uint32_t quads, uint32_t magic_quads, uint32_t last_slot) {
+                                                                      uint32_t quads, uint32_t magic_quads) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
   const int lane = threadIdx.x;
   uint32_t cq;
-  uint32_t slot = fastdiv(blockIdx.x, quads, magic_quads, cq);
+  const uint32_t slot = fastdiv(blockIdx.x, quads, magic_quads, cq);
   const uint32_t clip = 4 * cq + (uint32_t)(lane >> 4);
   const bool inb = clip < (uint32_t)A.n_clips;
   const uint32_t ni = inb ? n_intra[(size_t)clip * n_intra_stride] : 0u;
-  // The launch covers slots 0..last_slot.  When the host does not know the longest list (a step submitted before its parse has run:
-  // mobi_batch_submit launches MOBI_ASYNC_INTRA_SLOTS of them, not one per macroblock of the picture), the workgroup of the last slot
-  // walks on through whatever its four clips still have: those macroblocks depend on raster-earlier ones of the same clip only --
-  // earlier slots (dispatched before this workgroup) or this workgroup's own earlier rounds -- so the waits still cannot deadlock;
-  // they just run one after the other, which a raster chain that long mostly does anyway.
-  const bool walks = slot == last_slot; // (wave-uniform)
-  for (;;) {
+  const bool valid = slot < ni;
+  if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
+  const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
+  const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
+  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
+                valid ? desc->w2 & 0x3FFu : 0u, true, true};
+  recon_intra_quad(A, lds, I, lane);
+}
+// When the host does not know the longest list (a step submitted before its parse has run: mobi_batch_submit launches
+// MOBI_ASYNC_INTRA_SLOTS slots, not one per macroblock of the picture), this launch follows: one workgroup per clip quad walks through
+// whatever its four clips have beyond the slots already launched.  Those macroblocks depend on raster-earlier ones of the same clip
+// only -- the launch before, or this workgroup's own earlier rounds -- so the waits cannot deadlock; they run one after the other,
+// which a raster chain that long (an I-frame) mostly does anyway.  (r03 had the walk as a loop inside mobi_recon_intra_cl: with everything
+// lane-derived kept alive round it the kernel took 185 registers -- two waves per SIMD -- for every workgroup, walking or not.)
+extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_walk(MobiReconArgs A, const uint32_t *items, const uint32_t *n_intra, uint32_t n_intra_stride,
+                                                                        uint32_t first_slot) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
+  for (uint32_t slot = first_slot;; slot++) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane)); // (opaque: nothing derived from the lane number is carried from round to round)
+    const uint32_t clip = 4 * blockIdx.x + (uint32_t)(lane >> 4);
+    const bool inb = clip < (uint32_t)A.n_clips;
+    const uint32_t ni = inb ? n_intra[(size_t)clip * n_intra_stride] : 0u;
     const bool valid = slot < ni;
     if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
     const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
@@ -1643,8 +1668,6 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconAr
     const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
                   valid ? desc->w2 & 0x3FFu : 0u, true, true};
     recon_intra_quad(A, lds, I, lane);
-    if (!walks) return;
-    slot++;
     wave_sync();
   }
 }
@@ -1713,12 +1736,14 @@ extern "C" int mobi_launch_step(const MobiReconArgs *a, const uint32_t *items_de
   hipLaunchKernelGGL(mobi_recon_step, dim3(g8 + (unsigned)n_items / 4), dim3(64), 0, s, b, (const uint4 *)items_dev, (uint32_t)g8);
   return (int)hipGetLastError();
 }
-// K slots are launched; lists longer than K are finished by the workgroups of slot K - 1 (see the kernel)
-extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, hipStream_t s) {
+// K slots are launched; walk != 0: the lists may be longer than K (the host has not seen the counts): mobi_recon_intra_walk finishes them
+extern "C" int mobi_launch_intra_cl(const MobiReconArgs *a, const uint32_t *items_dev, const uint32_t *n_intra_dev, int n_intra_stride_words, int K, int walk, hipStream_t s) {
   if (K <= 0 || a->n_clips <= 0) return 0;
   const uint32_t quads = ((uint32_t)a->n_clips + 3) / 4;
   const uint64_t m = ((uint64_t)1 << 32) / quads;
   hipLaunchKernelGGL(mobi_recon_intra_cl, dim3((unsigned)K * quads), dim3(64), 0, s, *a, items_dev, n_intra_dev, (uint32_t)n_intra_stride_words, quads,
-                     (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m), (uint32_t)K - 1u);
+                     (uint32_t)(m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m));
+  if (walk && K < a->n_mbs)
+    hipLaunchKernelGGL(mobi_recon_intra_walk, dim3(quads), dim3(64), 0, s, *a, items_dev, n_intra_dev, (uint32_t)n_intra_stride_words, (uint32_t)K);
   return (int)hipGetLastError();
 }
