@@ -40,7 +40,7 @@ enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 //     [17:16] luma CopyBlock phase (dx&1)|((dy&1)<<1) of A   [19:18] chroma phase of A   [21:20], [23:22] the same for B
 // w3  inter: luma source position of leaf A = MB offset + (dy>>1)*Stride + (dx>>1), linear inside the reference's Y plane
 //            (signed: a bottom/right half may point above/left of its macroblock's origin; its own rows/columns add back)
-//     intra: [0] plane16 present, [31:16] plane16 parameter
+//     intra: [0] plane16 present, [1] some dependency (w4..w7) is an intra macroblock, [2] some intra macroblock depends on this one, [31:16] plane16 parameter
 // w4  inter: chroma source position of leaf A = MB offset/2 + ((dy>>1)>>1)*Stride + ((dx>>1)>>1), inside the UV plane (U half)
 // w5, w6  inter DUAL: the same two positions for leaf B
 // w7  reserved (0) for inter macroblocks

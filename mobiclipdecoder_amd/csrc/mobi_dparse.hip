@@ -270,6 +270,7 @@ struct DP {
     }
     return dual;
   }
+  bool dep_intra = false;
   __device__ __forceinline__ void add_dep(int o, uint32_t *deps, int &n_deps) {
     if (o < 0 || o >= cur_mb) return; // raster-later owners read as the fresh plane's zeros (the kernel masks them)
     #pragma nounroll
@@ -278,6 +279,7 @@ struct DP {
     if (n_deps == MOBI_INTRA_DEPS) { fail(MOBI_E_UNSUPPORTED); return; }
     const uint32_t inter = (desc[o].w1 & 1) == MOBI_MB_INTRA ? 0u : MOBI_DEP_INTER; // this lane wrote desc[o] itself
     deps[n_deps++] = (uint32_t)o | inter;
+    if (!inter) { desc[o].w3 |= 4u; dep_intra = true; } // w3 [1] has intra dependencies, [2] has intra dependents (mobi_recon_intra_cl)
   }
   __device__ __forceinline__ void end_mb() {
     if (r.err) return;
@@ -327,6 +329,7 @@ struct DP {
       // left and right change owner at most once, between the first row and the rest)
       uint32_t deps[MOBI_INTRA_DEPS];
       int n_deps = 0;
+      dep_intra = false;
       const int S = stride, o = cur_off;
       add_dep(owner_luma(o - S - 1), deps, n_deps);
       add_dep(owner_luma(o - S), deps, n_deps);
@@ -352,6 +355,7 @@ struct DP {
       d.w5 = deps[2] | (deps[3] << 16);
       d.w6 = deps[4] | (deps[5] << 16);
       d.w7 = deps[6] | (deps[7] << 16);
+      if (dep_intra) d.w3 |= 2u;
       items[n_items++] = MOBI_ITEM(clip, cur_mb);
     }
     d.w1 = (uint32_t)mb_type | (nl << 1) | (cbp6 << 8) | (t8mask << 14) | ((quant & 63) << 20) | ((uint32_t)dual << 26);

@@ -1627,8 +1627,8 @@ extern "C" __global__ __launch_bounds__(64, 4) void mobi_recon_step(MobiReconArg
 // Items as the device-side parser leaves them (mobi_dparse.hip): per clip, raster order, n_intra[clip] of them at a stride of
 // n_mbs.  Workgroup = slot * ceil(n_clips / 4) + clip quad: the four rows of a wave are the same slot of four clips, neighbours in
 // the dispatch order belong to different clips, so every clip advances along its own dependency chain at the same time, and what
-// a row waits for (raster-earlier, same clip) always sits in an earlier slot, i.e. was dispatched before it.  Nothing here
-// knows who depends on whom before the descriptor has been read: every macroblock looks at its dependency list and publishes its tag.
+// a row waits for (raster-earlier, same clip) always sits in an earlier slot, i.e. was dispatched before it.  Who has to poll and
+// who has to publish is in the descriptor (w3 bits 1 and 2: the parsers set them where they list the dependencies).
 extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconArgs A, const uint32_t *items, const uint32_t *n_intra, uint32_t n_intra_stride,
                                                                       uint32_t quads, uint32_t magic_quads) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[4 * IQ_WORDS];
@@ -1642,8 +1642,9 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconAr
   if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
   const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
   const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
-  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
-                valid ? desc->w2 & 0x3FFu : 0u, true, true};
+  const uint32_t w3 = valid ? desc->w3 : 0u; // [1] has intra dependencies: poll their tags; [2] has intra dependents: publish its own
+  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, w3 & 0xFFFF0001u,
+                valid ? desc->w2 & 0x3FFu : 0u, (w3 & 2u) != 0, (w3 & 4u) != 0};
   recon_intra_quad(A, lds, I, lane);
 }
 // When the host does not know the longest list (a step submitted before its parse has run: mobi_batch_submit launches
@@ -1665,8 +1666,9 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_walk(MobiRecon
     if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
     const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
     const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
-    const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, valid ? desc->w3 & 0xFFFF0001u : 0u,
-                  valid ? desc->w2 & 0x3FFu : 0u, true, true};
+    const uint32_t w3 = valid ? desc->w3 : 0u;
+    const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, w3 & 0xFFFF0001u,
+                  valid ? desc->w2 & 0x3FFu : 0u, (w3 & 2u) != 0, (w3 & 4u) != 0};
     recon_intra_quad(A, lds, I, lane);
     wave_sync();
   }

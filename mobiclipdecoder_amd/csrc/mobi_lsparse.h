@@ -818,6 +818,11 @@ LS_FN int ls_owner_chroma(const LsGeom &g, int a) {
   if (x >= g.width / 2 || row >= g.height / 2) return -1;
   return (row >> 3) * g.mbw + (x >> 3);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+LS_FN void ls_or_u32(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+#else
+LS_FN void ls_or_u32(uint32_t *p, uint32_t v) { *p |= v; }
+#endif
 // the raster-earlier macroblocks the prediction halo of macroblock mb touches, as mobi_dparse.hip's end_mb lists them.  desc = the clip's row.
 // Returns false when there are more than MOBI_INTRA_DEPS (mobi_parse_frames refuses such a stream).
 LS_FN bool ls_intra_deps(const LsGeom &g, MbDesc *desc, int mb) {
@@ -841,7 +846,12 @@ LS_FN bool ls_intra_deps(const LsGeom &g, MbDesc *desc, int mb) {
     for (int k = 0; k < n; k++) seen = seen || (int)(deps[k] & 0x1FFF) == ow;
     if (seen) continue;
     if (n == MOBI_INTRA_DEPS) { ok = false; break; }
-    deps[n++] = (uint32_t)ow | ((desc[ow].w1 & 1) == MOBI_MB_INTRA ? 0u : MOBI_DEP_INTER);
+    const bool intra = (desc[ow].w1 & 1) == MOBI_MB_INTRA;
+    deps[n++] = (uint32_t)ow | (intra ? 0u : MOBI_DEP_INTER);
+    if (intra) { // w3 [1] has intra dependencies, [2] has intra dependents (mobi_recon_intra_cl); other lanes mark other words' bits at the same time
+      ls_or_u32(&desc[ow].w3, 4u);
+      ls_or_u32(&desc[mb].w3, 2u);
+    }
   }
   for (int k = n; k < MOBI_INTRA_DEPS; k++) deps[k] = MOBI_DEP_NONE;
   desc[mb].w4 = deps[0] | (deps[1] << 16);

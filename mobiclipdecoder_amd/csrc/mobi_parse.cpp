@@ -680,7 +680,7 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     if (level[mb]) {
       const uint32_t at = cursor[level[mb]]++;
       out.intra_mbs[at] = (uint32_t)mb;
-      const MbDesc &d = out.desc[mb];
+      const MbDesc d = out.desc[mb];
       const int mbx = mb % g_.mbw;
       const bool interior = mbx >= 1 && mbx + 1 < g_.mbw && mb >= g_.mbw;
       uint32_t *it = &out.intra_items[(size_t)at * 4];
@@ -688,6 +688,7 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
       it[1] = d.w1;
       it[2] = d.payload_off;
       it[3] = (d.w3 & 0xFFFF0001u) | flag[mb] | (interior ? 0u : 8u) | ((d.w2 & 0x3FFu) << 5);
+      out.desc[mb].w3 |= flag[mb]; // (the device parsers' item lists carry no flags: mobi_recon_intra_cl reads these two bits from the descriptor)
     }
   out.hdr.n_mbs = (uint32_t)n;
   out.hdr.n_intra = (uint32_t)n_intra;

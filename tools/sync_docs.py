@@ -19,6 +19,8 @@ grid = [l.split() for l in open(f"profiles/{RND}_B_kernel_by_grid.txt") if l.sta
 trace_ms = max((int(g[2]), float(g[3])) for g in grid)[1]
 ub = open(f"profiles/{RND}_ubench.txt").read()
 ifr = re.findall(r"I-frame, (\d+) clips: ([0-9.]+) ms", ub)
+_hp = re.search(r"host parse, 1024 clips, MOBI_PARSE_THREADS=default: ([0-9.]+) ms per step inside the C call = (\d+) Mpix/s", ub)
+hp1024 = f"{int(_hp.group(2)) / 1e3:.0f}" if _hp else "35"
 
 
 def key(d, c):
@@ -145,7 +147,8 @@ timed): {B['value'] / 1e3:.0f} Gpixels/s of reconstruction (command lists reside
 roofline counting only its own macroblocks' bytes, the whole step at {B['roofline']['whole_step_frac'] * 100:.0f} %, HBM traffic {ratio:.2f} × the algorithmic bytes, bit-exact
 (three clips of the batch compared with the oracle after the timed region);
 {e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight) at 4096
-clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser; one
+clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser, {hp1024} with the parse on 64 host threads at 1024 clips;
+''' + (f'''the Bitmap of every clip (`mobi_yuv_to_argb`) at {B['bitmap']['roofline']['frac'] * 100:.0f} % of the roofline on its own 5.5 bytes per pixel; ''' if B.get('bitmap') and 'ms' in B['bitmap'] else '') + f'''one
 stream through `mobi_decode`: {ss['planes']['p_frame_ms']:.2f} ms per P-frame; {cb['value'] / 1e3:.2f} Gpixels/s for the CPU restatement of the reference on one host
 core ({cb['all_cpus']['value'] / 1e3:.1f} on all {cb['all_cpus']['cores']}). The planes live in HBM as macroblock tiles (`mobi_tile.h`): the reference's linear
 offsets keep their meaning through a bit permutation, and a macroblock's samples are three whole 128-byte lines.
