@@ -254,7 +254,7 @@ struct mobi_batch {
   size_t last_pay_cap = 0;
   float last_parse_ms = 0; // duration of the last mobi_parse_frames launch (kernel timing on)
   float last_decode_ms = 0, last_stage_ms = 0; // wall time of the last mobi_batch_decode call / of its host staging part
-  float phase_ms[6] = {0, 0, 0, 0, 0, 0};      // (profiling) host-parsed step: parse loop, plan, stage + upload enqueue, launch enqueue, sync, rest
+  float phase_ms[6] = {0, 0, 0, 0, 0, 0};      // (profiling) host-parsed step: parse loop, plan, stage + upload enqueue, launch enqueue, sync; device-parsed step: cumulative ms after gather + upload, parse enqueued, parse done, launches enqueued, all done
   float last_hostparse_ms = 0;                 // ... / of its host parse part (host parse mode)
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
   DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
@@ -595,7 +595,11 @@ static int dp_init(mobi_batch *b) {
 }
 // stage [bit_off u64 x nd][bit_len u32 x nd][bits: each clip 8-byte aligned, zero padded] of clips [0, nd) into pinned memory
 struct DpStaged { size_t hdr_bytes = 0, bytes = 0, max_len = 0; };
-static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const size_t *len, const int32_t *offsets, PinnedBuf &stage, DpStaged &st) {
+// dev != nullptr: the image is also sent to *dev on `up`, chunk by chunk while the next chunk is gathered (one thread of the pool sits in
+// the copy calls, which return when the bus is done: 8 ms for the 370 MB of a step of 24576 clips; the others gather) -- r04: gathering and
+// sending were 12 of the 45 ms of such a step, one after the other.
+static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const size_t *len, const int32_t *offsets, PinnedBuf &stage, DpStaged &st,
+                    DevBuf *dev = nullptr, bool dev_headroom = false, hipStream_t up = nullptr) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
   const auto t_stage0 = std::chrono::steady_clock::now();
   constexpr size_t kBitPad = 32; // the reader runs two 8-byte registers ahead
@@ -622,11 +626,36 @@ static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const siz
   uint8_t *hs = stage.p;
   memcpy(hs, boff.data(), (size_t)nd * 8);
   memcpy(hs + (size_t)nd * 8, blen.data(), (size_t)nd * 4);
-  b->pool->run(nd, [&](int i) {
+  auto gather = [&](int i) {
     uint8_t *dst = hs + hdr_bytes + boff[i];
     if (blen[i]) memcpy(dst, data[i] + offsets[i], blen[i]);
     memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
-  });
+  };
+  if (!dev) {
+    b->pool->run(nd, gather);
+  } else {
+    const size_t need = hdr_bytes + pos;
+    if (need > dev->cap) // growing frees and allocates (a device-wide stall): asynchronous steps leave room for the longer frames to come
+      if (int e = dev->reserve(dev_headroom ? need + need / 4 : need)) return e;
+    const int chunks = nd >= 2048 ? 4 : 1;
+    std::atomic<int> up_err{0};
+    auto end_of = [&](int c1) { return c1 < nd ? hdr_bytes + (size_t)boff[c1] : need; }; // byte offset where clip c1's bits start
+    for (int k = 0; k <= chunks; k++) {
+      const int c0 = k < chunks ? (int)((long)nd * k / chunks) : nd, c1 = k < chunks ? (int)((long)nd * (k + 1) / chunks) : nd;
+      const int u0 = k >= 1 ? (int)((long)nd * (k - 1) / chunks) : 0, u1 = k >= 1 ? (int)((long)nd * k / chunks) : 0; // gathered in the round before
+      const int n_up = u1 > u0 ? 1 : 0;
+      if (n_up + (c1 - c0) == 0) continue;
+      b->pool->run(n_up + (c1 - c0), [&](int j) {
+        if (j < n_up) {
+          const size_t a = u0 == 0 ? 0 : end_of(u0), e = end_of(u1); // (the first chunk takes the header along)
+          if (hipSetDevice(b->device) != hipSuccess || hipMemcpyAsync(dev->p + a, hs + a, e - a, hipMemcpyHostToDevice, up) != hipSuccess) up_err = 1;
+          return;
+        }
+        gather(c0 + (j - n_up));
+      });
+    }
+    if (up_err) return MOBI_E_DEVICE;
+  }
   b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
   st.hdr_bytes = hdr_bytes;
   st.bytes = hdr_bytes + pos;
@@ -700,10 +729,13 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   if (b->g.mbw > 64 || b->async_count) return MOBI_E_ARG; // (asynchronous steps in flight: mobi_batch_wait for them first)
   if (int e = dp_init(b)) return e;
   DpStaged st;
-  if (int e = dp_stage(b, nd, data, len, offsets, b->h_stage, st)) return e;
-  if (int e = b->d_bits.reserve(st.bytes)) return e;
-  HIP_TRY(hipMemcpyAsync(b->d_bits.p, b->h_stage.p, st.bytes, hipMemcpyHostToDevice, b->stream));
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point x) { return std::chrono::duration<float, std::milli>(clk::now() - x).count(); };
+  const auto q0 = clk::now();
+  if (int e = dp_stage(b, nd, data, len, offsets, b->h_stage, st, &b->d_bits, false, b->stream)) return e; // gathered and on their way
+  b->phase_ms[0] = ms_since(q0);
   if (int e = dp_parse(b, nd, b->d_bits.p, st, false, DpOut{&b->d_pdesc, &b->d_ppay, &b->d_pitems, b->d_pres, b->stream})) return e;
+  b->phase_ms[1] = ms_since(q0);
   const size_t cap_words = b->last_pay_cap;
   const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
   MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
@@ -752,6 +784,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     HIP_TRY(hipStreamSynchronize(b->stream2));
   }
   HIP_TRY(hipStreamSynchronize(b->stream)); // the launch sizes below depend on what the parse found
+  b->phase_ms[2] = ms_since(q0);
   if (ptime) { float ms = 0; if (hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
   uint32_t K = 0;
   if (b->lockstep) b->ls_finished = 0;
@@ -782,7 +815,9 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+  b->phase_ms[3] = ms_since(q0);
   HIP_TRY(hipStreamSynchronize(b->stream));
+  b->phase_ms[4] = ms_since(q0);
   fail_all.armed = false;
   for (int i = 0; i < n; i++)
     if (rc[i] == MOBI_OK && b->h_fault[i]) rc[i] = (b->h_fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
