@@ -93,7 +93,7 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
            "parse": "device: mobi_parse_frames_ls (64 clips per wavefront, lock step) in front of mobi_parse_frames" if device_parse == "lockstep"
                     else "device: mobi_parse_frames, one wavefront per clip",
            "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)",
-           "verified": verified}
+           "distinct_streams": len(streams), "verified": verified}
     # the same frames through mobi_batch_submit / mobi_batch_wait, two steps in flight: wall time per step over the timed P-frames.
     # The pointer arrays are packed beforehand (what a C caller hands over), as the synchronous figure is the time inside the C call.
     import ctypes as C
@@ -542,7 +542,14 @@ def main():
         e2e = end_to_end(m, streams, W, H, p0.version, local, args.e2e_clips, args.e2e_steps)
     if world == 1 and args.e2e_clips > 0 and min(args.e2e_large_clips, args.clips) >= 8192 and args.config == "B":  # (--e2e-clips 0 skips both legs)
         try:
-            e2e_large = end_to_end(m, streams, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
+            # The lock-step parser's 64 lanes run until the slowest is done and every round costs what the lanes' different states need:
+            # a wave of 4 x 16 copies is a quarter as diverse as a wave of 64 clips.  r04 measured 24.3 ms per step with 16 distinct streams
+            # and 34.4 with 64 or 128 (tools/exp_dparse.py, DISTINCT=...): this leg takes 64, so that no wave holds two copies of one.
+            wide = list(streams)
+            for i in range(len(streams), 64):
+                p = m.default_params(args.config, sharding.stream_seed(args.config, rank, i), n_frames=12, **gen_over)
+                wide.append((p,) + m.generate_clip(p))
+            e2e_large = end_to_end(m, wide, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
         except Exception as e:  # (e.g. does not fit beside what the allocator still holds: reported beside the headline value, not fatal to it)
             e2e_large = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and args.config4_clips > 0 and args.config == "B":

@@ -103,8 +103,9 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front (mobi_lsparse.hip: 64 clips per wavefront, one per
  * lane, all lanes in one instruction stream): it finishes the frames that decode without incident -- identically, word for word -- and
  * leaves every other clip (anything the reference throws on, refusals, data ending inside a frame) to the one-wavefront-per-clip
- * parser, which then runs for those alone.  Its time per frame step does not depend on the batch (24 ms for 640x480 P-frames, 36 ms for
- * I-frames, up to 32768 clips), so it pays from about 12000 resident clips and is the default from 12288 (MOBI_DEVICE_PARSE=1: never).
+ * parser, which then runs for those alone.  Its time per frame step does not depend on the batch (34 ms for 640x480 P-frames, 58 ms for
+ * I-frames, up to 32768 clips, when the 64 clips of a wave differ), so it pays from about 15000 resident clips and is the default from
+ * 16384 (MOBI_DEVICE_PARSE=1: never).
  * Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
 /* Parse mode 3: how many clips of the last finished frame step the lock-step parser finished itself (the rest went to the other one);

@@ -43,6 +43,7 @@ if __name__ == "__main__":
     modes = (False,) if "--host-only" in sys.argv else (True,) if "--device-only" in sys.argv else ("hybrid",) if "--hybrid" in sys.argv else ("lockstep",) if "--lockstep" in sys.argv else \
             (True, "lockstep") if "--device-both" in sys.argv else (False, True)
     sizes = [int(a) for a in args] or [512, 2048]
+    distinct = int(os.environ.get("DISTINCT", "64"))  # streams the clips are copies of (a lock-step wave of 64 lanes holds min(64, DISTINCT) different ones)
     for n in sizes:
         for dp in modes:
-            run(n, dp)
+            run(n, dp, distinct=distinct)
