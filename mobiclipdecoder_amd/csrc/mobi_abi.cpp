@@ -969,8 +969,8 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   }
   if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;
-  // 1. host: serial VLC parse of one frame per clip -> command lists.  The clips are taken in chunks: while the pool parses chunk k + 1, the
-  // descriptors and payload of chunk k -- staged by the same threads, still warm in their caches -- are on their way to the GPU (a step of
+  // 1. host: serial VLC parse of one frame per clip -> command lists.  The clips are taken in chunks, three stages deep: in one round of
+  // the pool chunk k is parsed, chunk k - 1 is written into the staging buffer, and chunk k - 2 is handed to the copy engine (a step of
   // 1024 clips of 640x480 is 100 MB of commands: as long on the bus as it is in the parsers).  A chunk's place in the payload arena is the
   // sum of the chunks before it, so nothing has to wait for the whole batch; only the launch list does (levels are sorted over all clips).
   // The pipelined path needs the step to fit the buffers as they are (they grow in the classic path below, with headroom): the first frame
@@ -988,7 +988,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   int uploaded = 0; // clips [0, uploaded) are staged and on their way
   std::vector<size_t> base(n + 1, 0); // where each clip's payload starts in the step's arena (words)
   uint8_t *hs = b->h_stage.p;
-  float parse_ms = 0, stage_ms = 0;
+  float parse_ms = 0;
   auto stage_range = [&](int c0, int c1) {
     for (int i = c0; i < c1; i++) step_write_clip(ok[i], base[i], n_mbs, (MbDesc *)hs + (size_t)i * n_mbs, (uint32_t *)(hs + desc_bytes));
   };
@@ -1070,7 +1070,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
     memcpy(b->h_items.p, plan.items.data(), plan.items.size() * 4);
     HIP_TRY(hipMemcpyAsync(b->d_items.p, b->h_items.p, plan.items.size() * 4, hipMemcpyHostToDevice, b->stream));
   }
-  b->last_stage_ms = stage_ms + std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
+  b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count(); // (what was not staged under the parse)
   const auto tp3 = std::chrono::steady_clock::now();
   // 3. device: reconstruction
   MobiReconArgs a = b->args(b->d_cmd.p, b->d_cmd.p + desc_bytes);
