@@ -86,7 +86,10 @@ uint32_t mobi_width(const mobi_dec *d);        /* d.Width      (MD.cs:17) */
 uint32_t mobi_height(const mobi_dec *d);       /* d.Height     (MD.cs:18) */
 
 /* ---- batch of independent clips (the throughput path) -------------------------------------- */
-/* N decoder instances that share geometry/version; they share nothing else (MD.cs:15-39). */
+/* N decoder instances that share geometry/version; they share nothing else (MD.cs:15-39).
+ * Tuning knobs read from the environment when a batch is created (none changes a result): MOBI_PARSE_THREADS (host parse pool; default
+ * one per two hardware threads, at most 64), MOBI_DEVICE_PARSE and MOBI_HYBRID_HOST_CLIPS (below), MOBI_FUSED_STEP_MBS (a frame step of
+ * at most this many macroblocks is ONE launch, mobi_recon_step; default 256 x 1200, 0 = always two launches). */
 mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int version, int device);
 void mobi_batch_destroy(mobi_batch *b);
 /* One DecodeFrame() per clip: data[i]/len[i]/offsets[i] as in mobi_decode; rc[i] per clip.
