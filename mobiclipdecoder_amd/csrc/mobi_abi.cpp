@@ -119,7 +119,11 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
     // Few intra macroblocks (small batches): every one gets a wave of its own (three null items behind it) -- the chip has room for
     // them all at once, and a lone macroblock's wave is shorter than a wave that runs the longest step list of four.  Measured
     // (640x480 P-frames, intra launch): 8 clips 45 -> 33 us, 64 clips 53 -> 41 us, 512 clips 78 -> 110 us: dense from there on.
-    static const int sparse_env = getenv("MOBI_INTRA_SPARSE") ? atoi(getenv("MOBI_INTRA_SPARSE")) : -1;
+#if defined(MOBI_PROFILING)
+    static const int sparse_env = getenv("MOBI_INTRA_SPARSE") ? atoi(getenv("MOBI_INTRA_SPARSE")) : -1; // (measurements only)
+#else
+    const int sparse_env = -1;
+#endif
     uint64_t total_intra = 0;
     for (auto *f : frames)
       if (f) total_intra += f->hdr.n_intra;
