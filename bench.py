@@ -90,7 +90,7 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
     b.close()
     t = float(np.median(ms))
     out = {"value": round(n_clips * W * H / t / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(t, 3), "clips": n_clips, "steps": n_steps,
-           "parse": "device: mobi_parse_frames_ls (64 clips per wavefront, lock step) in front of mobi_parse_frames" if device_parse == "lockstep"
+           "parse": "device: mobi_parse_frames_ls (32 clips per wavefront, lock step) in front of mobi_parse_frames" if device_parse == "lockstep"
                     else "device: mobi_parse_frames, one wavefront per clip",
            "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)",
            "distinct_streams": len(streams), "verified": verified}
@@ -542,7 +542,7 @@ def main():
         e2e = end_to_end(m, streams, W, H, p0.version, local, args.e2e_clips, args.e2e_steps)
     if world == 1 and args.e2e_clips > 0 and min(args.e2e_large_clips, args.clips) >= 8192 and args.config == "B":  # (--e2e-clips 0 skips both legs)
         try:
-            # The lock-step parser's 64 lanes run until the slowest is done and every round costs what the lanes' different states need:
+            # The lock-step parser's lanes (32 clips per wave) run until the slowest is done and every round costs what the lanes' different states need:
             # a wave of 4 x 16 copies is a quarter as diverse as a wave of 64 clips.  r04 measured 24.3 ms per step with 16 distinct streams
             # and 34.4 with 64 or 128 (tools/exp_dparse.py, DISTINCT=...): this leg takes 64, so that no wave holds two copies of one.
             wide = list(streams)

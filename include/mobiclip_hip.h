@@ -103,11 +103,11 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * unless the first call hands over far more than a frame per clip -- whole files as Data, MOC5 style -- which the device path
  * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1/2.  2 = hybrid: the GPU parses most clips while the
  * host pool parses a fixed share of them (a fifth, at most 1024; MOBI_HYBRID_HOST_CLIPS) at the same time; one set of
- * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front (mobi_lsparse.hip: 64 clips per wavefront, one per
+ * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front (mobi_lsparse.hip: 32 clips per wavefront, one per
  * lane, all lanes in one instruction stream): it finishes the frames that decode without incident -- identically, word for word -- and
  * leaves every other clip (anything the reference throws on, refusals, data ending inside a frame) to the one-wavefront-per-clip
- * parser, which then runs for those alone.  Its time per frame step does not depend on the batch (34 ms for 640x480 P-frames, 58 ms for
- * I-frames, up to 32768 clips, when the 64 clips of a wave differ), so it pays from about 15000 resident clips and is the default from
+ * parser, which then runs for those alone.  Its time per frame step does not depend on the batch (31 ms for 640x480 P-frames, 52 ms for
+ * I-frames, up to 32768 clips), so it pays from about 15000 resident clips and is the default from
  * 16384 (MOBI_DEVICE_PARSE=1: never).
  * Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);

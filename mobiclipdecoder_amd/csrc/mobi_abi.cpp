@@ -543,10 +543,10 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     // take a step of 1024 / 1536 / 2048 clips in 9.1 / 13.6 / 18.2 ms, parse to planes; mobi_parse_frames in 13.2 / 10.6 / 10.4 ms)
     b->parse_mode = n_clips >= std::max(640, 20 * (b->pool->size() + 1));
     b->parse_auto = true;
-    b->lockstep = n_clips >= 16384; // ... and from there on the lock-step parser in front (64 clips per wave: 34 ms per P-frame step of 64 different clips per wave,
-                                    // whatever the batch; mobi_parse_frames: 2.3 ms per 1024 clips)
+    b->lockstep = n_clips >= 16384; // ... and from there on the lock-step parser in front (32 clips per wave: 31 ms per P-frame step, whatever the
+                                    // batch up to 32768 clips; mobi_parse_frames: 2.3 ms per 1024 clips)
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) {
-      const int v = atoi(dp); // 3: on the GPU, the lock-step parser (64 clips per wave) in front
+      const int v = atoi(dp); // 3: on the GPU, the lock-step parser (32 clips per wave) in front
       b->parse_mode = v == 3 ? 1 : std::max(0, std::min(2, v));
       b->lockstep = v == 3;
       b->parse_auto = false;

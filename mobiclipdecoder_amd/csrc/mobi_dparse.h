@@ -43,7 +43,7 @@ struct MobiDevParseArgs {
   MobiDevResult *res;       // [clip] out
   uint32_t pay_cap;
   int n_clips, version, width, height, stride, lg, mbw, mbh;
-  // lockstep != 0: mobi_parse_frames_ls (mobi_lsparse.hip: 64 clips per wave) runs first; what it finishes carries MobiDevResult.pad ==
+  // lockstep != 0: mobi_parse_frames_ls (mobi_lsparse.hip: 32 clips per wave) runs first; what it finishes carries MobiDevResult.pad ==
   // LS_MAGIC and its new decoder state in state_ls[clip]; mobi_parse_frames then only moves that state into place and parses the others
   MobiDevState *state_ls;
   int lockstep;

@@ -1,15 +1,18 @@
-// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: 64 clips per wave, one per lane (mobi_lsparse.h has the state machine and
+// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: LS_CLIPS = 32 clips per wave, one per lane (mobi_lsparse.h has the state machine and
 // says why).
 //
-//   mobi_parse_frames_ls   one wave = 64 clips.  Every lane walks its own frame with ls_round(); the wave runs until the last one is done.
+//   mobi_parse_frames_ls   one wave = LS_CLIPS clips (the other lanes idle).  Every lane walks its own frame with ls_round(); the wave runs until the last one is done.
 //                          A lane that meets anything out of the ordinary bails out and leaves its clip to mobi_parse_frames.
 //   mobi_ls_deps           one lane per intra macroblock of the clips the first kernel finished: the dependency lists (MbDesc.w4..w7).
 //   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
 //                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
 //
 // LDS per wave: the table blob (18 KB), and per lane the motion-vector row cache (2 (mbw + 2) words), the partition-tree stack (16), the
-// intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all lane-interleaved (element i of lane l at i * 64 + l), so
-// that 64 lanes reading "their" element i hit 64 different addresses of one row.  61 KB at 640 pixels, 73 KB at 1024.
+// intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all lane-interleaved (element i of lane l at i * LS_CLIPS + l), so
+// that the lanes reading "their" element i hit different banks.  39 KB at 640 pixels with 32 clips per wave: four waves per CU, one per SIMD.
+// (r03 / early r04: 64 clips per wave, 61 KB, two waves per CU.  A wave's life grows with the number of DIFFERENT clips it holds -- it runs
+// until its slowest lane is done, and a round costs what its lanes' different states need: 34.5 ms per P-frame step of 24576 clips at 64,
+// 32.3 at 48, 31.0 at 32 (tools/exp_lsab.sh), and 768 waves still have a SIMD each.  Fewer would need more than the chip's 1024 SIMDs.)
 //
 // The bitstream reaches the ring through registers, 32 bytes per lane every LS_SERVICE rounds, committed one service later: the load has
 // that long to arrive, nobody waits for it.  A lane whose ring holds less than a round can ask for (LS_ROUND_BYTES) sits the round out.
@@ -21,7 +24,7 @@
 
 namespace {
 #ifndef LS_CLIPS
-#define LS_CLIPS 64 // clips per wave (lanes in use); tools/exp_lsclips.sh tries fewer
+#define LS_CLIPS 32 // clips per wave (lanes in use); tools/exp_lsab.sh "-DLS_CLIPS=64" ... tries others
 #endif
 #ifndef LS_SERVICE_N
 #define LS_SERVICE_N 4
@@ -33,11 +36,11 @@ struct DevStore {
   uint32_t *stk_, *rec_, *ring_;
   uint8_t *mc_;
   int lane;
-  __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * 64 + lane]; }
-  __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * 64 + lane]; }
-  __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * 64 + lane]; }
-  __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * 64 + lane]; }
-  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & (LS_RING_WORDS - 1)) * 64 + lane]; }
+  __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * LS_CLIPS + lane]; }
+  __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * LS_CLIPS + lane]; }
+  __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * LS_CLIPS + lane]; }
+  __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * LS_CLIPS + lane]; }
+  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & (LS_RING_WORDS - 1)) * LS_CLIPS + lane]; }
 };
 
 // 16 bytes of the stream at byte offset o (a multiple of 16), bytes at and beyond len2 read as zero (the reference never reads a word
@@ -70,10 +73,10 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   uint8_t *tab = lds;
   DevStore m;
   m.mvc_ = (int32_t *)(lds + MOBI_DT_BYTES);
-  m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * 64);
-  m.rec_ = m.stk_ + 16 * 64;
-  m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * 64;
-  m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * 64);
+  m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * LS_CLIPS);
+  m.rec_ = m.stk_ + 16 * LS_CLIPS;
+  m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
+  m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
   m.lane = lane;
   for (int i = lane; i < MOBI_DT_BYTES / 16; i += 64) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
@@ -110,8 +113,8 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
 #pragma unroll
     for (int k = 0; k < LS_RING / 16; k++) {
       const uint4 v = ls_chunk(base, 16u * k, len2);
-      m.ring_[(4 * k + 0) * 64 + lane] = v.x; m.ring_[(4 * k + 1) * 64 + lane] = v.y;
-      m.ring_[(4 * k + 2) * 64 + lane] = v.z; m.ring_[(4 * k + 3) * 64 + lane] = v.w;
+      m.ring_[(4 * k + 0) * LS_CLIPS + lane] = v.x; m.ring_[(4 * k + 1) * LS_CLIPS + lane] = v.y;
+      m.ring_[(4 * k + 2) * LS_CLIPS + lane] = v.z; m.ring_[(4 * k + 3) * LS_CLIPS + lane] = v.w;
     }
     wr = LS_RING;
     ls_begin_frame(s, m, c, len);
@@ -122,10 +125,10 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
     if ((round & (LS_SERVICE - 1)) == 0) {
       if (pending) { // what the last service asked for has had LS_SERVICE rounds to arrive
         const uint32_t k = (wr >> 2) & (LS_RING_WORDS - 1); // (a multiple of 8)
-        m.ring_[(k + 0) * 64 + lane] = pend0.x; m.ring_[(k + 1) * 64 + lane] = pend0.y;
-        m.ring_[(k + 2) * 64 + lane] = pend0.z; m.ring_[(k + 3) * 64 + lane] = pend0.w;
-        m.ring_[(k + 4) * 64 + lane] = pend1.x; m.ring_[(k + 5) * 64 + lane] = pend1.y;
-        m.ring_[(k + 6) * 64 + lane] = pend1.z; m.ring_[(k + 7) * 64 + lane] = pend1.w;
+        m.ring_[(k + 0) * LS_CLIPS + lane] = pend0.x; m.ring_[(k + 1) * LS_CLIPS + lane] = pend0.y;
+        m.ring_[(k + 2) * LS_CLIPS + lane] = pend0.z; m.ring_[(k + 3) * LS_CLIPS + lane] = pend0.w;
+        m.ring_[(k + 4) * LS_CLIPS + lane] = pend1.x; m.ring_[(k + 5) * LS_CLIPS + lane] = pend1.y;
+        m.ring_[(k + 6) * LS_CLIPS + lane] = pend1.z; m.ring_[(k + 7) * LS_CLIPS + lane] = pend1.w;
         wr += 32;
         pending = false;
       }
@@ -178,7 +181,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A
 extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64 || !a->state_ls) return (int)hipErrorInvalidValue;
-  const size_t lds = MOBI_DT_BYTES + (size_t)64 * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
+  const size_t lds = MOBI_DT_BYTES + (size_t)LS_CLIPS * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
   if (lds > 64 * 1024) // (per device; cheap)
     if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(mobi_parse_frames_ls, dim3((unsigned)((a->n_clips + LS_CLIPS - 1) / LS_CLIPS)), dim3(64), lds, s, *a);

@@ -1,4 +1,4 @@
-"""The lock-step parser on the GPU (mobi_parse_frames_ls, mobi_lsparse.hip: 64 clips per wavefront, parse mode 3): the device-parse tests of
+"""The lock-step parser on the GPU (mobi_parse_frames_ls, mobi_lsparse.hip: 32 clips per wavefront, parse mode 3): the device-parse tests of
 tests/test_device_parse.py once more with it in front -- oracle parity of planes, rc, Offset, Quantizer on good streams, on the streams the
 reference throws on (where it must hand the clip to mobi_parse_frames), on fuzzed streams against the host parser, and asynchronous steps --
 plus a check that it really finishes the intact frames itself instead of handing everything over."""

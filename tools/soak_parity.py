@@ -12,7 +12,7 @@ from tests.oracle_binding import OracleDecoder
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
 dparse = len(sys.argv) > 3 and sys.argv[3] in ("dparse", "lockstep")
-lockstep = dparse and sys.argv[3] == "lockstep"  # the lock-step parser in front (64 clips per wave)
+lockstep = dparse and sys.argv[3] == "lockstep"  # the lock-step parser in front (32 clips per wave)
 distinct, nfr = 16, (12 if dparse else 33)
 ps = [m.default_params(cfg, sharding.stream_seed(cfg, 0, i), n_frames=nfr, pm_intra=120 if i & 1 else 50, iframe_interval=11 if i % 5 == 0 else 0) for i in range(distinct)]
 clips = [m.generate_clip(p) for p in ps]
