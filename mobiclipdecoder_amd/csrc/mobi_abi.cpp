@@ -669,7 +669,7 @@ static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const siz
 }
 // output buffers + the parse launch.  A clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level
 // per bit read.  `busy`: earlier steps may still be using the buffers (asynchronous steps): drain the stream before growing one.
-struct DpOut { DevBuf *desc, *pay, *items; MobiDevResult *res; hipStream_t stream; };
+struct DpOut { DevBuf *desc, *pay, *items; MobiDevResult *res; hipStream_t stream; bool async = false; };
 static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged &st, bool busy, const DpOut &o) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
   // (the longest frame of a step varies from step to step: the bound follows it upwards in steps of a quarter, so that the payload
@@ -699,7 +699,7 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   pa.tables = b->d_ptables;
   pa.state = b->d_pstate;
   pa.state_ls = b->d_pstate_ls;
-  pa.lockstep = b->lockstep ? 1 : 0;
+  pa.lockstep = b->lockstep ? (o.async ? 2 : 1) : 0; // (2: 64 clips per wave, leaving LDS for the reconstruction it runs under)
   pa.pay_local = local ? 1 : 0;
   pa.desc = (MbDesc *)(*o.desc).p;
   pa.payload = (uint32_t *)(*o.pay).p;
@@ -889,7 +889,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   hipStream_t ps = b->lockstep ? b->stream_p : b->stream;
   HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
   MobiDevResult *d_res = (MobiDevResult *)S.d_pres.p;
-  if (int e = dp_parse(b, n, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps})) return e;
+  if (int e = dp_parse(b, n, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps, true})) return e;
   HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, ps));
   if (ps != b->stream) {
     HIP_TRY(hipEventRecord(S.ev_parsed, ps));

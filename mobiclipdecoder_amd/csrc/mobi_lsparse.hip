@@ -1,4 +1,4 @@
-// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: LS_CLIPS = 32 clips per wave, one per lane (mobi_lsparse.h has the state machine and
+// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: 32 (or 64) clips per wave, one per lane (mobi_lsparse.h has the state machine and
 // says why).
 //
 //   mobi_parse_frames_ls   one wave = LS_CLIPS clips (the other lanes idle).  Every lane walks its own frame with ls_round(); the wave runs until the last one is done.
@@ -23,24 +23,22 @@
 #include "mobi_lsparse.h"
 
 namespace {
-#ifndef LS_CLIPS
-#define LS_CLIPS 32 // clips per wave (lanes in use); tools/exp_lsab.sh "-DLS_CLIPS=64" ... tries others
-#endif
 #ifndef LS_SERVICE_N
 #define LS_SERVICE_N 4
 #endif
 enum { LS_SERVICE = LS_SERVICE_N, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
+template <int L> // L = clips per wave: the per-lane state is interleaved at that stride (element i of lane l at i * L + l)
 struct DevStore {
   int32_t *mvc_;
   uint32_t *stk_, *rec_, *ring_;
   uint8_t *mc_;
   int lane;
-  __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * LS_CLIPS + lane]; }
-  __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * LS_CLIPS + lane]; }
-  __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * LS_CLIPS + lane]; }
-  __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * LS_CLIPS + lane]; }
-  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & (LS_RING_WORDS - 1)) * LS_CLIPS + lane]; }
+  __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * L + lane]; }
+  __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * L + lane]; }
+  __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * L + lane]; }
+  __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * L + lane]; }
+  __device__ __forceinline__ uint32_t ring32(uint32_t rd) const { return ring_[((rd >> 2) & (LS_RING_WORDS - 1)) * L + lane]; }
 };
 
 // 16 bytes of the stream at byte offset o (a multiple of 16), bytes at and beyond len2 read as zero (the reference never reads a word
@@ -63,7 +61,8 @@ __device__ __forceinline__ uint4 ls_chunk(const uint8_t *base, uint32_t o, uint3
 }
 } // namespace
 
-extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevParseArgs A) {
+template <int LS_CLIPS>
+__device__ __forceinline__ void parse_frames_ls(const MobiDevParseArgs &A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // A wave of this kernel is one long chain of dependent instructions and the launch is as long as that chain.  When the reconstruction of
   // the step before runs beside it (asynchronous steps: four of its waves on the same SIMD), the chain must not queue behind them.
@@ -71,7 +70,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   const int lane = threadIdx.x;
   const int mvc_words = 2 * (A.mbw + 2);
   uint8_t *tab = lds;
-  DevStore m;
+  DevStore<LS_CLIPS> m;
   m.mvc_ = (int32_t *)(lds + MOBI_DT_BYTES);
   m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * LS_CLIPS);
   m.rec_ = m.stk_ + 16 * LS_CLIPS;
@@ -164,6 +163,15 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevPar
   }
   A.res[clip] = r;
 }
+// 32 clips per wave when a step is decoded on its own (mobi_batch_decode): the shortest life per wave that still leaves every wave of
+// 24576 clips a SIMD of its own (39 KB of LDS, four waves per CU).  64 per wave for asynchronous steps (mobi_batch_submit), whose parse runs
+// under the reconstruction of the step before: two waves of 61 KB leave a CU 38 KB for the reconstruction kernels' workgroups; four of 39
+// leave none, and the two would run one after the other (measured: 131 instead of 170 Gpixels/s).
+#ifndef MOBI_LS_SYNC_CLIPS
+#define MOBI_LS_SYNC_CLIPS 32 // tools/exp_lsab.sh "-DMOBI_LS_SYNC_CLIPS=64" ... tries others
+#endif
+extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevParseArgs A) { parse_frames_ls<MOBI_LS_SYNC_CLIPS>(A); }
+extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls64(MobiDevParseArgs A) { parse_frames_ls<64>(A); }
 
 // lane = one intra macroblock of a finished clip: workgroup = clip * chunks + chunk
 extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A, uint32_t chunks) {
@@ -181,10 +189,14 @@ extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A
 extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64 || !a->state_ls) return (int)hipErrorInvalidValue;
-  const size_t lds = MOBI_DT_BYTES + (size_t)LS_CLIPS * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
+  const int L = a->lockstep == 2 ? 64 : MOBI_LS_SYNC_CLIPS; // (2: an asynchronous step, see the kernels)
+  const size_t lds = MOBI_DT_BYTES + (size_t)L * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
+  const void *fn = L == 64 ? (const void *)mobi_parse_frames_ls64 : (const void *)mobi_parse_frames_ls;
   if (lds > 64 * 1024) // (per device; cheap)
-    if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
-  hipLaunchKernelGGL(mobi_parse_frames_ls, dim3((unsigned)((a->n_clips + LS_CLIPS - 1) / LS_CLIPS)), dim3(64), lds, s, *a);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
+  const dim3 grid((unsigned)((a->n_clips + L - 1) / L));
+  if (L == 64) hipLaunchKernelGGL(mobi_parse_frames_ls64, grid, dim3(64), lds, s, *a);
+  else hipLaunchKernelGGL(mobi_parse_frames_ls, grid, dim3(64), lds, s, *a);
   const uint32_t chunks = (uint32_t)(a->mbw * a->mbh + 63) / 64;
   hipLaunchKernelGGL(mobi_ls_deps, dim3((unsigned)a->n_clips * chunks), dim3(64), 0, s, *a, chunks);
   return (int)hipGetLastError();
