@@ -18,7 +18,7 @@ struct ParsedFrame {
   FrameHdr hdr;
   std::vector<MbDesc> desc;
   std::vector<uint32_t> payload;
-  std::vector<uint32_t> intra_mbs;   // MB indices, grouped by level (ascending), raster order inside a level
+  std::vector<uint32_t> intra_mbs;   // MB indices, grouped by level (ascending), by class inside a level (class_start), raster order inside a class
   std::vector<uint32_t> level_start; // size n_levels+2: intra_mbs[level_start[L] .. level_start[L+1]) for L = 1..n_levels
   // The same macroblocks as launch items (mobi_recon_intra; LevelPlan in mobi_abi.cpp), four words each, in the order of intra_mbs:
   //   [0] mb   [1] MbDesc.w1   [2] MbDesc.payload_off (inside this clip's payload)   [3] flags: [0] 16x16 plane present, [1] has intra
@@ -26,6 +26,7 @@ struct ParsedFrame {
   // Written by the parser while the descriptors are in its cache: the step's launch list is then a concatenation, not 60 random
   // reads per clip into descriptor tables other cores wrote (8 ms per step of 1024 clips, measured r04).
   std::vector<uint32_t> intra_items;
+  std::vector<uint32_t> class_start; // [L * 8 + class] -> first index of that class inside level L (class: mobi_parse.cpp, finish_levels); one more entry = the end
   void clear();
   size_t cmd_bytes() const { return desc.size() * sizeof(MbDesc) + payload.size() * 4; }
 };

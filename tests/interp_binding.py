@@ -20,11 +20,11 @@ def lib():
         L.mobi_cmdinterp_y.argtypes = [C.c_void_p, C.c_int]
         L.mobi_cmdinterp_uv.restype = C.POINTER(C.c_uint8)
         L.mobi_cmdinterp_uv.argtypes = [C.c_void_p, C.c_int]
-        for n in ("desc", "intra_mbs", "level_start", "intra_items"):
+        for n in ("desc", "intra_mbs", "level_start", "intra_items", "payload"):
             f = getattr(L, "mobi_cmdinterp_" + n)
             f.argtypes = [C.c_void_p]
             f.restype = C.POINTER(C.c_uint32)
-        for n in ("stride", "quantizer", "cmd_bytes", "levels", "n_mbs", "n_intra"):
+        for n in ("stride", "quantizer", "cmd_bytes", "levels", "n_mbs", "n_intra", "payload_words"):
             f = getattr(L, "mobi_cmdinterp_" + n)
             f.argtypes = [C.c_void_p]
             f.restype = C.c_uint32
@@ -84,3 +84,7 @@ class InterpDecoder:
         arr = lambda f, shape: np.ctypeslib.as_array(f(self.h), shape).copy() if int(np.prod(shape)) else np.zeros(shape, np.uint32)
         return (arr(self.L.mobi_cmdinterp_desc, (n, 8)), arr(self.L.mobi_cmdinterp_intra_mbs, (ni,)),
                 arr(self.L.mobi_cmdinterp_level_start, (nl + 2,)), arr(self.L.mobi_cmdinterp_intra_items, (ni, 4)))
+
+    def payload(self):
+        n = self.L.mobi_cmdinterp_payload_words(self.h)
+        return np.ctypeslib.as_array(self.L.mobi_cmdinterp_payload(self.h), (n,)).copy() if n else np.zeros(0, np.uint32)

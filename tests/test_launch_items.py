@@ -19,6 +19,7 @@ def test_items_say_what_the_descriptors_say(cfg, kw):
     d = InterpDecoder(p.width, p.height, p.version)
     mbw = p.width // 16
     seen_deps = seen_dependents = seen_edge = 0
+    seen_classes = set()
     for f in range(p.n_frames):
         d.Data, d.Offset = data[: fo[f + 1]], int(fo[f])
         assert d.DecodeFrame() is not None
@@ -33,6 +34,16 @@ def test_items_say_what_the_descriptors_say(cfg, kw):
                 if dep != DEP_NONE and not dep & DEP_INTER:
                     assert (desc[dep & 0x1FFF, 1] & 1) == 1 and (dep & 0x1FFF) < mb
                     named.add(int(dep & 0x1FFF))
+        # launch order inside a level: away from the picture's edges first, fewest split areas first (a wave of four runs the longest one's steps)
+        pay = d.payload()
+        def klass(mb):
+            splits = sum((int(pay[int(desc[mb, 0]) + 4 * a]) >> 5) & 1 for a in range(6))
+            mbx = int(mb) % mbw
+            return (0 if (mbx >= 1 and mbx + 1 < mbw and mb >= mbw) else 4) + min(splits, 3)
+        for L in range(1, len(ls) - 1):
+            keys = [(klass(mb), int(mb)) for mb in mbs[ls[L]:ls[L + 1]]]
+            assert keys == sorted(keys), (f, L)
+            seen_classes.update(k for k, _ in keys)
         level = {}
         for L in range(1, len(ls) - 1):
             for i in range(ls[L], ls[L + 1]):
@@ -52,4 +63,4 @@ def test_items_say_what_the_descriptors_say(cfg, kw):
             # a macroblock's level is one more than the highest level among the intra macroblocks it waits for
             assert level[int(mb)] == 1 + max([level[x] for x in intra_deps], default=0)
             seen_deps += bool(flags & 2); seen_dependents += bool(flags & 4); seen_edge += bool(flags & 8)
-    assert seen_deps and seen_dependents and seen_edge
+    assert seen_deps and seen_dependents and seen_edge and len(seen_classes) >= 3

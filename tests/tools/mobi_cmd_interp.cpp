@@ -291,4 +291,6 @@ uint32_t mobi_cmdinterp_n_intra(void *p) { return (uint32_t)((Interp *)p)->pf.in
 const uint32_t *mobi_cmdinterp_intra_mbs(void *p) { return ((Interp *)p)->pf.intra_mbs.data(); }
 const uint32_t *mobi_cmdinterp_level_start(void *p) { return ((Interp *)p)->pf.level_start.data(); }
 const uint32_t *mobi_cmdinterp_intra_items(void *p) { return ((Interp *)p)->pf.intra_items.data(); }
+uint32_t mobi_cmdinterp_payload_words(void *p) { return (uint32_t)((Interp *)p)->pf.payload.size(); }
+const uint32_t *mobi_cmdinterp_payload(void *p) { return ((Interp *)p)->pf.payload.data(); }
 }
