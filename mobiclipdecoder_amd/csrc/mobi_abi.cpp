@@ -148,15 +148,15 @@ struct LevelPlan { // launch plan of one frame step: the intra macroblocks of al
     items.reserve((sparse ? 4 : 1) * total + 16 * (size_t)maxl);
     const uint32_t none[4] = {MOBI_ITEM_NONE, 0, 0, 0};
     for (uint32_t L = 1; L <= maxl; L++) {
-      // inside a level by class (mobi_parse.cpp, finish_levels): macroblocks away from the picture's edges first, by the number of split areas
-      // (a wave runs as many steps as the longest of its four macroblocks has); the ones at an edge (on Width == Stride pictures their halo
+      // inside a level by class (mobi_parse.cpp, finish_levels): macroblocks away from the picture's edges first, those nobody depends on first, by the number of split areas
+      // (a wave runs as many steps as the longest of its four macroblocks has, and publishes if any of them must); the ones at an edge (on Width == Stride pictures their halo
       // needs the per-sample ownership test, mobi_recon_intra) behind them, so that few waves of four carry one.  The parsers wrote the items
       // (ParsedFrame::intra_items): this is a concatenation with the clip number and the clip's place in the arena added.
-      for (uint32_t k = 0; k < 8; k++)
+      for (uint32_t k = 0; k < MOBI_INTRA_CLASSES; k++)
         for (size_t c = 0; c < frames.size(); c++) {
           const ParsedFrame *f = frames[c];
           if (!f || L > f->hdr.n_levels) continue;
-          for (uint32_t i = f->class_start[(size_t)L * 8 + k]; i < f->class_start[(size_t)L * 8 + k + 1]; i++) {
+          for (uint32_t i = f->class_start[(size_t)L * MOBI_INTRA_CLASSES + k]; i < f->class_start[(size_t)L * MOBI_INTRA_CLASSES + k + 1]; i++) {
             const uint32_t *it = &f->intra_items[(size_t)i * 4];
             intra_cmd_bytes += sizeof(MbDesc) + 4 * (MOBI_INTRA_RECORDS + ((it[3] >> 5) & 0x3FFu));
             const uint32_t item[4] = {MOBI_ITEM(c, it[0]), it[1], it[2] + (uint32_t)base[c], it[3] & ~8u};

@@ -670,40 +670,41 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
     d.w6 = deps[4] | ((uint32_t)deps[5] << 16);
     d.w7 = deps[6] | ((uint32_t)deps[7] << 16);
   }
-  // Launch order inside a level: by CLASS = (at a picture edge ? 4 : 0) + min(split areas, 3).  A wave of mobi_recon_intra carries four
-  // macroblocks and runs as many steps as the longest of them has (6 + 3 per split area); three in four have no split area, but four taken
-  // as they come have one somewhere in 71 % of the waves.  Sorted, the waves of one kind run their own number of steps (r04).
+  // Launch order inside a level: by CLASS = (at a picture edge ? 8 : 0) + (has intra dependents ? 4 : 0) + min(split areas, 3).  A wave of
+  // mobi_recon_intra carries four macroblocks and runs as many steps as the longest of them has (6 + 3 per split area); three in four have
+  // no split area, but four taken as they come have one somewhere in 71 % of the waves.  Sorted, the waves of one kind run their own
+  // number of steps; and a wave in which nobody has dependents does not write through, drain and publish (r04).
   auto klass = [&](int mb) {
     const MbDesc &d = out.desc[mb];
     int splits = 0;
     for (int a = 0; a < 6; a++) splits += (out.payload[d.payload_off + 4 * a] >> 5) & 1; // the area's first block record, bit 5 (mobi_kernels.hip, the schedule)
     const int mbx = mb % g_.mbw;
     const bool interior = mbx >= 1 && mbx + 1 < g_.mbw && mb >= g_.mbw;
-    return (interior ? 0 : 4) + std::min(splits, 3);
+    return (interior ? 0 : 8) + ((flag[mb] & 4) ? 4 : 0) + std::min(splits, 3);
   };
-  out.class_start.assign((size_t)(maxl + 1) * 8 + 1, 0); // [L * 8 + class] -> first index into intra_mbs / intra_items; [.. + 1] = its end
+  out.class_start.assign((size_t)(maxl + 1) * MOBI_INTRA_CLASSES + 1, 0); // [L * MOBI_INTRA_CLASSES + class] -> first index into intra_mbs / intra_items; [.. + 1] = its end
   std::vector<uint8_t> kl(n, 0);
   for (int mb = 0; mb < n; mb++)
     if (level[mb]) {
       kl[mb] = (uint8_t)klass(mb);
-      out.class_start[(size_t)level[mb] * 8 + kl[mb] + 1]++;
+      out.class_start[(size_t)level[mb] * MOBI_INTRA_CLASSES + kl[mb] + 1]++;
     }
   for (size_t k = 1; k < out.class_start.size(); k++) out.class_start[k] += out.class_start[k - 1];
   out.level_start.assign(maxl + 2, 0);
-  for (int l = 1; l <= maxl + 1; l++) out.level_start[l] = l <= maxl ? out.class_start[(size_t)l * 8] : (uint32_t)n_intra;
+  for (int l = 1; l <= maxl + 1; l++) out.level_start[l] = l <= maxl ? out.class_start[(size_t)l * MOBI_INTRA_CLASSES] : (uint32_t)n_intra;
   out.intra_mbs.resize(n_intra);
   std::vector<uint32_t> cursor(out.class_start.begin(), out.class_start.end() - 1);
   out.intra_items.resize((size_t)n_intra * 4);
   for (int mb = 0; mb < n; mb++)
     if (level[mb]) {
-      const uint32_t at = cursor[(size_t)level[mb] * 8 + kl[mb]]++;
+      const uint32_t at = cursor[(size_t)level[mb] * MOBI_INTRA_CLASSES + kl[mb]]++;
       out.intra_mbs[at] = (uint32_t)mb;
       const MbDesc d = out.desc[mb];
       uint32_t *it = &out.intra_items[(size_t)at * 4];
       it[0] = (uint32_t)mb;
       it[1] = d.w1;
       it[2] = d.payload_off;
-      it[3] = (d.w3 & 0xFFFF0001u) | flag[mb] | (kl[mb] >= 4 ? 8u : 0u) | ((d.w2 & 0x3FFu) << 5);
+      it[3] = (d.w3 & 0xFFFF0001u) | flag[mb] | (kl[mb] >= 8 ? 8u : 0u) | ((d.w2 & 0x3FFu) << 5);
       out.desc[mb].w3 |= flag[mb]; // (the device parsers' item lists carry no flags: mobi_recon_intra_cl reads these two bits from the descriptor)
     }
   out.hdr.n_mbs = (uint32_t)n;

@@ -14,6 +14,7 @@
 
 #include "mobi_cmd.h"
 
+enum { MOBI_INTRA_CLASSES = 16 }; // launch classes of intra macroblocks inside a dependency level (finish_levels)
 struct ParsedFrame {
   FrameHdr hdr;
   std::vector<MbDesc> desc;
@@ -26,7 +27,7 @@ struct ParsedFrame {
   // Written by the parser while the descriptors are in its cache: the step's launch list is then a concatenation, not 60 random
   // reads per clip into descriptor tables other cores wrote (8 ms per step of 1024 clips, measured r04).
   std::vector<uint32_t> intra_items;
-  std::vector<uint32_t> class_start; // [L * 8 + class] -> first index of that class inside level L (class: mobi_parse.cpp, finish_levels); one more entry = the end
+  std::vector<uint32_t> class_start; // [L * MOBI_INTRA_CLASSES + class] -> first index of that class inside level L (class: mobi_parse.cpp, finish_levels); one more entry = the end
   void clear();
   size_t cmd_bytes() const { return desc.size() * sizeof(MbDesc) + payload.size() * 4; }
 };

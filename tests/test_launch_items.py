@@ -34,12 +34,12 @@ def test_items_say_what_the_descriptors_say(cfg, kw):
                 if dep != DEP_NONE and not dep & DEP_INTER:
                     assert (desc[dep & 0x1FFF, 1] & 1) == 1 and (dep & 0x1FFF) < mb
                     named.add(int(dep & 0x1FFF))
-        # launch order inside a level: away from the picture's edges first, fewest split areas first (a wave of four runs the longest one's steps)
+        # launch order inside a level: away from the picture's edges first, those nobody depends on first, fewest split areas first (a wave of four runs the longest one's steps)
         pay = d.payload()
         def klass(mb):
             splits = sum((int(pay[int(desc[mb, 0]) + 4 * a]) >> 5) & 1 for a in range(6))
             mbx = int(mb) % mbw
-            return (0 if (mbx >= 1 and mbx + 1 < mbw and mb >= mbw) else 4) + min(splits, 3)
+            return (0 if (mbx >= 1 and mbx + 1 < mbw and mb >= mbw) else 8) + (4 if int(mb) in named else 0) + min(splits, 3)
         for L in range(1, len(ls) - 1):
             keys = [(klass(mb), int(mb)) for mb in mbs[ls[L]:ls[L + 1]]]
             assert keys == sorted(keys), (f, L)
