@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage (GPU box): tools/exp_prio.sh -- the reconstruction kernels built with -DMOBI_NO_PRIO (no s_setprio around their request stages) and as they are, A/B on one box
+# usage (GPU box): VARIANTS="-DX -DY" tools/exp_variants.sh -- the reconstruction kernels rebuilt with each -D variant in turn, A/B on one box
+# (r03 used it as exp_prio.sh for the s_setprio decision: -DMOBI_NO_PRIO against the kernels as they are; those macros are gone)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; P=$REPO/mobiclipdecoder_amd; O=$P/_obj
 cp $P/libmobiclip_hip.so /tmp/lib_keep.so; cp $O/mobi_kernels.hip.o /tmp/k_keep.o
 OBJS="$O/mobi_abi.cpp.o $O/mobi_parse.cpp.o $O/mobi_demux.cpp.o $O/mobi_moflex.cpp.o $O/mobi_kernels.hip.o $O/mobi_rgb.hip.o $O/mobi_dparse.hip.o $O/mobi_lsparse.hip.o $O/mobi_analysis.hip.o"
