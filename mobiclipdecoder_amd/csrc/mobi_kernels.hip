@@ -445,7 +445,7 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
   if (PROF) { asm volatile("" : : "s"(off0), "s"(clip)); pa = prof_stamp(); }
 
   // A wave asks for its descriptors, windows and level words ahead of its neighbours' arithmetic: the sooner its requests are out, the
-  // shorter it holds its place (A/B on one box in r03, tools/exp_variants.sh: 7.31 -> 7.20 ms per launch; the stores at the end as well: -0.3 %)
+  // shorter it holds its place (A/B on one box, tools/exp_prio.sh: 7.31 -> 7.20 ms per launch; the stores at the end as well: -0.3 %)
   __builtin_amdgcn_s_setprio(3);
   // ---- stage A: descriptor, then every global read of the octet ----
   const uint4 *dp = (const uint4 *)(A.desc + (clip * (uint32_t)A.n_mbs + mby * mbw + mbx0) + g); // the table has slack past the last octet
