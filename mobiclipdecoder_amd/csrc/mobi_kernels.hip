@@ -1199,10 +1199,11 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   const int wdst = l < 4 ? (l == 0 ? 0 : 8 * l - 4) : ((l & 1) ? IQ_TCV : IQ_TCU) + (l < 6 ? 0 : l < 8 ? 4 : 12);
   const bool whalf = l == 0 || l == 4 || l == 5;
   const int b0dst = (l + 1) * TP + 3, b1dst = (l < 8 ? IQ_TCU : IQ_TCV) + ((l & 7) + 1) * TP + 3;
-  // ordinary loads, in flight beside the records (whoever has to wait for a producer loads again below and drops these)
+  // ordinary loads, in flight beside the records -- for the rows that will not have to wait for a producer: the others load below, behind
+  // their producers' tags, and would drop these (every macroblock of an I-frame but the first; every row of a one-launch step)
   uint2 w_early = uint2{0, 0};
   uint32_t b0_early = 0, b1_early = 0;
-  if (!(dbg & 16)) { w_early = *(const uint2 *)wp; b0_early = *b0p; b1_early = *b1p; }
+  if (!(dbg & 16) && !(I.valid && (FUSED || I.has_deps))) { w_early = *(const uint2 *)wp; b0_early = *b0p; b1_early = *b1p; }
 
   __builtin_amdgcn_s_setprio(0);
   { // zero the coefficients; dequant scales behind them
