@@ -42,11 +42,11 @@ extern "C" {
 #define MOBI_E_VERSION (-4)      /* VxDS / unknown version */
 #define MOBI_E_CLAMP (-5)        /* residual add left the clamp table domain (MobiConst.cs:587; MD.cs:3551);
                                     detected on the GPU, so the parser state has already advanced */
-#define MOBI_E_UNSUPPORTED (-6)  /* the reference decodes this frame to something and this library refuses: a coefficient run
-                                    that reads the transforms' scratch inside `Internal`, a motion vector beyond +-8191 half-pels
-                                    in a deeper partition tree, a plane parameter outside int16; and, when the parse runs on the
-                                    GPU, every run past its block and every ModsDS quantiser < 12 (the host parser decodes those
-                                    since r04: INTEGRATION.md, error table) */
+#define MOBI_E_UNSUPPORTED (-6)  /* the reference decodes this frame to something and this library refuses.  r05: ONE input is left -- a
+                                    coefficient run that walks through `Internal` (MD.cs:3424-3429) and leaves a coefficient beyond
+                                    int16 in a block whose residual nevertheless stays within +-319 everywhere (so that the clamp
+                                    table need not fault): sums that cancel through 32-bit wrap-around; never seen in 40 000 corrupted
+                                    frames.  Everything r01-r04 refused is decoded, wherever the parse runs (error table) */
 #define MOBI_E_ARG (-7)          /* bad argument / dimensions not a multiple of 16 (the reference cannot
                                     decode those either: MD.cs:216-217) */
 #define MOBI_E_DEVICE (-8)       /* HIP error (no device, allocation, launch) */
@@ -87,7 +87,8 @@ uint32_t mobi_height(const mobi_dec *d);       /* d.Height     (MD.cs:18) */
 
 /* ---- batch of independent clips (the throughput path) -------------------------------------- */
 /* N decoder instances that share geometry/version; they share nothing else (MD.cs:15-39).
- * Tuning knobs read from the environment when a batch is created (none changes a result): MOBI_PARSE_THREADS (host parse pool; default
+ * Tuning knobs read from the environment when a batch is created (none changes a result: rc, Offset, Quantizer and planes do not depend
+ * on where a clip is parsed -- see mobi_batch_set_parse_mode): MOBI_PARSE_THREADS (host parse pool; default
  * one per two hardware threads, at most 64), MOBI_DEVICE_PARSE and MOBI_HYBRID_HOST_CLIPS (below), MOBI_FUSED_STEP_MBS (a frame step of
  * at most this many macroblocks is ONE launch, mobi_recon_step; default 256 x 1200, 0 = always two launches). */
 mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int version, int device);
@@ -109,8 +110,16 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * parser, which then runs for those alone.  Its time per frame step does not depend on the batch (31 ms for 640x480 P-frames, 52 ms for
  * I-frames, up to 32768 clips), so it pays from about 15000 resident clips and is the default from
  * 16384 (MOBI_DEVICE_PARSE=1: never).
+ * THE RESULT DOES NOT DEPEND ON THE MODE (r05).  The device parsers finish the frames that decode without incident.  A frame they cannot
+ * finish -- anything the reference throws on, a coefficient run that walks through `Internal` (MD.cs:3424-3429), a ModsDS quantiser below
+ * 12, a value the command list has to escape -- is parsed again by the host parser inside the same call (mobi_batch_wait for asynchronous
+ * steps), from the decoder state the clip had when that frame started, which the device keeps for exactly this; the clip stays with the
+ * host parser from then on (mobi_batch_host_clips counts them), parsed beside the GPU's clips as the hybrid mode's share is.
  * Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
+/* how many clips of the batch the host parser parses at present: all of them in mode 0; in the other modes the hybrid share plus every
+ * clip that has had a frame the device parser could not finish */
+int mobi_batch_host_clips(const mobi_batch *b);
 /* Parse mode 3: how many clips of the last finished frame step the lock-step parser finished itself (the rest went to the other one);
  * -1 in the other modes or before the first step. */
 int mobi_batch_lockstep_finished(const mobi_batch *b);

@@ -262,8 +262,17 @@ struct mobi_batch {
   float last_hostparse_ms = 0;                 // ... / of its host parse part (host parse mode)
   DevBuf d_bits, d_pdesc, d_ppay, d_pitems;
   DevBuf d_src, d_search; // mobi_batch_motion_search: the pictures being analysed, the packed results
-  MobiDevState *d_pstate = nullptr;
+  // the decoder state of the device-parsed clips: a ring of three entries (a step reads ps_cur, writes ps_cur + 1), so that the state a frame
+  // STARTED from is still there when the host parser has to take the frame over (decode_device_parse, async_repair; mobi_state.h)
+  MobiDevState *d_pstate[3] = {nullptr, nullptr, nullptr};
+  MobiDevTail *d_ptail[3] = {nullptr, nullptr, nullptr};
+  int ps_cur = 0;
   MobiDevState *d_pstate_ls = nullptr; // shadow copy the lock-step parser writes (mobi_lsparse.hip)
+  std::vector<uint8_t> on_host;        // [clip] device-parse modes: this clip is the host parser's (the hybrid mode's share; clips with a frame the
+                                       // device parser could not finish, from that frame on)
+  unsigned long fallbacks = 0;         // frames taken over so far
+  PinnedBuf h_fix;                     // async_repair: one clip's command list
+  DevBuf d_fix;
   uint32_t pay_clip_words = 0;         // of the last device-parsed step (MobiReconArgs.pay_clip_words)
   int ls_finished = -1;                // clips of the last step it finished itself
   bool lockstep = false;               // mobi_batch_set_parse_mode(b, 3) / MOBI_DEVICE_PARSE=3: mobi_parse_frames_ls in front of mobi_parse_frames
@@ -276,7 +285,7 @@ struct mobi_batch {
   // asynchronous steps (mobi_batch_submit / mobi_batch_wait, device parse only): two sets of staging so that the bytes of step
   // n + 1 are gathered and uploaded while the GPU works on step n; everything else follows stream order
   struct AsyncSlot {
-    PinnedBuf h_stage, h_pres, h_fault;
+    PinnedBuf h_stage, h_pres, h_fault, h_over; // h_over: the command lists of the host parser's clips (dp_override)
     DevBuf d_bits;
     // what the parse of this step leaves in HBM: owned by the slot, so that the parse of step n + 1 (on stream_p) may run under the
     // reconstruction of step n (on stream), which still reads step n's
@@ -284,6 +293,12 @@ struct mobi_batch {
     hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_parsed = nullptr;
     std::vector<int32_t> offs; // Offset of every clip at submission
     int n_dev = 0;
+    int state_in = 0, ring_base = 0; // the entry of the state ring this step's parse read; the ring position its reconstruction wrote
+    size_t hdr_bytes = 0;            // of the staged bitstream image (h_stage: offsets, lengths, bits)
+    // clips whose result is the host parser's (its own clips at submission; clips repaired in mobi_batch_wait)
+    std::vector<uint8_t> is_host;
+    std::vector<int> host_rc;
+    std::vector<int32_t> host_off;
   };
   AsyncSlot aslot[2];
   hipStream_t stream_p = nullptr;      // asynchronous steps: the parse kernels (upload on stream2, reconstruction on stream)
@@ -342,10 +357,11 @@ struct mobi_batch {
   }
   // one frame step = the inter launch, then ONE intra launch for all dependency levels (items sorted by level, waves wait for
   // the tags of the macroblocks they depend on).  r01 also had a launch per level and a whole-step launch; both were slower.
-  int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev) {
+  int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev, int n_clips = -1) {
+    if (n_clips < 0) n_clips = n;
     // Small steps (BASELINE config 4: 8 clips per GPU): one launch carries both kinds of macroblock -- the kernel boundary between the two
     // launches is a fifth of such a step.  Large ones keep two: the fused kernel has the octet's registers and LDS for the intra fours too.
-    if (plan.any_inter && plan.n_items && (size_t)n * g.mbw * g.mbh <= fused_mbs) {
+    if (plan.any_inter && plan.n_items && (size_t)n_clips * g.mbw * g.mbh <= fused_mbs) {
       EvPair ep{nullptr, nullptr, 0};
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
       if (mobi_launch_step(&a, items_dev, (int)plan.n_items, stream) != 0) return MOBI_E_DEVICE;
@@ -400,7 +416,10 @@ struct mobi_batch {
     if (d_done) (void)hipFree(d_done);
     if (d_lin) (void)hipFree(d_lin);
     if (d_argb) (void)hipFree(d_argb);
-    if (d_pstate) (void)hipFree(d_pstate);
+    for (int k = 0; k < 3; k++) {
+      if (d_pstate[k]) (void)hipFree(d_pstate[k]);
+      if (d_ptail[k]) (void)hipFree(d_ptail[k]);
+    }
     if (d_pstate_ls) (void)hipFree(d_pstate_ls);
     if (d_pres) (void)hipFree(d_pres);
     if (d_ptables) (void)hipFree(d_ptables);
@@ -475,7 +494,7 @@ const char *mobi_error_string(int rc) {
     case MOBI_E_PARTCODE: return "illegal partition code";
     case MOBI_E_VERSION: return "unsupported codec version";
     case MOBI_E_CLAMP: return "residual left the clamp-table domain";
-    case MOBI_E_UNSUPPORTED: return "stream depends on Internal[] scratch aliasing (outside the parity domain)";
+    case MOBI_E_UNSUPPORTED: return "a walk through Internal[] left a coefficient beyond int16 that need not leave the clamp table's domain (the one input outside the parity domain)";
     case MOBI_E_ARG: return "bad argument";
     case MOBI_E_DEVICE: return g_last_hip_error[0] ? g_last_hip_error : "HIP error";
     default: return "unknown";
@@ -505,6 +524,7 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
   b->clip_bytes = 6 * b->slot_bytes;
   b->cur.resize(n_clips);
   b->h_fault.assign(n_clips, 0);
+  b->on_host.assign(n_clips, 0);
   size_t arena_clips = (size_t)n_clips;
   size_t total = kGuard * 2 + b->clip_bytes * arena_clips;
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -569,10 +589,19 @@ void mobi_batch_destroy(mobi_batch *b) {
 
 // DecodeFrame() of every clip with the bitstream parse on the GPU: upload Data[Offset..) of every clip, one parse launch
 // (one wave per clip) that leaves descriptors, payload and intra lists in HBM, then the usual reconstruction launches.
+//
+// r05: WHICH side parses never shows in the result.  The device parsers finish the frames that decode without incident.  A frame they
+// cannot finish -- every condition under which the reference throws, every walk through Internal[] (MD.cs:3424-3429), every value the
+// command list has to escape (mobi_parse.cpp) -- is parsed again by the host parser INSIDE THE SAME CALL, from the decoder state the clip
+// had when the frame started (the device keeps a ring of three states per clip: mobi_dparse.h, mobi_state.h), and its command list is
+// written over the blank one the parse kernel left.  rc, Offset, Quantizer and the planes are then the host parser's, i.e. the same as
+// at any other batch size; the clip stays with the host parser from there on (`on_host`), parsed beside the GPU's clips like the
+// host-parsed share of the hybrid mode, which is the same mechanism with the last clips of the batch marked from the start.
+//
 // first use of the device-side parser: zeroed decoder state (a new MobiclipDecoder), result array, tables -- all of it or none of it
 static int dp_init(mobi_batch *b) {
   const int n = b->n;
-  if (b->d_pstate) return MOBI_OK;
+  if (b->d_pstate[0]) return MOBI_OK;
   auto init = [&]() -> int {
     HIP_TRY(hipMalloc((void **)&b->d_pres, sizeof(MobiDevResult) * n));
     HIP_TRY(hipMemset(b->d_pres, 0, sizeof(MobiDevResult) * n));
@@ -581,31 +610,41 @@ static int dp_init(mobi_batch *b) {
     HIP_TRY(hipMalloc((void **)&b->d_ptables, MOBI_DT_BYTES));
     HIP_TRY(hipMemcpy(b->d_ptables, blob.data(), MOBI_DT_BYTES, hipMemcpyHostToDevice));
     if (int e = b->h_pres.reserve(sizeof(MobiDevResult) * n)) return e;
-    MobiDevState *st = nullptr;
-    HIP_TRY(hipMalloc((void **)&st, sizeof(MobiDevState) * n));
-    if (hipMemset(st, 0, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
-    if (hipMalloc((void **)&b->d_pstate_ls, sizeof(MobiDevState) * n) != hipSuccess) { (void)hipFree(st); return MOBI_E_DEVICE; }
-    b->d_pstate = st; // last: its presence means "initialised"
+    HIP_TRY(hipMalloc((void **)&b->d_pstate_ls, sizeof(MobiDevState) * n));
+    for (int k = 0; k < 3; k++) {
+      HIP_TRY(hipMalloc((void **)&b->d_ptail[k], sizeof(MobiDevTail) * n));
+      HIP_TRY(hipMemset(b->d_ptail[k], 0, sizeof(MobiDevTail) * n));
+    }
+    for (int k = 2; k >= 0; k--) { // entry 0 last: its presence means "initialised"
+      HIP_TRY(hipMalloc((void **)&b->d_pstate[k], sizeof(MobiDevState) * n));
+      HIP_TRY(hipMemset(b->d_pstate[k], 0, sizeof(MobiDevState) * n));
+    }
     return MOBI_OK;
   };
   if (int e = init()) {
     if (b->d_pres) { (void)hipFree(b->d_pres); b->d_pres = nullptr; }
     if (b->d_ptables) { (void)hipFree(b->d_ptables); b->d_ptables = nullptr; }
     if (b->d_pstate_ls) { (void)hipFree(b->d_pstate_ls); b->d_pstate_ls = nullptr; }
+    for (int k = 0; k < 3; k++) {
+      if (b->d_pstate[k]) { (void)hipFree(b->d_pstate[k]); b->d_pstate[k] = nullptr; }
+      if (b->d_ptail[k]) { (void)hipFree(b->d_ptail[k]); b->d_ptail[k] = nullptr; }
+    }
     return e;
   }
   b->dev_quant.assign(n, 0);
   b->dev_yuvfmt.assign(n, 0);
+  if ((int)b->on_host.size() != n) b->on_host.assign(n, 0);
   return MOBI_OK;
 }
-// stage [bit_off u64 x nd][bit_len u32 x nd][bits: each clip 8-byte aligned, zero padded] of clips [0, nd) into pinned memory
+// stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded] into pinned memory; the host parser's clips
+// (b->on_host) carry MOBI_DP_SKIP for a length and no bits
 struct DpStaged { size_t hdr_bytes = 0, bytes = 0, max_len = 0; };
 // dev != nullptr: the image is also sent to *dev on `up`, chunk by chunk while the next chunk is gathered (one thread of the pool sits in
 // the copy calls, which return when the bus is done: 8 ms for the 370 MB of a step of 24576 clips; the others gather) -- r04: gathering and
 // sending were 12 of the 45 ms of such a step, one after the other.
-static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const size_t *len, const int32_t *offsets, PinnedBuf &stage, DpStaged &st,
+static int dp_stage(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets, PinnedBuf &stage, DpStaged &st,
                     DevBuf *dev = nullptr, bool dev_headroom = false, hipStream_t up = nullptr) {
-  const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
+  const int n = b->n, nd = n, n_mbs = b->g.mbw * b->g.mbh;
   const auto t_stage0 = std::chrono::steady_clock::now();
   constexpr size_t kBitPad = 32; // the reader runs two 8-byte registers ahead
   std::vector<uint64_t> boff(nd);
@@ -619,19 +658,22 @@ static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const siz
     // once per syntax element: <= ~1450 refills per macroblock (127 partition nodes, 384 levels of up to three reads each), so
     // bytes beyond 4 KB per macroblock cannot influence the parse of this frame
     l = std::min(l, frame_bound);
-    max_len = std::max(max_len, l);
-    if (i >= nd) continue; // parsed on the host: only its share of the payload bound counts
+    max_len = std::max(max_len, l); // (the host parser's clips too: their share of the payload bound counts)
     boff[i] = pos;
+    if (b->on_host[i]) { blen[i] = MOBI_DP_SKIP; continue; }
     blen[i] = (uint32_t)l;
     pos += align_up(l + kBitPad, 8);
   }
+  pos += 64; // (a skipped clip's offset points at readable bytes too)
   const size_t hdr_bytes = align_up((size_t)nd * 12, 16);
   if (hdr_bytes + pos > stage.cap) // pinned memory is slow to allocate: leave room for the longer frames to come
     if (int e = stage.reserve(hdr_bytes + pos + (hdr_bytes + pos) / 4)) return e;
   uint8_t *hs = stage.p;
   memcpy(hs, boff.data(), (size_t)nd * 8);
   memcpy(hs + (size_t)nd * 8, blen.data(), (size_t)nd * 4);
+  memset(hs + hdr_bytes + pos - 64, 0, 64);
   auto gather = [&](int i) {
+    if (blen[i] == MOBI_DP_SKIP) return;
     uint8_t *dst = hs + hdr_bytes + boff[i];
     if (blen[i]) memcpy(dst, data[i] + offsets[i], blen[i]);
     memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
@@ -653,7 +695,7 @@ static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const siz
       b->pool->run(n_up + (c1 - c0), [&](int j) {
         if (j < n_up) {
           const size_t a = u0 == 0 ? 0 : end_of(u0), e = end_of(u1); // (the first chunk takes the header along)
-          if (hipSetDevice(b->device) != hipSuccess || hipMemcpyAsync(dev->p + a, hs + a, e - a, hipMemcpyHostToDevice, up) != hipSuccess) up_err = 1;
+          if (e > a && (hipSetDevice(b->device) != hipSuccess || hipMemcpyAsync(dev->p + a, hs + a, e - a, hipMemcpyHostToDevice, up) != hipSuccess)) up_err = 1;
           return;
         }
         gather(c0 + (j - n_up));
@@ -669,22 +711,17 @@ static int dp_stage(mobi_batch *b, int nd, const uint8_t *const *data, const siz
 }
 // output buffers + the parse launch.  A clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level
 // per bit read.  `busy`: earlier steps may still be using the buffers (asynchronous steps): drain the stream before growing one.
+// *state_in: which entry of the state ring the step reads (the state its frames start from).
 struct DpOut { DevBuf *desc, *pay, *items; MobiDevResult *res; hipStream_t stream; bool async = false; };
-static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged &st, bool busy, const DpOut &o) {
+static int dp_parse(mobi_batch *b, const uint8_t *d_bits, const DpStaged &st, bool busy, const DpOut &o, int *state_in) {
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
   // (the longest frame of a step varies from step to step: the bound follows it upwards in steps of a quarter, so that the payload
   // arena -- gigabytes for thousands of clips -- is not freed and allocated again every few frames)
   if (st.max_len > b->dp_len_hint) b->dp_len_hint = st.max_len + st.max_len / 4;
-  size_t cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * b->dp_len_hint) + 448 + 64;
-  // Every clip parsed on the GPU: MbDesc.payload_off is relative to the clip's own part of the arena, which may then be as large as HBM
-  // lets it (24576 clips of 640x480 need 13 G words for an I-frame).  Hybrid: the host-parsed clips' payload is packed behind the
-  // others, so the offsets stay relative to the arena and the arena below 2^32 words.
-  const bool local = nd == n;
-  if (!local) {
-    if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) cap_words = std::min<size_t>((size_t)n_mbs * 448, (size_t)n_mbs * 64 + 8 * st.max_len) + 448 + 64;
-    if ((uint64_t)cap_words * (uint64_t)n >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // payload offsets are 32-bit words
-  }
-  b->pay_clip_words = local ? (uint32_t)cap_words : 0u;
+  const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448 + MOBI_WIDE_PARAMS, (size_t)n_mbs * 64 + 8 * b->dp_len_hint) + 448 + 64;
+  // MbDesc.payload_off is relative to the clip's own part of the arena, which may then be as large as HBM lets it (24576 clips of
+  // 640x480 need 13 G words for an I-frame); the host parser's clips write into their own parts like everybody else (dp_override)
+  b->pay_clip_words = (uint32_t)cap_words;
   const size_t want_desc = align_up((size_t)n * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), want_pay = align_up((size_t)n * cap_words * 4 + kPaySlack, kAlign),
                want_items = (size_t)n * n_mbs * 4;
   if (busy && (want_desc > (*o.desc).cap || want_pay > (*o.pay).cap || want_items > (*o.items).cap)) HIP_TRY(hipStreamSynchronize(o.stream));
@@ -695,25 +732,92 @@ static int dp_parse(mobi_batch *b, int nd, const uint8_t *d_bits, const DpStaged
   memset(&pa, 0, sizeof(pa));
   pa.bits = d_bits + st.hdr_bytes;
   pa.bit_off = (const uint64_t *)d_bits;
-  pa.bit_len = (const uint32_t *)(d_bits + (size_t)nd * 8);
+  pa.bit_len = (const uint32_t *)(d_bits + (size_t)n * 8);
   pa.tables = b->d_ptables;
-  pa.state = b->d_pstate;
+  const int in = b->ps_cur, out = (b->ps_cur + 1) % 3;
+  pa.state_in = b->d_pstate[in]; pa.state_out = b->d_pstate[out];
+  pa.tail_in = b->d_ptail[in]; pa.tail_out = b->d_ptail[out];
+  pa.scale = b->d_scale;
   pa.state_ls = b->d_pstate_ls;
   pa.lockstep = b->lockstep ? (o.async ? 2 : 1) : 0; // (2: 64 clips per wave, leaving LDS for the reconstruction it runs under)
-  pa.pay_local = local ? 1 : 0;
+  pa.pay_local = 1;
   pa.desc = (MbDesc *)(*o.desc).p;
   pa.payload = (uint32_t *)(*o.pay).p;
   pa.items = (uint32_t *)(*o.items).p;
   pa.res = o.res;
   pa.pay_cap = (uint32_t)cap_words;
   b->last_pay_cap = cap_words;
-  pa.n_clips = nd; pa.version = b->version;
+  pa.n_clips = n; pa.version = b->version;
   pa.width = b->g.width; pa.height = b->g.height; pa.stride = b->g.stride; pa.lg = b->g.lg; pa.mbw = b->g.mbw; pa.mbh = b->g.mbh;
   if (b->ktiming && !b->ev_p0) { (void)hipEventCreate(&b->ev_p0); (void)hipEventCreate(&b->ev_p1); }
   const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
   if (ptime) (void)hipEventRecord(b->ev_p0, o.stream);
   if (mobi_launch_parse(&pa, o.stream) != 0) return MOBI_E_DEVICE;
   if (ptime) (void)hipEventRecord(b->ev_p1, o.stream);
+  b->ps_cur = out;
+  *state_in = in;
+  return MOBI_OK;
+}
+
+// The command lists of host-parsed clips of a device-parsed step (`clips`, ascending; b->cur[c] holds clip c's frame when rc[c] is MOBI_OK):
+// staged in pinned memory and copied into the clips' own rows of what the parse kernels leave -- descriptor rows, payload parts, item
+// rows, result records -- on stream s.  Runs of neighbouring clips (the hybrid mode's share) go as one copy per table.
+struct DpRows { uint8_t *desc, *pay, *items; MobiDevResult *res; size_t cap_words; };
+static int dp_override(mobi_batch *b, const std::vector<int> &clips, const int *rc, PinnedBuf &stage, const DpRows &d, hipStream_t s) {
+  const int k = (int)clips.size(), n_mbs = b->g.mbw * b->g.mbh;
+  if (k == 0) return MOBI_OK;
+  size_t pitch_w = 0; // payload words per clip in the staging area
+  for (int c : clips)
+    if (rc[c] == MOBI_OK) pitch_w = std::max(pitch_w, b->cur[c].payload.size());
+  pitch_w = align_up(pitch_w + 4, 4);
+  if (pitch_w > d.cap_words) return MOBI_E_DEVICE; // cannot happen: cap_words bounds any clip's payload
+  const size_t desc_b = (size_t)n_mbs * sizeof(MbDesc), item_b = (size_t)n_mbs * 4, res_b = sizeof(MobiDevResult), pay_b = pitch_w * 4;
+  const size_t o_item = align_up((size_t)k * desc_b, 16), o_res = o_item + align_up((size_t)k * item_b, 16), o_pay = o_res + align_up((size_t)k * res_b, 16);
+  if (int e = stage.reserve(o_pay + (size_t)k * pay_b)) return e;
+  uint8_t *h = stage.p;
+  const int groups = std::min(k, 32);
+  b->pool->run(groups, [&](int g) {
+    for (int j = (int)((long)k * g / groups), e = (int)((long)k * (g + 1) / groups); j < e; j++) {
+      const int c = clips[j];
+      const ParsedFrame *f = rc[c] == MOBI_OK ? &b->cur[c] : nullptr;
+      MbDesc *dd = (MbDesc *)(h + (size_t)j * desc_b);
+      uint32_t *it = (uint32_t *)(h + o_item + (size_t)j * item_b);
+      MobiDevResult *rr = (MobiDevResult *)(h + o_res + (size_t)j * res_b);
+      memset(rr, 0, sizeof(*rr));
+      rr->rc = rc[c];
+      if (!f) { // a failed clip: descriptors typed "intra" that no launch list references
+        for (int m = 0; m < n_mbs; m++) dd[m] = MbDesc{0, MOBI_MB_INTRA, 0, 0, 0, 0, 0, 0};
+        continue;
+      }
+      memcpy(dd, f->desc.data(), desc_b); // (payload_off counts from the clip's own part of the arena, as the parser wrote it)
+      if (!f->payload.empty()) memcpy(h + o_pay + (size_t)j * pay_b, f->payload.data(), f->payload.size() * 4);
+      if (!f->intra_mbs.empty()) memcpy(it, f->intra_mbs.data(), f->intra_mbs.size() * 4); // level order: a valid order for the waits
+      rr->n_intra = f->hdr.n_intra;
+      rr->payload_words = f->hdr.payload_words;
+      rr->quant = f->hdr.quantizer;
+      rr->frame_type = f->hdr.frame_type;
+    }
+  });
+  for (int j0 = 0; j0 < k;) {
+    int j1 = j0 + 1;
+    while (j1 < k && clips[j1] == clips[j1 - 1] + 1) j1++;
+    const size_t c0 = (size_t)clips[j0], run = (size_t)(j1 - j0);
+    HIP_TRY(hipMemcpyAsync(d.desc + c0 * desc_b, h + (size_t)j0 * desc_b, run * desc_b, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d.items + c0 * item_b, h + o_item + (size_t)j0 * item_b, run * item_b, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync((uint8_t *)(d.res + c0), h + o_res + (size_t)j0 * res_b, run * res_b, hipMemcpyHostToDevice, s));
+    if (run == 1) HIP_TRY(hipMemcpyAsync(d.pay + c0 * d.cap_words * 4, h + o_pay + (size_t)j0 * pay_b, pay_b, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemcpy2DAsync(d.pay + c0 * d.cap_words * 4, d.cap_words * 4, h + o_pay + (size_t)j0 * pay_b, pay_b, pay_b, run, hipMemcpyHostToDevice, s));
+    j0 = j1;
+  }
+  return MOBI_OK;
+}
+// the decoder state clip c had when the step that read ring entry `in` started, into its host parser
+static int dp_seed_parser(mobi_batch *b, int c, int in) {
+  MobiDevState st;
+  MobiDevTail tail;
+  HIP_TRY(hipMemcpy(&st, b->d_pstate[in] + c, sizeof(st), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&tail, b->d_ptail[in] + c, sizeof(tail), hipMemcpyDeviceToHost));
+  b->parsers[c]->import_state(st, tail);
   return MOBI_OK;
 }
 
@@ -725,65 +829,41 @@ struct FailAll {
 };
 
 static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
-  const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
-  const int nd = n - b->hybrid_host, nh = b->hybrid_host; // clips [0, nd): parsed on the GPU; [nd, n): by the host pool meanwhile
+  const int n = b->n;
   if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) {
     for (int i = 0; i < n; i++) rc[i] = MOBI_E_VERSION;
     return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
   }
   if (b->g.mbw > 64 || b->async_count) return MOBI_E_ARG; // (asynchronous steps in flight: mobi_batch_wait for them first)
   if (int e = dp_init(b)) return e;
+  if (b->hybrid_host && b->frames_started == 0) // hybrid: the last clips are the host parsers' from the start (their state is a new decoder's: nothing to seed)
+    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = 1;
+  std::vector<int> host_clips;
+  for (int i = 0; i < n; i++)
+    if (b->on_host[i]) host_clips.push_back(i);
   DpStaged st;
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point x) { return std::chrono::duration<float, std::milli>(clk::now() - x).count(); };
   const auto q0 = clk::now();
-  if (int e = dp_stage(b, nd, data, len, offsets, b->h_stage, st, &b->d_bits, false, b->stream)) return e; // gathered and on their way
+  if (int e = dp_stage(b, data, len, offsets, b->h_stage, st, &b->d_bits, false, b->stream)) return e; // gathered and on their way
   b->phase_ms[0] = ms_since(q0);
-  if (int e = dp_parse(b, nd, b->d_bits.p, st, false, DpOut{&b->d_pdesc, &b->d_ppay, &b->d_pitems, b->d_pres, b->stream})) return e;
+  int state_in = 0;
+  if (int e = dp_parse(b, b->d_bits.p, st, false, DpOut{&b->d_pdesc, &b->d_ppay, &b->d_pitems, b->d_pres, b->stream}, &state_in)) return e;
   b->phase_ms[1] = ms_since(q0);
   const size_t cap_words = b->last_pay_cap;
+  const DpRows rows{b->d_pdesc.p, b->d_ppay.p, b->d_pitems.p, b->d_pres, cap_words};
   const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
   MobiDevResult *res = (MobiDevResult *)b->h_pres.p;
-  HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * nd, hipMemcpyDeviceToHost, b->stream));
-  if (nh > 0) { // hybrid: while the GPU parses its clips, the host pool parses the others and sends their command lists up beside it
+  HIP_TRY(hipMemcpyAsync(res, b->d_pres, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, b->stream));
+  static const uint8_t kNoData2[2] = {0, 0};
+  auto host_parse = [&](const std::vector<int> &cl) {
+    b->pool->run((int)cl.size(), [&](int j) { const int i = cl[j]; rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData2, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); });
+  };
+  if (!host_clips.empty()) { // while the GPU parses its clips, the host pool parses its own and sends their command lists up beside it
     if (!b->stream2) HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
     if (!b->ev_up) HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
-    static const uint8_t kNoData2[2] = {0, 0};
-    b->pool->run(nh, [&](int j) { const int i = nd + j; rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData2, data[i] ? len[i] : 0, &offsets[i], b->cur[i]); });
-    std::vector<size_t> pbase(nh + 1, 0);
-    for (int j = 0; j < nh; j++) pbase[j + 1] = pbase[j] + (rc[nd + j] == MOBI_OK ? b->cur[nd + j].payload.size() : 0);
-    if (pbase[nh] > (size_t)nh * cap_words) return MOBI_E_DEVICE; // cannot happen: cap_words bounds any clip's payload
-    const size_t desc_b = (size_t)nh * n_mbs * sizeof(MbDesc), pay_b = align_up(pbase[nh] * 4 + 16, 16), item_b = (size_t)nh * n_mbs * 4, res_b = (size_t)nh * sizeof(MobiDevResult);
-    if (int e = b->h_stage2.reserve(desc_b + pay_b + item_b + res_b)) return e;
-    uint8_t *h2 = b->h_stage2.p;
-    const int groups = std::min(nh, 32);
-    b->pool->run(groups, [&](int g) {
-      for (int j = (int)((long)nh * g / groups), e = (int)((long)nh * (g + 1) / groups); j < e; j++) {
-        const int i = nd + j;
-        const ParsedFrame *f = rc[i] == MOBI_OK ? &b->cur[i] : nullptr;
-        MbDesc *dd = (MbDesc *)h2 + (size_t)j * n_mbs;
-        uint32_t *it = (uint32_t *)(h2 + desc_b + pay_b) + (size_t)j * n_mbs;
-        MobiDevResult *rr = (MobiDevResult *)(h2 + desc_b + pay_b + item_b) + j;
-        memset(rr, 0, sizeof(*rr));
-        rr->rc = rc[i];
-        if (!f) {
-          for (int k = 0; k < n_mbs; k++) dd[k] = MbDesc{0, MOBI_MB_INTRA, 0, 0, 0, 0, 0, 0};
-          continue;
-        }
-        const uint32_t base = (uint32_t)((size_t)nd * cap_words + pbase[j]); // where this clip's payload lands in the arena
-        for (int k = 0; k < n_mbs; k++) {
-          dd[k] = f->desc[k];
-          dd[k].payload_off += base;
-        }
-        if (!f->payload.empty()) memcpy((uint32_t *)(h2 + desc_b) + pbase[j], f->payload.data(), f->payload.size() * 4);
-        if (!f->intra_mbs.empty()) memcpy(it, f->intra_mbs.data(), f->intra_mbs.size() * 4); // level order: a valid order for the waits
-        rr->n_intra = f->hdr.n_intra;
-      }
-    });
-    HIP_TRY(hipMemcpyAsync(b->d_pdesc.p + (size_t)nd * n_mbs * sizeof(MbDesc), h2, desc_b, hipMemcpyHostToDevice, b->stream2));
-    HIP_TRY(hipMemcpyAsync(b->d_ppay.p + (size_t)nd * cap_words * 4, h2 + desc_b, pbase[nh] * 4 + 4, hipMemcpyHostToDevice, b->stream2));
-    HIP_TRY(hipMemcpyAsync(b->d_pitems.p + (size_t)nd * n_mbs * 4, h2 + desc_b + pay_b, item_b, hipMemcpyHostToDevice, b->stream2));
-    HIP_TRY(hipMemcpyAsync(b->d_pres + nd, h2 + desc_b + pay_b + item_b, res_b, hipMemcpyHostToDevice, b->stream2));
+    host_parse(host_clips);
+    if (int e = dp_override(b, host_clips, rc, b->h_stage2, rows, b->stream2)) return e; // (no kernel touches these clips' rows: MOBI_DP_SKIP)
     HIP_TRY(hipEventRecord(b->ev_up, b->stream2));
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_up, 0));
     HIP_TRY(hipStreamSynchronize(b->stream2));
@@ -791,27 +871,40 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   HIP_TRY(hipStreamSynchronize(b->stream)); // the launch sizes below depend on what the parse found
   b->phase_ms[2] = ms_since(q0);
   if (ptime) { float ms = 0; if (hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
+  // frames the device parsers could not finish: the host parser takes them over from the state they started with
+  std::vector<int> fb;
+  for (int i = 0; i < n; i++)
+    if (!b->on_host[i] && res[i].rc != MOBI_OK) fb.push_back(i);
+  if (!fb.empty()) {
+    for (int c : fb)
+      if (int e = dp_seed_parser(b, c, state_in)) return e;
+    host_parse(fb);
+    for (int c : fb) b->on_host[c] = 1;
+    b->fallbacks += fb.size();
+    if (int e = dp_override(b, fb, rc, b->h_stage2, rows, b->stream)) return e; // (behind the parse kernels, which blanked these clips' rows)
+  }
   uint32_t K = 0;
   if (b->lockstep) b->ls_finished = 0;
-  for (int i = 0; i < nd; i++) {
+  for (int i = 0; i < n; i++) {
+    if (b->on_host[i]) {
+      b->dev_quant[i] = b->parsers[i]->quantizer();
+      b->dev_yuvfmt[i] = b->parsers[i]->yuv_format();
+      if (rc[i] == MOBI_OK) K = std::max(K, b->cur[i].hdr.n_intra);
+      continue;
+    }
     if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
     rc[i] = res[i].rc;
     offsets[i] += res[i].consumed;
     b->dev_quant[i] = res[i].quant;
     b->dev_yuvfmt[i] = res[i].yuvfmt;
-    if (rc[i] == MOBI_OK) K = std::max(K, res[i].n_intra);
-  }
-  for (int i = nd; i < n; i++) {
-    b->dev_quant[i] = b->parsers[i]->quantizer();
-    b->dev_yuvfmt[i] = b->parsers[i]->yuv_format();
-    if (rc[i] == MOBI_OK) K = std::max(K, b->cur[i].hdr.n_intra);
+    K = std::max(K, res[i].n_intra);
   }
   // 3. reconstruction straight from what the parse left in HBM
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
-  FailAll fail_all{rc, n}; // rc[], Offset, the ring and the device-side decoder state have advanced: the launches below must complete
+  FailAll fail_all{rc, n}; // rc[], Offset, the ring and the decoder state have advanced: the launches below must complete
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
   a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
@@ -829,6 +922,38 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   return MOBI_OK;
 }
 
+// One clip's frame through the reconstruction kernels on its own, into the ring slot `ring_base` names: the repair of a clip whose
+// asynchronous step had been enqueued before anybody knew that its frame was not the device parser's to finish (mobi_batch_wait).
+static int recon_one_clip(mobi_batch *b, int c, int ring_base, const ParsedFrame &pf, int *fault_out) {
+  const int n_mbs = b->g.mbw * b->g.mbh;
+  std::vector<const ParsedFrame *> one(1, &pf);
+  LevelPlan plan;
+  plan.build(one, b->g.mbw);
+  const size_t desc_bytes = align_up((size_t)n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), pay_bytes = align_up(pf.payload.size() * 4 + kPaySlack, kAlign);
+  const size_t item_off = desc_bytes + pay_bytes, total = item_off + align_up(plan.items.size() * 4 + 16, kAlign);
+  if (int e = b->h_fix.reserve(total)) return e;
+  if (int e = b->d_fix.reserve(total)) return e;
+  memset(b->h_fix.p, 0, total);
+  step_write(one, n_mbs, (MbDesc *)b->h_fix.p, (uint32_t *)(b->h_fix.p + desc_bytes));
+  if (!plan.items.empty()) memcpy(b->h_fix.p + item_off, plan.items.data(), plan.items.size() * 4);
+  HIP_TRY(hipMemcpyAsync(b->d_fix.p, b->h_fix.p, total, hipMemcpyHostToDevice, b->stream));
+  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
+  MobiReconArgs a = b->args(b->d_fix.p, b->d_fix.p + desc_bytes);
+  a.planes += (size_t)c * b->clip_bytes;
+  a.n_clips = 1;
+  a.fault = b->d_fault + c;
+  a.done = b->d_done + (size_t)c * n_mbs;
+  a.ring_base = ring_base;
+  if (int e = b->launch_plan(a, plan, (const uint32_t *)(b->d_fix.p + item_off), 1)) return e;
+  int fault = 0;
+  HIP_TRY(hipMemcpyAsync(&fault, b->d_fault + c, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_fault + c, 0, sizeof(int), b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->drain_events();
+  *fault_out = fault;
+  return MOBI_OK;
+}
+
 // ---- asynchronous frame steps (device parse) -------------------------------------------------------------------------------
 // mobi_batch_decode is DecodeFrame(): it returns when the frame is there.  A caller that already holds the next frame of every clip
 // (demuxed Moflex / Mods packets: Offset does not depend on the previous frame's parse) can keep two steps in flight instead:
@@ -836,6 +961,8 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
 // previous step without a host round trip in between (the intra launch covers every slot a clip could use; workgroups past a
 // clip's count leave at once); wait hands out rc[] / Offset of the oldest step when its reconstruction is done.  The host gathers
 // step n + 1 while the GPU parses step n, and the GPU never waits for the host between parse and reconstruction.
+// A frame the device parser cannot finish shows up in wait: the clip's frame (and the next one, if a second step is in flight) is then
+// parsed by the host parser and reconstructed on its own there (async_repair), and the clip is the host parser's in later submits.
 int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets) {
   if (!b || !data || !len || !offsets) return MOBI_E_ARG;
   HIP_TRY(hipSetDevice(b->device));
@@ -857,7 +984,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (!b->stream2) HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
   if (!b->stream_p) HIP_TRY(hipStreamCreateWithFlags(&b->stream_p, hipStreamNonBlocking));
   DpStaged st;
-  if (int e = dp_stage(b, n, data, len, offsets, S.h_stage, st)) return e; // (this slot's previous step was waited for: its upload is done)
+  if (int e = dp_stage(b, data, len, offsets, S.h_stage, st)) return e; // (this slot's previous step was waited for: its upload is done)
   if (int e = S.d_pres.reserve(sizeof(MobiDevResult) * n)) return e;
   if (st.bytes > S.d_bits.cap) // growing frees and allocates (a device-wide stall): leave room for the longer frames to come
     if (int e = S.d_bits.reserve(st.bytes + st.bytes / 4)) return e;
@@ -865,6 +992,22 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (int e = S.h_fault.reserve(sizeof(int) * n)) return e;
   S.offs.assign(offsets, offsets + n);
   S.n_dev = n;
+  S.hdr_bytes = st.hdr_bytes;
+  S.is_host.assign(n, 0);
+  S.host_rc.assign(n, MOBI_OK);
+  S.host_off.assign(n, 0);
+  // the host parser's clips: parsed now (the caller's bytes are only good during this call), their command lists staged for the copy below
+  std::vector<int> host_clips;
+  for (int i = 0; i < n; i++)
+    if (b->on_host[i]) host_clips.push_back(i);
+  if (!host_clips.empty()) {
+    static const uint8_t kNoData2[2] = {0, 0};
+    for (int i : host_clips) { S.is_host[i] = 1; S.host_off[i] = offsets[i]; }
+    b->pool->run((int)host_clips.size(), [&](int j) {
+      const int i = host_clips[j];
+      S.host_rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData2, data[i] ? len[i] : 0, &S.host_off[i], b->cur[i]);
+    });
+  }
   // Everything that can fail without touching the device is behind us.  From the first enqueue on, a failure leaves work in flight
   // that reads this slot's pinned memory and (later) a ring that has turned without a step to wait for: the batch is drained and
   // POISONED -- every later call reports MOBI_E_DEVICE -- rather than left in a state where the next submit reuses the slot.
@@ -889,7 +1032,9 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   hipStream_t ps = b->lockstep ? b->stream_p : b->stream;
   HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
   MobiDevResult *d_res = (MobiDevResult *)S.d_pres.p;
-  if (int e = dp_parse(b, n, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps, true})) return e;
+  if (int e = dp_parse(b, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps, true}, &S.state_in)) return e;
+  if (!host_clips.empty())
+    if (int e = dp_override(b, host_clips, S.host_rc.data(), S.h_over, DpRows{S.d_pdesc.p, S.d_ppay.p, S.d_pitems.p, d_res, b->last_pay_cap}, ps)) return e;
   HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, ps));
   if (ps != b->stream) {
     HIP_TRY(hipEventRecord(S.ev_parsed, ps));
@@ -900,6 +1045,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
+  S.ring_base = b->ring_base;
   MobiReconArgs a = b->args(S.d_pdesc.p, S.d_ppay.p);
   a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
@@ -915,6 +1061,40 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->async_seq++;
   return MOBI_OK;
 }
+// Clips of the oldest step in flight whose frame the device parser could not finish.  Everything enqueued is drained first (a second step
+// in flight parsed these clips from a state the failed frame left behind: its frame is repaired as well); then, per clip: the state the
+// frame started from goes into the host parser, the staged bitstream is parsed again, and the frame is reconstructed on its own into the
+// ring slot its step wrote.  The results replace the device's in the slots' host-side tables.
+static int async_repair(mobi_batch *b, mobi_batch::AsyncSlot &S, const std::vector<int> &failed) {
+  if (b->stream2) HIP_TRY(hipStreamSynchronize(b->stream2));
+  if (b->stream_p) HIP_TRY(hipStreamSynchronize(b->stream_p));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  mobi_batch::AsyncSlot *S1 = b->async_count == 2 ? &b->aslot[(b->async_head + 1) & 1] : nullptr;
+  const int n = b->n;
+  ParsedFrame pf;
+  for (int c : failed) {
+    if (int e = dp_seed_parser(b, c, S.state_in)) return e;
+    for (mobi_batch::AsyncSlot *T : {&S, S1}) {
+      if (!T) continue;
+      const uint64_t boff = ((const uint64_t *)T->h_stage.p)[c];
+      const uint32_t blen = ((const uint32_t *)(T->h_stage.p + (size_t)n * 8))[c];
+      int32_t off = 0;
+      int rc = b->parsers[c]->parse_frame(T->h_stage.p + T->hdr_bytes + boff, blen, &off, pf);
+      T->is_host[c] = 1;
+      T->host_off[c] = T->offs[c] + off;
+      if (rc == MOBI_OK) {
+        int fault = 0;
+        if (int e = recon_one_clip(b, c, T->ring_base, pf, &fault)) return e;
+        if (fault) rc = (fault & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+      }
+      T->host_rc[c] = rc;
+      ((int *)T->h_fault.p)[c] = 0;
+    }
+    b->on_host[c] = 1;
+    b->fallbacks++;
+  }
+  return MOBI_OK;
+}
 int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   if (!b || !rc) return MOBI_E_ARG;
   HIP_TRY(hipSetDevice(b->device));
@@ -924,13 +1104,25 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   HIP_TRY(hipEventSynchronize(S.ev_done));
   const MobiDevResult *res = (const MobiDevResult *)S.h_pres.p;
   const int *fault = (const int *)S.h_fault.p;
+  std::vector<int> failed;
+  for (int i = 0; i < S.n_dev; i++)
+    if (!S.is_host[i] && res[i].rc != MOBI_OK) failed.push_back(i);
+  if (!failed.empty())
+    if (int e = async_repair(b, S, failed)) { b->poisoned = true; return e; }
   if (b->lockstep) b->ls_finished = 0;
   for (int i = 0; i < S.n_dev; i++) {
-    if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
-    rc[i] = res[i].rc;
-    if (offsets_out) offsets_out[i] = S.offs[i] + (int32_t)res[i].consumed;
-    b->dev_quant[i] = res[i].quant;
-    b->dev_yuvfmt[i] = res[i].yuvfmt;
+    if (S.is_host[i]) {
+      rc[i] = S.host_rc[i];
+      if (offsets_out) offsets_out[i] = S.host_off[i];
+      b->dev_quant[i] = b->parsers[i]->quantizer(); // (as of the parser's latest frame: a second step in flight has moved it on)
+      b->dev_yuvfmt[i] = b->parsers[i]->yuv_format();
+    } else {
+      if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
+      rc[i] = res[i].rc;
+      if (offsets_out) offsets_out[i] = S.offs[i] + (int32_t)res[i].consumed;
+      b->dev_quant[i] = res[i].quant;
+      b->dev_yuvfmt[i] = res[i].yuvfmt;
+    }
     if (rc[i] == MOBI_OK && fault[i]) rc[i] = (fault[i] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
   }
   b->async_head ^= 1;
@@ -939,6 +1131,13 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
 }
 
 int mobi_batch_in_flight(const mobi_batch *b) { return b ? b->async_count : 0; }
+int mobi_batch_host_clips(const mobi_batch *b) {
+  if (!b) return 0;
+  if (!b->parse_mode) return b->n;
+  int k = 0;
+  for (uint8_t h : b->on_host) k += h;
+  return k;
+}
 int mobi_batch_lockstep_finished(const mobi_batch *b) { return b && b->lockstep ? b->ls_finished : -1; }
 
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {

@@ -40,7 +40,8 @@ enum { MOBI_MB_INTER = 0, MOBI_MB_INTRA = 1 };
 //     [17:16] luma CopyBlock phase (dx&1)|((dy&1)<<1) of A   [19:18] chroma phase of A   [21:20], [23:22] the same for B
 // w3  inter: luma source position of leaf A = MB offset + (dy>>1)*Stride + (dx>>1), linear inside the reference's Y plane
 //            (signed: a bottom/right half may point above/left of its macroblock's origin; its own rows/columns add back)
-//     intra: [0] plane16 present, [1] some dependency (w4..w7) is an intra macroblock, [2] some intra macroblock depends on this one, [31:16] plane16 parameter
+//     intra: [0] plane16 present, [1] some dependency (w4..w7) is an intra macroblock, [2] some intra macroblock depends on this one,
+//            [4] the plane16 parameter does not fit [31:16]: it is wide parameter 24 (below), [31:16] plane16 parameter
 // w4  inter: chroma source position of leaf A = MB offset/2 + ((dy>>1)>>1)*Stride + ((dx>>1)>>1), inside the UV plane (U half)
 // w5, w6  inter DUAL: the same two positions for leaf B
 // w7  reserved (0) for inter macroblocks
@@ -99,11 +100,18 @@ MOBI_CMD_FN uint32_t mobi_coef(int area, int p, int level) {
 //  [3:0]  mode 0..9 (8x8 numbering; 4x4 blocks use the same numbering, MD.cs mode-10)
 //  [4]    residual coded for this block
 //  [5]    split: the area is four 4x4 blocks (slots 0..3 all valid)
+//  [7]    the plane parameter does not fit int16 (a code of 33 bits and more): it is WIDE PARAMETER r, r = this record's index
 //  [31:16] plane parameter (int16) when mode == 2                           (MD.cs:3019,3170,3255)
+// Wide parameters (r05): MOBI_WIDE_PARAMS words behind the macroblock's level words -- payload word MOBI_INTRA_RECORDS + n_coefs + r, r = the
+// record's index, 24 = the 16x16 plane's -- present only when some record or MbDesc.w3 says so.  The plane predictors compute in int32 and
+// OR their samples into words (MD.cs:3055-3062): every bit of the parameter reaches the picture.
 // MbDesc.w3: [0] luma plane16 present, [1] chroma plane8 pair present,
 //            [31:16] plane16 param; chroma plane params live in the U/V slot-0 records with mode 9:
 //            record bit [6] = "run plane8 with param before this area" (keeps decode order).
 #define MOBI_INTRA_RECORDS 24
+#define MOBI_WIDE_PARAMS 25
+#define MOBI_REC_WIDE 0x80u
+#define MOBI_W3_WIDE 0x10u
 MOBI_CMD_FN uint32_t mobi_intra_rec(int mode, int coded, int split, int pre_plane, int param) {
   return (uint32_t)(mode | (coded << 4) | (split << 5) | (pre_plane << 6)) | ((uint32_t)param << 16);
 }
@@ -134,5 +142,8 @@ struct FrameHdr {
 #define MOBI_SCALE_ROWS 64
 #define MOBI_SCALE_LITERAL 63 /* the row of ones: MbDesc.w1's quantiser field of a frame whose residual words carry coefficient VALUES
                                  (the host parser's Internal[] walk, mobi_parse.cpp); no real quantiser reaches 54 (MD.cs:3864-3880) */
+#define MOBI_TQ_NONE 62      /* a row of zeros: MbDesc.w1's field while SetupQuantizationTables has never run -- every dequant word is 0
+                                 (MD.cs:28: a fresh Internal[]), so every coefficient is.  The field is the quantiser the TABLES were built for,
+                                 which is not Quantizer after a SetupQuantizationTables that threw (MD.cs:3886-3890; ModsDS, q >= 54) */
 
 #endif

@@ -12,16 +12,8 @@
 #include "mobi_cmd.h"
 
 #include "mobi_dparse_tables.h"
+#include "mobi_state.h" // MobiDevState, MobiDevTail: the decoder state that survives from frame to frame
 
-// decoder state that survives from frame to frame (the rest of MobiclipDecoder's fields are per frame)
-struct MobiDevState {
-  uint32_t quant;         // Quantizer (MD.cs:26)
-  uint32_t yuvfmt;        // YuvFormat (MD.cs:27)
-  int32_t frames_started; // how many ring slots hold a frame
-  uint32_t tables_set;    // SetupQuantTables ran at least once (MD.cs:3884): the zigzag bytes of Internal[10..89] are valid
-  uint8_t mcache[40];     // bytes of Internal[0..9]: intra-mode neighbour cache (MD.cs:1840-1859)
-  uint32_t pad[2];
-};
 struct MobiDevResult { // per clip, read back by the host after the parse launch
   int32_t rc;          // MOBI_OK / MOBI_E_*
   int32_t consumed;    // bytes the bit reader advanced from the start offset (Offset out = Offset in + consumed)
@@ -34,9 +26,16 @@ struct MobiDevResult { // per clip, read back by the host after the parse launch
 struct MobiDevParseArgs {
   const uint8_t *bits;      // frame bytes of every clip; clip c starts at bits + bit_off[c] (8-byte aligned, >= 32 zero bytes follow)
   const uint64_t *bit_off;
-  const uint32_t *bit_len;  // Data.Length - Offset of clip c (0: nothing readable)
+  const uint32_t *bit_len;  // Data.Length - Offset of clip c (0: nothing readable; MOBI_DP_SKIP: the clip is the host parser's -- no kernel touches
+                            // anything of it, its command list is uploaded into its rows beside the parse)
   const uint8_t *tables;    // MOBI_DT_BYTES blob
-  MobiDevState *state;      // [clip]
+  // [clip] decoder state: read from *_in, written to *_out -- two entries of a ring of three (mobi_abi.cpp), so that the state a frame
+  // STARTED from is still there when its parse turns out not to be the device's to finish and the host parser takes the frame over
+  const MobiDevState *state_in;
+  MobiDevState *state_out;
+  const MobiDevTail *tail_in;
+  MobiDevTail *tail_out;    // .mvc: written by the parsers at the end of a P-frame; the rest by mobi_parse_tail
+  const int32_t *scale;     // [quantizer][MOBI_SCALE_STRIDE] dequant scales by natural index (MobiReconArgs.scale): mobi_parse_tail
   MbDesc *desc;             // [clip][n_mbs]  out
   uint32_t *payload;        // out: clip c owns words [c * pay_cap, (c + 1) * pay_cap)
   uint32_t *items;          // [clip][n_mbs] out: MOBI_ITEM(clip, mb) of the intra macroblocks in raster order, rest untouched
@@ -51,6 +50,7 @@ struct MobiDevParseArgs {
   // that n_clips * pay_cap may exceed 2^32 words; 0: relative to the arena (the hybrid mode, whose host-parsed clips sit behind the others)
   int pay_local;
 };
-extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s);
+#define MOBI_DP_SKIP 0xFFFFFFFFu
+extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s); // the parse kernels, then mobi_parse_tail
 extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s); // the two kernels in front (called by mobi_launch_parse)
 #endif

@@ -181,6 +181,7 @@ __device__ __noinline__ ResidOut resid_block_fn(BitR r, uint32_t n_coefs, lds_u8
     const int idx = (flags & 4) ? zz[p] : 0; // low byte of the dequant word = zigzag target (MD.cs:3426); all zero before the first SetupQuantTables
     p++;
     if (value != 0) out[n_coefs++] = (uint32_t)(tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
+    else r.fail(MOBI_E_UNSUPPORTED); // a token without a level: the frame's command list would not name every token (mobi_state.h): the host parser's
     if (e & 1) break;
   }
   return ResidOut{r, n_coefs};
@@ -703,15 +704,16 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
       all = all && (f || cw >= A.n_clips);
       if (w == wave) finished = f;
     }
-    if (finished && lane == 0) A.state[clip] = A.state_ls[clip];
+    if (finished && lane == 0) A.state_out[clip] = A.state_ls[clip];
     if (all) return; // (every thread of the workgroup sees the same four records)
   }
   for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += 64 * PWAVES) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
   if (clip >= A.n_clips || finished) return;
+  if (A.bit_len[clip] == MOBI_DP_SKIP) return; // the host parser's clip (wave-uniform)
   const int n_mbs = A.mbw * A.mbh;
   WaveLds *L = &wl[wave];
-  int rc_lane = 0;
+  int rc_lane = 0, ft_lane = 0;
   if (lane == 0) {
     DP p;
     p.T = (lds_u8)tab;
@@ -719,11 +721,11 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
     p.width = A.width; p.height = A.height; p.stride = A.stride; p.lg = A.lg; p.mbw = A.mbw; p.mbh = A.mbh;
     p.version = A.version;
     p.ver = A.version == MOBI_VERSION_MOFLEX3DS ? 0 : 1;
-    MobiDevState *st = A.state + clip;
+    const MobiDevState *st = A.state_in + clip;
     p.quant = st->quant; p.yuvfmt = st->yuvfmt; p.tables_set = st->tables_set;
     p.frames_started = st->frames_started + 1; // ring rotation + fresh planes happen before anything can throw (MD.cs:102-108)
     for (int i = 0; i < 40; i++) L->mcache[i] = st->mcache[i];
-    p.vlc = 0; p.predx = p.predy = 0;
+    p.vlc = 0; p.predx = st->predx; p.predy = st->predy; // (Internal[219], [220]: an I-frame leaves them as they are)
     p.desc = A.desc + (size_t)clip * n_mbs;
     p.pay = A.payload + (A.pay_local ? (size_t)clip * A.pay_cap : (size_t)0);
     p.pay_base = A.pay_local ? 0u : (uint32_t)clip * A.pay_cap;
@@ -757,8 +759,10 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
       ftype = iframe;
       p.parse_frame(iframe);
     }
-    st->quant = p.quant; st->yuvfmt = p.yuvfmt; st->tables_set = p.tables_set; st->frames_started = p.frames_started;
-    for (int i = 0; i < 40; i++) st->mcache[i] = L->mcache[i];
+    MobiDevState *so = A.state_out + clip;
+    so->quant = p.quant; so->yuvfmt = p.yuvfmt; so->tables_set = p.tables_set; so->frames_started = p.frames_started;
+    for (int i = 0; i < 40; i++) so->mcache[i] = L->mcache[i];
+    so->predx = p.predx; so->predy = p.predy;
     MobiDevResult r;
     r.rc = p.r.err;
     r.consumed = p.r.off;
@@ -767,9 +771,17 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
     r.quant = p.quant; r.yuvfmt = p.yuvfmt; r.frame_type = ftype; r.pad = 0;
     A.res[clip] = r;
     rc_lane = p.r.err;
+    ft_lane = (int)ftype;
+  }
+  // the MV row cache a P-frame leaves (Internal[221..]): a later I-frame's walk through Internal[] may read it (mobi_state.h)
+  const int rcl = __builtin_amdgcn_readfirstlane(rc_lane); // lane 0 is the first active lane
+  if (rcl == 0 && __builtin_amdgcn_readfirstlane(ft_lane) == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int32_t *mv = A.tail_out[clip].mvc;
+    for (int i = lane; i < 2 * (A.mbw + 2); i += 64) mv[i] = L->mvc[i];
   }
   // a failed clip: descriptors typed "intra" that no launch list references, so nothing of it is written (mobi_abi.cpp step_write)
-  if (__builtin_amdgcn_readfirstlane(rc_lane) != 0) { // lane 0 is the first active lane
+  if (rcl != 0) {
     uint4 *d = (uint4 *)(A.desc + (size_t)clip * n_mbs);
     for (int mb = lane; mb < n_mbs; mb += 64) {
       d[2 * mb] = uint4{0, MOBI_MB_INTRA, 0, 0};
@@ -778,11 +790,46 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
   }
 }
 
+// What a clean frame leaves in Internal[90..217], from its command list (mobi_state.h): one lane per clip, behind the parse kernels.  A clip
+// whose parse failed, or that is the host parser's anyway, is left alone: the host parser takes it over from the state the frame started with.
+extern "C" __global__ __launch_bounds__(64) void mobi_parse_tail(MobiDevParseArgs A) {
+  __shared__ uint8_t izz[80];
+  if (threadIdx.x < 64) izz[A.tables[MOBI_DT_ZZ8 + threadIdx.x]] = (uint8_t)threadIdx.x;
+  if (threadIdx.x < 16) izz[64 + A.tables[MOBI_DT_ZZ4 + threadIdx.x]] = (uint8_t)threadIdx.x;
+  __syncthreads();
+  const int clip = blockIdx.x * 64 + threadIdx.x;
+  if (clip >= A.n_clips || A.bit_len[clip] == MOBI_DP_SKIP) return;
+  const MobiDevResult r = A.res[clip];
+  if (r.rc != 0) return;
+  const int n_mbs = A.mbw * A.mbh;
+  const MbDesc *desc = A.desc + (size_t)clip * n_mbs;
+  const uint32_t *pay = A.payload + (A.pay_local ? (size_t)clip * A.pay_cap : (size_t)0);
+  const uint32_t rel = A.pay_local ? 0u : (uint32_t)clip * A.pay_cap; // MbDesc.payload_off counts from the arena's start then; the scan's offsets from the clip's
+  if (!A.pay_local) pay += rel;
+  MobiTailScan sc;
+  mobi_tail_scan_init(sc);
+  for (int mb = n_mbs - 1; mb >= 0 && !sc.done; mb--) {
+    const uint4 d = *(const uint4 *)(desc + mb);
+    const int n = (int)(d.z & 0x3FF);
+    if (!n) continue;
+    const bool intra = (d.y & 1) == MOBI_MB_INTRA;
+    const uint32_t nl = (d.y >> 1) & 0x7F, dual = (d.y >> 26) & 3;
+    const uint32_t woff = d.x - rel + (intra ? MOBI_INTRA_RECORDS : (nl > 1 && !dual) ? MOBI_MV_CELLS : 0);
+    mobi_tail_scan_mb(sc, pay + woff, n, woff, (d.y >> 14) & 0x3F, izz, izz + 64);
+  }
+  const MobiDevTail *in = A.tail_in + clip;
+  MobiDevTail *out = A.tail_out + clip;
+  mobi_tail_finish(sc, pay, A.scale + (size_t)(A.state_out[clip].quant & 63) * MOBI_SCALE_STRIDE, *in, *out);
+  if (r.frame_type == 1) // an I-frame does not touch the MV row cache (MD.cs:224-249)
+    for (int i = 0; i < 2 * (A.mbw + 2); i++) out->mvc[i] = in->mvc[i];
+}
+
 extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64) return (int)hipErrorInvalidValue;
   if (a->lockstep)
     if (int e = mobi_launch_parse_ls(a, s)) return e;
   hipLaunchKernelGGL(mobi_parse_frames, dim3((unsigned)((a->n_clips + PWAVES - 1) / PWAVES)), dim3(64 * PWAVES), 0, s, *a);
+  hipLaunchKernelGGL(mobi_parse_tail, dim3((unsigned)((a->n_clips + 63) / 64)), dim3(64), 0, s, *a);
   return (int)hipGetLastError();
 }

@@ -1061,7 +1061,8 @@ enum { SD_O = 0,           // [10:0]  byte offset of the block's top-left sample
        SD_KTAP = 1 << 23, SD_KDC = 1 << 24, SD_KPLANE = 1 << 25, // predictor kind; none of them: what is there stays (plane passes, mode 9)
        SD_TA = 1 << 26, SD_LA = 1 << 27,                         // DC: row above / column to the left available (MD.cs:1923-1924)
        SD_P4 = 1 << 30 };  // the plane is a 4x4 one
-// word 1: [8:0] index of the step's first residual (+ lane's), [31:16] plane parameter
+// word 1: [8:0] index of the step's first residual (+ lane's), [13:9] 1 + the plane parameter's index among the macroblock's wide parameters
+//         (mobi_cmd.h: a parameter that does not fit 16 bits; 0: it does), [31:16] plane parameter
 
 __device__ __forceinline__ uint32_t ldg_u8_sc1(const uint8_t *p) { // past this CU's L1; valid after vm_wait*
   uint32_t v = 0;
@@ -1134,7 +1135,7 @@ struct QItem {
   uint32_t clip, mb;
   uint32_t w1;       // MbDesc.w1
   uint32_t pay;      // MbDesc.payload_off
-  uint32_t w3;       // MbDesc.w3: [0] 16x16 plane present, [31:16] its parameter
+  uint32_t w3;       // MbDesc.w3: [0] 16x16 plane present, [4] its parameter is a wide one, [31:16] its parameter
   uint32_t ncoef;
   bool has_deps;     // some macroblock its halo reads is an intra one of this step: poll the tags, read the halo afterwards
   bool publish;      // an intra macroblock of this step may read these pixels: write through, drain, publish the tag
@@ -1349,6 +1350,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
       const bool vfix = !luma && (boff & (S - 1)) >= (S >> 1);                                              // MD.cs:1886
       const bool la = ((boff - (vfix ? (S >> 1) : 0)) & (S - 1)) != 0, ta = boff >= S;                      // :1923-1924
       const int ri = a * 64 + (split ? (s >> 1) * 32 + (s & 1) * 4 : 0);
+      const uint32_t widx = ((plane_blk ? rs : plane_pre ? r0 : 0u) & MOBI_REC_WIDE) ? (uint32_t)(a * 4 + (split ? s : 0) + 1) : 0u;
       uint32_t d0 = (uint32_t)o_blk | ((uint32_t)tapbase << SD_TAP);
       if (split) d0 |= SD_IS4;
       if (coded) d0 |= SD_CODED;
@@ -1358,7 +1360,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
       if (ta) d0 |= SD_TA;
       if (la) d0 |= SD_LA;
       if (plane_blk && split) d0 |= SD_P4;
-      return uint2{d0, (uint32_t)ri | (param << 16)};
+      return uint2{d0, (uint32_t)ri | (widx << 9) | (param << 16)};
     };
     int posA, posB;
     const uint2 dA = build(l, recA, quad_first(recA), posA);
@@ -1456,7 +1458,7 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
   if (__builtin_amdgcn_ballot_w64((w3 & 1) != 0) != 0) {
     if (w3 & 1) {
       const QNb nb{tile, TP + 4};
-      const int param = (int)(int16_t)(w3 >> 16);
+      const int param = (w3 & MOBI_W3_WIDE) ? (int)rec[MOBI_INTRA_RECORDS + ncoef + 24] : (int)(int16_t)(w3 >> 16);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int w = u * 16 + l, yy = w >> 2, x0 = (w & 3) * 4;
@@ -1488,7 +1490,9 @@ __device__ __forceinline__ void recon_intra_quad(const MobiReconArgs &A, uint32_
       const bool p4 = (d.x & SD_P4) != 0;
       if ((d.x & SD_KPLANE) && l < (p4 ? 4 : 16)) {
         const int yy = p4 ? l : l >> 1, x0 = p4 ? 0 : (l & 1) * 4;
-        *(uint32_t *)(tile + o + yy * TP + x0) = mobi_plane_word(p4 ? 4 : 8, (int)(int16_t)(d.y >> 16), yy, x0, QNb{tile, o});
+        const uint32_t widx = (d.y >> 9) & 31u;
+        const int param = widx ? (int)rec[MOBI_INTRA_RECORDS + ncoef + widx - 1] : (int)(int16_t)(d.y >> 16);
+        *(uint32_t *)(tile + o + yy * TP + x0) = mobi_plane_word(p4 ? 4 : 8, param, yy, x0, QNb{tile, o});
       }
       wave_sync();
     }
@@ -1596,7 +1600,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs 
   const int lane = threadIdx.x;
   const uint4 item = items[blockIdx.x * 4 + (lane >> 4)];
   const bool valid = item.x != 0xFFFFFFFFu;
-  const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
+  const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & (0xFFFF0001u | MOBI_W3_WIDE), (item.w >> 5) & 0x3FFu,
                 (item.w & 2) != 0, (item.w & 4) != 0};
   recon_intra_quad(A, lds, I, lane, dbg);
 }
@@ -1620,7 +1624,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void mobi_recon_step(MobiReconArg
   const int lane = threadIdx.x;
   const uint4 item = items[(blockIdx.x - n_inter) * 4 + (lane >> 4)];
   const bool valid = item.x != 0xFFFFFFFFu;
-  const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & 0xFFFF0001u, (item.w >> 5) & 0x3FFu,
+  const QItem I{valid, valid ? item.x >> 13 : 0u, valid ? item.x & 0x1FFFu : 0u, item.y, item.z, item.w & (0xFFFF0001u | MOBI_W3_WIDE), (item.w >> 5) & 0x3FFu,
                 (item.w & 2) != 0, (item.w & 4) != 0};
   recon_intra_quad<1>(A, (uint32_t *)lds, I, lane);
 }
@@ -1644,7 +1648,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_cl(MobiReconAr
   const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
   const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
   const uint32_t w3 = valid ? desc->w3 : 0u; // [1] has intra dependencies: poll their tags; [2] has intra dependents: publish its own
-  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, w3 & 0xFFFF0001u,
+  const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, w3 & (0xFFFF0001u | MOBI_W3_WIDE),
                 valid ? desc->w2 & 0x3FFu : 0u, (w3 & 2u) != 0, (w3 & 4u) != 0};
   recon_intra_quad(A, lds, I, lane);
 }
@@ -1668,7 +1672,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra_walk(MobiRecon
     const uint32_t mb = valid ? items[(size_t)clip * A.n_mbs + slot] & 0x1FFFu : 0u;
     const MbDesc *desc = A.desc + (size_t)(valid ? clip : 0) * A.n_mbs + mb;
     const uint32_t w3 = valid ? desc->w3 : 0u;
-    const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, w3 & 0xFFFF0001u,
+    const QItem I{valid, valid ? clip : 0u, mb, valid ? desc->w1 : 0u, valid ? desc->payload_off : 0u, w3 & (0xFFFF0001u | MOBI_W3_WIDE),
                   valid ? desc->w2 & 0x3FFu : 0u, (w3 & 2u) != 0, (w3 & 4u) != 0};
     recon_intra_quad(A, lds, I, lane);
     wave_sync();

@@ -177,7 +177,7 @@ template <class S>
 LS_FN void ls_begin_frame(LsLane &s, S &m, const LsCtx &c, uint32_t len) {
   s.W = 0; s.navail = 0; s.cbits = 0; s.rd = 0;
   s.bail = 0; s.st = LS_MB_BEGIN; s.ret = LS_DONE;
-  s.mb = 0; s.mx = 0; s.my = 0; s.cur_off = 0; s.mb_type = MOBI_MB_INTER; s.predx = s.predy = 0; s.mvslot = 2;
+  s.mb = 0; s.mx = 0; s.my = 0; s.cur_off = 0; s.mb_type = MOBI_MB_INTER; s.mvslot = 2; // (predx, predy: loaded with the state, Internal[219], [220])
   s.pay_pos = 0; s.mb_pay = 0; s.hdr_words = 0; s.n_coefs = 0; s.cbp6 = s.t8mask = s.w3 = 0; s.n_items = 0;
   s.sp = 0; s.nleaf = 0; s.l0a = s.l0b = s.l1a = s.l1b = 0;
   s.area_mask = s.sub_mask = 0; s.cur_area = 0; s.blk_p = s.blk_n = s.blk_tile = 0; s.blk_flags = 0;
@@ -320,6 +320,7 @@ LS_FN void ls_token(LsLane &s, S &m, const LsCtx &c) {
         ls_take(s, len);
       }
     }
+    if (value == 0) ls_bail(s, 17); // a token without a level: the command list would not name every token of the frame (mobi_state.h)
     if (!s.bail) {
       s.blk_p += skip;
       if (s.blk_p >= s.blk_n) ls_bail(s, 15);
@@ -451,13 +452,13 @@ LS_FN void ls_token_fast(LsLane &s, S &m, const LsCtx &c) {
       len = 19;
     }
     const int p = s.blk_p + skip;
-    if (len == 0 || p >= s.blk_n) s.st = LS_TOKEN_SLOW; // what the whole walk bails out on
+    if (len == 0 || p >= s.blk_n || value == 0) s.st = LS_TOKEN_SLOW; // what the whole walk bails out on
     else {
       value = neg ? -value : value;
       ls_take(s, pre + len);
       const int idx = (s.blk_flags & 4) ? T[((s.blk_flags & 1) ? MOBI_DT_ZZ8 : MOBI_DT_ZZ4) + p] : 0;
       s.blk_p = p + 1;
-      if (value != 0) s.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
+      s.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
       if (last & 1) s.st = (s.ret == LS_NEXT && !s.sub_mask && !s.area_mask) ? LS_MB_END : (s.ret == LS_I_FSUB && !s.sub_mask) ? LS_I_FIXED : s.ret;
     }
   }

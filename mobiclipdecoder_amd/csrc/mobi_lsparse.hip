@@ -83,7 +83,7 @@ __device__ __forceinline__ void parse_frames_ls(const MobiDevParseArgs &A) {
   __syncthreads();
 
   const int clip = blockIdx.x * LS_CLIPS + lane;
-  const bool live = lane < LS_CLIPS && clip < A.n_clips;
+  const bool live = lane < LS_CLIPS && clip < A.n_clips && A.bit_len[clip < A.n_clips ? clip : 0] != MOBI_DP_SKIP; // (not the host parser's clips)
   const int n_mbs = A.mbw * A.mbh;
   LsCtx c;
   c.T = tab;
@@ -96,8 +96,9 @@ __device__ __forceinline__ void parse_frames_ls(const MobiDevParseArgs &A) {
   uint32_t len = 0, len2 = 0, wr = 0;
   s.st = LS_DONE; s.bail = 0; s.rd = 0; s.cbits = 0; s.n_items = 0; s.pay_pos = 0; s.iframe = 0; s.quant = 0; s.yuvfmt = 0;
   if (live) {
-    const MobiDevState *st = A.state + clip;
+    const MobiDevState *st = A.state_in + clip;
     s.quant = st->quant; s.yuvfmt = st->yuvfmt; s.tables_set = st->tables_set;
+    s.predx = st->predx; s.predy = st->predy; // (Internal[219], [220]: an I-frame leaves them as they are)
     s.frames_started = st->frames_started + 1; // the ring turns before anything can throw (MD.cs:102-108)
     for (int i = 0; i < 40; i++) m.mc(i) = st->mcache[i];
     s.desc = A.desc + (size_t)clip * n_mbs;
@@ -160,6 +161,11 @@ __device__ __forceinline__ void parse_frames_ls(const MobiDevParseArgs &A) {
     MobiDevState *st = A.state_ls + clip; // the shadow copy: mobi_parse_frames moves it into place (unless mobi_ls_deps objects)
     st->quant = s.quant; st->yuvfmt = s.yuvfmt; st->tables_set = s.tables_set; st->frames_started = s.frames_started;
     for (int i = 0; i < 40; i++) st->mcache[i] = m.mc(i);
+    st->predx = s.predx; st->predy = s.predy;
+    if (!s.iframe) { // the MV row cache a P-frame leaves (Internal[221..]): a later I-frame's walk through Internal[] may read it (mobi_state.h)
+      int32_t *mv = A.tail_out[clip].mvc;
+      for (int i = 0; i < mvc_words; i++) mv[i] = m.mvc(i);
+    }
   }
   A.res[clip] = r;
 }
@@ -176,7 +182,7 @@ extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls64(MobiDevP
 // lane = one intra macroblock of a finished clip: workgroup = clip * chunks + chunk
 extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A, uint32_t chunks) {
   const uint32_t clip = blockIdx.x / chunks, chunk = blockIdx.x - clip * chunks;
-  if (clip >= (uint32_t)A.n_clips) return;
+  if (clip >= (uint32_t)A.n_clips || A.bit_len[clip] == MOBI_DP_SKIP) return;
   const MobiDevResult *r = A.res + clip;
   if (r->pad != LS_MAGIC) return;
   const uint32_t idx = chunk * 64 + threadIdx.x, n_mbs = (uint32_t)(A.mbw * A.mbh);

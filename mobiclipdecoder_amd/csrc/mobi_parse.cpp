@@ -91,14 +91,54 @@ int MobiStreamParser::se() { // odd codes map to non-positive values (MD.cs:3009
 // ------------------------------------------------------------------ quantiser (MD.cs:3884-3925)
 void MobiStreamParser::setup_quant(uint32_t q) {
   if (version_ == MOBI_VERSION_MOFLEX3DS) q = std::min<uint32_t>(std::max<uint32_t>(q, 12), 52);
-  quant_ = q; // assigned before the table index can throw
+  quant_ = q; // assigned before the table index can throw: the old tables then serve the new Quantizer (tq_)
   if (q >= sizeof(mobi_qdiv6)) fail(MOBI_E_INDEX);
-  int sh = mobi_qdiv6[q] + 8, m = mobi_qmod6[q];
-  for (int i = 0; i < 16; i++) dq4_[i] = (uint32_t)mobi_zz4[i] | shl(mobi_dq4[m * 16 + i], sh);
-  for (int i = 0; i < 64; i++) dq8_[i] = (uint32_t)mobi_zz8[i] | shl(mobi_dq8[m * 64 + i], sh - 2);
+  tq_ = q;
+  build_dq();
   static const int border[8] = {1, 2, 3, 4, 8, 0x10, 0x18, 0x20}; // "no neighbour" marks, re-armed only here
   for (int b : border) mcache_[b] = 9;
 }
+void MobiStreamParser::build_dq() { // Internal[10..89] for quantiser tq_ (MD.cs:3892-3911)
+  if (tq_ >= sizeof(mobi_qdiv6)) { memset(dq8_, 0, sizeof(dq8_)); memset(dq4_, 0, sizeof(dq4_)); return; }
+  const int sh = mobi_qdiv6[tq_] + 8, m = mobi_qmod6[tq_];
+  for (int i = 0; i < 16; i++) dq4_[i] = (uint32_t)mobi_zz4[i] | shl(mobi_dq4[m * 16 + i], sh);
+  for (int i = 0; i < 64; i++) dq8_[i] = (uint32_t)mobi_zz8[i] | shl(mobi_dq8[m * 64 + i], sh - 2);
+}
+
+// ------------------------------------------------------------------ the state that survives a frame (mobi_state.h)
+void MobiStreamParser::import_state(const MobiDevState &st, const MobiDevTail &tail) {
+  quant_ = st.quant;
+  yuvfmt_ = st.yuvfmt;
+  frames_started_ = st.frames_started;
+  tq_ = st.tables_set ? st.quant : (uint32_t)MOBI_TQ_NONE; // (a frame after which the two differ never finishes on the device)
+  build_dq();
+  memcpy(mcache_, st.mcache, sizeof(mcache_));
+  predx_ = st.predx;
+  predy_ = st.predy;
+  memcpy(ib_, tail.ib, sizeof(ib_));
+  memcpy(scr_, tail.scratch, sizeof(scr_));
+  pend64_ = pend16_ = false;
+  for (size_t i = 0; i < mvc_.size(); i++) mvc_[i] = tail.mvc[i];
+  memset(itail_, 0, sizeof(itail_)); // (only a walk writes there, and a frame with a walk is not the device's)
+  i218_ = 0;
+  vlc_table_ = 0;
+}
+void MobiStreamParser::export_state(MobiDevState &st, MobiDevTail &tail) {
+  memset(&st, 0, sizeof(st));
+  memset(&tail, 0, sizeof(tail));
+  st.quant = quant_;
+  st.yuvfmt = yuvfmt_;
+  st.frames_started = frames_started_;
+  st.tables_set = tq_ != MOBI_TQ_NONE;
+  memcpy(st.mcache, mcache_, sizeof(mcache_));
+  st.predx = predx_;
+  st.predy = predy_;
+  scratch_materialise();
+  memcpy(tail.ib, ib_, sizeof(ib_));
+  memcpy(tail.scratch, scr_, sizeof(scr_));
+  for (size_t i = 0; i < mvc_.size(); i++) tail.mvc[i] = mvc_[i];
+}
+uint32_t MobiStreamParser::internal_word(uint32_t idx) { return internal_read(idx); }
 
 // ------------------------------------------------------------------ per-MB assembly
 void MobiStreamParser::begin_mb(int mb, int type) {
@@ -110,6 +150,7 @@ void MobiStreamParser::begin_mb(int mb, int type) {
   n_coefs_ = 0;
   memset(recs_, 0, sizeof(recs_));
   cbp6_ = t8mask_ = w3_ = 0;
+  any_wide_ = false;
   mb_type_ = type;
 }
 void MobiStreamParser::end_mb() {
@@ -147,7 +188,8 @@ void MobiStreamParser::end_mb() {
     out_->payload.insert(out_->payload.end(), recs_, recs_ + MOBI_INTRA_RECORDS);
   }
   out_->payload.insert(out_->payload.end(), coefs_, coefs_ + n_coefs_);
-  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14) | ((quant_ & 63) << 20) | ((uint32_t)dual << 26);
+  if (mb_type_ == MOBI_MB_INTRA && any_wide_) out_->payload.insert(out_->payload.end(), (const uint32_t *)wide_, (const uint32_t *)wide_ + MOBI_WIDE_PARAMS);
+  d.w1 = (uint32_t)mb_type_ | (nl << 1) | (cbp6_ << 8) | (t8mask_ << 14) | ((tq_ & 63) << 20) | ((uint32_t)dual << 26);
   out_->desc.push_back(d);
 }
 long MobiStreamParser::area_offset(int area, int sub) const {
@@ -177,9 +219,9 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
   mvc_[mv_slot + 1] = dy;
   if (ref > std::min(5, frames_started_ - 1)) fail(MOBI_E_NULLREF); // Y[ref] == null
   const long off = cur_off_ + (long)y * S + x;
-  const int cdx = dx >> 1, cdy = dy >> 1;
-  const long cpos = off / 2 + (long)(cdy >> 1) * S + (cdx >> 1);
-  const int cph = (cdx & 1) | ((cdy & 1) << 1);
+  const long cdx = (long)dx >> 1, cdy = (long)dy >> 1;
+  const long cpos = off / 2 + (cdy >> 1) * S + (cdx >> 1);
+  const int cph = (int)((cdx & 1) | ((cdy & 1) << 1));
   if (dx >= -MOBI_MV_LIMIT && dx <= MOBI_MV_LIMIT && dy >= -MOBI_MV_LIMIT && dy <= MOBI_MV_LIMIT) {
     // the three windows at once: the luma one, and of the two chroma ones U starts first and V (S/2 further) ends last
     const long pos = off + (long)(dy >> 1) * S + (dx >> 1), ylen = S * g_.height;
@@ -190,7 +232,16 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
     check_window(off + (long)(dy >> 1) * S + (dx >> 1), w, h, (dx & 1) | ((dy & 1) << 1), S * g_.height);
     check_window(cpos, w >> 1, h >> 1, cph, S * g_.height / 2);
     check_window(cpos + S / 2, w >> 1, h >> 1, cph, S * g_.height / 2);
-    refuse(MOBI_REFUSE_MV);
+    // A vector beyond the command list's fields whose windows lie inside the planes (r01-r04: refused).  The reference addresses LINEARLY
+    // (MD.cs:400-416): luma source = off + (dy >> 1) * S + (dx >> 1), chroma = off / 2 + (dy >> 2) * S + (dx >> 2), phases = the low bits --
+    // so (dx - 4 t S, dy + 4 t) is the same copy for every t (t rows down and t * S samples back, in luma: 2 t rows and 2 t S samples;
+    // no low bit of dx, dx >> 1, dy, dy >> 1 moves).  The t that brings |dx| below 2 S leaves |dy| within the plane's height (the window
+    // was just checked), i.e. both inside the cell map's 14 bits.  The MV row cache above keeps the vector as it was read.
+    const long t = ((long)dx + (dx >= 0 ? 2 * S : -2 * S)) / (4 * S);
+    const long ndx = (long)dx - 4 * t * S, ndy = (long)dy + 4 * t;
+    if (ndx < -MOBI_MV_LIMIT || ndx > MOBI_MV_LIMIT || ndy < -MOBI_MV_LIMIT || ndy > MOBI_MV_LIMIT) fail(MOBI_E_INDEX); // (cannot happen: see above)
+    dx = (int)ndx;
+    dy = (int)ndy;
   }
   leaves_[n_leaf_words_++] = mobi_leaf_w0(x, y, wi, hi, ref); // at most 64 leaves: the tree bottoms out at 2x2
   leaves_[n_leaf_words_++] = mobi_leaf_w1(dx, dy);
@@ -241,13 +292,24 @@ void MobiStreamParser::pblock(int wi, int hi, int x, int y, int mv_slot) {
 // predictors and row cache -- while below quantiser 12 (ModsDS) the words' own low byte carries table bits and the "zigzag index" reaches
 // 255.  r03 refused both.  r04 keeps the words of Internal[] such a walk can touch (all but the scratch) and walks with it: the block's
 // coefficients are then whatever Internal[90..] holds when the transform starts, shipped as LITERAL values (see literal_frame).
-uint32_t MobiStreamParser::internal_read(uint32_t idx) const {
+// The first passes the last transforms left in Internal[154..217] (mobi_state.h: what each variant writes), made when somebody looks
+void MobiStreamParser::scratch_materialise() {
+  if (pend64_) mobi_scratch_from64(sc64_, scr_);
+  if (pend16_) {
+    uint32_t c[64];
+    for (int k = 0; k < 4; k++)
+      for (int m = 0; m < 4; m++) c[8 * k + m] = sc16_[4 * k + m];
+    mobi_scratch_from16(c, scr_);
+  }
+  pend64_ = pend16_ = false;
+}
+uint32_t MobiStreamParser::internal_read(uint32_t idx) {
   if (idx >= 392) fail(MOBI_E_INDEX); // managed array bounds
   if (idx < 10) fail(MOBI_E_INDEX);   // (never: r12 starts at 10 and only grows)
   if (idx < 74) return dq8_[idx - 10];
   if (idx < 90) return dq4_[idx - 74];
   if (idx < 154) return ib_[idx - 90];
-  if (idx < 218) refuse(MOBI_REFUSE_RUN); // the first pass of the last transform of each variant: not kept
+  if (idx < 218) { scratch_materialise(); return scr_[idx - 154]; }
   if (idx == 218) return i218_;
   if (idx == 219) return (uint32_t)predx_;
   if (idx == 220) return (uint32_t)predy_;
@@ -256,7 +318,7 @@ uint32_t MobiStreamParser::internal_read(uint32_t idx) const {
 }
 void MobiStreamParser::internal_write(uint32_t idx, uint32_t v) { // idx = 90 + a byte: 90..345
   if (idx < 154) ib_[idx - 90] = v;
-  else if (idx < 218) {} // scratch: every transform writes what it reads there first, and a run that reads it is refused
+  else if (idx < 218) { scratch_materialise(); scr_[idx - 154] = v; }
   else if (idx == 218) { i218_ = v; vlc_table_ = v == 1; } // (the tables of the block being read were chosen at its start, MD.cs:3332-3333)
   else if (idx == 219) predx_ = (int)v; // (dead: set again before the next macroblock's first leaf, MD.cs:207-208)
   else if (idx == 220) predy_ = (int)v;
@@ -270,7 +332,8 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
   const uint16_t *A = vlc_table_ == 1 ? mobi_vx2table1_a : mobi_vx2table0_a;
   const uint8_t *B = vlc_table_ == 1 ? mobi_vx2table1_b : mobi_vx2table0_b;
   memset(ib_, 0, sizeof(uint32_t) * N); // MD.cs:2933-2936 / 2948-2951, 2960-2963
-  bool odd = quant_ < 12;               // below 12 every dequant word may point anywhere (MD.cs:3907-3911 vs :3426)
+  bool big = false;                     // some coefficient of the block is beyond int16 (only a frame of literal values minds: literal_frame)
+  bool odd = tq_ < 12;                  // tables built below 12: every 8x8 dequant word may point anywhere (MD.cs:3907-3911 vs :3426)
   uint32_t r12 = start;
   const int n0 = n_coefs_;
   const int tile = is8 ? area * 64 : area * 64 + sub * 16;
@@ -334,8 +397,9 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
     }
     r12 += (uint32_t)skip;
     if (!odd && r12 < start + (uint32_t)N) { // the word is the block's own and its low byte a position inside the block
-      const uint32_t word = dq[r12 - start];
-      ib_[word & 0xFF] = (word >> 8) * (uint32_t)value; // (int * int in the reference: the low 32 bits either way)
+      const uint32_t word = dq[r12 - start], cv = (word >> 8) * (uint32_t)value; // (int * int in the reference: the low 32 bits either way)
+      ib_[word & 0xFF] = cv;
+      big |= cv + 32768u > 65535u;
       // The reference picks a reduced IDCT from the final scan index (MD.cs:2939-2942, 2954-2955); the reduced transforms only
       // look at part of the block, but for q >= 12 nothing they skip can be nonzero: scan positions 0, 0..2, 0..9 map inside the
       // respective regions (tests/test_oracle_identities.py pins that property of the zigzag tables), so every level is kept.
@@ -360,25 +424,68 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
       const bool read = variant == VALL || p == 0 || (variant == V3 && (p == 1 || p == 8)) || (variant == V16 && (p & 7) < 4 && p < 32);
       const int32_t v = (int32_t)ib_[p];
       if (!read || v == 0) continue;
-      if (v != (int16_t)v) refuse(MOBI_REFUSE_RUN); // a literal travels in the level's 16 bits
+      if (v != (int16_t)v) { // a literal travels in the level's 16 bits
+        if (!surely_faults(is8, variant)) refuse(MOBI_REFUSE_RUN);
+        frame_fault_ = true; // (the frame is rejected at its end, as a fault the kernels find is; the word itself no longer matters)
+        continue;
+      }
       coefs_[n_coefs_++] = (uint32_t)(tile + p) | 0x8000u | ((uint32_t)v << 16); // bit 15: a value, not a level (literal_frame clears it)
     }
   }
-  // what the transforms themselves leave in Internal[90..153] (a later run past a block may read it)
-  if (is8 && variant == V3) { // IDCT3Px8 keeps its first pass in Internal[90..97] (MD.cs:3661-3707)
-    const int r8 = (int)ib_[0] + 32, r9 = (int)ib_[1];
-    const int r7 = r9 + (r9 >> 1), r11 = r7 >> 2, r3 = r9 + ((-r9) >> 2), r5 = r9 + (r9 >> 2);
-    ib_[0] = (uint32_t)(r8 + r7); ib_[7] = (uint32_t)(r8 - r7);
-    ib_[1] = (uint32_t)(r8 + r5); ib_[6] = (uint32_t)(r8 - r5);
-    ib_[2] = (uint32_t)(r8 + r3); ib_[5] = (uint32_t)(r8 - r3);
-    ib_[3] = (uint32_t)(r8 + r11); ib_[4] = (uint32_t)(r8 - r11);
-  } else if (!is8 && variant == VALL) { // IDCT16Px4's first pass goes to Internal[106..121] (MD.cs:3728-3784)
+  if (big && !odd && !surely_faults(is8, variant)) big_unsure_ = true;
+  // what the transforms themselves leave in Internal[90..217] (a later run past a block may read it; mobi_state.h)
+  if (is8 && variant == V3) mobi_ib_after3(ib_);         // IDCT3Px8 keeps its first pass in Internal[90..97] (MD.cs:3661-3707)
+  else if (!is8 && variant == VALL) mobi_ib_after16x4(ib_); // IDCT16Px4's first pass goes to Internal[106..121] (MD.cs:3728-3784)
+  else if (is8 && variant == VALL) { // IDCT64Px8's first pass fills Internal[154..217] (MD.cs:3452-3500): kept as its coefficients until read
+    memcpy(sc64_, ib_, sizeof(sc64_));
+    pend64_ = true;
+    pend16_ = false;
+  } else if (is8 && variant == V16) { // IDCT16Px8's goes to Internal[154..185] (MD.cs:3577-3612)
+    for (int k = 0; k < 4; k++)
+      for (int m = 0; m < 4; m++) sc16_[4 * k + m] = ib_[8 * k + m];
+    pend16_ = true;
+  }
+}
+// A coefficient outside int16 in a frame that ships literal values.  The transform of such a block leaves the clamp table's domain whatever
+// the prediction when some residual is beyond +-319 (index = 0x40 + pixel + residual must stay in [0, 384), MobiConst.cs:587, MD.cs:3551):
+// the reference throws at this block, and this library rejects the frame with MOBI_E_CLAMP as it does when the kernels find the fault.  A
+// block that stays within +-319 everywhere with a coefficient that large would need its sums to cancel through 32-bit wrap-around: the one
+// input left that is refused (MOBI_REFUSE_RUN).  ib_ = the block as its transform finds it.
+bool MobiStreamParser::surely_faults(bool is8, int variant) const {
+  int res_min = 0, res_max = 0;
+  auto see = [&](int r) { res_min = std::min(res_min, r); res_max = std::max(res_max, r); };
+  if (variant == 0) { // IDCT1Px8 / IDCT1Px4 (MD.cs:3710-3725, 3787-3798)
+    see(((int)ib_[0] + 32) >> 6);
+  } else if (is8) { // every 8x8 variant equals the full transform on the coefficients it reads (tests/test_oracle_identities.py)
+    int c[64], t[64], in[8], out[8];
+    for (int p = 0; p < 64; p++) {
+      const bool read = variant == 3 || p == 0 || (variant == 1 && (p == 1 || p == 8)) || (variant == 2 && (p & 7) < 4 && p < 32);
+      c[p] = read ? (int)ib_[p] : 0;
+    }
+    for (int k = 0; k < 8; k++) {
+      for (int m = 0; m < 8; m++) in[m] = c[8 * k + m];
+      if (k == 0) in[0] += 32;
+      mobi_bfly8(in, out);
+      for (int m = 0; m < 8; m++) t[8 * m + k] = out[m];
+    }
+    for (int i = 0; i < 8; i++) {
+      mobi_bfly8(&t[8 * i], out);
+      for (int j = 0; j < 8; j++) see(out[j] >> 6);
+    }
+  } else {
+    int t[16], in[4], out[4];
     for (int k = 0; k < 4; k++) {
-      int in[4] = {(int)ib_[4 * k] + (k == 0 ? 0x20 : 0), (int)ib_[4 * k + 1], (int)ib_[4 * k + 2], (int)ib_[4 * k + 3]}, out[4];
+      for (int m = 0; m < 4; m++) in[m] = (int)ib_[4 * k + m];
+      if (k == 0) in[0] += 32;
       mobi_bfly4(in, out);
-      for (int m = 0; m < 4; m++) ib_[16 + 4 * m + k] = (uint32_t)out[m];
+      for (int m = 0; m < 4; m++) t[4 * m + k] = out[m];
+    }
+    for (int i = 0; i < 4; i++) {
+      mobi_bfly4(&t[4 * i], out);
+      for (int j = 0; j < 4; j++) see(out[j] >> 6);
     }
   }
+  return res_min < -319 || res_max > 319;
 }
 // A frame in which some block's stores left their place (frame_literal_): every residual of the frame is shipped DEQUANTISED, as the value
 // the transform reads, and the frame's macroblocks name scale row MOBI_SCALE_LITERAL (all ones) instead of their quantiser -- the
@@ -387,7 +494,7 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
 void MobiStreamParser::literal_frame(ParsedFrame &out) {
   mobi_literal_frame_count.fetch_add(1, std::memory_order_relaxed);
   int32_t sc[MOBI_SCALE_STRIDE];
-  mobi_build_scale_table((int)quant_, sc);
+  mobi_build_scale_table((int)tq_, sc);
   for (MbDesc &d : out.desc) {
     const bool intra = (d.w1 & 1) == MOBI_MB_INTRA;
     const uint32_t nl = (d.w1 >> 1) & 0x7F, dual = (d.w1 >> 26) & 3, t8 = (d.w1 >> 14) & 0x3F;
@@ -396,7 +503,12 @@ void MobiStreamParser::literal_frame(ParsedFrame &out) {
       if (w[i] & 0x8000u) { w[i] &= ~0x8000u; continue; }
       const int t = (int)(w[i] & 0x1FF), p = t & 63;
       const int32_t v = sc[((t8 >> (t >> 6)) & 1) ? p : 64 + (p & 15)] * (int32_t)(int16_t)(w[i] >> 16);
-      if (v != (int16_t)v) refuse(MOBI_REFUSE_RUN);
+      if (v != (int16_t)v) { // an ordinary block with a coefficient beyond int16: resid_block looked at its transform (big_unsure_)
+        if (big_unsure_) refuse(MOBI_REFUSE_RUN);
+        frame_fault_ = true;
+        w[i] = (uint32_t)t; // (level 0: the frame is rejected, the word no longer matters)
+        continue;
+      }
       w[i] = (uint32_t)t | ((uint32_t)v << 16);
     }
     d.w1 = (d.w1 & ~(63u << 20)) | ((uint32_t)MOBI_SCALE_LITERAL << 20);
@@ -444,9 +556,14 @@ int MobiStreamParser::pmode(int ci, bool four) {
   take(nb);
   return mode;
 }
-static inline int16_t param16(int p, bool &ok) {
-  ok = p >= -32768 && p <= 32767;
-  return (int16_t)p;
+// A plane parameter for record r (24: the 16x16 plane's): the record's 16-bit field, or -- a code of 33 bits and more -- a wide parameter
+// behind the macroblock's level words (mobi_cmd.h).  Returns the bits to OR into the record (MbDesc.w3 for r = 24: shifted by the caller).
+uint32_t MobiStreamParser::plane_param(int p, int r) {
+  if (p >= -32768 && p <= 32767) return (uint32_t)(uint16_t)(int16_t)p << 16;
+  if (!any_wide_) memset(wide_, 0, sizeof(wide_));
+  any_wide_ = true;
+  wide_[r] = p;
+  return MOBI_REC_WIDE;
 }
 // sub_116508 (MD.cs:2869-2896) or a bare PredictIntra: one 8x8 area whose mode is already known
 void MobiStreamParser::intra_area_fixed(int area, int mode, bool coded) {
@@ -484,11 +601,9 @@ void MobiStreamParser::intra_chroma(uint32_t cbp) { // loc_116290, MD.cs:1864-18
   if (m == 2) {
     m = 9;
     for (int area = 4; area < 6; area++) {
-      bool ok;
-      int16_t p = param16(se(), ok);
+      const int p = se();
       check_intra_reads(2, area_offset(area, 0), false);
-      if (!ok) refuse(MOBI_REFUSE_PLANE);
-      recs_[area * 4] |= mobi_intra_rec(0, 0, 0, 1, p);
+      recs_[area * 4] |= mobi_intra_rec(0, 0, 0, 1, 0) | plane_param(p, area * 4);
     }
   }
   intra_area_fixed(4, m, (cbp >> 4) & 1);
@@ -502,11 +617,10 @@ void MobiStreamParser::intra_full() { // DecIntraFullBlockPMode, MD.cs:1759-1786
   take(3);
   if (m == 2) {
     m = 9;
-    bool ok;
-    int16_t p = param16(se(), ok);
+    const int p = se();
     check_intra_reads(2, cur_off_, false);
-    if (!ok) refuse(MOBI_REFUSE_PLANE);
-    w3_ = 1u | ((uint32_t)(uint16_t)p << 16);
+    const uint32_t pp = plane_param(p, 24);
+    w3_ = 1u | (pp == MOBI_REC_WIDE ? MOBI_W3_WIDE : pp);
   }
   for (int k = 0; k < 4; k++) intra_area_fixed(k, m, (cbp >> k) & 1);
   intra_chroma(cbp);
@@ -525,14 +639,10 @@ void MobiStreamParser::intra_sub() { // DecIntraSubBlockPMode, MD.cs:1789-1807
     }
     if (whole) {
       int m = pmode(ci[k], false);
-      int p = 0;
-      if (m == 2) { // the predictor itself reads its parameter (MD.cs:1915-1919)
-        bool ok;
-        p = param16(se(), ok);
-        if (!ok) refuse(MOBI_REFUSE_PLANE);
-      }
+      uint32_t pp = 0;
+      if (m == 2) pp = plane_param(se(), k * 4); // the predictor itself reads its parameter (MD.cs:1915-1919)
       check_intra_reads(m, area_offset(k, 0), false);
-      recs_[k * 4] |= mobi_intra_rec(m, coded, 0, 0, p);
+      recs_[k * 4] |= mobi_intra_rec(m, coded, 0, 0, 0) | pp;
       if (coded) {
         cbp6_ |= 1u << k;
         t8mask_ |= 1u << k;
@@ -544,15 +654,11 @@ void MobiStreamParser::intra_sub() { // DecIntraSubBlockPMode, MD.cs:1789-1807
       uint32_t m4 = mobi_cbp4_intra[u4];
       for (int sub = 0; sub < 4; sub++) {
         int m = pmode(ci[k] + d5[sub], true);
-        int p = 0;
-        if (m == 2) {
-          bool ok;
-          p = param16(se(), ok);
-          if (!ok) refuse(MOBI_REFUSE_PLANE);
-        }
+        uint32_t pp = 0;
+        if (m == 2) pp = plane_param(se(), k * 4 + sub);
         check_intra_reads(m, area_offset(k, sub), true);
         int c = (m4 >> sub) & 1;
-        recs_[k * 4 + sub] |= mobi_intra_rec(m, c, 1, 0, p);
+        recs_[k * 4 + sub] |= mobi_intra_rec(m, c, 1, 0, 0) | pp;
         if (c) {
           cbp6_ |= 1u << k;
           resid_block(k, sub, false);
@@ -704,7 +810,7 @@ void MobiStreamParser::finish_levels(ParsedFrame &out) {
       it[0] = (uint32_t)mb;
       it[1] = d.w1;
       it[2] = d.payload_off;
-      it[3] = (d.w3 & 0xFFFF0001u) | flag[mb] | (kl[mb] >= 8 ? 8u : 0u) | ((d.w2 & 0x3FFu) << 5);
+      it[3] = (d.w3 & (0xFFFF0001u | MOBI_W3_WIDE)) | flag[mb] | (kl[mb] >= 8 ? 8u : 0u) | ((d.w2 & 0x3FFu) << 5);
       out.desc[mb].w3 |= flag[mb]; // (the device parsers' item lists carry no flags: mobi_recon_intra_cl reads these two bits from the descriptor)
     }
   out.hdr.n_mbs = (uint32_t)n;
@@ -731,9 +837,10 @@ int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offs
     win_ <<= 16;
     bool iframe = (win_ >> 31) == 1;
     win_ += win_;
-    frame_literal_ = false;
+    frame_literal_ = frame_fault_ = big_unsure_ = false;
     if (iframe) parse_i(out); else parse_p(out);
     if (frame_literal_) literal_frame(out);
+    if (frame_fault_) fail(MOBI_E_CLAMP); // (behind the whole parse, where the kernels' own clamp faults are reported: Offset is the frame's end)
     finish_levels(out);
   } catch (const Err &e) {
     rc = e.code;

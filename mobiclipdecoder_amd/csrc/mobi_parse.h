@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "mobi_cmd.h"
+#include "mobi_state.h"
 
 enum { MOBI_INTRA_CLASSES = 16 }; // launch classes of intra macroblocks inside a dependency level (finish_levels)
 struct ParsedFrame {
@@ -58,12 +59,14 @@ void mobi_build_scale_table(int q, int32_t out[MOBI_SCALE_STRIDE]);
 // directional intra predictors as four tile offsets per sample (see mobi_parse.cpp); out: MOBI_TAP_ENTRIES x 4 int16; false = self-check failed
 bool mobi_build_intra_taps(int16_t *out, int pitch);
 
-// The four classes of streams the reference decodes and this library refuses (MOBI_E_UNSUPPORTED); process-wide counters, a measuring aid
-enum { MOBI_REFUSE_MV = 0,     // |MV| > MOBI_MV_LIMIT half-pels (the cell map's 14-bit fields)
+// Streams the reference decodes and this library refuses (MOBI_E_UNSUPPORTED), by cause; process-wide counters, a measuring aid.  r05: one
+// cause is left -- the others are decoded (mc_leaf: vectors are normalised; resid_block: the transforms' scratch is kept; intra_*: wide
+// plane parameters travel behind the level words).
+enum { MOBI_REFUSE_MV = 0,     // (r01-r04: |MV| > MOBI_MV_LIMIT half-pels; r05: nothing counts here any more)
        MOBI_REFUSE_QUANT = 1,  // (r03: ModsDS quantiser < 12; r04 decodes those frames: nothing counts here any more)
-       MOBI_REFUSE_RUN = 2,    // a coefficient run past its block (MD.cs:3424-3429) that reads the transforms' scratch, Internal[154..217], or
-                               // leaves a coefficient outside int16 (r04: the other such runs are decoded, see resid_block)
-       MOBI_REFUSE_PLANE = 3,  // a plane-predictor parameter outside int16 (the record's 16-bit field): |se| >= 2^15 needs a code of >= 33 bits
+       MOBI_REFUSE_RUN = 2,    // a walk through Internal[] (MD.cs:3424-3429) left a coefficient outside int16 in a block whose residual stays within
+                               // +-319 everywhere (so that the clamp table need not fault, MobiConst.cs:587): a literal travels in the level's 16 bits
+       MOBI_REFUSE_PLANE = 3,  // (r01-r04: a plane-predictor parameter outside int16; r05: nothing counts here any more)
        MOBI_REFUSE_CLASSES = 4 };
 extern std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES];
 extern std::atomic<unsigned long> mobi_literal_frame_count; // frames shipped as literal values (MobiStreamParser::literal_frame): a measuring aid too
@@ -74,6 +77,12 @@ class MobiStreamParser {
   // d.Data=data; d.Offset=*offset; DecodeFrame(); *offset=d.Offset.  Returns MOBI_OK or MOBI_E_*.
   // On error `out` is not to be executed; the ring still advances (MD.cs:102-108 ran already).
   int parse_frame(const uint8_t *data, size_t len, int32_t *offset, ParsedFrame &out);
+
+  // The decoder state that survives a frame, as the device parsers keep it (mobi_state.h): a clip whose frame the device parser could not
+  // finish is parsed again here from the state it had when that frame started, and stays with this parser from then on (mobi_abi.cpp).
+  void import_state(const MobiDevState &st, const MobiDevTail &tail);
+  void export_state(MobiDevState &st, MobiDevTail &tail);
+  uint32_t internal_word(uint32_t idx); // Internal[idx] as the reference holds it between frames, 10 <= idx < 392 (tests: against the oracle's)
 
   uint32_t quantizer() const { return quant_; }
   uint32_t yuv_format() const { return yuvfmt_; }
@@ -105,14 +114,18 @@ class MobiStreamParser {
   void p_residual();
   void resid_area(int area);
   void resid_block(int area, int sub, bool is8);
-  uint32_t internal_read(uint32_t idx) const;
+  uint32_t internal_read(uint32_t idx);
   void internal_write(uint32_t idx, uint32_t v);
+  void scratch_materialise();
+  void build_dq();
   void literal_frame(ParsedFrame &out);
+  bool surely_faults(bool is8, int variant) const;
   void intra_full();
   void intra_sub();
   void intra_chroma(uint32_t cbp);
   void intra_area_fixed(int area, int mode, bool coded);
   int pmode(int ci, bool four);
+  uint32_t plane_param(int p, int r);
   void check_intra_reads(int mode, long off, bool four) const;
   long area_offset(int area, int sub) const;
   void begin_mb(int mb, int type);
@@ -129,17 +142,25 @@ class MobiStreamParser {
   int nbr_ = 0;      // nrBitsRemaining
   // persistent decoder state
   uint32_t quant_ = 0, yuvfmt_ = 0;
+  uint32_t tq_ = MOBI_TQ_NONE; // the quantiser dq8_ / dq4_ were built for: SetupQuantizationTables assigns Quantizer before its table index can
+                               // throw (MD.cs:3886-3890), so after a throw the OLD tables serve the new Quantizer (ModsDS, q >= 54)
   uint32_t dq8_[64], dq4_[16]; // Internal[10..73], Internal[74..89]
   uint8_t mcache_[40];         // bytes of Internal[0..9]
   int vlc_table_ = 0;          // Internal[218] == 1
   // r04: the part of Internal[] that a coefficient run past its block, or a ModsDS quantiser below 12, reads and writes (MD.cs:3424-3429):
   // the coefficient block Internal[90..153] as every residual block and every transform variant leaves it, the table select as a word,
-  // and whatever was written behind the MV row cache.  (Internal[154..217], the transforms' scratch, is not kept: a run that READS it
-  // stays a refusal.)
+  // and whatever was written behind the MV row cache.  r05: the transforms' scratch Internal[154..217] too, lazily -- the coefficients of the
+  // last full 8x8 transform and of the last 16-coefficient one behind it are kept, and their first passes are made when a walk reads or
+  // writes there (scratch_materialise).
   uint32_t ib_[64] = {0};      // Internal[90..153]
+  uint32_t scr_[64] = {0};     // Internal[154..217] as of the last scratch_materialise()
+  uint32_t sc64_[64], sc16_[16]; // coefficients of the pending transforms (pend64_: IDCT64Px8 -> all of scr_; pend16_: IDCT16Px8 -> scr_[0..31], behind it)
+  bool pend64_ = false, pend16_ = false;
   uint32_t i218_ = 0;          // Internal[218]
   uint32_t itail_[392] = {0};  // Internal[idx] for indices that are nothing else (behind the MV row cache)
   bool frame_literal_ = false; // a block of this frame read or wrote Internal[] out of its place: its residuals ship as literal values
+  bool frame_fault_ = false;   // ... and one of them holds a coefficient beyond int16 whose transform must leave the clamp table's domain
+  bool big_unsure_ = false;    // an ordinary block of this frame holds such a coefficient and need NOT leave it (surely_faults)
   int frames_started_ = 0;
   std::vector<int> mvc_; // MV row cache, Internal[221..]
   int predx_ = 0, predy_ = 0;
@@ -152,6 +173,8 @@ class MobiStreamParser {
   uint32_t recs_[MOBI_INTRA_RECORDS];
   uint32_t cells_[MOBI_MV_CELLS];
   uint32_t cbp6_ = 0, t8mask_ = 0, w3_ = 0;
+  int32_t wide_[MOBI_WIDE_PARAMS];      // plane parameters outside int16 of the macroblock being built (mobi_cmd.h)
+  bool any_wide_ = false;
   int mb_type_ = 0;
 };
 

@@ -54,6 +54,7 @@ _SIGS = {
     "mobi_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_in_flight": (C.c_int, [C.c_void_p]),
+    "mobi_batch_host_clips": (C.c_int, [C.c_void_p]),
     "mobi_forward_dct": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
@@ -231,7 +232,10 @@ class MobiclipBatch:
             raise MobiclipError(f"mobi_batch_create failed: {error_string(-8)}")
         self.Stride = self._lib.mobi_batch_stride(self._h)
         if device_parse is not None:
-            mode = 2 if device_parse == "hybrid" else 3 if device_parse == "lockstep" else int(bool(device_parse))
+            if isinstance(device_parse, int) and not isinstance(device_parse, bool):
+                mode = device_parse  # the library's own numbering: 0 host, 1 device, 2 hybrid, 3 device with the lock-step parser in front
+            else:
+                mode = 2 if device_parse == "hybrid" else 3 if device_parse == "lockstep" else int(bool(device_parse))
             rc = self._lib.mobi_batch_set_parse_mode(self._h, mode)
             if rc != 0:
                 raise MobiclipError(error_string(rc))
@@ -259,6 +263,11 @@ class MobiclipBatch:
         e = self._lib.mobi_batch_submit(self._h, ptrs, lens, offs)
         if e != 0:
             raise MobiclipError(error_string(e))
+
+    def host_clips(self):
+        """clips the host parser parses at present: all of them in host mode, else the hybrid share plus every clip that has had a frame
+        the device parser could not finish (the result is the same either way: mobiclip_hip.h, mobi_batch_set_parse_mode)"""
+        return self._lib.mobi_batch_host_clips(self._h)
 
     def lockstep_finished(self):
         """device_parse="lockstep": clips of the last finished step the lock-step parser finished itself (-1 in other modes)."""

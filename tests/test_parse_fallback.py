@@ -1,0 +1,378 @@
+"""r05: the answer must not depend on which side parses.  The device parsers finish frames that decode without incident; every other frame
+is parsed again by the host parser from the decoder state the clip had when the frame started (mobi_state.h, mobi_abi.cpp).  What that rests
+on, checked here without a GPU:
+
+  * the host parser's picture of Internal[] -- dequant words, the coefficient block, the transforms' scratch, the MV predictor and row
+    cache -- equals the ORACLE's Internal[] (which follows the reference statement by statement) after every frame both decode;
+  * what mobi_parse_tail rebuilds from a clean frame's command list (mobi_tail_scan_mb / mobi_tail_finish, the same functions on the CPU)
+    equals the parser's own bookkeeping, frame after frame;
+  * a parser seeded with that state takes a clip over in the middle and produces the same rc, Offset, command list and pictures as a parser
+    that saw the clip from its first frame.
+GPU: the same streams through the C ABI in all four parse modes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mobiclipdecoder_amd import default_params, generate_clip
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+from tests.interp_binding import InterpDecoder, lib as interp_lib
+from tests.oracle_binding import OracleDecoder, lib as oracle_lib
+
+
+class DevState(C.Structure):
+    _fields_ = [("quant", C.c_uint32), ("yuvfmt", C.c_uint32), ("frames_started", C.c_int32), ("tables_set", C.c_uint32),
+                ("mcache", C.c_uint8 * 40), ("predx", C.c_int32), ("predy", C.c_int32)]
+
+
+class DevTail(C.Structure):
+    _fields_ = [("ib", C.c_uint32 * 64), ("scratch", C.c_uint32 * 64), ("mvc", C.c_int32 * 132), ("pad", C.c_uint32 * 4)]
+
+
+def _bind():
+    L = interp_lib()
+    L.mobi_cmdinterp_internal.restype = C.c_uint32
+    L.mobi_cmdinterp_internal.argtypes = [C.c_void_p, C.c_uint32]
+    L.mobi_cmdinterp_export_state.argtypes = [C.c_void_p, C.POINTER(DevState), C.POINTER(DevTail)]
+    L.mobi_cmdinterp_import_state.argtypes = [C.c_void_p, C.POINTER(DevState), C.POINTER(DevTail), C.c_int]
+    L.mobi_cmdinterp_copy_ring.argtypes = [C.c_void_p, C.c_void_p]
+    L.mobi_cmdinterp_tail.argtypes = [C.c_void_p, C.POINTER(DevTail), C.POINTER(DevTail)]
+    return L
+
+
+def _rich(trial, version=None, **kw):
+    ver = version if version is not None else 1 + trial % 2
+    args = dict(n_frames=5, width=96, height=64, version=ver, pm_intra=120, pm_deep=150, pm_multiref=250, qdelta_prob=250, escape_prob=80,
+                table1_prob=400)
+    args.update(kw)
+    return default_params("AB"[trial % 2], BASE_SEED + 9000 + trial, **args)
+
+
+def _flipped(trial, rng, n_flips=None, **kw):
+    p = _rich(trial, **kw)
+    data, fo = generate_clip(p)
+    data = data.copy()
+    for _ in range(int(rng.integers(1, 8)) if n_flips is None else n_flips):
+        data[int(rng.integers(0, data.size))] ^= 1 << int(rng.integers(0, 8))
+    return p, data, fo
+
+
+def test_internal_words_match_the_oracle():
+    """Internal[10..] of the host parser against the oracle's after every frame both decode: clean streams and bit-flipped ones (walks
+    through Internal[], transforms of every variant, I-frames behind P-frames)"""
+    L = _bind()
+    OL = oracle_lib()
+    rng = np.random.default_rng(55)
+    frames = walked = 0
+    for trial in range(120):
+        p, data, fo = _flipped(trial, rng, n_flips=0 if trial % 3 == 0 else None)
+        a, o = InterpDecoder(p.width, p.height, p.version), OracleDecoder(p.width, p.height, p.version)
+        n_words = 221 + 2 * (p.width // 16 + 2)
+        for f in range(p.n_frames):
+            a.Data = o.Data = data[: fo[f + 1]]
+            a.Offset = o.Offset = int(fo[f])
+            a.DecodeFrame(); o.DecodeFrame()
+            if a.last_error != 0 or o.last_error != 0:
+                break
+            I = np.ctypeslib.as_array(OL.mobi_oracle_internal(o.h), (392,))
+            mine = np.array([L.mobi_cmdinterp_internal(a.h, i) for i in range(10, n_words)], dtype=np.uint32)
+            assert np.array_equal(mine, I[10:n_words]), (p.seed, f, np.nonzero(mine != I[10:n_words])[0][:8] + 10)
+            frames += 1
+        a.close(); o.close()
+    assert frames > 250, frames
+
+
+def test_tail_from_the_command_list_equals_the_parsers_bookkeeping():
+    """mobi_parse_tail's arithmetic on the CPU: ib / scratch rebuilt from the command list of every clean frame, chained from frame to frame,
+    against the parser's own Internal[90..217]"""
+    L = _bind()
+    frames = 0
+    for trial in range(60):
+        for content in ({}, dict(cbp_prob=150), dict(cbp_prob=700, pm_intra=300)):
+            p = _rich(trial, **content)
+            data, fo = generate_clip(p)
+            a = InterpDecoder(p.width, p.height, p.version)
+            tail = DevTail()
+            for f in range(p.n_frames):
+                a.Data = data[: fo[f + 1]]
+                a.Offset = int(fo[f])
+                a.DecodeFrame()
+                assert a.last_error == 0
+                out = DevTail()
+                L.mobi_cmdinterp_tail(a.h, C.byref(tail), C.byref(out))
+                st, mine = DevState(), DevTail()
+                L.mobi_cmdinterp_export_state(a.h, C.byref(st), C.byref(mine))
+                assert list(out.ib) == list(mine.ib), (p.seed, f, "ib")
+                assert list(out.scratch) == list(mine.scratch), (p.seed, f, "scratch")
+                tail = out
+                frames += 1
+            a.close()
+    assert frames >= 800
+
+
+def _takeover(L, p, data, fo, at):
+    """frames [0, at) by decoder A ("the device": its state leaves as MobiDevState + a tail chained through mobi_cmdinterp_tail), frame `at`
+    and the rest by a NEW decoder seeded with that state; beside them decoder R that sees everything.  Returns the per-frame results of both."""
+    A, R = InterpDecoder(p.width, p.height, p.version), InterpDecoder(p.width, p.height, p.version)
+    tail = DevTail()
+    ra, rr = [], []
+    for f in range(p.n_frames):
+        R.Data = data[: fo[f + 1]]; R.Offset = int(fo[f])
+        pr = R.DecodeFrame()
+        rr.append((R.last_error, R.Offset, R.Quantizer, None if pr is None else (pr[0].copy(), pr[1].copy())))
+    B = None
+    for f in range(p.n_frames):
+        if f == at:
+            st, own = DevState(), DevTail()
+            L.mobi_cmdinterp_export_state(A.h, C.byref(st), C.byref(own))
+            own.ib[:] = tail.ib[:]        # what the device would hold: rebuilt from the command lists, not the parser's own words
+            own.scratch[:] = tail.scratch[:]
+            B = InterpDecoder(p.width, p.height, p.version)
+            L.mobi_cmdinterp_import_state(B.h, C.byref(st), C.byref(own), f)
+            L.mobi_cmdinterp_copy_ring(B.h, A.h)
+        d = B if B is not None else A
+        d.Data = data[: fo[f + 1]]; d.Offset = int(fo[f])
+        pd = d.DecodeFrame()
+        ra.append((d.last_error, d.Offset, d.Quantizer, None if pd is None else (pd[0].copy(), pd[1].copy())))
+        if B is None:
+            if d.last_error != 0:
+                return None  # (frames before the take-over must be clean: the device would not have kept them)
+            out = DevTail()
+            L.mobi_cmdinterp_tail(A.h, C.byref(tail), C.byref(out))
+            tail = out
+    return ra, rr
+
+
+def test_a_seeded_parser_takes_a_clip_over_in_the_middle():
+    L = _bind()
+    rng = np.random.default_rng(77)
+    compared = errors = 0
+    for trial in range(150):
+        p = _rich(trial, n_frames=6)
+        data, fo = generate_clip(p)
+        data = data.copy()
+        at = 1 + trial % 4
+        # corrupt frames from `at` on only: the frames before it are the device's
+        lo, hi = int(fo[at]), int(fo[p.n_frames])
+        for _ in range(int(rng.integers(1, 8))):
+            data[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
+        r = _takeover(L, p, data, fo, at)
+        assert r is not None
+        ra, rr = r
+        for f in range(p.n_frames):
+            assert ra[f][:3] == rr[f][:3], (p.seed, at, f, ra[f][:3], rr[f][:3])
+            if ra[f][0] != 0:
+                errors += 1
+                break
+            assert np.array_equal(ra[f][3][0], rr[f][3][0]) and np.array_equal(ra[f][3][1], rr[f][3][1]), (p.seed, at, f)
+            compared += 1
+    assert compared > 500 and errors > 20, (compared, errors)
+
+
+def test_stale_quantiser_tables():
+    """SetupQuantizationTables assigns Quantizer before its table index can throw (MD.cs:3886-3890).  ModsDS, I-frames with
+    q = 20, then 60 (throws: Quantizer = 60, tables of 20), then 60 again (no set-up: decodes with the tables of 20)"""
+    from tests.test_internal_walk import _set_quantizer
+    for q_bad in (54, 60, 63):
+        p = default_params("A", BASE_SEED + 4242, n_frames=1, width=64, height=48, quantizer=20, pm_intra=1000, cbp_prob=600)
+        data, fo = generate_clip(p)
+        good = data[: fo[1]].copy()
+        bad = good.copy()
+        _set_quantizer(bad, q_bad)
+        a, o = InterpDecoder(p.width, p.height, p.version), OracleDecoder(p.width, p.height, p.version)
+        for k, frame in enumerate((good, bad, bad)):
+            a.Data = o.Data = frame
+            a.Offset = o.Offset = 0
+            ra, ro = a.DecodeFrame(), o.DecodeFrame()
+            assert (a.last_error == 0) == (o.last_error == 0), (q_bad, k, a.last_error, o.last_error)
+            if k == 1:
+                assert a.last_error != 0
+            else:
+                assert a.last_error == 0 and a.Quantizer == o.Quantizer
+                assert np.array_equal(ra[0], ro[0]) and np.array_equal(ra[1], ro[1]), (q_bad, k)
+        a.close(); o.close()
+
+
+def _se_code(v):
+    """Elias-gamma bits of the signed value v (MD.cs:2998-3015: odd codes map to non-positive values)"""
+    u = 2 * v if v > 0 else 1 - 2 * v  # se: u even -> u >> 1, u odd -> (1 - u) >> 1
+    z = u.bit_length() - 1
+    return "0" * z + format(u, "b")
+
+
+def _ue_code(v):
+    u = v + 1
+    z = u.bit_length() - 1
+    return "0" * z + format(u, "b")
+
+
+def _part_code(ver, shape, code):
+    """bits of partition code `code` for block shape index `shape` (wi * 4 + hi), from the decoder's own look-up tables (Appendix B)"""
+    from tests.tables import load
+    T = load()
+    v = 0 if ver == 2 else 1
+    nbits, width = int(T["mobi_part_bits"][v][shape][code]), 32 - int(T["mobi_part_shift"][v][shape])
+    for peek in range(1 << width):
+        if int(T["mobi_part_lut"][v][shape][peek]) == code and (peek & ((1 << (width - nbits)) - 1)) == 0:
+            return format(peek >> (width - nbits), "0%db" % nbits)
+    raise AssertionError((ver, shape, code))
+
+
+def _frame(bits):
+    bits += "0" * ((-len(bits)) % 16) + "0" * 64
+    out = bytearray()
+    for i in range(0, len(bits), 16):
+        w = int(bits[i:i + 16], 2)
+        out += bytes((w & 0xFF, w >> 8))
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+
+
+def _decode_both(w, h, ver, frames):
+    a, o = InterpDecoder(w, h, ver), OracleDecoder(w, h, ver)
+    n_ok = 0
+    for data in frames:
+        a.Data = o.Data = data
+        a.Offset = o.Offset = 0
+        ra, ro = a.DecodeFrame(), o.DecodeFrame()
+        assert a.last_error == o.last_error, (a.last_error, o.last_error)
+        if o.last_error != 0:
+            break
+        assert a.Offset == o.Offset and np.array_equal(ra[0], ro[0]) and np.array_equal(ra[1], ro[1])
+        n_ok += 1
+    a.close(); o.close()
+    return n_ok
+
+
+_DC_MB = "0" + _ue_code(0) + "011" + "011"  # full intra macroblock, nothing coded, luma mode 3 (DC), chroma mode 3
+
+
+def test_wide_plane_parameters_travel():
+    """r01-r04 refused a plane parameter beyond int16 (a code of 33 bits and more).  A 32x32 ModsDS I-frame whose last macroblock -- the one
+    with a row above and a column to its left -- is a 16x16 plane and two chroma planes with such parameters: the oracle's picture"""
+    hdr = "1" + "0" + "0" + format(20, "06b")
+    for py, pu, pv in ((40000, 3, -2), (-70000, 65536, -65537), (2 ** 20 + 5, -(2 ** 22), 12345678), (5, -40000, 7)):
+        bits = hdr + _DC_MB * 3 + "0" + _ue_code(0) + "010" + _se_code(py) + "010" + _se_code(pu) + _se_code(pv)
+        assert _decode_both(32, 32, 1, [_frame(bits)]) == 1, (py, pu, pv)
+
+
+def test_far_motion_vectors_travel():
+    """r01-r04 refused |MV| > 8191 half-pels.  The reference addresses linearly (MD.cs:400-416): on a 32x32 picture (Stride 256) the vector
+    (+8192, 0) is "sixteen rows down".  Once as the single leaf of a macroblock, once in a three-leaf tree (the MV cell map's 14-bit fields)"""
+    for ver in (1, 2):
+        hdr = "1" + "0" + "0" + format(20, "06b")
+        iframe = _frame(hdr + _DC_MB * 4)
+        skip = _part_code(ver, 0, 0) + _ue_code(0)  # 16x16, predicted vector, nothing coded
+        far = _part_code(ver, 0, 1) + _se_code(8192) + _se_code(0) + _ue_code(0)  # 16x16, ref 1, dx = +8192 half-pels
+        # code 8 at 16x16 (two 16x8), the top one split again by code 9 (two 8x8): three leaves.  Shapes: 16x8 = wi 0, hi 1 -> 1; 8x8 -> 5.
+        deep = (_part_code(ver, 0, 8) + _part_code(ver, 1, 9) + _part_code(ver, 5, 1) + _se_code(8192) + _se_code(0) +
+                _part_code(ver, 5, 1) + _se_code(8190) + _se_code(1) + _part_code(ver, 1, 1) + _se_code(8196) + _se_code(-3) + _ue_code(0))
+        for first in (far, deep):
+            pframe = _frame("0" + _se_code(0) + first + skip * 3)
+            assert _decode_both(32, 32, ver, [iframe, pframe]) == 2, ver
+
+
+# ---- GPU: all four parse modes give the host parser's answer -------------------------------------------------------------------------
+def _fuzz_streams(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for trial in range(n):
+        p, data, fo = _flipped(trial, rng, n_frames=6)
+        out.append((p, data, fo))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_gpu_every_parse_mode_gives_the_same_answer(mode):
+    """bit-flipped streams as a BATCH per geometry / version through mobi_batch_decode in parse mode 0..3: rc, Offset, Quantizer and the
+    planes of every frame equal the oracle's (the same assertion in every mode), and the device modes did hand clips to the host parser"""
+    from mobiclipdecoder_amd import MobiclipBatch
+    streams = _fuzz_streams(96, 909)
+    total_same = total_rej = handed = 0
+    for ver in (1, 2):
+        group = [s for s in streams if s[0].version == ver]
+        p0 = group[0][0]
+        b = MobiclipBatch(len(group), p0.width, p0.height, ver, device=0, device_parse=mode)
+        oras = [OracleDecoder(p0.width, p0.height, ver) for _ in group]
+        alive = [True] * len(group)
+        for f in range(p0.n_frames):
+            datas = [g[1][: g[2][f + 1]] for g in group]
+            offs = [int(g[2][f]) for g in group]
+            rcs, offs_out = b.decode(datas, offs)
+            for i, (p, data, fo) in enumerate(group):
+                o = oras[i]
+                o.Data = datas[i]; o.Offset = offs[i]
+                ro = o.DecodeFrame()
+                if not alive[i]:
+                    continue
+                assert rcs[i] != -6, (mode, p.seed, f)
+                if rcs[i] == -5:
+                    assert o.last_error == -1, (mode, p.seed, f, o.last_error)
+                    alive[i] = False; total_rej += 1
+                    continue
+                assert (rcs[i] == 0) == (o.last_error == 0), (mode, p.seed, f, rcs[i], o.last_error)
+                if rcs[i] != 0:
+                    alive[i] = False; total_rej += 1
+                    continue
+                assert offs_out[i] == o.Offset and b.quantizer(i) == o.Quantizer, (mode, p.seed, f)
+                y, uv = b.planes(i)
+                assert np.array_equal(y, ro[0]) and np.array_equal(uv, ro[1]), (mode, p.seed, f)
+                total_same += 1
+        handed += b.host_clips()
+        b.close()
+        for o in oras:
+            o.close()
+    assert total_same > 250 and total_rej > 20, (total_same, total_rej)
+    if mode == 0:
+        assert handed == len(streams)
+    else:
+        assert 10 < handed < len(streams), handed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_gpu_asynchronous_steps_repair_what_the_device_cannot_finish(lockstep):
+    """mobi_batch_submit / mobi_batch_wait with two steps in flight over bit-flipped streams: a frame the device parser cannot finish is found
+    in wait, parsed by the host parser and reconstructed on its own -- and so is the frame of the step already in flight behind it"""
+    from mobiclipdecoder_amd import MobiclipBatch
+    streams = [s for s in _fuzz_streams(64, 1234) if s[0].version == 2]
+    p0 = streams[0][0]
+    b = MobiclipBatch(len(streams), p0.width, p0.height, 2, device=0, device_parse=3 if lockstep else 1)
+    oras = [OracleDecoder(p0.width, p0.height, 2) for _ in streams]
+    alive = [True] * len(streams)
+    same = 0
+
+    def check(f, rcs, offs_out, ring_idx):
+        nonlocal same
+        for i, (p, data, fo) in enumerate(streams):
+            o = oras[i]
+            o.Data = data[: fo[f + 1]]; o.Offset = int(fo[f])
+            ro = o.DecodeFrame()
+            if not alive[i]:
+                continue
+            assert rcs[i] != -6
+            if rcs[i] == -5:
+                assert o.last_error == -1
+                alive[i] = False
+                continue
+            assert (rcs[i] == 0) == (o.last_error == 0), (p.seed, f, rcs[i], o.last_error)
+            if rcs[i] != 0:
+                alive[i] = False
+                continue
+            assert offs_out[i] == o.Offset, (p.seed, f)
+            y, uv = b.planes(i, ring_idx)
+            assert np.array_equal(y, ro[0]) and np.array_equal(uv, ro[1]), (p.seed, f)
+            same += 1
+
+    nf = p0.n_frames
+    b.submit([s[1][: s[2][1]] for s in streams], [int(s[2][0]) for s in streams])
+    for f in range(1, nf):
+        b.submit([s[1][: s[2][f + 1]] for s in streams], [int(s[2][f]) for s in streams])
+        rcs, offs_out = b.wait()
+        check(f - 1, rcs, offs_out, 1)
+    rcs, offs_out = b.wait()
+    check(nf - 1, rcs, offs_out, 0)
+    assert same > 100 and 3 < b.host_clips() < len(streams), (same, b.host_clips())
+    b.close()
+    for o in oras:
+        o.close()

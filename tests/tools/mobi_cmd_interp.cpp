@@ -220,20 +220,22 @@ void exec_intra(Interp &I, int mb, const MbDesc &d) {
   }
   int coef[6 * 64];
   dequant_into((d.w1 >> 20) & 63, rec + MOBI_INTRA_RECORDS, ncoef, t8, coef);
-  if (d.w3 & 1) run_block(I, ty, 0, 0, 16, 2, (int16_t)(d.w3 >> 16), false, nullptr, false, 0, off, false);
+  const int32_t *wide = (const int32_t *)rec + MOBI_INTRA_RECORDS + ncoef; // parameters that do not fit a record's 16 bits (mobi_cmd.h)
+  auto param_of = [&](uint32_t r, int idx) { return (r & MOBI_REC_WIDE) ? wide[idx] : (int)(int16_t)(r >> 16); };
+  if (d.w3 & 1) run_block(I, ty, 0, 0, 16, 2, (d.w3 & MOBI_W3_WIDE) ? wide[24] : (int16_t)(d.w3 >> 16), false, nullptr, false, 0, off, false);
   for (int a = 0; a < 6; a++) {
     uint8_t *tile = a < 4 ? ty : tc[a - 4];
     int ay = a < 4 ? (a >> 1) * 8 : 0, ax = a < 4 ? (a & 1) * 8 : 0;
     long aoff = a < 4 ? off + (long)ay * S + ax : off / 2 + (a - 4) * (S / 2);
     uint32_t r0 = rec[a * 4];
-    if ((r0 >> 6) & 1) run_block(I, tile, ay, ax, 8, 2, (int16_t)(r0 >> 16), false, nullptr, false, 0, aoff, a >= 4);
+    if ((r0 >> 6) & 1) run_block(I, tile, ay, ax, 8, 2, param_of(r0, a * 4), false, nullptr, false, 0, aoff, a >= 4);
     if (!((r0 >> 5) & 1)) {
-      run_block(I, tile, ay, ax, 8, r0 & 15, ((r0 >> 6) & 1) ? 0 : (int16_t)(r0 >> 16), (r0 >> 4) & 1, coef + 64 * a, true, 0, aoff, a >= 4);
+      run_block(I, tile, ay, ax, 8, r0 & 15, ((r0 >> 6) & 1) ? 0 : param_of(r0, a * 4), (r0 >> 4) & 1, coef + 64 * a, true, 0, aoff, a >= 4);
     } else {
       for (int s = 0; s < 4; s++) {
         uint32_t r = rec[a * 4 + s];
         int sy = (s >> 1) * 4, sx = (s & 1) * 4;
-        int param = (s == 0 && ((r >> 6) & 1)) ? 0 : (int16_t)(r >> 16);
+        int param = (s == 0 && ((r >> 6) & 1)) ? 0 : param_of(r, a * 4 + s);
         run_block(I, tile, ay + sy, ax + sx, 4, r & 15, param, (r >> 4) & 1, coef + 64 * a, false, s, aoff + (long)sy * S + sx, a >= 4);
       }
     }
@@ -246,6 +248,11 @@ void exec_intra(Interp &I, int mb, const MbDesc &d) {
 } // namespace
 
 #include "../../mobiclipdecoder_amd/csrc/mobi_tile.h"
+#include "../../mobiclipdecoder_amd/csrc/mobi_dparse_tables.h"
+static uint8_t g_blob[MOBI_DT_BYTES];
+static const uint8_t *blob() { static bool once = (mobi_dparse_build_tables(MOBI_VERSION_MOFLEX3DS, g_blob), true); (void)once; return g_blob; }
+static int mobi_test_zz8(int i) { return blob()[MOBI_DT_ZZ8 + i]; }
+static int mobi_test_zz4(int i) { return blob()[MOBI_DT_ZZ4 + i]; }
 extern "C" {
 // the private plane layout's address map (mobi_tile.h), for tests/test_tile_layout.py
 uint32_t mobi_test_ty(uint32_t a, int lgS) { return mobi_ty(a, lgS); }
@@ -292,5 +299,41 @@ const uint32_t *mobi_cmdinterp_intra_mbs(void *p) { return ((Interp *)p)->pf.int
 const uint32_t *mobi_cmdinterp_level_start(void *p) { return ((Interp *)p)->pf.level_start.data(); }
 const uint32_t *mobi_cmdinterp_intra_items(void *p) { return ((Interp *)p)->pf.intra_items.data(); }
 uint32_t mobi_cmdinterp_payload_words(void *p) { return (uint32_t)((Interp *)p)->pf.payload.size(); }
+// r05, tests/test_parse_fallback.py: the decoder state that survives a frame (mobi_state.h).  Internal[idx] as the parser holds it; its
+// export / import in the form the device parsers keep; and what mobi_parse_tail would rebuild from the last frame's command list.
+uint32_t mobi_cmdinterp_internal(void *p, uint32_t idx) { return ((Interp *)p)->parser.internal_word(idx); }
+void mobi_cmdinterp_export_state(void *p, MobiDevState *st, MobiDevTail *tail) { ((Interp *)p)->parser.export_state(*st, *tail); }
+void mobi_cmdinterp_import_state(void *p, const MobiDevState *st, const MobiDevTail *tail, int ring_frames) {
+  Interp &I = *(Interp *)p;
+  I.parser.import_state(*st, *tail);
+  (void)ring_frames;
+}
+// copy the ring (planes) of another interpreter: the host parser takes a clip over with the pictures the device decoded so far
+void mobi_cmdinterp_copy_ring(void *dst, void *src) {
+  Interp &D = *(Interp *)dst, &S = *(Interp *)src;
+  for (int i = 0; i < 6; i++) { D.slot[i] = S.slot[i]; D.ring[i] = S.ring[i]; }
+}
+void mobi_cmdinterp_tail(void *p, const MobiDevTail *in, MobiDevTail *out) {
+  Interp &I = *(Interp *)p;
+  uint8_t izz8[64], izz4[16];
+  for (int i = 0; i < 64; i++) izz8[mobi_test_zz8(i)] = (uint8_t)i;
+  for (int i = 0; i < 16; i++) izz4[mobi_test_zz4(i)] = (uint8_t)i;
+  MobiTailScan sc;
+  mobi_tail_scan_init(sc);
+  const ParsedFrame &f = I.pf;
+  for (int mb = (int)f.desc.size() - 1; mb >= 0 && !sc.done; mb--) {
+    const MbDesc &d = f.desc[mb];
+    const int n = (int)(d.w2 & 0x3FF);
+    if (!n) continue;
+    const bool intra = (d.w1 & 1) == MOBI_MB_INTRA;
+    const uint32_t nl = (d.w1 >> 1) & 0x7F, dual = (d.w1 >> 26) & 3;
+    const uint32_t woff = d.payload_off + (intra ? MOBI_INTRA_RECORDS : (nl > 1 && !dual) ? MOBI_MV_CELLS : 0);
+    mobi_tail_scan_mb(sc, f.payload.data() + woff, n, woff, (d.w1 >> 14) & 0x3F, izz8, izz4);
+  }
+  int32_t scale[MOBI_SCALE_STRIDE];
+  mobi_build_scale_table((int)(f.desc.empty() ? 0 : (f.desc[0].w1 >> 20) & 63), scale);
+  *out = *in;
+  mobi_tail_finish(sc, f.payload.data(), scale, *in, *out);
+}
 const uint32_t *mobi_cmdinterp_payload(void *p) { return ((Interp *)p)->pf.payload.data(); }
 }

@@ -36,7 +36,7 @@ struct Clip {
   HostStore m;
   LsLane s;
   uint32_t quant = 0, yuvfmt = 0, tables_set = 0;
-  int frames_started = 0;
+  int frames_started = 0, predx = 0, predy = 0;
   std::vector<MbDesc> desc;
   std::vector<uint32_t> pay, items;
   long rounds = 0, rounds_by_state[16] = {0};
@@ -76,6 +76,7 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
   LsLane s;
   memset(&s, 0, sizeof(s));
   s.quant = C.quant; s.yuvfmt = C.yuvfmt; s.tables_set = C.tables_set; s.frames_started = C.frames_started + 1;
+  s.predx = C.predx; s.predy = C.predy;
   s.desc = C.desc.data(); s.pay = C.pay.data(); s.pay_base = 0; s.clip = 0; s.items = C.items.data();
   ls_begin_frame(s, m, c, (uint32_t)len);
   while (s.st != LS_DONE) {
@@ -94,6 +95,7 @@ int mobi_lshost_parse(void *p, const uint8_t *data, size_t len, int32_t *consume
     if (!ls_intra_deps(g, C.desc.data(), (int)(C.items[i] & 0x1FFF))) return 17;
   C.m = m;
   C.quant = s.quant; C.yuvfmt = s.yuvfmt; C.tables_set = s.tables_set; C.frames_started = s.frames_started;
+  C.predx = s.predx; C.predy = s.predy;
   *n_intra = s.n_items;
   *pay_words = s.pay_pos;
   *frame_type = (uint32_t)s.iframe;
