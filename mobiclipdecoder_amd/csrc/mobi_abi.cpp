@@ -357,11 +357,14 @@ struct mobi_batch {
   }
   // one frame step = the inter launch, then ONE intra launch for all dependency levels (items sorted by level, waves wait for
   // the tags of the macroblocks they depend on).  r01 also had a launch per level and a whole-step launch; both were slower.
-  int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev, int n_clips = -1) {
+  bool last_fused = false; // the last launch_plan went out as one launch (mobi_recon_step)
+  int launch_plan(const MobiReconArgs &a, const LevelPlan &plan, const uint32_t *items_dev, int n_clips = -1, bool allow_fused = true) {
     if (n_clips < 0) n_clips = n;
+    last_fused = false;
     // Small steps (BASELINE config 4: 8 clips per GPU): one launch carries both kinds of macroblock -- the kernel boundary between the two
     // launches is a fifth of such a step.  Large ones keep two: the fused kernel has the octet's registers and LDS for the intra fours too.
-    if (plan.any_inter && plan.n_items && (size_t)n_clips * g.mbw * g.mbh <= fused_mbs) {
+    if (allow_fused && plan.any_inter && plan.n_items && (size_t)n_clips * g.mbw * g.mbh <= fused_mbs) {
+      last_fused = true;
       EvPair ep{nullptr, nullptr, 0};
       if (ktiming) { ep.a = get_event(); ep.b = get_event(); (void)hipEventRecord(ep.a, stream); }
       if (mobi_launch_step(&a, items_dev, (int)plan.n_items, stream) != 0) return MOBI_E_DEVICE;
@@ -824,8 +827,13 @@ static int dp_seed_parser(mobi_batch *b, int c, int in) {
 // Once the parsers have consumed a frame and the ring has turned, a call that fails before its reconstruction is complete must not leave
 // any clip reporting MOBI_OK for a frame that was never reconstructed (host-parsed and device-parsed steps alike: ADVICE r03)
 struct FailAll {
-  int *rc; int n; bool armed = true;
-  ~FailAll() { if (armed) for (int i = 0; i < n; i++) if (rc[i] == MOBI_OK) rc[i] = MOBI_E_DEVICE; }
+  int *rc; int n; hipStream_t stream = nullptr; bool armed = true;
+  ~FailAll() {
+    if (!armed) return;
+    for (int i = 0; i < n; i++) if (rc[i] == MOBI_OK) rc[i] = MOBI_E_DEVICE;
+    //  copies out of the pinned staging buffers may still be in flight on the error paths: the next call refills those buffers
+    if (stream) (void)hipStreamSynchronize(stream);
+  }
 };
 
 static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
@@ -904,7 +912,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
   b->argb_all_valid = false;
   b->frames_started++;
-  FailAll fail_all{rc, n}; // rc[], Offset, the ring and the decoder state have advanced: the launches below must complete
+  FailAll fail_all{rc, n, b->stream}; // rc[], Offset, the ring and the decoder state have advanced: the launches below must complete
   MobiReconArgs a = b->args(b->d_pdesc.p, b->d_ppay.p);
   a.pay_clip_words = b->pay_clip_words;
   a.done = b->d_done;
@@ -1248,7 +1256,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   b->frames_started++;
   // From here on the parsers have consumed the frame and the ring has turned (the two must stay in step: a parser's reference
   // bookkeeping counts frames).  If the call itself fails below, no clip may report MOBI_OK for a frame that was never reconstructed.
-  FailAll fail_all{rc, n};
+  FailAll fail_all{rc, n, b->stream};
   if (up_err) return MOBI_E_DEVICE;
   if (base[n] + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG; // MbDesc.payload_off is a 32-bit word offset into the step's arena
   LevelPlan plan;
@@ -1282,6 +1290,16 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
   const auto tp4 = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->last_fused) { // a one-launch step whose intra fours gave up waiting (fault bit 2: a dispatch order this library has never seen, see
+    bool gave_up = false; // mobi_recon_step): the same step again as two launches, which need no order -- the step only writes ring slot 0
+    for (int i = 0; i < n; i++) gave_up = gave_up || (b->h_fault[i] & 2);
+    if (gave_up) {
+      if (int e = b->launch_plan(a, plan, (const uint32_t *)b->d_items.p, -1, false)) return e;
+      HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
+      HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+      HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+  }
   {
     const auto tp5 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<float, std::milli>(y - x).count(); };

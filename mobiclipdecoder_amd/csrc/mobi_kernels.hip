@@ -1024,7 +1024,9 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
 // lanes of an area do not meet in one bank when they add the residual: 55 % of the LDS cycles are bank conflicts): 2.754 against 2.758 --
 // LDS time is not on the critical path of a kernel that waits for memory requests.
 MOBI_OCT_KERNEL(mobi_recon_inter8, 4, 0, 16)
-MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16)
+#if defined(MOBI_PROFILING)
+MOBI_OCT_KERNEL(mobi_recon_inter8_prof, 4, 1, 16) // (in-kernel cycle records, MOBI_DEBUG=9: the profiling twin of the library only)
+#endif
 
 // =====================================================================================================
 // intra macroblocks, FOUR per wavefront (sixteen lanes each)
@@ -1606,7 +1608,12 @@ extern "C" __global__ __launch_bounds__(64) void mobi_recon_intra(MobiReconArgs 
 }
 
 // Small batches: the whole frame step in ONE launch.  Workgroups [0, n_inter) are octets of inter macroblocks, the rest fours of intra
-// items as above.  Two launches cost a kernel boundary (the second waits until the first has drained, then starts cold) -- at 8 clips per
+// items as above.
+// ASSUMPTION: workgroups start in blockIdx order per XCD, so every octet workgroup holds a wave slot before an intra four that
+// waits for it can fill the chip.  HIP does not promise that order; the hardware dispatcher has always kept it.  Should a driver change it,
+// the waits do not hang: a four gives up after 2^21 polls and sets fault bit 2 -- and mobi_batch_decode then runs the SAME step again as
+// two launches (mobi_abi.cpp, launch_plan's retry), which need no order at all.  The padding tiles behind a picture's last macroblock are
+// not rewritten here (the two-launch octet kernel stores zeros there): they hold the zeros mobi_batch_create cleared the arena with.  Two launches cost a kernel boundary (the second waits until the first has drained, then starts cold) -- at 8 clips per
 // GPU (BASELINE config 4) that boundary is a fifth of the step; here an intra macroblock starts as soon as the inter macroblocks its halo
 // reads carry the step's tag.  Inter workgroups never wait and are dispatched first, so the waits cannot deadlock.
 extern "C" __global__ __launch_bounds__(64, 4) void mobi_recon_step(MobiReconArgs A, const uint4 *items, uint32_t n_inter) {
@@ -1716,8 +1723,11 @@ extern "C" int mobi_launch_inter(const MobiReconArgs *a, hipStream_t s) {
   b.magic_qpc = magic(b.qpc);
   const unsigned g8 = (unsigned)(((long)b.qpc * b.n_clips + 7) / 8 * 8); // whole number of workgroups per XCD
   b.inter_per_xcd = g8 / 8;
+#if defined(MOBI_PROFILING)
   if (b.prof) hipLaunchKernelGGL(mobi_recon_inter8_prof, dim3(g8), dim3(64), lds_pad, s, b);
-  else hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), lds_pad, s, b);
+  else
+#endif
+  hipLaunchKernelGGL(mobi_recon_inter8, dim3(g8), dim3(64), lds_pad, s, b);
   return (int)hipGetLastError();
 }
 extern "C" int mobi_launch_intra(const MobiReconArgs *a, const uint32_t *items_dev, int n_items, hipStream_t s) {
