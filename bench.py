@@ -268,24 +268,28 @@ def launch_ranks(n, argv):
 
 
 def verify_clips(b, streams, distinct, clips, frame, W, H):
-    """After the timed region: the planes of three clips (first, middle, last) as they sit in HBM against the oracle's frame at that
-    stream position -- the bench line says whether the pixels it counted were the right ones.  (The checker, used as the checker.)"""
+    """After the timed region: EVERY clip's newest frame as it sits in HBM.  Clip c decodes the stream of clip c mod `distinct`: the
+    `distinct` source clips are read back and compared with the oracle's frame at that stream position, every other clip is compared with
+    its source clip on the device, byte for byte (mobi_batch_compare_clips) -- the bench line says whether the pixels it counted were the
+    right ones, all of them.  (The checker, used as the checker.)"""
     from tests.oracle_binding import OracleDecoder
-    picked = sorted({0, clips // 2, clips - 1})
-    ok, ref = True, {}
-    for c in picked:
-        sidx = c % distinct
-        if sidx not in ref:
-            p, data, fo = streams[sidx]
-            o = OracleDecoder(W, H, p.version)
-            for f in range(frame + 1):
-                o.Data, o.Offset = data[fo[f]:fo[f + 1]], 0
-                assert o.DecodeFrame() is not None
-            ref[sidx] = (o.y(0), o.uv(0))
-            o.close()
-        got = b.planes(c)
-        ok = ok and got is not None and np.array_equal(got[0][:, :W], ref[sidx][0][:, :W]) and np.array_equal(got[1], ref[sidx][1])
-    return {"clips": len(picked), "which": picked, "frame": int(frame), "ok": bool(ok), "against": "CPU oracle, Y and UV planes of ring slot 0"}
+    n_src = min(distinct, clips)
+    bad_sources = []
+    for sidx in range(n_src):
+        p, data, fo = streams[sidx]
+        o = OracleDecoder(W, H, p.version)
+        for f in range(frame + 1):
+            o.Data, o.Offset = data[fo[f]:fo[f + 1]], 0
+            assert o.DecodeFrame() is not None
+        got = b.planes(sidx)
+        if got is None or not np.array_equal(got[0][:, :W], o.y(0)[:, :W]) or not np.array_equal(got[1], o.uv(0)):
+            bad_sources.append(sidx)
+        o.close()
+    differing_copies = b.compare_clips(n_src)
+    return {"clips": int(clips), "frame": int(frame), "ok": not bad_sources and differing_copies == 0,
+            "sources_against_oracle": n_src, "sources_that_differ": bad_sources,
+            "copies_against_their_source_on_device": int(clips - n_src), "copies_that_differ": int(differing_copies),
+            "against": "CPU oracle (Y and UV planes of ring slot 0 of the distinct source clips); every other clip byte for byte against its source clip"}
 
 
 def content_leg(m, sharding, config, rank, local, clips, distinct, overrides, chains=2):
@@ -357,10 +361,12 @@ def dry_run(args, rank, world):
         dist.init_process_group("gloo")
         dist.barrier()
     elapsed = sharding.max_over_ranks(dist if group else None, 1.0 + rank)
-    gathered = [{"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes}]
+    gathered = [{"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes,
+                 "clips_per_gpu": int(args.clips), "verified_ok": None}]
     if group:
         gathered = [None] * world
-        dist.all_gather_object(gathered, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes})
+        dist.all_gather_object(gathered, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes,
+                 "clips_per_gpu": int(args.clips), "verified_ok": None})
         dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "decoded Mpixels/s @ 640x480 P-frames", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
@@ -493,12 +499,14 @@ def main():
 
     kt = 0 if (args.no_kernel_events or one_launch) else 2
     b.set_kernel_timing(kt)
-    elapsed, stream_ms, timed_frames = 0.0, 0.0, []
+    elapsed, stream_ms, timed_frames, iframe_ms = 0.0, 0.0, [], []
     acc = {"inter_ms": 0.0, "intra_ms": 0.0, "inter_launches": 0, "intra_launches": 0}
     while s < total:
-        if s % N_PFRAMES == 0:  # chain wrap: re-seed the ring, untimed
+        if s % N_PFRAMES == 0:  # chain wrap: re-seed the ring, outside the timed region (its own time is reported as iframe_step_ms)
             b.set_kernel_timing(0)
+            b.time_begin()
             b.replay(0)
+            iframe_ms.append(b.time_end())
             assert b.sync() == 0
             b.set_kernel_timing(kt)
         seg = min(total - s, N_PFRAMES - s % N_PFRAMES)
@@ -525,11 +533,17 @@ def main():
     my_elapsed = elapsed
     elapsed = sharding.max_over_ranks(dist, elapsed)
     per_rank = [my_elapsed]
+    steps = args.steps
+    # every rank checks its own clips (all of them: verify_clips) and says how many it ran: a rank that silently ran half the batch, or the
+    # wrong pictures, shows in the one line
+    verified = verify_clips(b, streams, distinct, args.clips, timed_frames[-1], W, H) if timed_frames else None
+    rank_report = [{"rank": rank, "device": local, "clips_per_gpu": int(args.clips), "verified_ok": bool(verified and verified["ok"]), "ms_per_step": round(my_elapsed * 1e3 / steps, 4)}]
     if dist is not None:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, my_elapsed)
-    steps = args.steps
-    verified = verify_clips(b, streams, distinct, args.clips, timed_frames[-1], W, H) if rank == 0 and timed_frames else None
+        rank_report = [None] * world
+        dist.all_gather_object(rank_report, {"rank": rank, "device": local, "clips_per_gpu": int(args.clips), "verified_ok": bool(verified and verified["ok"]),
+                                             "ms_per_step": round(my_elapsed * 1e3 / steps, 4)})
     cmd_bytes = sum(b.cmd_bytes(f) for f in timed_frames) / steps          # per step, all clips of this GPU
     stats = [b.intra_stats(f) for f in timed_frames]
     n_intra = sum(x[0] for x in stats) / steps
@@ -595,7 +609,17 @@ def main():
                     "whole_step_bytes": int(step_bytes), "whole_step_ms": round(step_ms, 5),
                     "intra_macroblocks_per_step": round(n_intra, 1),
                     "intra_kernel_ms_per_step": round(km["intra_ms"] / steps, 5) if km["intra_launches"] else None,
-                    "intra_launches_per_step": round(km["intra_launches"] / steps, 2) if km["intra_launches"] else None}
+                    "intra_launches_per_step": round(km["intra_launches"] / steps, 2) if km["intra_launches"] else None,
+                    # SURVEY's formula charges every macroblock a reference read (384 B); an intra macroblock has none:
+                    "whole_step_frac_intra_without_reference_read": round((step_bytes - 384.0 * n_intra) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if km["intra_launches"]:  # mobi_recon_intra against its own bytes: SURVEY's (768 B per macroblock + commands), and what it can need (384 B written)
+                ims = km["intra_ms"] / km["intra_launches"]
+                roof["intra"] = {"kernel": "mobi_recon_intra", "avg_launch_ms": round(ims, 5),
+                                 "algorithmic_bytes_per_launch": int(n_intra * 768.0 + intra_cmd), "frac": round((n_intra * 768.0 + intra_cmd) / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "frac_without_reference_read": round((n_intra * 384.0 + intra_cmd) / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}
+            if iframe_ms:  # an all-intra step (the I-frame that re-seeds the ring at every chain wrap), timed on its own
+                ifr = float(np.median(iframe_ms))
+                roof["iframe_step"] = {"ms": round(ifr, 4), "frac_of_bytes_written": round(args.clips * 1.5 * W * H / (ifr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": len(iframe_ms)}
             prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(prof):  # HBM bytes per launch from a separate rocprofv3 --pmc run (see profiles/README.md)
                 try:
@@ -604,6 +628,8 @@ def main():
                     if t and t.get("kernels_sha16") == kernels_sha16() and not gen_over:
                         roof["traffic"] = t["hbm_bytes_per_launch"]
                         roof["traffic_source"] = t.get("source")
+                        if "intra" in roof and t.get("intra_hbm_bytes_per_launch"):
+                            roof["intra"]["traffic"] = t["intra_hbm_bytes_per_launch"]
                     elif t:
                         roof["traffic_source"] = "stale: profiles/pmc_traffic.json was taken with other kernel sources (" + str(t.get("kernels_sha16")) + ")"
                 except Exception:
@@ -627,7 +653,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "verified": verified, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
+            "verified": verified, "ranks": rank_report, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

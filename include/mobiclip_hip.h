@@ -166,6 +166,11 @@ int mobi_batch_motion_search(mobi_batch *b, const uint8_t *const *src_y, uint32_
  * out as the reference returns it (the second pass stores transposed).  Integer arithmetic, truncating divisions: bit-exact.
  * The quantiser behind it (float division + Math.Round, MacroBlock.cs:591-595) is not part of this library. */
 int mobi_forward_dct(int device, int n, const int32_t *in, int32_t *out, size_t n_blocks);
+/* For batches made of copies (clip c was given the same stream as clip c mod modulus: a benchmark, a soak run): compares the newest frame
+ * (ring slot 0) of EVERY clip with that of its source clip on the device, byte for byte, and returns how many clips differ (0 = none; < 0 =
+ * MOBI_E_*).  n_diff_out, if not NULL, receives the number of differing 16-byte words per clip (n_clips entries).  Checking the `modulus`
+ * source clips against the reference decoder then vouches for all of them (the reference has no counterpart: one decoder, one stream). */
+int mobi_batch_compare_clips(mobi_batch *b, int modulus, uint32_t *n_diff_out);
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip);
 uint32_t mobi_batch_yuv_format(const mobi_batch *b, int clip);
 int mobi_batch_stride(const mobi_batch *b);

@@ -1401,6 +1401,25 @@ int mobi_forward_dct(int device, int n, const int32_t *in, int32_t *out, size_t 
   return rc;
 }
 
+// Batches made of copies (clip c decodes the same stream as clip c mod modulus: bench.py, soak runs): how many clips' newest frame differs
+// from their source clip's, compared on the device byte for byte; n_diff_out[c] (optional, n_clips entries) = differing 16-byte words of clip c.
+int mobi_batch_compare_clips(mobi_batch *b, int modulus, uint32_t *n_diff_out) {
+  if (!b || modulus < 1 || modulus > b->n) return MOBI_E_ARG;
+  if (b->frames_started < 1) return MOBI_E_NULLREF;
+  HIP_TRY(hipSetDevice(b->device));
+  if (int e = b->d_search.reserve((size_t)b->n * 4)) return e;
+  HIP_TRY(hipMemsetAsync(b->d_search.p, 0, (size_t)b->n * 4, b->stream));
+  MobiReconArgs a = b->args(nullptr, nullptr);
+  if (mobi_launch_compare_clips(&a, modulus, (uint32_t *)b->d_search.p, b->stream) != 0) return MOBI_E_DEVICE;
+  std::vector<uint32_t> h(b->n);
+  HIP_TRY(hipMemcpyAsync(h.data(), b->d_search.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  int bad = 0;
+  for (int i = 0; i < b->n; i++) bad += h[i] != 0;
+  if (n_diff_out) memcpy(n_diff_out, h.data(), (size_t)b->n * 4);
+  return bad;
+}
+
 uint32_t mobi_batch_quantizer(const mobi_batch *b, int clip) {
   if (!b || clip < 0 || clip >= b->n) return 0;
   if (b->parse_mode) return b->dev_quant.empty() ? 0 : b->dev_quant[clip];

@@ -168,3 +168,30 @@ extern "C" int mobi_launch_fwd_dct(int n, const int32_t *in_dev, int32_t *out_de
   else return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
 }
+
+// ---- "a checksum of checksums" for batches made of copies (bench.py, soak runs): ring slot 0 of every clip against the same slot of clip
+// (clip mod modulus), byte for byte in the private tiled layout (padding included: it is zero everywhere).  One workgroup = 16 KB of one clip;
+// out[clip] += 16-byte words that differ. ----
+extern "C" __global__ __launch_bounds__(256) void mobi_compare_clips(const uint8_t *planes, uint64_t clip_bytes, uint32_t slot_bytes, int slot, uint32_t modulus,
+                                                                       uint32_t chunks, uint32_t *out) {
+  const uint32_t clip = blockIdx.x / chunks, chunk = blockIdx.x - clip * chunks, ref = clip % modulus;
+  if (ref == clip) return;
+  const uint8_t *a = planes + (size_t)clip * clip_bytes + (size_t)slot * slot_bytes, *r = planes + (size_t)ref * clip_bytes + (size_t)slot * slot_bytes;
+  uint32_t bad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t o = chunk * 16384u + (uint32_t)(k * 256 + threadIdx.x) * 16u;
+    if (o < slot_bytes) {
+      const uint4 x = *(const uint4 *)(a + o), y = *(const uint4 *)(r + o);
+      bad += (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+  }
+  if (bad) atomicAdd(out + clip, bad);
+}
+extern "C" int mobi_launch_compare_clips(const MobiReconArgs *a, int modulus, uint32_t *out_dev, hipStream_t s) {
+  if (a->n_clips <= 0 || modulus <= 0) return (int)hipErrorInvalidValue;
+  const uint32_t chunks = (a->slot_bytes + 16383u) / 16384u;
+  hipLaunchKernelGGL(mobi_compare_clips, dim3((unsigned)a->n_clips * chunks), dim3(256), 0, s, (const uint8_t *)a->planes, (uint64_t)a->clip_bytes, a->slot_bytes,
+                     a->ring_base, (uint32_t)modulus, chunks, out_dev);
+  return (int)hipGetLastError();
+}

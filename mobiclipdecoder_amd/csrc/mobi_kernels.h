@@ -52,6 +52,8 @@ extern "C" long long mobi_launch_div239_check(hipStream_t s); // mismatches of t
 extern "C" int mobi_launch_motion_search(const MobiReconArgs *a, const uint8_t *src_dev, uint32_t *out_dev, int n_past, hipStream_t s);
 // MobiEncoder.DCT64 / DCT16 (Encoder/MobiEncoder.cs:962, 1146) of n_blocks residual blocks of n x n int32, n = 8 or 4 (mobi_analysis.hip)
 extern "C" int mobi_launch_fwd_dct(int n, const int32_t *in_dev, int32_t *out_dev, uint32_t n_blocks, hipStream_t s);
+// ring slot 0 of every clip against clip (clip mod modulus): out_dev[clip] += differing 16-byte words (mobi_analysis.hip); out_dev zeroed by the caller
+extern "C" int mobi_launch_compare_clips(const MobiReconArgs *a, int modulus, uint32_t *out_dev, hipStream_t s);
 // slot (tiled Y + UV planes of one frame) -> lin_dev: the same frame as the reference's row-major Y[stride*height] then UV[stride*height/2]
 extern "C" int mobi_launch_untile(const uint8_t *slot, uint8_t *lin_dev, int stride, int height, hipStream_t s);
 // intra launch item, word 0: (clip << 13) | mb; words 1..3: MbDesc.w1, MbDesc.payload_off, flags (mobi_recon_intra in mobi_kernels.hip)

@@ -55,6 +55,7 @@ _SIGS = {
     "mobi_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_in_flight": (C.c_int, [C.c_void_p]),
     "mobi_batch_host_clips": (C.c_int, [C.c_void_p]),
+    "mobi_batch_compare_clips": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mobi_forward_dct": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
@@ -263,6 +264,13 @@ class MobiclipBatch:
         e = self._lib.mobi_batch_submit(self._h, ptrs, lens, offs)
         if e != 0:
             raise MobiclipError(error_string(e))
+
+    def compare_clips(self, modulus):
+        """clips whose newest frame differs from that of clip (index mod modulus), compared on the device (batches made of copies)"""
+        e = self._lib.mobi_batch_compare_clips(self._h, int(modulus), None)
+        if e < 0:
+            raise MobiclipError(error_string(e))
+        return e
 
     def host_clips(self):
         """clips the host parser parses at present: all of them in host mode, else the hybrid share plus every clip that has had a frame

@@ -31,6 +31,8 @@ def test_gpus_2_spawns_two_ranks_with_disjoint_seeds():
     seeds = [s for x in out["ranks"] for s in x["seeds"]]
     assert len(set(seeds)) == len(seeds)          # every rank generates its own streams
     assert out["elapsed_max_s"] == 2.0            # MAX over ranks (rank r reports 1 + r)
+    # every rank reports what it ran on which device, so that a rank that silently ran half the batch (or the wrong pictures) shows in the one line
+    assert [x["device"] for x in out["ranks"]] == [0, 1] and all(x["clips_per_gpu"] == 24576 and "verified_ok" in x for x in out["ranks"])
 
 
 def test_gpus_1_is_one_rank_and_the_line_is_unchanged_in_shape():
