@@ -462,8 +462,10 @@ def main():
         except m.MobiclipError as e:
             if clips <= 512:
                 raise
-            print(f"bench.py: rank {rank}: {clips} clips do not fit ({e}); retrying with {clips // 2}", file=sys.stderr, flush=True)
-            clips //= 2
+            # three quarters, then half, of the size asked for, and so on down (24576 -> 18432 -> 12288 -> 9216 ...)
+            nxt = clips * 3 // 4 if (clips & (clips - 1)) == 0 or clips % 3 else clips * 2 // 3
+            print(f"bench.py: rank {rank}: {clips} clips do not fit ({e}); retrying with {nxt}", file=sys.stderr, flush=True)
+            clips = nxt
     agreed = -int(sharding.max_over_ranks(dist, -clips))  # the smallest size any rank settled on
     if agreed != clips:
         b.close()

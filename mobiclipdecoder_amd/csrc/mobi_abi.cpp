@@ -39,6 +39,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
     hipError_t e_ = (expr);                                                       \
     if (e_ != hipSuccess) {                                                       \
       snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s: %s", #expr, hipGetErrorString(e_)); \
+      (void)hipGetLastError(); /* HIP keeps the error until somebody reads it: the next launch wrapper's hipGetLastError() must not find this one \
+                                  (r05: an allocation that failed in one batch made the first launch of the NEXT batch report "out of memory") */ \
       return MOBI_E_DEVICE;                                                       \
     }                                                                             \
   } while (0)

@@ -12,6 +12,7 @@
 
 std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES]; // (parse-pool threads count concurrently: relaxed adds)
 std::atomic<unsigned long> mobi_literal_frame_count;
+std::atomic<unsigned long> mobi_scratch_read_count; // walks that read the transforms' scratch, Internal[154..217] (r01-r04 refused them): a measuring aid
 
 namespace {
 inline uint32_t shl(uint32_t x, int n) { return x << (n & 31); } // C# masks shift counts to 5 bits
@@ -309,7 +310,7 @@ uint32_t MobiStreamParser::internal_read(uint32_t idx) {
   if (idx < 74) return dq8_[idx - 10];
   if (idx < 90) return dq4_[idx - 74];
   if (idx < 154) return ib_[idx - 90];
-  if (idx < 218) { scratch_materialise(); return scr_[idx - 154]; }
+  if (idx < 218) { mobi_scratch_read_count.fetch_add(1, std::memory_order_relaxed); scratch_materialise(); return scr_[idx - 154]; }
   if (idx == 218) return i218_;
   if (idx == 219) return (uint32_t)predx_;
   if (idx == 220) return (uint32_t)predy_;

@@ -69,6 +69,7 @@ enum { MOBI_REFUSE_MV = 0,     // (r01-r04: |MV| > MOBI_MV_LIMIT half-pels; r05:
        MOBI_REFUSE_PLANE = 3,  // (r01-r04: a plane-predictor parameter outside int16; r05: nothing counts here any more)
        MOBI_REFUSE_CLASSES = 4 };
 extern std::atomic<unsigned long> mobi_refusal_count[MOBI_REFUSE_CLASSES];
+extern std::atomic<unsigned long> mobi_scratch_read_count;
 extern std::atomic<unsigned long> mobi_literal_frame_count; // frames shipped as literal values (MobiStreamParser::literal_frame): a measuring aid too
 
 class MobiStreamParser {

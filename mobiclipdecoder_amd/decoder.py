@@ -107,6 +107,13 @@ def load_library():
     return _LIB
 
 
+def default_device():
+    """HIP ordinal used when a caller names none: MOBI_DEVICE (default 0).  Lets a whole test run exercise another GPU of the node --
+    MOBI_DEVICE=1 python -m pytest tests -m gpu -- so that no code path is only ever reached with ordinal 0 (the path shards by clip over
+    GPUs: SURVEY.md 8(e))."""
+    return int(os.environ.get("MOBI_DEVICE", "0"))
+
+
 def error_string(rc):
     return load_library().mobi_error_string(rc).decode()
 
@@ -132,9 +139,10 @@ class _PlaneRing:
 
 
 class MobiclipDecoder:
-    def __init__(self, Width, Height, Version, device=0):
+    def __init__(self, Width, Height, Version, device=None):
         self._lib = load_library()
         self.Width, self.Height, self.Version = int(Width), int(Height), MobiclipVersion(Version)
+        device = default_device() if device is None else device
         self._h = self._lib.mobi_create(self.Width, self.Height, int(self.Version), device)
         if not self._h:
             raise MobiclipError(
@@ -221,13 +229,14 @@ class MobiclipBatch:
     (decoder instances share nothing: MD.cs:15-39).  Also the pre-parsed replay path used for
     throughput measurement."""
 
-    def __init__(self, n_clips, Width, Height, Version, device=0, device_parse=None):
+    def __init__(self, n_clips, Width, Height, Version, device=None, device_parse=None):
         """device_parse: True = decode() parses the bitstreams on the GPU (one wavefront per clip, mobi_dparse.hip),
         "lockstep" = the same with the lock-step parser in front (32 clips per wavefront, mobi_lsparse.hip),
         False = on host threads, "hybrid" = most clips on the GPU and a fixed share (a fifth, at most 1024) on the host pool at the same
         time, None = library default (device parse from 20 clips per host parse thread, 640 at least; env MOBI_DEVICE_PARSE=0/1/2)."""
         self._lib = load_library()
         self.n, self.Width, self.Height, self.Version = int(n_clips), int(Width), int(Height), MobiclipVersion(Version)
+        device = default_device() if device is None else device
         self._h = self._lib.mobi_batch_create(self.n, self.Width, self.Height, int(self.Version), device)
         if not self._h:
             raise MobiclipError(f"mobi_batch_create failed: {error_string(-8)}")
@@ -407,14 +416,14 @@ class MobiclipBatch:
             pass
 
 
-def forward_dct(blocks, device=0):
+def forward_dct(blocks, device=None):
     """MobiEncoder.DCT64 / DCT16 (Encoder/MobiEncoder.cs:962, 1146) on the GPU: blocks = int32 array (n_blocks, 64) or (n_blocks, 16)
     of residuals -> coefficients of the same shape, as the reference returns them."""
     a = np.ascontiguousarray(blocks, dtype=np.int32)
     if a.ndim != 2 or a.shape[1] not in (64, 16):
         raise ValueError("blocks must be (n, 64) or (n, 16)")
     out = np.empty_like(a)
-    rc = load_library().mobi_forward_dct(device, 8 if a.shape[1] == 64 else 4, a.ctypes.data, out.ctypes.data, a.shape[0])
+    rc = load_library().mobi_forward_dct(default_device() if device is None else device, 8 if a.shape[1] == 64 else 4, a.ctypes.data, out.ctypes.data, a.shape[0])
     if rc != 0:
         raise MobiclipError(error_string(rc))
     return out

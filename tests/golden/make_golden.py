@@ -36,6 +36,73 @@ CASES = [
     ("moflex_q52", "B", dict(width=64, height=48, n_frames=4, quantizer=52)),
 ]
 
+# r05: one stream per class of input that r01-r04 refused (MOBI_E_UNSUPPORTED) and that is decoded now -- streams the reference decodes
+# only through what ReadDCTMatrix's stores do to `Internal` (MD.cs:3424-3429), or with values beyond the command list's old fields.
+# Found by tools-style searches over bit-flipped generated streams (every frame decodes in the oracle) or written by hand.
+_FUZZ = dict(n_frames=4, width=64, height=48, pm_intra=120, pm_deep=150, pm_multiref=250, qdelta_prob=250, escape_prob=80, table1_prob=400)
+
+
+def _flipped(cfg, version, trial, flips):
+    p = default_params(cfg, BASE_SEED + 20000 + trial, version=version, **_FUZZ)
+    data, fo = generate_clip(p)
+    data = data.copy()
+    for pos, bit in flips:
+        data[pos] ^= 1 << bit
+    return p.width, p.height, p.version, data, [int(x) for x in fo]
+
+
+def _low_quantiser():
+    p = default_params("A", BASE_SEED + 3005, n_frames=4, width=64, height=48, quantizer=12, pm_intra=150, cbp_prob=500)
+    data, fo = generate_clip(p)
+    data = data.copy()
+    w = int(data[0]) | (int(data[1]) << 8)  # the I-frame header's 6-bit quantiser, bits 12..7 of the first word (MD.cs:224-236)
+    w = (w & ~(0x3F << 7)) | (5 << 7)
+    data[0], data[1] = w & 0xFF, w >> 8
+    return p.width, p.height, p.version, data, [int(x) for x in fo]
+
+
+def _bits_to_words(bits):
+    bits += "0" * ((-len(bits)) % 16) + "0" * 64
+    out = bytearray()
+    for i in range(0, len(bits), 16):
+        w = int(bits[i:i + 16], 2)
+        out += bytes((w & 0xFF, w >> 8))
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def _hand_made(kind, version):
+    """32x32 pictures written bit by bit (tests/test_parse_fallback.py has the same frames): a 16x16 plane and two chroma planes with
+    parameters beyond int16; motion vectors of +8192 half-pels ("sixteen rows down" in the reference's linear addressing), once as the single
+    leaf of a macroblock and once inside a three-leaf tree"""
+    from tests.test_parse_fallback import _DC_MB, _part_code, _se_code, _ue_code
+    hdr = "1" + "0" + "0" + format(20, "06b")
+    frames = []
+    if kind == "wide_plane":
+        frames.append(hdr + _DC_MB * 3 + "0" + _ue_code(0) + "010" + _se_code(-70000) + "010" + _se_code(65536) + _se_code(-65537))
+    else:
+        skip = _part_code(version, 0, 0) + _ue_code(0)
+        far = _part_code(version, 0, 1) + _se_code(8192) + _se_code(0) + _ue_code(0)
+        deep = (_part_code(version, 0, 8) + _part_code(version, 1, 9) + _part_code(version, 5, 1) + _se_code(8192) + _se_code(0) +
+                _part_code(version, 5, 1) + _se_code(8190) + _se_code(1) + _part_code(version, 1, 1) + _se_code(8196) + _se_code(-3) + _ue_code(0))
+        frames += [hdr + _DC_MB * 4, "0" + _se_code(0) + far + skip * 3, "0" + _se_code(0) + deep + skip * 3]
+    chunks = [_bits_to_words(b) for b in frames]
+    fo = [0]
+    for c in chunks:
+        fo.append(fo[-1] + int(c.size))
+    return 32, 32, version, np.concatenate(chunks), fo
+
+
+RAW_CASES = [
+    ("r05_walk_mods_64x48", lambda: _flipped("A", 1, 64, [(74, 4), (93, 7), (403, 0)])),              # a run past its block: literal frame
+    ("r05_walk_moflex_64x48", lambda: _flipped("B", 2, 3, [(714, 0), (574, 4), (408, 6)])),
+    ("r05_scratch_mods_64x48", lambda: _flipped("A", 1, 514, [(228, 4), (241, 3), (245, 5), (90, 5)])),  # ... that reads Internal[154..217]
+    ("r05_scratch_moflex_64x48", lambda: _flipped("B", 2, 5049, [(149, 3), (349, 2), (132, 2)])),
+    ("r05_lowq_mods_64x48", _low_quantiser),                                                          # ModsDS quantiser 5
+    ("r05_wide_plane_mods_32x32", lambda: _hand_made("wide_plane", 1)),
+    ("r05_far_mv_mods_32x32", lambda: _hand_made("far_mv", 1)),
+    ("r05_far_mv_moflex_32x32", lambda: _hand_made("far_mv", 2)),
+]
+
 
 def csref():
     so = os.path.join(ROOT, "oracle", "_ref", "libmobi_csref.so")
@@ -54,13 +121,27 @@ def csref():
 def main():
     L = csref()
     manifest = {"generator": "tests/golden/make_golden.py", "csref_checked": L is not None, "cases": []}
+    from tests import oracle_binding
+    OL = oracle_binding.lib()
+    OL.mobi_oracle_coverage.argtypes = [C.c_void_p, C.c_int]
+    OL.mobi_oracle_coverage.restype = None
+    todo = []
     for i, (name, cfg, kw) in enumerate(CASES):
         kw = dict(kw)
         seed = BASE_SEED + 7000 + i + kw.pop("seed_add", 0)
         p = default_params(cfg, seed, **kw)
         data, fo = generate_clip(p)
+        todo.append((name, p.width, p.height, p.version, data, [int(x) for x in fo]))
+    todo += [(name,) + tuple(make()) for name, make in RAW_CASES]
+    for name, width, height, version, data, fo in todo:
+        class P:  # (what the loop below needs of the generator's parameter block)
+            pass
+        p = P()
+        p.width, p.height, p.version, p.n_frames = width, height, version, len(fo) - 1
+        data = np.ascontiguousarray(data, dtype=np.uint8)
         open(os.path.join(HERE, name + ".bin"), "wb").write(data.tobytes())
         o = OracleDecoder(p.width, p.height, p.version)
+        OL.mobi_oracle_coverage(None, 1)
         h = L.csref_create(p.width, p.height, p.version) if L else None
         frames = []
         for f in range(p.n_frames):
@@ -76,11 +157,21 @@ def main():
                 assert np.array_equal(np.ctypeslib.as_array(L.csref_uv(h, 0), (p.height // 2, S)), r[1])
             frames.append({"y_sha256": hashlib.sha256(r[0].tobytes()).hexdigest(), "uv_sha256": hashlib.sha256(r[1].tobytes()).hexdigest(),
                            "offset_after": o.Offset, "quantizer": o.Quantizer})
+        cov = np.zeros(363, np.uint64)  # MOBI_COV_WORDS (oracle/mobi_oracle.h): what this fixture exercises = what a green VerifyGolden run pins
+        OL.mobi_oracle_coverage(cov.ctypes.data, 1)
         manifest["cases"].append({"name": name, "width": p.width, "height": p.height, "version": p.version, "stride": o.Stride,
-                                  "frame_off": [int(x) for x in fo], "bytes": int(data.size), "frames": frames})
+                                  "frame_off": [int(x) for x in fo], "bytes": int(data.size), "frames": frames, "covers": covers(cov)})
         print(name, data.size, "bytes", p.n_frames, "frames")
     json.dump(manifest, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     write_text_manifest(manifest)
+
+
+def covers(cov):
+    """the oracle's coverage counters of one fixture (oracle/mobi_oracle.h, MOBI_COV_*) as a short description"""
+    part = sum(1 for k in range(320) if cov[k])
+    lst = lambda base, n: ",".join(str(k) for k in range(n) if cov[base + k]) or "-"
+    return (f"partition-codes={part} intra-modes={lst(320, 20)} planes(16/8/4)={lst(340, 3)} escapes(level/run/raw)={lst(343, 3)} vlc-tables={lst(346, 2)} "
+            f"refs={lst(348, 5)} phases={lst(353, 4)} idct(1p8/3p8/16p8/64p8/1p4/16p4)={lst(357, 6)}")
 
 
 def write_text_manifest(manifest):
@@ -90,6 +181,8 @@ def write_text_manifest(manifest):
         f.write("# written by tests/golden/make_golden.py from golden.json; read by tests/golden/verify/VerifyGolden.cs\n")
         for c in manifest["cases"]:
             f.write(f"case {c['name']} {c['width']} {c['height']} {c['version']} {len(c['frames'])}\n")
+            if c.get("covers"):
+                f.write(f"covers {c['covers']}\n")
             for i, fr in enumerate(c["frames"]):
                 f.write(f"frame {c['frame_off'][i]} {c['frame_off'][i + 1]} {fr['y_sha256']} {fr['uv_sha256']} {fr['offset_after']} {fr['quantizer']}\n")
 

@@ -7,9 +7,10 @@
 // the reference's own callers do (MobiConverter/Program.cs:57-71: d.Data = frame; d.Offset = o; d.DecodeFrame(); MobiConverter/
 // Program.cs:243-250 reads d.Offset afterwards) and compares the SHA-256 of d.Y[0] / d.UV[0], d.Offset and d.Quantizer with the manifest.
 //
+//   tests/golden/verify/build.sh <reference checkout>     builds and runs this program and VerifyUnits with mcs / mono or with dotnet; by hand:
 //   mcs -unsafe -r:System.Drawing.dll -out:VerifyGolden.exe VerifyGolden.cs <reference>/LibMobiclip/Codec/Mobiclip/MobiclipDecoder.cs \
 //       <reference>/LibMobiclip/Codec/Mobiclip/MobiConst.cs <reference>/LibMobiclip/Utils/IOUtil.cs
-//   mono VerifyGolden.exe <repo>/tests/golden            (or: dotnet build with the same three files linked, then dotnet run -- <dir>)
+//   mono VerifyGolden.exe <repo>/tests/golden
 //
 // DecodeFrame() also builds a System.Drawing.Bitmap (MobiclipDecoder.cs:260-323).  Where libgdiplus is missing that throws inside the
 // decoder's own try / catch (:99, :325-328), after the planes are complete: the planes, Offset and Quantizer compared here are unaffected.
@@ -36,23 +37,35 @@ public static class VerifyGolden
             return 2;
         }
         string dir = args[0];
-        int bad = 0, frames = 0;
+        int bad = 0, frames = 0, badInCase = 0;
         MobiclipDecoder d = null;
         byte[] data = null;
-        string name = null;
+        string name = null, covers = null;
         // golden_manifest.txt (written by tests/golden/make_golden.py next to golden.json):
         //   case <name> <width> <height> <version 1=ModsDS 2=Moflex3DS> <n_frames>
+        //   covers <what the fixture exercises, from the oracle's coverage counters: what a run without differences pins>
         //   frame <start offset> <end offset> <sha256 of Y[0]> <sha256 of UV[0]> <Offset after DecodeFrame> <Quantizer>
-        foreach (string line in File.ReadAllLines(Path.Combine(dir, "golden_manifest.txt")))
+        string[] lines = File.ReadAllLines(Path.Combine(dir, "golden_manifest.txt"));
+        for (int li = 0; li <= lines.Length; li++)
         {
+            string line = li < lines.Length ? lines[li] : "case";   // (a last, empty "case" closes the last fixture)
             string[] t = line.Split(new[] { ' ' }, StringSplitOptions.RemoveEmptyEntries);
             if (t.Length == 0 || t[0].StartsWith("#")) continue;
             if (t[0] == "case")
             {
+                if (name != null)
+                    Console.WriteLine("{0} {1}: {2}", badInCase == 0 ? "pins" : "DOES NOT PIN", name, covers ?? "");
+                badInCase = 0;
+                covers = null;
+                if (t.Length < 6) continue;
                 name = t[1];
                 data = File.ReadAllBytes(Path.Combine(dir, name + ".bin"));
                 d = new MobiclipDecoder(uint.Parse(t[2]), uint.Parse(t[3]),
                                         int.Parse(t[4]) == 1 ? MobiclipDecoder.MobiclipVersion.ModsDS : MobiclipDecoder.MobiclipVersion.Moflex3DS);
+            }
+            else if (t[0] == "covers")
+            {
+                covers = line.Substring(line.IndexOf(' ') + 1);
             }
             else if (t[0] == "frame")
             {
@@ -68,6 +81,7 @@ public static class VerifyGolden
                 if (!ok)
                 {
                     bad++;
+                    badInCase++;
                     Console.WriteLine("DIFFERENT {0} frame at {1}: Y {2} UV {3} Offset {4} (want {5}) Quantizer {6} (want {7})", name, start,
                                       y == t[3] ? "ok" : y, uv == t[4] ? "ok" : uv, d.Offset, t[5], d.Quantizer, t[6]);
                 }

@@ -54,8 +54,13 @@ def test_text_manifest_for_the_reference_side_check_matches_golden_json():
     it = iter(lines)
     for c in g["cases"]:
         assert next(it) == ["case", c["name"], str(c["width"]), str(c["height"]), str(c["version"]), str(len(c["frames"]))]
+        assert next(it) == ["covers"] + c["covers"].split()  # what the fixture exercises (the oracle's coverage counters): what a green run pins
         for i, fr in enumerate(c["frames"]):
             assert next(it) == ["frame", str(c["frame_off"][i]), str(c["frame_off"][i + 1]), fr["y_sha256"], fr["uv_sha256"], str(fr["offset_after"]), str(fr["quantizer"])]
     assert next(it, None) is None
     src = open(os.path.join(HERE, "verify", "VerifyGolden.cs")).read()
     assert "new MobiclipDecoder(" in src and "DecodeFrame()" in src and "golden_manifest.txt" in src
+    # one stream per class of input r01-r04 refused and r05 decodes (walks through Internal[], the transforms' scratch, quantisers below 12,
+    # plane parameters and motion vectors beyond the command list's old fields) is part of what the reference-side check pins
+    names = {c["name"] for c in g["cases"]}
+    assert {"r05_walk_mods_64x48", "r05_scratch_moflex_64x48", "r05_lowq_mods_64x48", "r05_wide_plane_mods_32x32", "r05_far_mv_moflex_32x32"} <= names

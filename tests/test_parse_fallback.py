@@ -292,7 +292,7 @@ def test_gpu_every_parse_mode_gives_the_same_answer(mode):
     for ver in (1, 2):
         group = [s for s in streams if s[0].version == ver]
         p0 = group[0][0]
-        b = MobiclipBatch(len(group), p0.width, p0.height, ver, device=0, device_parse=mode)
+        b = MobiclipBatch(len(group), p0.width, p0.height, ver, device_parse=mode)
         oras = [OracleDecoder(p0.width, p0.height, ver) for _ in group]
         alive = [True] * len(group)
         for f in range(p0.n_frames):
@@ -337,7 +337,7 @@ def test_gpu_asynchronous_steps_repair_what_the_device_cannot_finish(lockstep):
     from mobiclipdecoder_amd import MobiclipBatch
     streams = [s for s in _fuzz_streams(64, 1234) if s[0].version == 2]
     p0 = streams[0][0]
-    b = MobiclipBatch(len(streams), p0.width, p0.height, 2, device=0, device_parse=3 if lockstep else 1)
+    b = MobiclipBatch(len(streams), p0.width, p0.height, 2, device_parse=3 if lockstep else 1)
     oras = [OracleDecoder(p0.width, p0.height, 2) for _ in streams]
     alive = [True] * len(streams)
     same = 0

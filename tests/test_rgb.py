@@ -102,7 +102,7 @@ def test_division_by_239_is_correctly_rounded_for_every_float():
     """The Bitmap kernel divides by 239 with q0 = x*r, q = fma(fma(-239, q0, x), r, q0).  That is not correctly
     rounded for arbitrary divisors, so it is checked for this one over all 2^32 bit patterns on the device."""
     from mobiclipdecoder_amd import decoder
-    assert decoder.load_library().mobi_selftest_div239(0) == 0
+    assert decoder.load_library().mobi_selftest_div239(decoder.default_device()) == 0
 
 
 @pytest.mark.gpu

@@ -19,6 +19,9 @@
 
 #include "../../include/mobiclip_hip.h"
 
+/* HIP ordinal: MOBI_DEVICE (default 0), so that a node with several GPUs can run this caller on any of them */
+static int test_device(void) { const char *e = getenv("MOBI_DEVICE"); return e ? atoi(e) : 0; }
+
 /* ---- SHA-256 (FIPS 180-4), small and slow ---- */
 static const uint32_t K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
@@ -62,7 +65,7 @@ static void sha256_hex(const uint8_t *data, size_t len, char out[65]) {
 
 static int run_batch_async(const uint8_t *data, uint32_t w, uint32_t hgt, int version, int nf, char **offs) {
   enum { N = 3 };
-  mobi_batch *b = mobi_batch_create(N, w, hgt, version, 0);
+  mobi_batch *b = mobi_batch_create(N, w, hgt, version, test_device());
   if (!b) { fprintf(stderr, "mobi_batch_create failed\n"); return 3; }
   if (mobi_batch_set_parse_mode(b, 1) != MOBI_OK) return 3;             /* the bitstreams are parsed on the GPU */
   const size_t ysz = (size_t)mobi_batch_stride(b) * hgt;
@@ -112,7 +115,7 @@ int main(int argc, char **argv) {
   fclose(f);
 
   if (batch_async) { const int e = run_batch_async(data, w, hgt, version, nf, argv + 6); free(data); return e; }
-  mobi_dec *d = mobi_create(w, hgt, version, 0);                    /* new MobiclipDecoder(Width, Height, Version) */
+  mobi_dec *d = mobi_create(w, hgt, version, test_device());                    /* new MobiclipDecoder(Width, Height, Version) */
   if (!d) { fprintf(stderr, "mobi_create failed: %s\n", mobi_error_string(MOBI_E_DEVICE)); return 3; }
   const int stride = mobi_stride(d);
   const size_t ysz = (size_t)stride * hgt;

@@ -258,6 +258,7 @@ extern "C" {
 uint32_t mobi_test_ty(uint32_t a, int lgS) { return mobi_ty(a, lgS); }
 uint32_t mobi_test_tc(uint32_t a, int lgS) { return mobi_tc(a, lgS); }
 // how often the parser refused a stream (MOBI_E_UNSUPPORTED) in this process, by cause (mobi_parse.h: MOBI_REFUSE_*); tools/exp_refusals.py
+unsigned long mobi_cmdinterp_scratch_reads(void) { return mobi_scratch_read_count; } // Internal[154..217] read by a walk (r05)
 unsigned long mobi_cmdinterp_literal_frames(void) { return mobi_literal_frame_count; } // frames the host parser shipped as literal values
 void mobi_cmdinterp_refusals(unsigned long out[4]) { for (int i = 0; i < MOBI_REFUSE_CLASSES; i++) out[i] = mobi_refusal_count[i]; }
 void *mobi_cmdinterp_create(uint32_t w, uint32_t h, int version) {
