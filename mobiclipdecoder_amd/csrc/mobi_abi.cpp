@@ -826,6 +826,14 @@ static int dp_seed_parser(mobi_batch *b, int c, int in) {
   return MOBI_OK;
 }
 
+// Hybrid mode: how many clips (the last ones of the batch) the host pool parses beside the GPU.  (r05, tools/exp_hybrid.py: no share makes
+// a step of up to 4096 clips faster than parse mode 1 -- 14.1 ms against 14.6 .. 16.2 -- because every clip has a wave slot of its own there
+// and the parse launch is as long as ONE clip's parse whatever their number; the mode only pays beyond what the chip holds at once.)
+static void hybrid_share(mobi_batch *b) {
+  b->hybrid_host = std::min(1024, b->n / 5);
+  if (const char *hh = getenv("MOBI_HYBRID_HOST_CLIPS")) b->hybrid_host = std::max(0, std::min(b->n - 1, atoi(hh)));
+}
+
 // Once the parsers have consumed a frame and the ring has turned, a call that fails before its reconstruction is complete must not leave
 // any clip reporting MOBI_OK for a frame that was never reconstructed (host-parsed and device-parsed steps alike: ADVICE r03)
 struct FailAll {
@@ -978,13 +986,16 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   HIP_TRY(hipSetDevice(b->device));
   const int n = b->n, n_mbs = b->g.mbw * b->g.mbh;
   if (b->frames_started == 0 && b->async_seq == 0) { // an asynchronous batch parses on the GPU from its first frame
-    if (b->parse_auto || b->parse_mode == 1) { b->parse_mode = 1; b->parse_auto = false; b->hybrid_host = 0; }
+    if (b->parse_auto) { b->parse_mode = 1; b->parse_auto = false; }
+    if (b->parse_mode == 2) hybrid_share(b);
   }
   if (b->poisoned) return MOBI_E_DEVICE;
-  if (b->parse_mode != 1 || b->hybrid_host != 0) return MOBI_E_ARG; // the decoder state of this batch lives in the host parsers
+  if (b->parse_mode == 0) return MOBI_E_ARG; // the decoder state of this batch lives in the host parsers
   if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) return MOBI_E_VERSION;
   if (b->g.mbw > 64 || b->async_count >= 2) return MOBI_E_ARG;
   if (int e = dp_init(b)) return e;
+  if (b->hybrid_host && b->frames_started == 0)
+    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = 1;
   mobi_batch::AsyncSlot &S = b->aslot[(b->async_head + b->async_count) & 1];
   if (!S.ev_up) {
     HIP_TRY(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
@@ -1177,8 +1188,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
   }
   b->parse_auto = false; // the decoder state lives on one side from the first frame on
   if (b->parse_mode == 2 && b->frames_started == 0) { // hybrid: a fixed share of the clips stays with the host parsers (their state lives there)
-    b->hybrid_host = std::min(1024, b->n / 5);
-    if (const char *hh = getenv("MOBI_HYBRID_HOST_CLIPS")) b->hybrid_host = std::max(0, std::min(b->n - 1, atoi(hh)));
+    hybrid_share(b);
   }
   if (b->parse_mode) return decode_device_parse(b, data, len, offsets, rc);
   const int n = b->n;

@@ -260,6 +260,9 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
 // the truncation of at most a handful of shifts), so after both passes |x| <= 9/4 * (sum of |coefficient| of the area + 32) + 104.  The
 // scatter adds up |coefficient| per area (P_SUM); an octet with an area above MOBI_PK_LIMIT takes the 32-bit rounds instead (wave-uniform).
 #define MOBI_PK_LIMIT 14000 /* 9/4 * (14000 + 32) + 104 = 31676 < 32768 */
+// (r05, measured and not kept: the same bound says when the clamp table CANNOT be left -- sums below 1700 give |x >> 6| <= 64 -- and an octet
+// of such areas could run its pixel update without the sixteen packed min / max per lane that track the range; with the second copy of the
+// pixel update and the ballot that picks it the launch was no faster: profiles/r05_ubench.txt.)
 namespace {
 __device__ __forceinline__ void bfly8_pk(const s16x2 in[8], s16x2 out[8]) { // mobi_bfly8, two at a time
   const s16x2 a0 = in[0] + in[4], a1 = in[0] - in[4];
@@ -387,7 +390,11 @@ enum {
   P_OUT = 0,      // 3072 B
   P_COEF = 3072,  // coefficient tiles of P_TILE words: 8 tiles of int16 PAIRS (two areas each) per packed round, or P_ROUND tiles of int32
   P_TILE = 72,
-  P_PAIRS = 8,    // packed round: 16 coded areas (an octet has 14 on average in the generator's mix, more than 16 in one out of five)
+#ifndef MOBI_PK_PAIRS
+#define MOBI_PK_PAIRS 12
+#endif
+  P_PAIRS = MOBI_PK_PAIRS, // packed round: the level words are scattered ONCE for up to 24 coded areas (an octet has 14 on average in the generator's
+                  // mix, more than 16 in one out of five: r04 scattered twice for those); the transforms take the pair tiles eight at a time
   P_ROUND = 22,   // 32-bit rounds (the fall-back when some area's coefficients are too large for 16-bit butterflies): three half rounds of eight
   P_SUM = P_COEF + P_PAIRS * P_TILE * 4, // sum of |coefficient| per coded area (48 words), behind the packed tiles; dead before a 32-bit round
   P_SC = 9728,    // dequant scales (320 B): on top of the chroma windows, once the chroma has been interpolated
@@ -870,8 +877,8 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
     const int s4 = r >> 1, rowa4 = (s4 >> 1) * 4 + (r & 1) * 2, cola4 = (s4 & 1) * 4;
     const int Ca8 = P_OUT + r * 384, Cb8 = Ca8 + 4, x8 = r << 4;
     const int Ca4 = P_OUT + rowa4 * 384 + cola4, Cb4 = P_OUT + (rowa4 + 1) * 384 + cola4, xa4 = rowa4 << 4, xb4 = (rowa4 + 1) << 4;
-    bool wide = false; // (wave-uniform) some area's coefficients are too large for the 16-bit butterflies
-    for (int base = 0; base < n_slots; base += 2 * P_PAIRS) {
+    bool wide = false;  // (wave-uniform) some area's coefficients are too large for the 16-bit butterflies
+    for (int base = 0; base < n_slots && !wide; base += 2 * P_PAIRS) {
       zero_tiles(n_slots - base < 2 * P_PAIRS ? (n_slots - base + 1) >> 1 : P_PAIRS);
       wave_sync();
       scatter_all(std::true_type{}, base);
@@ -881,21 +888,24 @@ __device__ __forceinline__ void recon_inter_oct(const MobiReconArgs &A, uint8_t 
         if (__builtin_amdgcn_ballot_w64(sm > (uint32_t)MOBI_PK_LIMIT) != 0) { wide = true; break; }
       }
       MOBI_STOP(9);
-      const int slot0 = base + 2 * grp;           // the group's pair: slots slot0 (A), slot0 + 1 (B)
-      const bool act = slot0 < n_slots, is8g = slot0 < first4;
-      const bool actB = slot0 + 1 < n_slots && slot0 + 1 != n8;
-      uint32_t *tile = (uint32_t *)(L + P_COEF) + P_TILE * grp;
-      if (act) idct_pass1_pk(tile, is8g, r);
-      wave_sync();
-      MOBI_STOP(10);
-      if (act) {
-        const uint32_t recA = lds32(L, P_TAB + 4 * slot0), recB = actB ? lds32(L, P_TAB + 4 * slot0 + 4) : recA;
-        const int Ca = is8g ? Ca8 : Ca4, Cb = is8g ? Cb8 : Cb4, xa = is8g ? x8 : xa4, xb = is8g ? x8 : xb4;
-        const int gA = (int)(recA & 0x70u), KA = (int)(recA >> 16), gB = (int)(recB & 0x70u), KB = (int)(recB >> 16);
-        idct_pass2_pk(tile, is8g, r, L + (Ca + (gA ^ xa) + KA), L + (Cb + (gA ^ xb) + KA), L + (Ca + (gB ^ xa) + KB), L + (Cb + (gB ^ xb) + KB), actB, lo, hi);
+      for (int sub = 0; sub < P_PAIRS && base + 2 * sub < n_slots; sub += 8) { // the pair tiles eight at a time: one per group of eight lanes
+        const int slot0 = base + 2 * (sub + grp);  // the group's pair: slots slot0 (A), slot0 + 1 (B)
+        const bool act = sub + grp < P_PAIRS && slot0 < n_slots, is8g = slot0 < first4;
+        const bool actB = slot0 + 1 < n_slots && slot0 + 1 != n8;
+        uint32_t *tile = (uint32_t *)(L + P_COEF) + P_TILE * (sub + grp);
+        if (act) idct_pass1_pk(tile, is8g, r);
+        wave_sync();
+        MOBI_STOP(10);
+        if (act) {
+          const uint32_t recA = lds32(L, P_TAB + 4 * slot0), recB = actB ? lds32(L, P_TAB + 4 * slot0 + 4) : recA;
+          const int Ca = is8g ? Ca8 : Ca4, Cb = is8g ? Cb8 : Cb4, xa = is8g ? x8 : xa4, xb = is8g ? x8 : xb4;
+          const int gA = (int)(recA & 0x70u), KA = (int)(recA >> 16), gB = (int)(recB & 0x70u), KB = (int)(recB >> 16);
+          uint8_t *wa = L + (Ca + (gA ^ xa) + KA), *wb = L + (Cb + (gA ^ xb) + KA), *wc = L + (Ca + (gB ^ xa) + KB), *wd = L + (Cb + (gB ^ xb) + KB);
+          idct_pass2_pk(tile, is8g, r, wa, wb, wc, wd, actB, lo, hi);
+        }
+        wave_sync();
+        MOBI_STOP(11);
       }
-      wave_sync();
-      MOBI_STOP(11);
     }
     if (wide) { // the same in int32, eight lanes per area, P_ROUND areas per round (r03's residual stage)
       const int hole = (n8 & 1) ? n8 : -1; // (n8 odd: slot n8 is empty)
