@@ -277,7 +277,8 @@ struct mobi_batch {
   DevBuf d_fix;
   uint32_t pay_clip_words = 0;         // of the last device-parsed step (MobiReconArgs.pay_clip_words)
   int ls_finished = -1;                // clips of the last step it finished itself
-  bool lockstep = false;               // mobi_batch_set_parse_mode(b, 3) / MOBI_DEVICE_PARSE=3: mobi_parse_frames_ls in front of mobi_parse_frames
+  int ls_policy = 0;                   // 0: never (parse modes 1, 2 named by the caller); 1: always (mode 3); 2: by step (the default, ls_decide)
+  bool lockstep = false;               // this step: mobi_parse_frames_ls in front of mobi_parse_frames
   int host_chunk = 256;                // host-parsed steps: clips per chunk of the parse / stage / upload pipeline (mobi_batch_decode)
   size_t fused_mbs = kFusedStepMbs;     // launch_plan: steps of at most this many macroblocks go out as one launch
   MobiDevResult *d_pres = nullptr;
@@ -295,6 +296,7 @@ struct mobi_batch {
     hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_parsed = nullptr;
     std::vector<int32_t> offs; // Offset of every clip at submission
     int n_dev = 0;
+    bool parsed_recorded = false;    // ev_parsed has been recorded at least once
     int state_in = 0, ring_base = 0; // the entry of the state ring this step's parse read; the ring position its reconstruction wrote
     size_t hdr_bytes = 0;            // of the staged bitstream image (h_stage: offsets, lengths, bits)
     // clips whose result is the host parser's (its own clips at submission; clips repaired in mobi_batch_wait)
@@ -489,7 +491,7 @@ long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *ite
 #pragma GCC visibility pop
 #endif // MOBI_PROFILING
 
-const char *mobi_build_info(void) { return "libmobiclip_hip 0.4 (gfx950, macroblock-tiled planes; HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_step, mobi_recon_intra_cl, mobi_recon_intra_walk, mobi_parse_frames, mobi_parse_frames_ls, mobi_parse_frames_ls64, mobi_ls_deps, mobi_untile, mobi_yuv_to_argb, mobi_motion_search_2x2, mobi_fwd_dct8, mobi_fwd_dct4; no CPU reconstruction path)"; }
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.5 (gfx950, macroblock-tiled planes; HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_step, mobi_recon_intra_cl, mobi_recon_intra_walk, mobi_parse_frames, mobi_parse_frames_ls, mobi_ls_deps, mobi_parse_tail, mobi_untile, mobi_yuv_to_argb, mobi_motion_search_2x2, mobi_fwd_dct8, mobi_fwd_dct4; no CPU reconstruction path)"; }
 
 const char *mobi_error_string(int rc) {
   switch (rc) {
@@ -568,12 +570,11 @@ mobi_batch *mobi_batch_create(int n_clips, uint32_t width, uint32_t height, int 
     // take a step of 1024 / 1536 / 2048 clips in 9.1 / 13.6 / 18.2 ms, parse to planes; mobi_parse_frames in 13.2 / 10.6 / 10.4 ms)
     b->parse_mode = n_clips >= std::max(640, 20 * (b->pool->size() + 1));
     b->parse_auto = true;
-    b->lockstep = n_clips >= 16384; // ... and from there on the lock-step parser in front (32 clips per wave: 31 ms per P-frame step, whatever the
-                                    // batch up to 32768 clips; mobi_parse_frames: 2.3 ms per 1024 clips)
+    b->ls_policy = 2; // ... and which device parser is in front is decided step by step (ls_decide)
     if (const char *dp = getenv("MOBI_DEVICE_PARSE")) {
-      const int v = atoi(dp); // 3: on the GPU, the lock-step parser (32 clips per wave) in front
+      const int v = atoi(dp); // 3: on the GPU, the lock-step parser in front of every step
       b->parse_mode = v == 3 ? 1 : std::max(0, std::min(2, v));
-      b->lockstep = v == 3;
+      b->ls_policy = v == 3 ? 1 : 0;
       b->parse_auto = false;
     }
   }
@@ -643,7 +644,18 @@ static int dp_init(mobi_batch *b) {
 }
 // stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded] into pinned memory; the host parser's clips
 // (b->on_host) carry MOBI_DP_SKIP for a length and no bits
-struct DpStaged { size_t hdr_bytes = 0, bytes = 0, max_len = 0; };
+struct DpStaged { size_t hdr_bytes = 0, bytes = 0, max_len = 0; int n_dev = 0, n_iframes = 0; }; // n_dev: clips the GPU parses; n_iframes: of them, I-frames (first bit)
+// Which device parser is in front of this step (parse mode by default, r05; tools/exp_lsab.sh, tools/exp_dparse.py, 640x480, ms per step,
+// mobi_parse_frames against the lock-step parser at its best number of clips per wave):
+//   P-frames: 2048 clips 8.8 / 9.2, 4096: 11.2 / 13.7, 8192: 21.2 / 18.5, 16384: 42 / 23.5, 24576: 63 / 26.2
+//   I-frames: 1024 clips 23.4 / 11.7, 2048: 30.0 / 11.3, 4096: 30.0 / 16.5, 8192: 54.9 / 23.6
+// -- one wave per clip wins while every clip has a wave slot of its own and the frames are P-frames; an I-frame's macroblocks are all of one
+// kind, which is what lanes in lock step like.
+static bool ls_decide(const mobi_batch *b, const DpStaged &st) {
+  if (b->ls_policy != 2) return b->ls_policy == 1;
+  const bool iframe_step = 2 * st.n_iframes > st.n_dev;
+  return st.n_dev >= 6144 || (iframe_step && st.n_dev >= 768);
+}
 // dev != nullptr: the image is also sent to *dev on `up`, chunk by chunk while the next chunk is gathered (one thread of the pool sits in
 // the copy calls, which return when the bus is done: 8 ms for the 370 MB of a step of 24576 clips; the others gather) -- r04: gathering and
 // sending were 12 of the 45 ms of such a step, one after the other.
@@ -668,6 +680,8 @@ static int dp_stage(mobi_batch *b, const uint8_t *const *data, const size_t *len
     if (b->on_host[i]) { blen[i] = MOBI_DP_SKIP; continue; }
     blen[i] = (uint32_t)l;
     pos += align_up(l + kBitPad, 8);
+    st.n_dev++;
+    st.n_iframes += l >= 2 && (data[i][o + 1] & 0x80) != 0; // the frame's first bit: the top bit of its first 16-bit little-endian word (MD.cs:110-113)
   }
   pos += 64; // (a skipped clip's offset points at readable bytes too)
   const size_t hdr_bytes = align_up((size_t)nd * 12, 16);
@@ -744,7 +758,7 @@ static int dp_parse(mobi_batch *b, const uint8_t *d_bits, const DpStaged &st, bo
   pa.tail_in = b->d_ptail[in]; pa.tail_out = b->d_ptail[out];
   pa.scale = b->d_scale;
   pa.state_ls = b->d_pstate_ls;
-  pa.lockstep = b->lockstep ? (o.async ? 2 : 1) : 0; // (2: 64 clips per wave, leaving LDS for the reconstruction it runs under)
+  pa.lockstep = b->lockstep ? (o.async ? 2 : 1) : 0; // (2: clips per wave chosen so that LDS is left for the reconstruction it runs under)
   pa.pay_local = 1;
   pa.desc = (MbDesc *)(*o.desc).p;
   pa.payload = (uint32_t *)(*o.pay).p;
@@ -865,6 +879,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   const auto q0 = clk::now();
   if (int e = dp_stage(b, data, len, offsets, b->h_stage, st, &b->d_bits, false, b->stream)) return e; // gathered and on their way
   b->phase_ms[0] = ms_since(q0);
+  b->lockstep = ls_decide(b, st);
   int state_in = 0;
   if (int e = dp_parse(b, b->d_bits.p, st, false, DpOut{&b->d_pdesc, &b->d_ppay, &b->d_pitems, b->d_pres, b->stream}, &state_in)) return e;
   b->phase_ms[1] = ms_since(q0);
@@ -1013,6 +1028,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (int e = S.h_fault.reserve(sizeof(int) * n)) return e;
   S.offs.assign(offsets, offsets + n);
   S.n_dev = n;
+  b->lockstep = ls_decide(b, st);
   S.hdr_bytes = st.hdr_bytes;
   S.is_host.assign(n, 0);
   S.host_rc.assign(n, MOBI_OK);
@@ -1052,15 +1068,18 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   // waves, and a reconstruction launched beside it waits for them to leave anyway -- 20.5 instead of 13.2 ms per step of 4096 clips.)
   hipStream_t ps = b->lockstep ? b->stream_p : b->stream;
   HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
+  { // the parser in front is chosen step by step (ls_decide), and with it the stream: the state this parse reads is the one the step before wrote
+    mobi_batch::AsyncSlot &prev = b->aslot[(b->async_head + b->async_count + 1) & 1];
+    if (b->async_seq > 0 && prev.ev_parsed && prev.parsed_recorded) HIP_TRY(hipStreamWaitEvent(ps, prev.ev_parsed, 0));
+  }
   MobiDevResult *d_res = (MobiDevResult *)S.d_pres.p;
   if (int e = dp_parse(b, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps, true}, &S.state_in)) return e;
   if (!host_clips.empty())
     if (int e = dp_override(b, host_clips, S.host_rc.data(), S.h_over, DpRows{S.d_pdesc.p, S.d_ppay.p, S.d_pitems.p, d_res, b->last_pay_cap}, ps)) return e;
   HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, ps));
-  if (ps != b->stream) {
-    HIP_TRY(hipEventRecord(S.ev_parsed, ps));
-    HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
-  }
+  HIP_TRY(hipEventRecord(S.ev_parsed, ps));
+  S.parsed_recorded = true;
+  if (ps != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
   // reconstruction straight from what the parse leaves in HBM (failed clips: blank descriptors, no items)
   b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse throws
   b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
@@ -1164,7 +1183,7 @@ int mobi_batch_lockstep_finished(const mobi_batch *b) { return b && b->lockstep 
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
   if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
   b->parse_mode = device_parse == 2 ? 2 : device_parse != 0;
-  b->lockstep = device_parse == 3;
+  b->ls_policy = device_parse == 3 ? 1 : 0;
   b->parse_auto = false;
   return MOBI_OK;
 }

@@ -17,6 +17,7 @@
 // The bitstream reaches the ring through registers, 32 bytes per lane every LS_SERVICE rounds, committed one service later: the load has
 // that long to arrive, nobody waits for it.  A lane whose ring holds less than a round can ask for (LS_ROUND_BYTES) sits the round out.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "mobi_dparse.h"
 #include "mobi_kernels.h"
@@ -28,12 +29,11 @@ namespace {
 #endif
 enum { LS_SERVICE = LS_SERVICE_N, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
-template <int L> // L = clips per wave: the per-lane state is interleaved at that stride (element i of lane l at i * L + l)
-struct DevStore {
+struct DevStore { // L = clips per wave: the per-lane state is interleaved at that stride (element i of lane l at i * L + l)
   int32_t *mvc_;
   uint32_t *stk_, *rec_, *ring_;
   uint8_t *mc_;
-  int lane;
+  int lane, L;
   __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * L + lane]; }
   __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * L + lane]; }
   __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * L + lane]; }
@@ -61,28 +61,32 @@ __device__ __forceinline__ uint4 ls_chunk(const uint8_t *base, uint32_t o, uint3
 }
 } // namespace
 
-template <int LS_CLIPS>
-__device__ __forceinline__ void parse_frames_ls(const MobiDevParseArgs &A) {
+#ifndef MOBI_LS_WAVES
+#define MOBI_LS_WAVES 4 // waves per workgroup: they share one copy of the table blob in LDS (18 KB), everything else is a wave's own
+#endif
+extern "C" __global__ __launch_bounds__(64 * MOBI_LS_WAVES) void mobi_parse_frames_ls(MobiDevParseArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int LS_CLIPS = A.ls_clips; // clips per wave (mobi_launch_parse_ls picks it: the launch is fastest with about two waves per SIMD)
   // A wave of this kernel is one long chain of dependent instructions and the launch is as long as that chain.  When the reconstruction of
   // the step before runs beside it (asynchronous steps: four of its waves on the same SIMD), the chain must not queue behind them.
   __builtin_amdgcn_s_setprio(3);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mvc_words = 2 * (A.mbw + 2);
   uint8_t *tab = lds;
-  DevStore<LS_CLIPS> m;
-  m.mvc_ = (int32_t *)(lds + MOBI_DT_BYTES);
+  DevStore m;
+  m.L = LS_CLIPS;
+  m.mvc_ = (int32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvc_words + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
   m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * LS_CLIPS);
   m.rec_ = m.stk_ + 16 * LS_CLIPS;
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
   m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
   m.lane = lane;
-  for (int i = lane; i < MOBI_DT_BYTES / 16; i += 64) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
+  for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += 64 * MOBI_LS_WAVES) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
-  for (int i = lane; i < 1024; i += 64) ls_prepare_tables(tab, i);
+  for (int i = threadIdx.x; i < 1024; i += 64 * MOBI_LS_WAVES) ls_prepare_tables(tab, i);
   __syncthreads();
 
-  const int clip = blockIdx.x * LS_CLIPS + lane;
+  const int clip = (blockIdx.x * MOBI_LS_WAVES + wave) * LS_CLIPS + lane;
   const bool live = lane < LS_CLIPS && clip < A.n_clips && A.bit_len[clip < A.n_clips ? clip : 0] != MOBI_DP_SKIP; // (not the host parser's clips)
   const int n_mbs = A.mbw * A.mbh;
   LsCtx c;
@@ -169,16 +173,6 @@ __device__ __forceinline__ void parse_frames_ls(const MobiDevParseArgs &A) {
   }
   A.res[clip] = r;
 }
-// 32 clips per wave when a step is decoded on its own (mobi_batch_decode): the shortest life per wave that still leaves every wave of
-// 24576 clips a SIMD of its own (39 KB of LDS, four waves per CU).  64 per wave for asynchronous steps (mobi_batch_submit), whose parse runs
-// under the reconstruction of the step before: two waves of 61 KB leave a CU 38 KB for the reconstruction kernels' workgroups; four of 39
-// leave none, and the two would run one after the other (measured: 131 instead of 170 Gpixels/s).
-#ifndef MOBI_LS_SYNC_CLIPS
-#define MOBI_LS_SYNC_CLIPS 32 // tools/exp_lsab.sh "-DMOBI_LS_SYNC_CLIPS=64" ... tries others
-#endif
-extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls(MobiDevParseArgs A) { parse_frames_ls<MOBI_LS_SYNC_CLIPS>(A); }
-extern "C" __global__ __launch_bounds__(64) void mobi_parse_frames_ls64(MobiDevParseArgs A) { parse_frames_ls<64>(A); }
-
 // lane = one intra macroblock of a finished clip: workgroup = clip * chunks + chunk
 extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A, uint32_t chunks) {
   const uint32_t clip = blockIdx.x / chunks, chunk = blockIdx.x - clip * chunks;
@@ -195,14 +189,27 @@ extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A
 extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64 || !a->state_ls) return (int)hipErrorInvalidValue;
-  const int L = a->lockstep == 2 ? 64 : MOBI_LS_SYNC_CLIPS; // (2: an asynchronous step, see the kernels)
-  const size_t lds = MOBI_DT_BYTES + (size_t)L * (4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40);
-  const void *fn = L == 64 ? (const void *)mobi_parse_frames_ls64 : (const void *)mobi_parse_frames_ls;
+  // Clips per wave.  A wave is one long chain of dependent look-ups: it runs until its slowest lane is done, a round costs what the different
+  // states of its lanes need, and alone on a SIMD it issues an instruction every ~20 clocks.  r04 gave every wave a SIMD of its own (32 clips
+  // per wave, each with its own 18 KB copy of the tables: 31 ms per P-frame step of 24576 clips, whatever the batch).  r05: four waves share a
+  // workgroup's copy of the tables, so that a CU holds twelve and more of them, and the clips are dealt to about TWO WAVES PER SIMD -- fewer
+  // clips per wave make every wave's life shorter, and two or three such chains interleave on a SIMD for nothing (tools/exp_lsab.sh,
+  // 24576 clips: 4 / 6 / 8 / 12 / 16 / 32 clips per wave = 40.7 / 43.0 / 27.0 / 25.7 / 27.9 / 31.3 ms -- below 8 the waves no longer all
+  // fit the chip at once; 8192 clips: 2 / 4 / 8 / 32 per wave = 26.5 / 18.2 / 29.1 / 31.5 ms).
+  const int per_clip = 4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
+  int L = a->lockstep == 2 ? 16 : (a->n_clips + 2047) / 2048; // (2: an asynchronous step -- 16 per wave: two workgroups of 61 KB per CU leave LDS for
+  L = L < 4 ? 4 : L > 64 ? 64 : L;                             //  the reconstruction of the step before, under which this parse runs)
+#if defined(MOBI_PROFILING)
+  if (const char *e = getenv("MOBI_LS_CLIPS")) L = atoi(e);    // (tools/exp_lsab.sh)
+#endif
+  MobiDevParseArgs b = *a;
+  b.ls_clips = L;
+  const size_t lds = MOBI_DT_BYTES + (size_t)MOBI_LS_WAVES * L * per_clip;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (lds > 64 * 1024) // (per device; cheap)
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
-  const dim3 grid((unsigned)((a->n_clips + L - 1) / L));
-  if (L == 64) hipLaunchKernelGGL(mobi_parse_frames_ls64, grid, dim3(64), lds, s, *a);
-  else hipLaunchKernelGGL(mobi_parse_frames_ls, grid, dim3(64), lds, s, *a);
+    if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
+  const dim3 grid((unsigned)((a->n_clips + L * MOBI_LS_WAVES - 1) / (L * MOBI_LS_WAVES)));
+  hipLaunchKernelGGL(mobi_parse_frames_ls, grid, dim3(64 * MOBI_LS_WAVES), lds, s, b);
   const uint32_t chunks = (uint32_t)(a->mbw * a->mbh + 63) / 64;
   hipLaunchKernelGGL(mobi_ls_deps, dim3((unsigned)a->n_clips * chunks), dim3(64), 0, s, *a, chunks);
   return (int)hipGetLastError();
