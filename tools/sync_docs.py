@@ -54,8 +54,11 @@ text = f'''Results, MI355X, {RND} build (`profiles/{RND}_{{A,B,C}}_bench.json`; 
 {row("B 640×480 Moflex3DS", B, "B")}
 {row("C 848×480 Moflex3DS", C, "C")}
 
-After the timed region `bench.py` reads back the planes of three clips (first, middle, last) and compares them with the oracle's frame at
-that stream position: `verified` = {json.dumps(ver)}; the same in both end-to-end legs.
+After the timed region `bench.py` checks EVERY clip's newest frame: the {ver.get('sources_against_oracle', '?')} distinct source clips against the oracle's frame at that
+stream position, the other {ver.get('copies_against_their_source_on_device', '?')} byte for byte against their source clip on the device: `verified.ok` = {str(ver.get('ok')).lower()}
+({ver.get('copies_that_differ', '?')} copies differ); the same in both end-to-end legs. `mobi_recon_intra` on its own bytes (`roofline.intra`): {((B['roofline'].get('intra') or {{}}).get('frac') or 0):.3f} by
+SURVEY's formula, {((B['roofline'].get('intra') or {{}}).get('frac_without_reference_read') or 0):.3f} without the reference read an intra macroblock does not make; whole step without it: {(B['roofline'].get('whole_step_frac_intra_without_reference_read') or 0):.3f};
+an I-frame step of the batch (`roofline.iframe_step`): {((B['roofline'].get('iframe_step') or {{}}).get('ms') or 0):.1f} ms.
 What the counters say about B (`profiles/{RND}_B_pmc_summary.txt`): per octet {pw[0][0]} VALU + {pw[0][1]} SALU instructions, {float(pw[0][2] or 0):.0f} vector-memory and {pw[0][3]} LDS
 instructions, {pw[0][4]} read + {pw[0][5]} write requests L1→L2, HBM read {rd_gb:.1f} GB + write {wr_gb:.1f} GB per launch = {ratio:.2f} × the
 {B['roofline']['algorithmic_bytes_per_launch'] / 1e9:.1f} GB of algorithmic bytes. `mobi_recon_intra`: {pw[1][0]} VALU + {pw[1][1]} SALU per wave of four macroblocks.
@@ -130,8 +133,8 @@ Mpix/s (GPU kernel) = whole P-frame step (`mobi_recon_inter8` + `mobi_recon_intr
 timed steps in stream order, every row's timed region ≥ 1 s (A {A['timed_region_s']:.1f} s, B {B['timed_region_s']:.1f} s, C {C['timed_region_s']:.1f} s). HBM GB/s (rocprof) = PMC traffic of
 `mobi_recon_inter8` ÷ its launch time. "% of 8 TB/s" = algorithmic bytes of the inter kernel ÷ launch time (`roofline.frac`) / of the whole
 step (`roofline.whole_step_frac`). Bit-exact = planes, `Offset`, `Quantizer` equal to the oracle's on the parity suite of that geometry
-(`tests/test_gpu_parity.py`), three clips of the bench batch itself compared with the oracle after the timed region (`verified` in the JSON
-line), the oracle's unit functions equal to vectors made by the reference's decoder and encoder statements (`tests/test_unit_vectors.py`),
+(`tests/test_gpu_parity.py`), every clip of the bench batch itself checked after the timed region (`verified` in the JSON line: the distinct sources against the oracle,
+the copies against their source on the device), the oracle's unit functions equal to vectors made by the reference's decoder and encoder statements (`tests/test_unit_vectors.py`),
 and the full-size bench streams decoded bit-exactly by the C# transliteration (`test_csref_differential.py::test_bench_streams`).
 Multi-GPU rows are the driver's to run (`SCALE_rNN.json`; `python bench.py --gpus N` starts its N ranks itself); clips share nothing, so N
 GPUs run N copies of the 1-GPU row. Earlier rounds: r03 B 908 067 Mpix/s (41.2 / 37.4 %), r02 B 775 054 (37.9 / 31.9 %).
@@ -145,7 +148,7 @@ a, b = s.index("<!-- measured:begin -->") + len("<!-- measured:begin -->\n"), s.
 s = s[:a] + f'''Measured on one MI355X (round {int(RND[1:])}, `python bench.py`, 640×480 Moflex3DS P-frames in stream order, {B['config']['clips_per_gpu']} resident clips, {B['timed_region_s']:.1f} s
 timed): {B['value'] / 1e3:.0f} Gpixels/s of reconstruction (command lists resident in HBM), the dominant kernel at {B['roofline']['frac'] * 100:.0f} % of the 8 TB/s HBM
 roofline counting only its own macroblocks' bytes, the whole step at {B['roofline']['whole_step_frac'] * 100:.0f} %, HBM traffic {ratio:.2f} × the algorithmic bytes, bit-exact
-(three clips of the batch compared with the oracle after the timed region);
+(every clip of the batch checked after the timed region: the distinct streams against the oracle, the copies against their source on the device);
 {e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight) at 4096
 clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser, {hp1024} with the parse on 64 host threads at 1024 clips;
 ''' + (f'''the Bitmap of every clip (`mobi_yuv_to_argb`) at {B['bitmap']['roofline']['frac'] * 100:.0f} % of the roofline on its own 5.5 bytes per pixel; ''' if B.get('bitmap') and 'ms' in B['bitmap'] else '') + f'''one
