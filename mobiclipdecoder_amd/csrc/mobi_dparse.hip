@@ -11,7 +11,12 @@
 //  * levels go straight to their place in the payload (no per-macroblock staging);
 //  * intra macroblocks are listed in raster order (a valid order for the dependency waits of mobi_recon_intra: every
 //    dependency is raster-earlier); the launch interleaves clips so that a clip's chain never fills the machine;
-//  * exceptions become a sticky error code.  The first error freezes the bit reader (Offset stays where the reference threw) and
+//  * exceptions become a sticky error code -- which, since r05, nobody outside sees: a frame this parser cannot finish (any error, any
+//    refusal) is parsed again by the HOST parser inside the same call, from the state the frame started with (the state ring: state_in /
+//    state_out, mobi_state.h, mobi_abi.cpp), and rc / Offset / planes are the host parser's.  All this parser owes is to be right on frames
+//    that decode without incident and never to report one that does not as finished.  (What follows is how the error paths behave
+//    anyway: they were written to match the reference's exceptions and still do.)
+//  * The first error freezes the bit reader (Offset stays where the reference threw) and
 //    the decoder state that survives a frame; the walk then runs on to the end of the current macroblock without testing the
 //    code after every read -- every loop of the syntax is bounded by its structure, not by the data (a macroblock holds at
 //    most 127 partition nodes, 6 areas of 4 blocks, 64 tokens per block) -- and the frame loop stops there.  Testing after

@@ -1,18 +1,20 @@
-// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: 32 (or 64) clips per wave, one per lane (mobi_lsparse.h has the state machine and
+// mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: a few clips per wave, one per lane (mobi_lsparse.h has the state machine and
 // says why).
 //
-//   mobi_parse_frames_ls   one wave = LS_CLIPS clips (the other lanes idle).  Every lane walks its own frame with ls_round(); the wave runs until the last one is done.
-//                          A lane that meets anything out of the ordinary bails out and leaves its clip to mobi_parse_frames.
+//   mobi_parse_frames_ls   one wave = `ls_clips` clips (the other lanes idle), four waves per workgroup.  Every lane walks its own frame with
+//                          ls_round(); the wave runs until the last one is done.  A lane that meets anything out of the ordinary bails out and
+//                          leaves its clip to mobi_parse_frames (which, r05, leaves what it cannot finish to the host parser: mobi_abi.cpp).
 //   mobi_ls_deps           one lane per intra macroblock of the clips the first kernel finished: the dependency lists (MbDesc.w4..w7).
 //   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
 //                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
 //
-// LDS per wave: the table blob (18 KB), and per lane the motion-vector row cache (2 (mbw + 2) words), the partition-tree stack (16), the
-// intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all lane-interleaved (element i of lane l at i * LS_CLIPS + l), so
-// that the lanes reading "their" element i hit different banks.  39 KB at 640 pixels with 32 clips per wave: four waves per CU, one per SIMD.
-// (r03 / early r04: 64 clips per wave, 61 KB, two waves per CU.  A wave's life grows with the number of DIFFERENT clips it holds -- it runs
-// until its slowest lane is done, and a round costs what its lanes' different states need: 34.5 ms per P-frame step of 24576 clips at 64,
-// 32.3 at 48, 31.0 at 32 (tools/exp_lsab.sh), and 768 waves still have a SIMD each.  Fewer would need more than the chip's 1024 SIMDs.)
+// LDS per workgroup: ONE copy of the table blob (18 KB) for its four waves, and per wave and lane the motion-vector row cache (2 (mbw + 2)
+// words), the partition-tree stack (16), the intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all
+// lane-interleaved (element i of lane l at i * ls_clips + l), so that the lanes reading "their" element i hit different banks.
+// How many clips a wave carries is a launch argument (mobi_launch_parse_ls, with the measurements): a wave's life grows with the number of
+// DIFFERENT clips it holds -- it runs until its slowest lane is done, a round costs what its lanes' different states need -- and alone on a
+// SIMD it issues an instruction every ~20 clocks, so two or three short-lived waves per SIMD beat one long-lived one (r04: 32 clips per
+// wave, a table copy per wave, one wave per SIMD: 31 ms per P-frame step of 24576 clips; r05: 12 per wave: 26 ms).
 //
 // The bitstream reaches the ring through registers, 32 bytes per lane every LS_SERVICE rounds, committed one service later: the load has
 // that long to arrive, nobody waits for it.  A lane whose ring holds less than a round can ask for (LS_ROUND_BYTES) sits the round out.
