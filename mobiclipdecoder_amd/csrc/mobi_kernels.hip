@@ -262,7 +262,7 @@ __device__ __forceinline__ void idct_pass2_q(const int *t, bool is8, int r, uint
 #define MOBI_PK_LIMIT 14000 /* 9/4 * (14000 + 32) + 104 = 31676 < 32768 */
 // (r05, measured and not kept: the same bound says when the clamp table CANNOT be left -- sums below 1700 give |x >> 6| <= 64 -- and an octet
 // of such areas could run its pixel update without the sixteen packed min / max per lane that track the range; with the second copy of the
-// pixel update and the ballot that picks it the launch was no faster: profiles/r05_ubench.txt.)
+// pixel update and the ballot that picks it the launch was no faster: profiles/r05_experiments.txt.)
 namespace {
 __device__ __forceinline__ void bfly8_pk(const s16x2 in[8], s16x2 out[8]) { // mobi_bfly8, two at a time
   const s16x2 a0 = in[0] + in[4], a1 = in[0] - in[4];

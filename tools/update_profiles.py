@@ -49,6 +49,8 @@ for cfg in "BAC":
             tail[-1] += f" = {hbm / algo:.2f} x the {algo / 1e6:.0f} MB of algorithmic bytes"
             traffic[f"{cfg}:{clips}"] = {"hbm_bytes_per_launch": int(hbm), "kernels_sha16": KSHA, "source": f"profiles/{RND}_{cfg}_pmc_summary.txt: 2*FETCH_SIZE + WRITE_SIZE of mobi_recon_inter8 "
                                          "(rocprofv3 --pmc, separate passes; FETCH_SIZE reports half the bytes on gfx950)"}
+        if k == "mobi_recon_intra" and f"{cfg}:{clips}" in traffic:
+            traffic[f"{cfg}:{clips}"]["intra_hbm_bytes_per_launch"] = int(hbm)  # (bench.py: roofline.intra.traffic)
         wv, va, sa = val(k, "SQ_WAVES"), val(k, "SQ_INSTS_VALU"), val(k, "SQ_INSTS_SALU")
         if wv:
             tail.append(f"#   {wv:.0f} waves; per wave: {va / wv:.0f} VALU + {sa / wv:.0f} SALU instructions"
