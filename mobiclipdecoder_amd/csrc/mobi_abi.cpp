@@ -303,6 +303,7 @@ struct mobi_batch {
     std::vector<uint8_t> is_host;
     std::vector<int> host_rc;
     std::vector<int32_t> host_off;
+    std::vector<uint32_t> host_quant, host_yuv; // Quantizer / YuvFormat behind that frame (the parser itself may be a step further by the time of wait)
   };
   AsyncSlot aslot[2];
   hipStream_t stream_p = nullptr;      // asynchronous steps: the parse kernels (upload on stream2, reconstruction on stream)
@@ -1033,6 +1034,8 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   S.is_host.assign(n, 0);
   S.host_rc.assign(n, MOBI_OK);
   S.host_off.assign(n, 0);
+  S.host_quant.assign(n, 0);
+  S.host_yuv.assign(n, 0);
   // the host parser's clips: parsed now (the caller's bytes are only good during this call), their command lists staged for the copy below
   std::vector<int> host_clips;
   for (int i = 0; i < n; i++)
@@ -1043,6 +1046,8 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
     b->pool->run((int)host_clips.size(), [&](int j) {
       const int i = host_clips[j];
       S.host_rc[i] = b->parsers[i]->parse_frame(data[i] ? data[i] : kNoData2, data[i] ? len[i] : 0, &S.host_off[i], b->cur[i]);
+      S.host_quant[i] = b->parsers[i]->quantizer();
+      S.host_yuv[i] = b->parsers[i]->yuv_format();
     });
   }
   // Everything that can fail without touching the device is behind us.  From the first enqueue on, a failure leaves work in flight
@@ -1122,6 +1127,8 @@ static int async_repair(mobi_batch *b, mobi_batch::AsyncSlot &S, const std::vect
       int rc = b->parsers[c]->parse_frame(T->h_stage.p + T->hdr_bytes + boff, blen, &off, pf);
       T->is_host[c] = 1;
       T->host_off[c] = T->offs[c] + off;
+      T->host_quant[c] = b->parsers[c]->quantizer();
+      T->host_yuv[c] = b->parsers[c]->yuv_format();
       if (rc == MOBI_OK) {
         int fault = 0;
         if (int e = recon_one_clip(b, c, T->ring_base, pf, &fault)) return e;
@@ -1154,8 +1161,8 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
     if (S.is_host[i]) {
       rc[i] = S.host_rc[i];
       if (offsets_out) offsets_out[i] = S.host_off[i];
-      b->dev_quant[i] = b->parsers[i]->quantizer(); // (as of the parser's latest frame: a second step in flight has moved it on)
-      b->dev_yuvfmt[i] = b->parsers[i]->yuv_format();
+      b->dev_quant[i] = S.host_quant[i];
+      b->dev_yuvfmt[i] = S.host_yuv[i];
     } else {
       if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
       rc[i] = res[i].rc;

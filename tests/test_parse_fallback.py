@@ -376,3 +376,72 @@ def test_gpu_asynchronous_steps_repair_what_the_device_cannot_finish(lockstep):
     b.close()
     for o in oras:
         o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_gpu_every_clip_of_a_batch_handed_over_at_once(mode):
+    """every clip's second frame is damaged beyond what the device parsers finish (a ModsDS I-frame header re-written to quantiser 5: every
+    residual block then walks through Internal[]): the whole batch goes to the host parser within that call, and stays decodable"""
+    from mobiclipdecoder_amd import MobiclipBatch
+    from tests.test_internal_walk import _set_quantizer
+    n = 12
+    ps = [default_params("A", BASE_SEED + 3005 + 100 * (i % 3), n_frames=4, width=64, height=48, quantizer=12, pm_intra=150, cbp_prob=500, iframe_interval=2) for i in range(n)]
+    clips = []
+    for p in ps:
+        data, fo = generate_clip(p)
+        data = data.copy()
+        frame2 = data[fo[2]:fo[3]]      # iframe_interval=2: frame 2 is an I-frame
+        assert frame2[1] & 0x80
+        _set_quantizer(frame2, 5)
+        clips.append((data, fo))
+    b = MobiclipBatch(n, 64, 48, 1, device_parse=mode)
+    oras = [OracleDecoder(64, 48, 1) for _ in range(n)]
+    for f in range(4):
+        datas = [c[0][c[1][f]:c[1][f + 1]] for c in clips]
+        rcs, offs = b.decode(datas, [0] * n)
+        if f == 1:
+            assert b.host_clips() < n
+        if f == 2:
+            assert b.host_clips() == n  # (hybrid: its share was there already; the others came with this frame)
+        for i in range(n):
+            oras[i].Data, oras[i].Offset = datas[i], 0
+            ro = oras[i].DecodeFrame()
+            assert rcs[i] == oras[i].last_error == 0 and offs[i] == oras[i].Offset and b.quantizer(i) == oras[i].Quantizer, (mode, f, i, rcs[i], oras[i].last_error)
+            y, uv = b.planes(i)
+            assert np.array_equal(y, ro[0]) and np.array_equal(uv, ro[1]), (mode, f, i)
+    b.close()
+    for o in oras:
+        o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_hybrid_mode_in_asynchronous_steps():
+    """r05: the hybrid mode's host share is parsed inside mobi_batch_submit, its command lists ride behind the parse kernels"""
+    from mobiclipdecoder_amd import MobiclipBatch
+    n, nfr = 10, 6
+    ps = [default_params("A", BASE_SEED + 5100 + i, n_frames=nfr, pm_intra=120, iframe_interval=4) for i in range(n)]
+    clips = [generate_clip(p) for p in ps]
+    b = MobiclipBatch(n, 256, 192, 1, device_parse="hybrid")
+    oras = [OracleDecoder(256, 192, 1) for _ in range(n)]
+
+    def check(f, rcs, offs, ring_idx):
+        for i in range(n):
+            oras[i].Data, oras[i].Offset = clips[i][0][clips[i][1][f]:clips[i][1][f + 1]], 0
+            ro = oras[i].DecodeFrame()
+            assert rcs[i] == 0 and offs[i] == oras[i].Offset, (f, i)
+            y, uv = b.planes(i, ring_idx)
+            assert np.array_equal(y, ro[0]) and np.array_equal(uv, ro[1]), (f, i)
+
+    frames = [[c[0][c[1][f]:c[1][f + 1]] for c in clips] for f in range(nfr)]
+    b.submit(frames[0], [0] * n)
+    for f in range(1, nfr):
+        b.submit(frames[f], [0] * n)
+        rcs, offs = b.wait()
+        check(f - 1, rcs, offs, 1)
+    rcs, offs = b.wait()
+    check(nfr - 1, rcs, offs, 0)
+    assert b.host_clips() == 2  # a fifth of ten
+    b.close()
+    for o in oras:
+        o.close()
