@@ -102,14 +102,13 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * HBM; same rc / Offset / planes.  The parse of one clip is serial and a GPU lane is slow at it; the GPU wins by running
  * thousands of clips at once, from about 20 resident clips per host parse thread upward.  Default: by batch size (device parse from max(640, 20 x threads) clips,
  * unless the first call hands over far more than a frame per clip -- whole files as Data, MOC5 style -- which the device path
- * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1/2.  2 = hybrid: the GPU parses most clips while the
+ * would have to upload again for every frame), or MOBI_DEVICE_PARSE=0/1/2/3.  2 = hybrid: the GPU parses most clips while the
  * host pool parses a fixed share of them (a fifth, at most 1024; MOBI_HYBRID_HOST_CLIPS) at the same time; one set of
- * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front (mobi_lsparse.hip: 32 clips per wavefront, one per
- * lane, all lanes in one instruction stream): it finishes the frames that decode without incident -- identically, word for word -- and
- * leaves every other clip (anything the reference throws on, refusals, data ending inside a frame) to the one-wavefront-per-clip
- * parser, which then runs for those alone.  Its time per frame step does not depend on the batch (31 ms for 640x480 P-frames, 52 ms for
- * I-frames, up to 32768 clips), so it pays from about 15000 resident clips and is the default from
- * 16384 (MOBI_DEVICE_PARSE=1: never).
+ * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front of EVERY step (mobi_lsparse.hip: a few clips per
+ * wavefront, one per lane, all lanes in one instruction stream): it finishes the frames that decode without incident -- identically, word
+ * for word -- and leaves every other clip to the one-wavefront-per-clip parser, which then runs for those alone.  By default the parser in
+ * front is chosen step by step: the lock-step parser from 6144 clips (26 ms per 640x480 P-frame step of 24576 clips against 57) and for
+ * I-frame steps from 768 clips (16 ms against 30 at 4096 clips); 1 = never.
  * THE RESULT DOES NOT DEPEND ON THE MODE (r05).  The device parsers finish the frames that decode without incident.  A frame they cannot
  * finish -- anything the reference throws on, a coefficient run that walks through `Internal` (MD.cs:3424-3429), a ModsDS quantiser below
  * 12, a value the command list has to escape -- is parsed again by the host parser inside the same call (mobi_batch_wait for asynchronous
