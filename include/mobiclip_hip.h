@@ -112,12 +112,13 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * THE RESULT DOES NOT DEPEND ON THE MODE (r05).  The device parsers finish the frames that decode without incident.  A frame they cannot
  * finish -- anything the reference throws on, a coefficient run that walks through `Internal` (MD.cs:3424-3429), a ModsDS quantiser below
  * 12, a value the command list has to escape -- is parsed again by the host parser inside the same call (mobi_batch_wait for asynchronous
- * steps), from the decoder state the clip had when that frame started, which the device keeps for exactly this; the clip stays with the
- * host parser from then on (mobi_batch_host_clips counts them), parsed beside the GPU's clips as the hybrid mode's share is.
+ * steps), from the decoder state the clip had when that frame started, which the device keeps for exactly this; the clip then stays with the
+ * host parser (mobi_batch_host_clips counts them), parsed beside the GPU's clips as the hybrid mode's share is, until it has had a run of
+ * frames the device parsers finish (4, doubled with every hand-over, at most 256), and goes back with the host parser's state.
  * Can only be changed before the first frame: the decoder state lives on one side. */
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse);
-/* how many clips of the batch the host parser parses at present: all of them in mode 0; in the other modes the hybrid share plus every
- * clip that has had a frame the device parser could not finish */
+/* how many clips of the batch the host parser parses at present: all of them in mode 0; in the other modes the hybrid share plus the clips
+ * that have had a frame the device parsers could not finish and have not gone back yet */
 int mobi_batch_host_clips(const mobi_batch *b);
 /* Parse mode 3: how many clips of the last finished frame step the lock-step parser finished itself (the rest went to the other one);
  * -1 in the other modes or before the first step. */

@@ -273,6 +273,10 @@ struct mobi_batch {
   std::vector<uint8_t> on_host;        // [clip] device-parse modes: this clip is the host parser's (the hybrid mode's share; clips with a frame the
                                        // device parser could not finish, from that frame on)
   unsigned long fallbacks = 0;         // frames taken over so far
+  unsigned long returns = 0;           // clips handed back to the device parsers so far (dp_return)
+  std::vector<uint8_t> host_share;     // [clip] 1: the hybrid mode's share (stays with the host parser by design)
+  std::vector<uint16_t> clean_run, clean_need; // [clip] consecutive frames the device parsers could have finished; how many it takes to go back
+  PinnedBuf h_ret;                     // dp_return: states on their way back to the device
   PinnedBuf h_fix;                     // async_repair: one clip's command list
   DevBuf d_fix;
   uint32_t pay_clip_words = 0;         // of the last device-parsed step (MobiReconArgs.pay_clip_words)
@@ -288,7 +292,7 @@ struct mobi_batch {
   // asynchronous steps (mobi_batch_submit / mobi_batch_wait, device parse only): two sets of staging so that the bytes of step
   // n + 1 are gathered and uploaded while the GPU works on step n; everything else follows stream order
   struct AsyncSlot {
-    PinnedBuf h_stage, h_pres, h_fault, h_over; // h_over: the command lists of the host parser's clips (dp_override)
+    PinnedBuf h_stage, h_pres, h_fault, h_over, h_ret; // h_over: the command lists of the host parser's clips (dp_override); h_ret: dp_return
     DevBuf d_bits;
     // what the parse of this step leaves in HBM: owned by the slot, so that the parse of step n + 1 (on stream_p) may run under the
     // reconstruction of step n (on stream), which still reads step n's
@@ -641,6 +645,9 @@ static int dp_init(mobi_batch *b) {
   b->dev_quant.assign(n, 0);
   b->dev_yuvfmt.assign(n, 0);
   if ((int)b->on_host.size() != n) b->on_host.assign(n, 0);
+  b->host_share.assign(n, 0);
+  b->clean_run.assign(n, 0);
+  b->clean_need.assign(n, 4);
   return MOBI_OK;
 }
 // stage [bit_off u64 x n][bit_len u32 x n][bits: each clip 8-byte aligned, zero padded] into pinned memory; the host parser's clips
@@ -849,6 +856,36 @@ static void hybrid_share(mobi_batch *b) {
   if (const char *hh = getenv("MOBI_HYBRID_HOST_CLIPS")) b->hybrid_host = std::max(0, std::min(b->n - 1, atoi(hh)));
 }
 
+// A clip the host parser took over goes BACK to the device parsers once its frames are again the kind they finish: `clean_need`
+// consecutive frames without a walk, a token without a level or a value beyond the device parsers' fields (MobiStreamParser::device_ready),
+// doubled with every hand-over (4, 8, ... 256: a clip whose every frame needs the host parser -- a ModsDS stream below quantiser 12 -- costs
+// a wasted device parse every few hundred frames, a glitch in an otherwise clean stream a handful of host-parsed frames).  The parser's state
+// goes into entry `entry` of the state ring -- the one the next step's parse reads -- on stream s, through `stage`.
+static int dp_return(mobi_batch *b, const std::vector<int> &host_clips, const int *rc, int entry, PinnedBuf &stage, hipStream_t s) {
+  std::vector<int> back;
+  for (int c : host_clips) {
+    if (b->host_share[c]) continue;
+    if (rc[c] == MOBI_OK && b->parsers[c]->device_ready()) b->clean_run[c]++;
+    else b->clean_run[c] = 0;
+    if (b->clean_run[c] >= b->clean_need[c]) back.push_back(c);
+  }
+  if (back.empty()) return MOBI_OK;
+  const size_t rec = sizeof(MobiDevState) + sizeof(MobiDevTail);
+  if (int e = stage.reserve(back.size() * rec)) return e;
+  for (size_t k = 0; k < back.size(); k++) {
+    const int c = back[k];
+    MobiDevState *st = (MobiDevState *)(stage.p + k * rec);
+    MobiDevTail *tail = (MobiDevTail *)(stage.p + k * rec + sizeof(MobiDevState));
+    b->parsers[c]->export_state(*st, *tail);
+    HIP_TRY(hipMemcpyAsync(b->d_pstate[entry] + c, st, sizeof(*st), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->d_ptail[entry] + c, tail, sizeof(*tail), hipMemcpyHostToDevice, s));
+    b->on_host[c] = 0;
+    b->clean_run[c] = 0;
+    b->returns++;
+  }
+  return MOBI_OK;
+}
+
 // Once the parsers have consumed a frame and the ring has turned, a call that fails before its reconstruction is complete must not leave
 // any clip reporting MOBI_OK for a frame that was never reconstructed (host-parsed and device-parsed steps alike: ADVICE r03)
 struct FailAll {
@@ -870,7 +907,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   if (b->g.mbw > 64 || b->async_count) return MOBI_E_ARG; // (asynchronous steps in flight: mobi_batch_wait for them first)
   if (int e = dp_init(b)) return e;
   if (b->hybrid_host && b->frames_started == 0) // hybrid: the last clips are the host parsers' from the start (their state is a new decoder's: nothing to seed)
-    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = 1;
+    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = b->host_share[i] = 1;
   std::vector<int> host_clips;
   for (int i = 0; i < n; i++)
     if (b->on_host[i]) host_clips.push_back(i);
@@ -913,7 +950,12 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     for (int c : fb)
       if (int e = dp_seed_parser(b, c, state_in)) return e;
     host_parse(fb);
-    for (int c : fb) b->on_host[c] = 1;
+    for (int c : fb) {
+      b->on_host[c] = 1;
+      b->clean_run[c] = 0;
+      b->clean_need[c] = (uint16_t)std::min(256, 2 * (int)b->clean_need[c]);
+      host_clips.push_back(c);
+    }
     b->fallbacks += fb.size();
     if (int e = dp_override(b, fb, rc, b->h_stage2, rows, b->stream)) return e; // (behind the parse kernels, which blanked these clips' rows)
   }
@@ -947,6 +989,8 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     return MOBI_E_DEVICE;
   HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * n, hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_fault, 0, sizeof(int) * n, b->stream));
+  if (!host_clips.empty())
+    if (int e = dp_return(b, host_clips, rc, b->ps_cur, b->h_ret, b->stream)) return e; // (ps_cur: what the next step's parse reads)
   b->phase_ms[3] = ms_since(q0);
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->phase_ms[4] = ms_since(q0);
@@ -1011,7 +1055,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (b->g.mbw > 64 || b->async_count >= 2) return MOBI_E_ARG;
   if (int e = dp_init(b)) return e;
   if (b->hybrid_host && b->frames_started == 0)
-    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = 1;
+    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = b->host_share[i] = 1;
   mobi_batch::AsyncSlot &S = b->aslot[(b->async_head + b->async_count) & 1];
   if (!S.ev_up) {
     HIP_TRY(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
@@ -1079,8 +1123,10 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   }
   MobiDevResult *d_res = (MobiDevResult *)S.d_pres.p;
   if (int e = dp_parse(b, S.d_bits.p, st, false, DpOut{&S.d_pdesc, &S.d_ppay, &S.d_pitems, d_res, ps, true}, &S.state_in)) return e;
-  if (!host_clips.empty())
+  if (!host_clips.empty()) {
     if (int e = dp_override(b, host_clips, S.host_rc.data(), S.h_over, DpRows{S.d_pdesc.p, S.d_ppay.p, S.d_pitems.p, d_res, b->last_pay_cap}, ps)) return e;
+    if (int e = dp_return(b, host_clips, S.host_rc.data(), b->ps_cur, S.h_ret, ps)) return e; // (the parse kernels skip these clips: their entries are free to write)
+  }
   HIP_TRY(hipMemcpyAsync(S.h_pres.p, d_res, sizeof(MobiDevResult) * n, hipMemcpyDeviceToHost, ps));
   HIP_TRY(hipEventRecord(S.ev_parsed, ps));
   S.parsed_recorded = true;
@@ -1138,6 +1184,8 @@ static int async_repair(mobi_batch *b, mobi_batch::AsyncSlot &S, const std::vect
       ((int *)T->h_fault.p)[c] = 0;
     }
     b->on_host[c] = 1;
+    b->clean_run[c] = 0;
+    b->clean_need[c] = (uint16_t)std::min(256, 2 * (int)b->clean_need[c]);
     b->fallbacks++;
   }
   return MOBI_OK;

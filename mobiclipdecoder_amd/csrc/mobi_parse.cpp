@@ -140,6 +140,13 @@ void MobiStreamParser::export_state(MobiDevState &st, MobiDevTail &tail) {
   for (size_t i = 0; i < mvc_.size(); i++) tail.mvc[i] = mvc_[i];
 }
 uint32_t MobiStreamParser::internal_word(uint32_t idx) { return internal_read(idx); }
+bool MobiStreamParser::device_ready() const {
+  if (!last_frame_ok_ || frame_literal_ || frame_host_only_) return false;
+  if (tq_ != quant_ && tq_ != MOBI_TQ_NONE) return false; // (tables of another quantiser than Quantizer: the device's state has one field for both)
+  for (uint32_t v : itail_)
+    if (v) return false;
+  return true;
+}
 
 // ------------------------------------------------------------------ per-MB assembly
 void MobiStreamParser::begin_mb(int mb, int type) {
@@ -243,6 +250,7 @@ void MobiStreamParser::mc_leaf(int wi, int hi, int x, int y, int ref, int dx, in
     if (ndx < -MOBI_MV_LIMIT || ndx > MOBI_MV_LIMIT || ndy < -MOBI_MV_LIMIT || ndy > MOBI_MV_LIMIT) fail(MOBI_E_INDEX); // (cannot happen: see above)
     dx = (int)ndx;
     dy = (int)ndy;
+    frame_host_only_ = true;
   }
   leaves_[n_leaf_words_++] = mobi_leaf_w0(x, y, wi, hi, ref); // at most 64 leaves: the tree bottoms out at 2x2
   leaves_[n_leaf_words_++] = mobi_leaf_w1(dx, dy);
@@ -405,6 +413,7 @@ void MobiStreamParser::resid_block(int area, int sub, bool is8) {
       // look at part of the block, but for q >= 12 nothing they skip can be nonzero: scan positions 0, 0..2, 0..9 map inside the
       // respective regions (tests/test_oracle_identities.py pins that property of the zigzag tables), so every level is kept.
       if (value != 0) coefs_[n_coefs_++] = (uint32_t)(tile + (int)(word & 0xFF)) | ((uint32_t)(int)(int16_t)value << 16); // = mobi_coef()
+      else frame_host_only_ = true; // (a token without a level: the device parsers stop there, mobi_state.h)
     } else { // MD.cs:3424-3429 as written
       odd = true;
       const uint32_t r8 = internal_read(r12);
@@ -563,6 +572,7 @@ uint32_t MobiStreamParser::plane_param(int p, int r) {
   if (p >= -32768 && p <= 32767) return (uint32_t)(uint16_t)(int16_t)p << 16;
   if (!any_wide_) memset(wide_, 0, sizeof(wide_));
   any_wide_ = true;
+  frame_host_only_ = true;
   wide_[r] = p;
   return MOBI_REC_WIDE;
 }
@@ -838,7 +848,7 @@ int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offs
     win_ <<= 16;
     bool iframe = (win_ >> 31) == 1;
     win_ += win_;
-    frame_literal_ = frame_fault_ = big_unsure_ = false;
+    frame_literal_ = frame_fault_ = big_unsure_ = frame_host_only_ = false;
     if (iframe) parse_i(out); else parse_p(out);
     if (frame_literal_) literal_frame(out);
     if (frame_fault_) fail(MOBI_E_CLAMP); // (behind the whole parse, where the kernels' own clamp faults are reported: Offset is the frame's end)
@@ -847,6 +857,7 @@ int MobiStreamParser::parse_frame(const uint8_t *data, size_t len, int32_t *offs
     rc = e.code;
   }
   *offset = off_;
+  last_frame_ok_ = rc == MOBI_OK;
   return rc;
 }
 

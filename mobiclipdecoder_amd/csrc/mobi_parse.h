@@ -84,6 +84,9 @@ class MobiStreamParser {
   void import_state(const MobiDevState &st, const MobiDevTail &tail);
   void export_state(MobiDevState &st, MobiDevTail &tail);
   uint32_t internal_word(uint32_t idx); // Internal[idx] as the reference holds it between frames, 10 <= idx < 392 (tests: against the oracle's)
+  // The last frame was one the device parsers would have finished too (no walk, no token without a level, no value beyond their fields),
+  // and nothing a walk once wrote behind the MV row cache is left: the clip may go back to the device parsers (mobi_abi.cpp, dp_return).
+  bool device_ready() const;
 
   uint32_t quantizer() const { return quant_; }
   uint32_t yuv_format() const { return yuvfmt_; }
@@ -161,6 +164,8 @@ class MobiStreamParser {
   uint32_t itail_[392] = {0};  // Internal[idx] for indices that are nothing else (behind the MV row cache)
   bool frame_literal_ = false; // a block of this frame read or wrote Internal[] out of its place: its residuals ship as literal values
   bool frame_fault_ = false;   // ... and one of them holds a coefficient beyond int16 whose transform must leave the clamp table's domain
+  bool frame_host_only_ = false; // this frame holds something the device parsers stop at although it decodes (dp_return: the clip stays here)
+  bool last_frame_ok_ = false;
   bool big_unsure_ = false;    // an ordinary block of this frame holds such a coefficient and need NOT leave it (surely_faults)
   int frames_started_ = 0;
   std::vector<int> mvc_; // MV row cache, Internal[221..]

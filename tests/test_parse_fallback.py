@@ -445,3 +445,103 @@ def test_gpu_hybrid_mode_in_asynchronous_steps():
     b.close()
     for o in oras:
         o.close()
+
+
+def _glitch_then_clean(seed, n_clean):
+    """a clip whose first four frames are the golden walk stream (one of them a run through Internal[]: the host parser's) followed by the
+    P-frames of a clean generated stream of the same geometry -- the syntax of a frame does not depend on the pictures before it"""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import json
+    case = [c for c in json.load(open(os.path.join(here, "golden.json")))["cases"] if c["name"] == "r05_walk_moflex_64x48"][0]
+    x = np.fromfile(os.path.join(here, case["name"] + ".bin"), dtype=np.uint8)
+    frames = [x[case["frame_off"][f]:case["frame_off"][f + 1]] for f in range(len(case["frames"]))]
+    p = default_params("B", seed, n_frames=n_clean + 1, width=64, height=48, version=2, pm_intra=80, pm_deep=100)
+    y, fo = generate_clip(p)
+    frames += [y[fo[f]:fo[f + 1]] for f in range(1, n_clean + 1)]
+    return frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,asynchronous", [(1, False), (3, False), (1, True)])
+def test_gpu_a_clip_goes_back_to_the_device_parser(mode, asynchronous):
+    """a glitch, then clean frames: the host parser takes the clip over at the glitch and hands it back -- with its state -- after a run of
+    frames the device parsers finish; every frame of every clip equals the oracle's on the way there and back"""
+    from mobiclipdecoder_amd import MobiclipBatch
+    n_clean = 22
+    clips = [_glitch_then_clean(BASE_SEED + 7700 + i, n_clean) for i in range(3)]
+    for i in range(2):  # and two clips that never leave the device parsers
+        p = default_params("B", BASE_SEED + 7750 + i, n_frames=4 + n_clean, width=64, height=48, version=2, pm_intra=80)
+        y, fo = generate_clip(p)
+        clips.append([y[fo[f]:fo[f + 1]] for f in range(4 + n_clean)])
+    n, nfr = len(clips), 4 + n_clean
+    b = MobiclipBatch(n, 64, 48, 2, device_parse=mode)
+    oras = [OracleDecoder(64, 48, 2) for _ in range(n)]
+    on_host = []
+
+    def check(f, rcs, offs, ring_idx):
+        for i in range(n):
+            oras[i].Data, oras[i].Offset = clips[i][f], 0
+            ro = oras[i].DecodeFrame()
+            assert rcs[i] == oras[i].last_error == 0 and offs[i] == oras[i].Offset, (mode, f, i, rcs[i], oras[i].last_error)
+            y, uv = b.planes(i, ring_idx)
+            assert np.array_equal(y, ro[0]) and np.array_equal(uv, ro[1]), (mode, f, i)
+
+    if not asynchronous:
+        for f in range(nfr):
+            rcs, offs = b.decode([c[f] for c in clips], [0] * n)
+            check(f, rcs, offs, 0)
+            on_host.append(b.host_clips())
+    else:
+        b.submit([c[0] for c in clips], [0] * n)
+        for f in range(1, nfr):
+            b.submit([c[f] for c in clips], [0] * n)
+            rcs, offs = b.wait()
+            check(f - 1, rcs, offs, 1)
+            on_host.append(b.host_clips())
+        rcs, offs = b.wait()
+        check(nfr - 1, rcs, offs, 0)
+        on_host.append(b.host_clips())
+    assert max(on_host) == 3 and on_host[-1] == 0, on_host  # handed over at the glitch, back after eight clean frames
+    b.close()
+    for o in oras:
+        o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 3])
+def test_gpu_long_streams_with_sparse_glitches(mode):
+    """48 clips x 40 frames, one or two damaged frames per clip somewhere: clips leave for the host parser at a glitch and come back after a
+    clean run, some of them twice -- and every frame's rc, Offset, Quantizer and planes equal those of a batch parsed on the host throughout"""
+    from mobiclipdecoder_amd import MobiclipBatch
+    n, nfr = 48, 40
+    rng = np.random.default_rng(4040 + mode)
+    clips = []
+    for i in range(n):
+        p = default_params("AB"[mode % 2], BASE_SEED + 8800 + i, n_frames=nfr, width=64, height=48, version=2, pm_intra=100, pm_deep=120, pm_multiref=200,
+                           qdelta_prob=150, escape_prob=60, table1_prob=300, iframe_interval=13)
+        data, fo = generate_clip(p)
+        data = data.copy()
+        if i % 6:  # (every sixth clip stays intact)
+            for f in rng.choice(np.arange(2, nfr - 10), size=int(rng.integers(1, 3)), replace=False):
+                for _ in range(int(rng.integers(1, 4))):
+                    data[int(rng.integers(fo[f], fo[f + 1]))] ^= 1 << int(rng.integers(0, 8))
+        clips.append((data, fo))
+    db, hb = MobiclipBatch(n, 64, 48, 2, device_parse=mode), MobiclipBatch(n, 64, 48, 2, device_parse=0)
+    seen_host, decoded = [], 0
+    for f in range(nfr):
+        datas = [c[0][c[1][f]:c[1][f + 1]] for c in clips]
+        r1, o1 = db.decode(datas, [0] * n)
+        r2, o2 = hb.decode(datas, [0] * n)
+        assert r1 == r2 and o1 == o2, (mode, f, [(i, a, b) for i, (a, b) in enumerate(zip(r1, r2)) if a != b])
+        for i in range(n):
+            assert db.quantizer(i) == hb.quantizer(i), (mode, f, i)
+            if r1[i] == 0:
+                ya, ua = db.planes(i)
+                yb, ub = hb.planes(i)
+                assert np.array_equal(ya, yb) and np.array_equal(ua, ub), (mode, f, i)
+                decoded += 1
+        seen_host.append(db.host_clips())
+    assert max(seen_host) >= 8 and seen_host[-1] < max(seen_host) and decoded > n * nfr * 0.8, (seen_host, decoded)
+    db.close()
+    hb.close()
