@@ -212,6 +212,72 @@ int mobi_lshost_wave_sched(void *const *clips, const uint8_t *const *data, const
   return 0;
 }
 
+// Population-driven schedule: every iteration runs the ONE part whose (lanes waiting for it) / (its cost) is largest.  cost[4] = M, I, N, T
+// in instructions.  counts[0] = iterations, counts[1..4] = runs of M, I, N, T.
+int mobi_lshost_wave_greedy(void *const *clips, const uint8_t *const *data, const size_t *len, int n_lanes, const double cost[4], long counts[5]) {
+  struct Lane { Clip *C; HostStore m; LsLane s; LsCtx c; };
+  std::vector<Lane> L(n_lanes);
+  for (int i = 0; i < n_lanes; i++) {
+    Clip &C = *(Clip *)clips[i];
+    Lane &l = L[i];
+    l.C = &C;
+    l.c.T = C.tables.data();
+    l.c.width = C.w; l.c.height = C.h; l.c.stride = C.g.stride; l.c.lg = C.g.lg; l.c.mbw = C.g.mbw; l.c.mbh = C.g.mbh; l.c.n_mbs = C.g.mbw * C.g.mbh;
+    l.c.version = C.version;
+    l.c.pay_cap = (uint32_t)C.pay.size();
+    l.m = C.m;
+    l.m.data = data[i];
+    l.m.len2 = (uint32_t)len[i] & ~1u;
+    memset(&l.s, 0, sizeof(l.s));
+    l.s.quant = C.quant; l.s.yuvfmt = C.yuvfmt; l.s.tables_set = C.tables_set; l.s.frames_started = C.frames_started + 1;
+    l.s.desc = C.desc.data(); l.s.pay = C.pay.data(); l.s.pay_base = 0; l.s.clip = 0; l.s.items = C.items.data();
+    ls_begin_frame(l.s, l.m, l.c, (uint32_t)len[i]);
+  }
+  for (int k = 0; k < 5; k++) counts[k] = 0;
+  for (;;) {
+    int n[4] = {0, 0, 0, 0}, live = 0;
+    for (auto &l : L) {
+      const int st = l.s.st;
+      if (st == LS_DONE) continue;
+      live++;
+      if (st == LS_NEXT) n[2]++;
+      else if (st == LS_TOKEN) n[3]++;
+      else if (ls_in_intra(l.s)) n[1]++;
+      else n[0]++;
+    }
+    if (!live) break;
+    int best = 0;
+    if (cost[0] < 0) { // threshold policy: -cost[0] = share of the live lanes that must wait for M / I before they run; cheap parts otherwise
+      const double th = -cost[0];
+      const int slow = n[0] + n[1];
+      if (slow >= th * live || n[2] + n[3] == 0) best = n[0] >= n[1] ? 0 : 1;
+      else best = n[2] > n[3] ? 2 : 3;
+      if (best <= 1 && cost[1] < 0) { // both slow parts in one go
+        counts[0]++;
+        if (n[0]) counts[1]++;
+        if (n[1]) counts[2]++;
+        for (auto &l : L) { ls_step_main(l.s, l.m, l.c); ls_step_intra(l.s, l.m, l.c); }
+        continue;
+      }
+    } else
+      for (int k = 1; k < 4; k++) if (n[k] / cost[k] > n[best] / cost[best]) best = k;
+    counts[0]++;
+    counts[1 + best]++;
+    for (auto &l : L) {
+      if (best == 0) ls_step_main(l.s, l.m, l.c);
+      else if (best == 1) ls_step_intra(l.s, l.m, l.c);
+      else if (best == 2) ls_next_fast(l.s, l.m, l.c);
+      else ls_token_fast(l.s, l.m, l.c);
+    }
+  }
+  for (auto &l : L) {
+    if (l.s.bail) return l.s.bail;
+    l.C->m = l.m;
+    l.C->quant = l.s.quant; l.C->yuvfmt = l.s.yuvfmt; l.C->tables_set = l.s.tables_set; l.C->frames_started = l.s.frames_started;
+  }
+  return 0;
+}
+
 // The whole differential in one call: every frame of a clip through both parsers.  Returns the number of frames that compared equal
 // (all of them: n_frames), or -(frame + 1) at the first difference (what differs goes to stderr).  *bails = frames the lock-step parser
 // left to the other one (allowed only when allow_bail is set or the host parser did not return MOBI_OK).

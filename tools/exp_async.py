@@ -10,7 +10,8 @@ from mobiclipdecoder_amd import sharding
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 streams = []
-for i in range(16):
+ND = int(os.environ.get("DISTINCT", 64))  # a lock-step wave must not hold copies of one stream
+for i in range(ND):
     p = m.default_params("B", sharding.stream_seed("B", 0, i), n_frames=3 + steps, **({"iframe_interval": 1} if os.environ.get("IFRAMES") else {}))  # IFRAMES=1: every frame an I-frame
     d, fo = m.generate_clip(p)
     streams.append((d, fo))
@@ -18,7 +19,7 @@ b = m.MobiclipBatch(n, 640, 480, p.version, device_parse="lockstep" if os.enviro
 lib, h = b._lib, b._h
 # ctypes arrays built once per frame, outside the timed calls: what a C caller would hand over
 def pack(f):
-    bufs = [streams[c % 16][0][streams[c % 16][1][f]:streams[c % 16][1][f + 1]] for c in range(n)]
+    bufs = [streams[c % ND][0][streams[c % ND][1][f]:streams[c % ND][1][f + 1]] for c in range(n)]
     ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in bufs])
     lens = (C.c_size_t * n)(*[x.size for x in bufs])
     return bufs, ptrs, lens

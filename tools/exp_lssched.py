@@ -43,6 +43,27 @@ def sched(order, lanes=64):
     def mi(c): return (c[1] * W["M"] + c[2] * W["I"] + c[3] * W["N"] + c[4] * W["T"]) / 1e6
     i, p = out[0], out[2]
     print(f"{order:28s} P: rounds {p[0]:5d} M {p[1]:5d} I {p[2]:5d} N {p[3]:5d} T {p[4]:5d} -> {mi(p):5.2f} M instr | I-frame: rounds {i[0]:5d} I {i[2]:5d} N {i[3]:5d} T {i[4]:5d} -> {mi(i):5.2f} M", flush=True)
+L.mobi_lshost_wave_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+def greedy(cost, lanes=12, label=""):
+    """every iteration ONE part: cost = [M, I, N, T] instructions -> the part with the most waiting lanes per instruction; cost[0] < 0: M (and I, if
+    cost[1] < 0 in the same go) only when that share of the live lanes waits for them, the fuller of N / T otherwise"""
+    clips = [L.mobi_lshost_create(640, 480, 2) for _ in range(lanes)]
+    out = []
+    for f in range(3):
+        bufs = [np.ascontiguousarray(streams[i % 16][0][streams[i % 16][1][f]:streams[i % 16][1][f + 1]]) for i in range(lanes)]
+        cp = (C.c_void_p * lanes)(*clips); dp = (C.c_void_p * lanes)(*[b.ctypes.data for b in bufs]); lp = (C.c_size_t * lanes)(*[b.size for b in bufs])
+        cnt = (C.c_long * 5)()
+        assert L.mobi_lshost_wave_greedy(cp, dp, lp, lanes, (C.c_double * 4)(*cost), cnt) == 0
+        out.append(list(cnt))
+    for c in clips: L.mobi_lshost_destroy(c)
+    def mi(c): return (c[1] * W["M"] + c[2] * W["I"] + c[3] * W["N"] + c[4] * W["T"]) / 1e6
+    i, p = out[0], out[2]
+    print(f"{label:28s} P: iterations {p[0]:5d} M {p[1]:5d} I {p[2]:5d} N {p[3]:5d} T {p[4]:5d} -> {mi(p):5.2f} M instr | I-frame: {i[0]:5d} M {i[1]:5d} I {i[2]:5d} T {i[4]:5d} -> {mi(i):5.2f} M", flush=True)
+if __name__ == "__main__" and "--greedy" in sys.argv:  # r05: does choosing the part by the lanes waiting for it beat the fixed round?  (12 clips per wave)
+    sched("MINTNTNTNT", 12)
+    greedy([W["M"], W["I"], W["N"], W["T"]], 12, "most lanes per instruction")
+    for th in (0.25, 0.5, 0.75, 1.0): greedy([-th, -1, W["N"], W["T"]], 12, f"M + I when {th:.2f} of lanes wait")
+    sys.exit(0)
 if __name__ == "__main__" and "--orders" in sys.argv:
     for o in ["MINTNTNTNTNT", "MINTTTNTTT", "MINTTNTTNTT", "MINTTTTNTTTT", "MINTTTTTT", "MINTNTTTNTTT", "MNTINTNTTNTT", "MINTTNTTTNTTT", "MINTTTNTTTNTTT"]:
         sched(o)
