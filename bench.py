@@ -90,7 +90,7 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
     b.close()
     t = float(np.median(ms))
     out = {"value": round(n_clips * W * H / t / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(t, 3), "clips": n_clips, "steps": n_steps,
-           "parse": "device: mobi_parse_frames_ls (32 clips per wavefront, lock step) in front of mobi_parse_frames" if device_parse == "lockstep"
+           "parse": "device: mobi_parse_frames_ls (clips in lock step, one per lane; about two wavefronts per SIMD) in front of mobi_parse_frames" if device_parse == "lockstep"
                     else "device: mobi_parse_frames, one wavefront per clip",
            "includes": "host staging and H2D of the frame bytes, parse, reconstruction, result read-back, sync (wall time inside mobi_batch_decode)",
            "distinct_streams": len(streams), "verified": verified}
@@ -387,7 +387,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--e2e-clips", type=int, default=4096, help="clips of the end-to-end leg (bitstream in, device-side parse); 0 = skip")
     ap.add_argument("--e2e-steps", type=int, default=12)
-    ap.add_argument("--e2e-large-clips", type=int, default=24576, help="clips of the second end-to-end leg, at the headline batch size with the lock-step parser (64 clips per wavefront); 0 = skip")
+    ap.add_argument("--e2e-large-clips", type=int, default=24576, help="clips of the second end-to-end leg, at the headline batch size with the lock-step parser in front; 0 = skip")
+    ap.add_argument("--e2e-xl-clips", type=int, default=49152, help="clips of the third end-to-end leg: what 288 GB of HBM hold at 640x480 (40960 or 32768 if that does not fit); 0 = skip")
     ap.add_argument("--bitmap-clips", type=int, default=512, help="clips of the Bitmap leg (row f1: mobi_yuv_to_argb on a resident batch); 0 = skip")
     ap.add_argument("--config4-clips", type=int, default=8, help="clips of the config-4 leg (64 clips / 8 GPUs); 0 = skip")
     ap.add_argument("--single-stream", type=int, default=1, help="1: time one clip through mobi_decode / mobi_get_argb (the boundary's own shape); 0 = skip")
@@ -568,6 +569,21 @@ def main():
             e2e_large = end_to_end(m, wide, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
         except Exception as e:  # (e.g. does not fit beside what the allocator still holds: reported beside the headline value, not fatal to it)
             e2e_large = {"error": f"{type(e).__name__}: {e}"}
+    # The lock-step parser's cost per clip falls with the batch (more clips per wave share every round of the walk): the same leg once more
+    # with as many clips as the device holds.  Skipped rather than tried when the memory is visibly not there (a failed allocation of tens
+    # of GB is not a cheap way to find out).
+    e2e_xl = None
+    if world == 1 and args.e2e_xl_clips > max(args.e2e_large_clips, 0) and isinstance(e2e_large, dict) and "error" not in e2e_large and args.config == "B":
+        for n_xl in sorted({args.e2e_xl_clips, min(args.e2e_xl_clips, 40960), min(args.e2e_xl_clips, 32768)}, reverse=True):
+            free = torch.cuda.mem_get_info(local)[0]
+            if free < n_xl * 4.9e6 + 8e9:  # rings 4.42 MB per clip, two steps' command lists, staging
+                e2e_xl = {"error": f"{n_xl} clips need ~{(n_xl * 4.9e6 + 8e9) / 1e9:.0f} GB, {free / 1e9:.0f} GB free"}
+                continue
+            try:
+                e2e_xl = end_to_end(m, wide, W, H, p0.version, local, n_xl, 6, device_parse="lockstep")
+                break
+            except Exception as e:
+                e2e_xl = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and args.config4_clips > 0 and args.config == "B":
         c4 = config4_leg(m, streams, W, H, p0.version, local, args.config4_clips, 24)
     bitmap = None
@@ -655,7 +671,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "verified": verified, "ranks": rank_report, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
+            "verified": verified, "ranks": rank_report, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "end_to_end_xl": e2e_xl, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

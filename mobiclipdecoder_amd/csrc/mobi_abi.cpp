@@ -737,7 +737,8 @@ static int dp_stage(mobi_batch *b, const uint8_t *const *data, const size_t *len
   return MOBI_OK;
 }
 // output buffers + the parse launch.  A clip's payload can never exceed 448 words per macroblock, nor 64 per macroblock + one level
-// per bit read.  `busy`: earlier steps may still be using the buffers (asynchronous steps): drain the stream before growing one.
+// per THREE bits read (a level word stands for a token with a level, and the shortest of those -- either table, either version -- has two
+// bits and a sign: mobi_dparse_build_tables; tests/test_parse_fallback.py checks the tables for it).  `busy`: earlier steps may still be using the buffers (asynchronous steps): drain the stream before growing one.
 // *state_in: which entry of the state ring the step reads (the state its frames start from).
 struct DpOut { DevBuf *desc, *pay, *items; MobiDevResult *res; hipStream_t stream; bool async = false; };
 static int dp_parse(mobi_batch *b, const uint8_t *d_bits, const DpStaged &st, bool busy, const DpOut &o, int *state_in) {
@@ -745,7 +746,7 @@ static int dp_parse(mobi_batch *b, const uint8_t *d_bits, const DpStaged &st, bo
   // (the longest frame of a step varies from step to step: the bound follows it upwards in steps of a quarter, so that the payload
   // arena -- gigabytes for thousands of clips -- is not freed and allocated again every few frames)
   if (st.max_len > b->dp_len_hint) b->dp_len_hint = st.max_len + st.max_len / 4;
-  const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448 + MOBI_WIDE_PARAMS, (size_t)n_mbs * 64 + 8 * b->dp_len_hint) + 448 + 64;
+  const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448 + MOBI_WIDE_PARAMS, (size_t)n_mbs * 64 + (8 * b->dp_len_hint + 2) / 3) + 448 + 64;
   // MbDesc.payload_off is relative to the clip's own part of the arena, which may then be as large as HBM lets it (24576 clips of
   // 640x480 need 13 G words for an I-frame); the host parser's clips write into their own parts like everybody else (dp_override)
   b->pay_clip_words = (uint32_t)cap_words;

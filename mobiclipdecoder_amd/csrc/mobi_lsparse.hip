@@ -1,14 +1,14 @@
 // mobi_lsparse.hip -- the lock-step bitstream parser on gfx950: a few clips per wave, one per lane (mobi_lsparse.h has the state machine and
 // says why).
 //
-//   mobi_parse_frames_ls   one wave = `ls_clips` clips (the other lanes idle), four waves per workgroup.  Every lane walks its own frame with
+//   mobi_parse_frames_ls   one wave = `ls_clips` clips (the other lanes idle), four or eight waves per workgroup (mobi_launch_parse_ls).  Every lane walks its own frame with
 //                          ls_round(); the wave runs until the last one is done.  A lane that meets anything out of the ordinary bails out and
 //                          leaves its clip to mobi_parse_frames (which, r05, leaves what it cannot finish to the host parser: mobi_abi.cpp).
 //   mobi_ls_deps           one lane per intra macroblock of the clips the first kernel finished: the dependency lists (MbDesc.w4..w7).
 //   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
 //                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
 //
-// LDS per workgroup: ONE copy of the table blob (18 KB) for its four waves, and per wave and lane the motion-vector row cache (2 (mbw + 2)
+// LDS per workgroup: ONE copy of the table blob (18 KB) for its waves, and per wave and lane the motion-vector row cache (2 (mbw + 2)
 // words), the partition-tree stack (16), the intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all
 // lane-interleaved (element i of lane l at i * ls_clips + l), so that the lanes reading "their" element i hit different banks.
 // How many clips a wave carries is a launch argument (mobi_launch_parse_ls, with the measurements): a wave's life grows with the number of
@@ -65,8 +65,8 @@ __device__ __forceinline__ uint4 ls_chunk(const uint8_t *base, uint32_t o, uint3
 
 #ifndef MOBI_LS_WAVES
 #define MOBI_LS_WAVES 4 // waves per workgroup: they share one copy of the table blob in LDS (18 KB), everything else is a wave's own
-#endif
-extern "C" __global__ __launch_bounds__(64 * MOBI_LS_WAVES) void mobi_parse_frames_ls(MobiDevParseArgs A) {
+#endif             // (the launch's choice: 4, or 8 where two workgroups of four would not fit a CU's LDS -- mobi_launch_parse_ls)
+extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevParseArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int LS_CLIPS = A.ls_clips; // clips per wave (mobi_launch_parse_ls picks it: the launch is fastest with about two waves per SIMD)
   // A wave of this kernel is one long chain of dependent instructions and the launch is as long as that chain.  When the reconstruction of
@@ -83,12 +83,12 @@ extern "C" __global__ __launch_bounds__(64 * MOBI_LS_WAVES) void mobi_parse_fram
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
   m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
   m.lane = lane;
-  for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += 64 * MOBI_LS_WAVES) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
+  for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += (int)blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
-  for (int i = threadIdx.x; i < 1024; i += 64 * MOBI_LS_WAVES) ls_prepare_tables(tab, i);
+  for (int i = threadIdx.x; i < 1024; i += (int)blockDim.x) ls_prepare_tables(tab, i);
   __syncthreads();
 
-  const int clip = (blockIdx.x * MOBI_LS_WAVES + wave) * LS_CLIPS + lane;
+  const int clip = (int)(blockIdx.x * (blockDim.x >> 6) + wave) * LS_CLIPS + lane;
   const bool live = lane < LS_CLIPS && clip < A.n_clips && A.bit_len[clip < A.n_clips ? clip : 0] != MOBI_DP_SKIP; // (not the host parser's clips)
   const int n_mbs = A.mbw * A.mbh;
   LsCtx c;
@@ -191,27 +191,40 @@ extern "C" __global__ __launch_bounds__(64) void mobi_ls_deps(MobiDevParseArgs A
 extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->n_clips <= 0) return 0;
   if (a->mbw > 64 || !a->state_ls) return (int)hipErrorInvalidValue;
-  // Clips per wave.  A wave is one long chain of dependent look-ups: it runs until its slowest lane is done, a round costs what the different
-  // states of its lanes need, and alone on a SIMD it issues an instruction every ~20 clocks.  r04 gave every wave a SIMD of its own (32 clips
-  // per wave, each with its own 18 KB copy of the tables: 31 ms per P-frame step of 24576 clips, whatever the batch).  r05: four waves share a
-  // workgroup's copy of the tables, so that a CU holds twelve and more of them, and the clips are dealt to about TWO WAVES PER SIMD -- fewer
-  // clips per wave make every wave's life shorter, and two or three such chains interleave on a SIMD for nothing (tools/exp_lsab.sh,
-  // 24576 clips: 4 / 6 / 8 / 12 / 16 / 32 clips per wave = 40.7 / 43.0 / 27.0 / 25.7 / 27.9 / 31.3 ms -- below 8 the waves no longer all
-  // fit the chip at once; 8192 clips: 2 / 4 / 8 / 32 per wave = 26.5 / 18.2 / 29.1 / 31.5 ms).
+  // Clips per wave, waves per workgroup.  A wave is one long chain of dependent look-ups: it runs until its slowest lane is done, a round costs
+  // what the different states of its lanes need, and alone on a SIMD it issues an instruction every ~20 clocks.  r04 gave every wave a SIMD of
+  // its own (32 clips per wave, each with its own 18 KB copy of the tables: 31 ms per P-frame step of 24576 clips, whatever the batch).  r05:
+  // the waves of a workgroup share one copy of the tables, and the clips are dealt to about TWO WAVES PER SIMD = 2048 waves -- fewer clips per
+  // wave make every wave's life shorter, and two or three such chains interleave on a SIMD for nothing (tools/exp_lsab.sh, 24576 clips: 4 / 6
+  // / 8 / 12 / 16 / 32 clips per wave = 40.7 / 43.0 / 27.0 / 25.7 / 27.9 / 31.3 ms -- below 8 the waves no longer all fit the chip at once;
+  // 8192 clips: 2 / 4 / 8 / 32 per wave = 26.5 / 18.2 / 29.1 / 31.5 ms; 2048 clips: 1 / 2 = 9.2 / 15.3).
+  // A full machine's worth of waves goes out as ONE WORKGROUP OF EIGHT PER CU (256 workgroups).  With two workgroups of four per CU the launch
+  // is as fast on its own (25.9 ms either way) but not when the reconstruction of the step before runs beside it (asynchronous steps): a CU
+  // that is slow to free LDS and wave slots gets its second workgroup late or not at all, another CU takes a third, and the launch lasts two
+  // rounds -- 32768 clips: 68.9 ms per step against 39.9, 24576: 37.4 (16 per wave, r05's first rule) against 35.1, 16384: 34.8 against 28.7,
+  // 40960: 55.3 against 47.7 (tools/exp_async.py, profiles/r05_experiments.txt).  49152 clips (24 per wave, what 288 GB hold at 640x480) only
+  // fit a CU's LDS this way.
   const int per_clip = 4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
-  int L = a->lockstep == 2 ? 16 : (a->n_clips + 2047) / 2048; // (2: an asynchronous step -- 16 per wave: two workgroups of 61 KB per CU leave LDS for
-  L = L < 4 ? 4 : L > 64 ? 64 : L;                             //  the reconstruction of the step before, under which this parse runs)
+  auto lds_of = [&](int w, int l) { return (size_t)MOBI_DT_BYTES + (size_t)w * l * per_clip; };
+  const size_t lds_max = 160 * 1024;
+  int L = (a->n_clips + 2047) / 2048;
+  L = L < 1 ? 1 : L > 64 ? 64 : L;
+  while (L > 1 && lds_of(MOBI_LS_WAVES, L) > lds_max) L--; // (more than two waves per SIMD then: the launch takes turns, but runs)
+  int W = MOBI_LS_WAVES;
+  if ((a->n_clips + L - 1) / L > 1536 && lds_of(2 * W, L) <= lds_max) W *= 2;
 #if defined(MOBI_PROFILING)
-  if (const char *e = getenv("MOBI_LS_CLIPS")) L = atoi(e);    // (tools/exp_lsab.sh)
+  if (const char *e = getenv("MOBI_LS_CLIPS")) L = atoi(e);    // (tools/exp_lsab.sh, tests/test_lsparse_gpu.py)
+  if (const char *e = getenv("MOBI_LS_WG_WAVES")) W = atoi(e);
 #endif
+  if (L < 1 || L > 64 || W < 1 || W > 8) return (int)hipErrorInvalidValue;
   MobiDevParseArgs b = *a;
   b.ls_clips = L;
-  const size_t lds = MOBI_DT_BYTES + (size_t)MOBI_LS_WAVES * L * per_clip;
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  if (lds > 64 * 1024) // (per device; cheap)
+  const size_t lds = lds_of(W, L);
+  if (lds > lds_max) return (int)hipErrorInvalidValue;
+  if (lds > 64 * 1024) // (per device and per size; cheap)
     if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
-  const dim3 grid((unsigned)((a->n_clips + L * MOBI_LS_WAVES - 1) / (L * MOBI_LS_WAVES)));
-  hipLaunchKernelGGL(mobi_parse_frames_ls, grid, dim3(64 * MOBI_LS_WAVES), lds, s, b);
+  const dim3 grid((unsigned)((a->n_clips + L * W - 1) / (L * W)));
+  hipLaunchKernelGGL(mobi_parse_frames_ls, grid, dim3(64 * W), lds, s, b);
   const uint32_t chunks = (uint32_t)(a->mbw * a->mbh + 63) / 64;
   hipLaunchKernelGGL(mobi_ls_deps, dim3((unsigned)a->n_clips * chunks), dim3(64), 0, s, *a, chunks);
   return (int)hipGetLastError();

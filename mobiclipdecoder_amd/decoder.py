@@ -231,7 +231,7 @@ class MobiclipBatch:
 
     def __init__(self, n_clips, Width, Height, Version, device=None, device_parse=None):
         """device_parse: True = decode() parses the bitstreams on the GPU (one wavefront per clip, mobi_dparse.hip),
-        "lockstep" = the same with the lock-step parser in front (32 clips per wavefront, mobi_lsparse.hip),
+        "lockstep" = the same with the lock-step parser in front (clips in lock step, one per lane, mobi_lsparse.hip),
         False = on host threads, "hybrid" = most clips on the GPU and a fixed share (a fifth, at most 1024) on the host pool at the same
         time, None = library default (device parse from 20 clips per host parse thread, 640 at least; env MOBI_DEVICE_PARSE=0/1/2)."""
         self._lib = load_library()

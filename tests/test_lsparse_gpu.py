@@ -1,4 +1,4 @@
-"""The lock-step parser on the GPU (mobi_parse_frames_ls, mobi_lsparse.hip: 32 clips per wavefront, parse mode 3): the device-parse tests of
+"""The lock-step parser on the GPU (mobi_parse_frames_ls, mobi_lsparse.hip: clips in lock step, one per lane, parse mode 3): the device-parse tests of
 tests/test_device_parse.py once more with it in front -- oracle parity of planes, rc, Offset, Quantizer on good streams, on the streams the
 reference throws on (where it must hand the clip to mobi_parse_frames), on fuzzed streams against the host parser, and asynchronous steps --
 plus a check that it really finishes the intact frames itself instead of handing everything over."""
@@ -67,6 +67,37 @@ def test_intact_frames_are_finished_by_the_lock_step_parser_itself():
             y, uv = b.planes(i)
             assert np.array_equal(y, o[0]) and np.array_equal(uv, o[1]), (f, i)
         bad_hist.append(rcs[bad])
+    b.close()
+    for o in oras:
+        o.close()
+
+
+@pytest.mark.parametrize("clips_per_wave, waves", [(1, 4), (3, 8), (12, 8), (24, 8), (27, 8), (32, 4), (64, 2), (7, 1)])
+def test_every_shape_of_the_launch(clips_per_wave, waves, monkeypatch, profiling_library):
+    """mobi_launch_parse_ls deals the clips by batch size (1 .. 64 per wave, four or eight waves per workgroup: one workgroup per CU for a full
+    machine); a test batch is small and would only ever see one clip per wave.  The profiling twin takes both numbers from the environment:
+    every shape the product chooses somewhere, on 150 clips (so that the last wave and the last workgroup are partly empty), every clip
+    against the oracle at every frame, and every frame finished by the lock-step parser itself."""
+    monkeypatch.setenv("MOBI_LS_CLIPS", str(clips_per_wave))
+    monkeypatch.setenv("MOBI_LS_WG_WAVES", str(waves))
+    n, nfr = 150, 4
+    ps = [default_params("A", BASE_SEED + 5100 + (i % 37), n_frames=nfr, pm_intra=120, pm_deep=200, iframe_interval=3) for i in range(n)]
+    clips = [generate_clip(p) for p in ps[:37]]
+    b = MobiclipBatch(n, ps[0].width, ps[0].height, ps[0].version, device_parse="lockstep")
+    oras = [OracleDecoder(ps[0].width, ps[0].height, ps[0].version) for _ in range(37)]
+    for f in range(nfr):
+        datas = [clips[i % 37][0][clips[i % 37][1][f]:clips[i % 37][1][f + 1]] for i in range(n)]
+        rcs, offs = b.decode(datas, [0] * n)
+        assert b.lockstep_finished() == n, (f, b.lockstep_finished())
+        want = []
+        for k in range(37):
+            oras[k].Data, oras[k].Offset = datas[k], 0
+            want.append(oras[k].DecodeFrame())
+            assert oras[k].last_error == 0
+        for i in range(n):
+            assert rcs[i] == 0 and offs[i] == oras[i % 37].Offset, (f, i, rcs[i])
+            y, uv = b.planes(i)
+            assert np.array_equal(y, want[i % 37][0]) and np.array_equal(uv, want[i % 37][1]), (f, i)
     b.close()
     for o in oras:
         o.close()

@@ -281,6 +281,46 @@ def _fuzz_streams(n, seed):
     return out
 
 
+def test_the_payload_bound_the_device_arena_is_sized_by():
+    """mobi_abi.cpp dp_parse sizes a clip's part of the payload arena as 64 words per macroblock + one level word per THREE bits of the frame
+    (+ slack): every command list -- the device parsers' and the host parser's, which is copied over a clip's rows when it takes the clip
+    over -- has to fit, whatever the stream.  Clean and corrupted frames, both versions; and the reason it holds: no table code with a level
+    is shorter than three bits."""
+    blob = (C.c_uint8 * 65536)()
+    L = interp_lib()
+    if hasattr(L, "mobi_cmdinterp_tables"):
+        for ver in (1, 2):
+            n = L.mobi_cmdinterp_tables(ver, blob)
+            A = np.frombuffer(bytes(blob[:16384]), np.uint16)
+            short = A[(A & 15) < 3]
+            assert short.size and not np.any((short >> 4) & 31), "a table code with a level and fewer than three bits"
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for trial in range(120):
+        ver = 1 + trial % 2
+        p = default_params("AB"[trial % 2], BASE_SEED + 31000 + trial, n_frames=3, width=96, height=64, version=ver, pm_intra=150, pm_deep=250,
+                           escape_prob=120, table1_prob=400, qdelta_prob=200)
+        data, fo = generate_clip(p)
+        d = data.copy()
+        if trial % 3:
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(0, d.size))] ^= 1 << int(rng.integers(0, 8))
+        a = InterpDecoder(p.width, p.height, p.version)
+        n_mbs = (p.width // 16) * (p.height // 16)
+        for f in range(p.n_frames):
+            a.Data = d[: fo[f + 1]]
+            a.Offset = int(fo[f])
+            a.DecodeFrame()
+            if a.last_error != 0:
+                break
+            words, bits = int(a.payload().size), 8 * int(fo[f + 1] - fo[f])
+            bound = n_mbs * 64 + (bits + 2) // 3
+            assert words <= bound, (trial, f, words, bound)
+            worst = max(worst, words / bound)
+        a.close()
+    assert worst > 0.05  # (the check is not vacuous: real lists come within sight of the bound)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_gpu_every_parse_mode_gives_the_same_answer(mode):

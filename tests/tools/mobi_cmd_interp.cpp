@@ -336,5 +336,6 @@ void mobi_cmdinterp_tail(void *p, const MobiDevTail *in, MobiDevTail *out) {
   *out = *in;
   mobi_tail_finish(sc, f.payload.data(), scale, *in, *out);
 }
+int mobi_cmdinterp_tables(int version, uint8_t *out) { mobi_dparse_build_tables(version, out); return MOBI_DT_BYTES; } // (the device parsers' table blob)
 const uint32_t *mobi_cmdinterp_payload(void *p) { return ((Interp *)p)->pf.payload.data(); }
 }
