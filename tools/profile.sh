@@ -40,5 +40,6 @@ bash $REPO/tools/exp_fused.sh $TAG/fused_raw > "$OUT/fused.txt" 2>&1
 { for N in 256 512 1024 2048; do timeout 200 python $REPO/tools/exp_hostparse.py $N | tail -1; done; MOBI_HOST_CHUNK=0 timeout 200 python $REPO/tools/exp_hostparse.py 1024 | tail -1 | sed "s/^/no pipeline: /"; MOBI_PARSE_THREADS=32 timeout 200 python $REPO/tools/exp_hostparse.py 1024 | tail -1; } > "$OUT/hostparse.txt" 2>&1
 { timeout 600 python $REPO/tools/exp_dparse.py 4096 8192 24576 --device-both; } > "$OUT/lsparse.txt" 2>&1
 timeout 300 python $REPO/tools/exp_async.py 4096 12 > "$OUT/async.txt" 2>&1
-{ timeout 600 python $REPO/tools/fuzz_intra_gpu.py 2000 100; timeout 600 python $REPO/tools/fuzz_inter_gpu.py 3000 100; timeout 900 python $REPO/tools/soak_parity.py 4096 B; timeout 900 python $REPO/tools/soak_parity.py 8192 B lockstep; } > "$OUT/fuzz.txt" 2>&1
+{ for N in 8192 24576 49152; do echo "== $N clips, lock-step parser in front"; LOCKSTEP=1 timeout 300 python $REPO/tools/exp_async.py $N 8 | grep -E "^asynchronous|^synchronous"; done; } >> "$OUT/async.txt" 2>&1
+{ timeout 600 python $REPO/tools/fuzz_intra_gpu.py 2000 100; timeout 600 python $REPO/tools/fuzz_inter_gpu.py 3000 100; timeout 900 python $REPO/tools/soak_parity.py 4096 B; timeout 900 python $REPO/tools/soak_parity.py 8192 B lockstep; timeout 900 python $REPO/tools/exp_refusals.py 1500 --gpu; } > "$OUT/fuzz.txt" 2>&1
 ls "$OUT" > /dev/null
