@@ -43,6 +43,9 @@ ss, e2e, c4, cb = B["single_stream"], B["end_to_end"], B["config4"], B["cpu_base
 e2l = B.get("end_to_end_large") or {}
 if "value" not in e2l:
     e2l = {"value": 0, "ms_per_step": 0, "clips": 0, "async": {"value": 0, "ms_per_step": 0}}
+e2x = B.get("end_to_end_xl") or {}
+xl_text = (f" With as many clips as HBM holds (`end_to_end_xl`, {e2x['clips']} clips): {e2x['ms_per_step']:.1f} ms per step = **{e2x['value'] / 1e3:.0f} Gpixels/s**, "
+           f"asynchronous {e2x['async']['ms_per_step']:.1f} ms = **{e2x['async']['value'] / 1e3:.0f} Gpixels/s** (the lock-step parser's cost per clip falls with the batch).") if "value" in e2x else ""
 lf = B.get("content_lowfreq") or {}
 ver = B.get("verified") or {}
 text = f'''Results, MI355X, {RND} build (`profiles/{RND}_{{A,B,C}}_bench.json`; the rocprofv3 kernel-trace average of the same command,
@@ -91,7 +94,7 @@ End to end (`mobi_batch_decode`: bitstream bytes in host memory → planes in HB
 read-back of 32 B per clip, synchronisation): {e2e['ms_per_step']:.1f} ms per step of 4096 clips = {e2e['value'] / 1e3:.0f} Gpixels/s (`end_to_end`);
 `mobi_batch_submit` / `mobi_batch_wait` with two steps in flight: {e2e['async']['ms_per_step']:.1f} ms = {e2e['async']['value'] / 1e3:.0f} Gpixels/s (`end_to_end.async`).
 At the headline batch with the lock-step parser in front (`end_to_end_large`, {e2l['clips']} clips): {e2l['ms_per_step']:.1f} ms per step = **{e2l['value'] / 1e3:.0f} Gpixels/s**,
-asynchronous {e2l['async']['ms_per_step']:.1f} ms = **{e2l['async']['value'] / 1e3:.0f} Gpixels/s**. The parse is what such a step waits for (`HISTORY.md`, parsers). PCIe-inclusive rate of the
+asynchronous {e2l['async']['ms_per_step']:.1f} ms = **{e2l['async']['value'] / 1e3:.0f} Gpixels/s**.{xl_text} The parse is what such a step waits for (`HISTORY.md`, parsers). PCIe-inclusive rate of the
 *reconstruction* path fed with host-parsed command lists: ≈90 KB of commands per 640×480 frame, 10 % of the pixel bytes, 35 Gpixels/s with
 64 parse threads at 1024 clips (`profiles/{RND}_ubench.txt`, hostparse: parse, staging and upload pipelined; the parse, not PCIe, limits).
 '''
@@ -114,7 +117,7 @@ def pct(d):
 
 
 rows = [f"| A 256×192 Mods P-stream | 1 | {A['config']['clips_per_gpu']} | {n(A['value'])} | {gb(A, 'A')} | {pct(A)} | — | {A['cpu_baseline']['value']:.0f} / — | yes |",
-        f"| B 640×480 Moflex P-stream | 1 | {B['config']['clips_per_gpu']} | {n(B['value'])} | {gb(B, 'B')} | {pct(B)} | {n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous) (4096 clips, device parse); {n(e2l['value'])} ({n(e2l['async']['value'])}) at {e2l['clips']} clips, lock-step parse | {cb['value']:.0f} / {cb['all_cpus']['value']:.0f} (N = {cb['all_cpus']['cores']}) | yes |",
+        f"| B 640×480 Moflex P-stream | 1 | {B['config']['clips_per_gpu']} | {n(B['value'])} | {gb(B, 'B')} | {pct(B)} | {n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous) (4096 clips, device parse); {n(e2l['value'])} ({n(e2l['async']['value'])}) at {e2l['clips']} clips, lock-step parse" + (f"; {n(e2x['value'])} ({n(e2x['async']['value'])}) at {e2x['clips']}" if 'value' in e2x else '') + f" | {cb['value']:.0f} / {cb['all_cpus']['value']:.0f} (N = {cb['all_cpus']['cores']}) | yes |",
         f"| B, DC / low-frequency content profile (`content_lowfreq`) | 1 | {lf.get('clips', 0)} | {n(lf.get('value', 0))} | — | {lf.get('inter_frac', 0) * 100:.1f} / {lf.get('whole_step_frac', 0) * 100:.1f} | — | | yes |",
         f"| C 848×480 Moflex P-stream | 1 | {C['config']['clips_per_gpu']} | {n(C['value'])} | {gb(C, 'C')} | {pct(C)} | — | {C['cpu_baseline']['value']:.0f} / — | yes |",
         f"| B ×8 clips (64 over 8 GPUs) | 1 | 8 | {n(c4['value'])} | — | — | — | | yes |"]
