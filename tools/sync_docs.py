@@ -46,6 +46,7 @@ if "value" not in e2l:
 e2x = B.get("end_to_end_xl") or {}
 xl_text = (f" With as many clips as HBM holds (`end_to_end_xl`, {e2x['clips']} clips): {e2x['ms_per_step']:.1f} ms per step = **{e2x['value'] / 1e3:.0f} Gpixels/s**, "
            f"asynchronous {e2x['async']['ms_per_step']:.1f} ms = **{e2x['async']['value'] / 1e3:.0f} Gpixels/s** (the lock-step parser's cost per clip falls with the batch).") if "value" in e2x else ""
+xl_readme = f" and {e2x['value'] / 1e3:.0f} ({e2x['async']['value'] / 1e3:.0f}) at {e2x['clips']}" if "value" in e2x else ""
 lf = B.get("content_lowfreq") or {}
 ver = B.get("verified") or {}
 text = f'''Results, MI355X, {RND} build (`profiles/{RND}_{{A,B,C}}_bench.json`; the rocprofv3 kernel-trace average of the same command,
@@ -153,7 +154,7 @@ timed): {B['value'] / 1e3:.0f} Gpixels/s of reconstruction (command lists reside
 roofline counting only its own macroblocks' bytes, the whole step at {B['roofline']['whole_step_frac'] * 100:.0f} %, HBM traffic {ratio:.2f} × the algorithmic bytes, bit-exact
 (every clip of the batch checked after the timed region: the distinct streams against the oracle, the copies against their source on the device);
 {e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight) at 4096
-clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser, {hp1024} with the parse on 64 host threads at 1024 clips;
+clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser{xl_readme}, {hp1024} with the parse on 64 host threads at 1024 clips;
 ''' + (f'''the Bitmap of every clip (`mobi_yuv_to_argb`) at {B['bitmap']['roofline']['frac'] * 100:.0f} % of the roofline on its own 5.5 bytes per pixel; ''' if B.get('bitmap') and 'ms' in B['bitmap'] else '') + f'''one
 stream through `mobi_decode`: {ss['planes']['p_frame_ms']:.2f} ms per P-frame; {cb['value'] / 1e3:.2f} Gpixels/s for the CPU restatement of the reference on one host
 core ({cb['all_cpus']['value'] / 1e3:.1f} on all {cb['all_cpus']['cores']}). The planes live in HBM as macroblock tiles (`mobi_tile.h`): the reference's linear
