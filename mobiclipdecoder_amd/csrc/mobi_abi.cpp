@@ -767,7 +767,7 @@ static int dp_parse(mobi_batch *b, const uint8_t *d_bits, const DpStaged &st, bo
   pa.tail_in = b->d_ptail[in]; pa.tail_out = b->d_ptail[out];
   pa.scale = b->d_scale;
   pa.state_ls = b->d_pstate_ls;
-  pa.lockstep = b->lockstep ? (o.async ? 2 : 1) : 0; // (2: clips per wave chosen so that LDS is left for the reconstruction it runs under)
+  pa.lockstep = b->lockstep ? (o.async ? 2 : 1) : 0; // (2: an asynchronous step; the launch has had one shape for both since r05: mobi_launch_parse_ls)
   pa.pay_local = 1;
   pa.desc = (MbDesc *)(*o.desc).p;
   pa.payload = (uint32_t *)(*o.pay).p;
