@@ -1,4 +1,4 @@
-// mobi_lsparse.h -- the bitstream parser as a LOCK-STEP state machine: one clip per LANE, 64 clips per wave.
+// mobi_lsparse.h -- the bitstream parser as a LOCK-STEP state machine: one clip per LANE, 1 .. 64 clips per wave.
 //
 // mobi_dparse.hip runs the syntax walk of mobi_parse.cpp on one lane of a wave: 1060 vector + 800 scalar instructions per macroblock for
 // one clip, the other 63 lanes idle.  Here every lane of a wave owns a clip and all of them run the SAME instruction stream: the walk is cut
@@ -6,8 +6,9 @@
 // end) laid out in the order a macroblock passes through them; every round of the loop each lane executes the regions its state lets it
 // enter, falling through from one to the next, and a region costs the wave its instructions once however many lanes are in it.  The lanes
 // are never synchronised on macroblocks: each walks its own frame; the number of rounds is the longest lane's, and the law of large numbers
-// keeps that close to the mean (a frame is 1200 macroblocks).  Behind every round of the whole walk come cheap ones of "next block" and "one token"
-// only (ls_round: ls_next_fast, ls_token_fast): those two are most of what a frame consists of.
+// keeps that close to the mean (a frame is 1200 macroblocks).  Behind every round of the whole walk come cheap ones of "one token" only
+// (ls_round: ls_token_fast -- which also finds an inter macroblock's next block wherever that reads at most one bit): tokens are most of
+// what a frame consists of.
 //
 // This is the FAST path only.  It produces exactly what mobi_parse_frames produces (descriptors, payload, intra items, result record,
 // persistent state) for streams that decode without incident; at anything else -- every condition under which the reference throws, a
@@ -40,16 +41,20 @@ enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I
        LS_NEXT_SLOW, LS_TOKEN_SLOW }; // what the cheap rounds leave to the whole walk: a 4x4 area's pattern, an escape token, anything odd
 #define LS_MAGIC MOBI_LS_MAGIC
 #ifndef LS_K
-#define LS_K 3 // A/B on one box (tools/exp_lsab.sh): 1: 25.4, 2: 23.9, 3: 23.8, 4: 24.2, 5: 25.2, 6: 26.2 ms per P-frame step
+#define LS_K 3 // A/B on one box (tools/exp_lsab.sh, 24576 clips, 12 per wave): 2: 24.84, 3: 24.45, 4: 24.70, 5: 25.25 ms per P-frame step
 #endif
-enum { LS_TOKEN_ROUNDS = LS_K,  // ls_next_fast() + ls_token_fast() on their own this many times behind every round of the whole walk
+enum { LS_TOKEN_ROUNDS = LS_K,  // ls_token_fast() on its own this many times behind every round of the whole walk
        LS_ROUND_BYTES = 64, // what one such round can take from the ring at most (an intra macroblock's header and every area's mode in one visit:
-                            // ~310 bits, + 5 x (15 + 28) of the cheap rounds)
+                            // ~310 bits, + LS_K x (28 + 1) of the cheap rounds: a token and the 8x8 flag of the block behind it)
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
 // ls_refill() reads the ring without looking at the write pointer: a round must not be able to take more than LS_ROUND_BYTES from it.
-// The walk's worst case is ~310 bits, a cheap round's 15 + 28: beyond LS_K = 4 the sum passes 512 bits and a mis-tuned build would parse
+// The walk's worst case is ~310 bits, a cheap round's 28 + 1: beyond LS_K = 6 the sum passes 512 bits and a mis-tuned build would parse
 // stale ring bytes and still call the clip finished -- so such a build does not compile.
-static_assert(310 + LS_K * 43 <= LS_ROUND_BYTES * 8, "LS_K: the cheap rounds could outrun the bitstream ring");
+#if !defined(LS_CHEAP_NT)
+static_assert(311 + LS_K * 29 <= LS_ROUND_BYTES * 8, "LS_K: the cheap rounds could outrun the bitstream ring");
+#else
+static_assert(311 + LS_K * 44 <= LS_ROUND_BYTES * 8, "LS_K: the cheap rounds could outrun the bitstream ring");
+#endif
 
 struct LsCtx { // wave-uniform
   const uint8_t *T; // the table blob (mobi_dparse_tables.h)
@@ -459,7 +464,29 @@ LS_FN void ls_token_fast(LsLane &s, S &m, const LsCtx &c) {
       const int idx = (s.blk_flags & 4) ? T[((s.blk_flags & 1) ? MOBI_DT_ZZ8 : MOBI_DT_ZZ4) + p] : 0;
       s.blk_p = p + 1;
       s.pay[s.pay_base + s.mb_pay + s.hdr_words + s.n_coefs++] = (uint32_t)(s.blk_tile + idx) | ((uint32_t)(int)(int16_t)value << 16);
-      if (last & 1) s.st = (s.ret == LS_NEXT && !s.sub_mask && !s.area_mask) ? LS_MB_END : (s.ret == LS_I_FSUB && !s.sub_mask) ? LS_I_FIXED : s.ret;
+      if (last & 1) {
+        s.st = (s.ret == LS_NEXT && !s.sub_mask && !s.area_mask) ? LS_MB_END : (s.ret == LS_I_FSUB && !s.sub_mask) ? LS_I_FIXED : s.ret;
+#ifndef LS_NO_FOLD
+        // An inter macroblock's next block, where finding it reads at most one bit (ls_next_fast's first and third cases: the next 4x4 block
+        // of a pattern already read, an area coded as one 8x8 transform): the lane stays with its tokens instead of waiting for a visit of
+        // "next block" -- which served 2.4 lanes of 12 per visit and was a fifth of the walk's instructions (r05).  At least four bits are
+        // left in the window: the refill above left more than 32 and the longest token has 28.
+        if (s.st == LS_NEXT) {
+          const bool more4 = s.sub_mask != 0;
+          const bool next8 = !more4 && (ls_win(s) >> 31) != 0; // (area_mask != 0 here: the state would be LS_MB_END)
+          const int a = ls_ctz(more4 ? s.sub_mask : s.area_mask); // (the masks are not both zero)
+          s.sub_mask = more4 ? (s.sub_mask & (s.sub_mask - 1)) : s.sub_mask;
+          s.area_mask = next8 ? (s.area_mask & (s.area_mask - 1)) : s.area_mask;
+          s.t8mask |= next8 ? 1u << a : 0u;
+          ls_take(s, next8 ? 1 : 0);
+          s.blk_tile = more4 ? s.cur_area * 64 + a * 16 : next8 ? a * 64 : s.blk_tile;
+          s.blk_n = next8 ? 64 : s.blk_n; // (more4: the block before was a 4x4 one of the same area)
+          s.blk_flags = next8 ? (s.blk_flags | 1u) : s.blk_flags;
+          s.blk_p = 0;
+          s.st = (more4 || next8) ? LS_TOKEN : LS_NEXT;
+        }
+#endif
+      }
     }
   }
 }
@@ -590,6 +617,21 @@ LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
         s.area_mask = s.cbp6;
         s.sub_mask = 0;
         s.st = s.cbp6 ? LS_NEXT : LS_MB_END;
+#ifndef LS_NO_FOLD
+        // the first coded area as one 8x8 transform (one bit; at least 17 are left behind a pattern code of at most 15): straight to its tokens
+        if (s.cbp6 && s.quant >= 12 && (ls_win(s) >> 31)) {
+          const int a = ls_ctz(s.area_mask);
+          s.area_mask &= s.area_mask - 1;
+          ls_take(s, 1);
+          s.t8mask |= 1u << a;
+          s.blk_p = 0;
+          s.blk_n = 64;
+          s.blk_tile = a * 64;
+          s.blk_flags = 1u | (s.vlc == 1 ? 2u : 0u) | (s.tables_set ? 4u : 0u);
+          s.ret = LS_NEXT;
+          s.st = LS_TOKEN;
+        }
+#endif
       }
     }
   }
@@ -791,8 +833,12 @@ LS_FN void ls_round(LsLane &s, S &m, const LsCtx &c) {
   for (int k = 0; k < LS_TOKEN_ROUNDS; k++) {
     // The exit is the WAVE's (no lane has a block or a token to read), not the lane's: a lane leaving a loop on its own makes every piece of
     // its state a value that has to be kept apart from the others' -- a third of the loop's vector instructions were register copies.
+#if !defined(LS_CHEAP_NT) // (r05: "next block" is folded into the token part wherever it reads at most one bit; what is left of it -- a 4x4
+    if (!LS_ANY(s.st == LS_TOKEN)) break; //  pattern, 420 of a frame's 2500 -- waits for the round's one visit: 24.97 -> 24.45 ms)
+#else
     if (!LS_ANY(s.st == LS_TOKEN || s.st == LS_NEXT)) break;
     ls_next_fast(s, m, c);
+#endif
     ls_token_fast(s, m, c);
   }
 }
