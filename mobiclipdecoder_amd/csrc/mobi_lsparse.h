@@ -246,6 +246,18 @@ LS_FN int ls_pmode(LsLane &s, S &m, int ci, bool four) {
 }
 // one motion-compensated leaf (MD.cs:400-456): would CopyBlock throw?  then bail out.  Its cells go straight into the cell map when the
 // macroblock is split (the map is only kept if it turns out to be more than two halves)
+// one leaf's cells of the 8 x 8 MV cell map at the head of the macroblock's payload (a row of the leaf at a time: 8, 4, 2 or 1 cells; the lanes
+// of a wave run as many rows as the tallest leaf has)
+LS_FN void ls_cells(LsLane &s, int x, int y, int wi, int hi, uint32_t cell) {
+  const int w = 16 >> wi, h = 16 >> hi;
+  uint32_t *cells = s.pay + s.pay_base + s.mb_pay + (y >> 1) * 8 + (x >> 1);
+  for (int r = 0; r < (h >> 1); r++, cells += 8) {
+    if (w == 16) { LS_STORE4(cells, cell); LS_STORE4(cells + 4, cell); }
+    else if (w == 8) LS_STORE4(cells, cell);
+    else if (w == 4) { cells[0] = cell; cells[1] = cell; }
+    else cells[0] = cell;
+  }
+}
 template <class S>
 LS_FN void ls_leaf(LsLane &s, S &m, const LsCtx &c, int wi, int hi, int x, int y, int ref, int dx, int dy) {
   const int w = 16 >> wi, h = 16 >> hi, S_ = c.stride;
@@ -265,16 +277,26 @@ LS_FN void ls_leaf(LsLane &s, S &m, const LsCtx &c, int wi, int hi, int x, int y
   s.l0a = first ? w0 : s.l0a; s.l0b = first ? w1 : s.l0b;
   s.l1a = second ? w0 : s.l1a; s.l1b = second ? w1 : s.l1b;
   s.nleaf++;
-  if (wi | hi) { // (a row of the leaf at a time: 8, 4, 2 or 1 cells; the lanes of a wave run as many rows as the tallest leaf has)
-    uint32_t *cells = s.pay + s.pay_base + s.mb_pay + (y >> 1) * 8 + (x >> 1);
-    const uint32_t cell = mobi_cell(dx, dy, ref);
-    for (int r = 0; r < (h >> 1); r++, cells += 8) {
-      if (w == 16) { LS_STORE4(cells, cell); LS_STORE4(cells + 4, cell); }
-      else if (w == 8) LS_STORE4(cells, cell);
-      else if (w == 4) { cells[0] = cell; cells[1] = cell; }
-      else cells[0] = cell;
+#ifdef LS_CELLS_ALWAYS
+  if (wi | hi) ls_cells(s, x, y, wi, hi, mobi_cell(dx, dy, ref));
+#else
+  // The MV cell map is only read for deeper trees: a macroblock of one or two leaves travels as leaf records (MbDesc, hdr_words = 0: its
+  // level words start where the map would).  Two leaves are 44 % of the macroblocks, and their cells -- 4 or 8 rows of stores that the
+  // whole wave steps through -- were written for nothing: they wait in the lane's two leaf records until a third leaf says the map is needed.
+  if (s.nleaf >= 3) {
+    if (s.nleaf == 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+      for (int k = 0; k < 2; k++) {
+        const uint32_t a = k ? s.l1a : s.l0a, b = k ? s.l1b : s.l0b;
+        ls_cells(s, (int)(a & 15) * 2, (int)((a >> 4) & 15) * 2, (int)((a >> 8) & 3), (int)((a >> 10) & 3),
+                 mobi_cell((int)(int16_t)(b & 0xFFFF), (int)(int16_t)(b >> 16), (int)((a >> 12) & 7)));
+      }
     }
+    ls_cells(s, x, y, wi, hi, mobi_cell(dx, dy, ref));
   }
+#endif
 }
 LS_FN int ls_classify(const LsLane &s) {
   if (s.nleaf != 2) return MOBI_DUAL_NONE;
