@@ -493,7 +493,7 @@ LS_FN void ls_token_fast(LsLane &s, S &m, const LsCtx &c) {
         // of a pattern already read, an area coded as one 8x8 transform): the lane stays with its tokens instead of waiting for a visit of
         // "next block" -- which served 2.4 lanes of 12 per visit and was a fifth of the walk's instructions (r05).  At least four bits are
         // left in the window: the refill above left more than 32 and the longest token has 28.
-        if (s.st == LS_NEXT) {
+        if (s.st == LS_NEXT || s.st == LS_I_FSUB) { // (LS_I_FSUB: the next 4x4 block of an intra area whose pattern is read: sub_mask != 0)
           const bool more4 = s.sub_mask != 0;
           const bool next8 = !more4 && (ls_win(s) >> 31) != 0; // (area_mask != 0 here: the state would be LS_MB_END)
           const int a = ls_ctz(more4 ? s.sub_mask : s.area_mask); // (the masks are not both zero)
