@@ -107,8 +107,8 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
  * reconstruction launches serves both.  3 = as 1 with the lock-step parser in front of EVERY step (mobi_lsparse.hip: a few clips per
  * wavefront, one per lane, all lanes in one instruction stream): it finishes the frames that decode without incident -- identically, word
  * for word -- and leaves every other clip to the one-wavefront-per-clip parser, which then runs for those alone.  By default the parser in
- * front is chosen step by step: the lock-step parser from 6144 clips (26 ms per 640x480 P-frame step of 24576 clips against 57) and for
- * I-frame steps from 768 clips (16 ms against 30 at 4096 clips); 1 = never.
+ * front is chosen step by step: the lock-step parser from 5120 clips (23 ms per 640x480 P-frame step of 24576 clips against 57) and for
+ * I-frame steps from 768 clips (15 ms against 30 at 4096 clips); 1 = never.
  * THE RESULT DOES NOT DEPEND ON THE MODE (r05).  The device parsers finish the frames that decode without incident.  A frame they cannot
  * finish -- anything the reference throws on, a coefficient run that walks through `Internal` (MD.cs:3424-3429), a ModsDS quantiser below
  * 12, a value the command list has to escape -- is parsed again by the host parser inside the same call (mobi_batch_wait for asynchronous

@@ -662,7 +662,7 @@ struct DpStaged { size_t hdr_bytes = 0, bytes = 0, max_len = 0; int n_dev = 0, n
 static bool ls_decide(const mobi_batch *b, const DpStaged &st) {
   if (b->ls_policy != 2) return b->ls_policy == 1;
   const bool iframe_step = 2 * st.n_iframes > st.n_dev;
-  return st.n_dev >= 6144 || (iframe_step && st.n_dev >= 768);
+  return st.n_dev >= 5120 || (iframe_step && st.n_dev >= 768);
 }
 // dev != nullptr: the image is also sent to *dev on `up`, chunk by chunk while the next chunk is gathered (one thread of the pool sits in
 // the copy calls, which return when the bus is done: 8 ms for the 370 MB of a step of 24576 clips; the others gather) -- r04: gathering and
