@@ -506,6 +506,30 @@ LS_FN void ls_token_fast(LsLane &s, S &m, const LsCtx &c) {
           s.blk_flags = next8 ? (s.blk_flags | 1u) : s.blk_flags;
           s.blk_p = 0;
           s.st = (more4 || next8) ? LS_TOKEN : LS_NEXT;
+#ifndef LS_NO_FOLD_PATTERN
+          // ... and the third case, an area coded as 4x4 blocks: its pattern (MD.cs:2917-2927; up to 15 bits: a refill first) and the
+          // first block of it.  With that "next block" has no visits of its own left in a stream that decodes without incident.
+          if (LS_ANY(s.st == LS_NEXT)) {
+            if (s.st == LS_NEXT) {
+              ls_refill(s, m);
+              const uint32_t w = ls_win(s); // (its first bit is 0)
+              const int z = ls_clz(w);
+              const uint32_t u = (z ? ((w << (z + 1)) >> (32 - z)) : 0u) + (1u << z) - 1u;
+              const uint32_t pat = (z < 8 && u < 16) ? c.T[MOBI_DT_CBP4_P + u] : 0u;
+              if (pat) { // (anything else -- a code the table does not have, a pattern without blocks -- is left to ls_next_fast / ls_next)
+                const int ar = ls_ctz(s.area_mask), sub = ls_ctz(pat);
+                s.area_mask &= s.area_mask - 1;
+                ls_take(s, 2 * z + 1);
+                s.cur_area = ar;
+                s.sub_mask = pat & (pat - 1);
+                s.blk_tile = ar * 64 + sub * 16;
+                s.blk_n = 16;
+                s.blk_flags &= ~1u;
+                s.st = LS_TOKEN;
+              }
+            }
+          }
+#endif
         }
 #endif
       }
@@ -653,6 +677,27 @@ LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
           s.ret = LS_NEXT;
           s.st = LS_TOKEN;
         }
+#ifndef LS_NO_FOLD_PATTERN
+        else if (s.cbp6 && s.quant >= 12) { // ... or as 4x4 blocks: the pattern (a code of at most 15 bits whose first is that 0; 17 are left)
+          const uint32_t w = ls_win(s);
+          const int z = ls_clz(w | 1u);
+          const uint32_t u = (z ? ((w << (z + 1)) >> (32 - z)) : 0u) + (1u << z) - 1u;
+          const uint32_t pat = (z < 8 && u < 16) ? T[MOBI_DT_CBP4_P + u] : 0u;
+          if (pat) {
+            const int ar = ls_ctz(s.area_mask), sub = ls_ctz(pat);
+            s.area_mask &= s.area_mask - 1;
+            ls_take(s, 2 * z + 1);
+            s.cur_area = ar;
+            s.sub_mask = pat & (pat - 1);
+            s.blk_p = 0;
+            s.blk_n = 16;
+            s.blk_tile = ar * 64 + sub * 16;
+            s.blk_flags = (s.vlc == 1 ? 2u : 0u) | (s.tables_set ? 4u : 0u);
+            s.ret = LS_NEXT;
+            s.st = LS_TOKEN;
+          }
+        }
+#endif
 #endif
       }
     }
