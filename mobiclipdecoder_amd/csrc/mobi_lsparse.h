@@ -44,16 +44,19 @@ enum { LS_DONE = 0, LS_MB_BEGIN, LS_NODE, LS_P_CBP, LS_I_HDR, LS_I_SUBAREA, LS_I
 #define LS_K 3 // A/B on one box (tools/exp_lsab.sh, 24576 clips, 12 per wave): 2: 24.84, 3: 24.45, 4: 24.70, 5: 25.25 ms per P-frame step
 #endif
 enum { LS_TOKEN_ROUNDS = LS_K,  // ls_token_fast() on its own this many times behind every round of the whole walk
-       LS_ROUND_BYTES = 64, // what one such round can take from the ring at most (an intra macroblock's header and every area's mode in one visit:
-                            // ~310 bits, + LS_K x (28 + 1) of the cheap rounds: a token and the 8x8 flag of the block behind it)
+       LS_ROUND_BYTES = 64, // what one round can take from the ring at most (below)
        LS_RING = 128 };      // bytes of bitstream per lane in LDS
-// ls_refill() reads the ring without looking at the write pointer: a round must not be able to take more than LS_ROUND_BYTES from it.
-// The walk's worst case is ~310 bits, a cheap round's 28 + 1: beyond LS_K = 6 the sum passes 512 bits and a mis-tuned build would parse
-// stale ring bytes and still call the clip finished -- so such a build does not compile.
+// ls_refill() reads the ring without looking at the write pointer: a round must not be able to take more than LS_ROUND_BYTES from it, or a
+// mis-tuned build would parse stale ring bytes and still call the clip finished -- so such a build does not compile.  A round
+// is the macroblock part, the intra part, "next block", LS_K + 1 token parts; the most a lane can take on its way through them:
+//   an intra macroblock   a partition code that says "intra" (12 bits) + the header and every area's mode in one visit of the intra part
+//                         (~310) + a token (28; what follows a block of an intra macroblock reads nothing here) per token part
+//   an inter macroblock   a partition code and two vector components (12 + 2 x 15), the coded-block pattern and the first area's flag or
+//                         4x4 pattern (15 + 15), "next block" (15), and per token part a token and the next area's flag or pattern (28 + 15)
 #if !defined(LS_CHEAP_NT)
-static_assert(311 + LS_K * 29 <= LS_ROUND_BYTES * 8, "LS_K: the cheap rounds could outrun the bitstream ring");
+static_assert(12 + 310 + (LS_K + 1) * 28 <= LS_ROUND_BYTES * 8 && 72 + 15 + (LS_K + 1) * 43 <= LS_ROUND_BYTES * 8, "LS_K: a round could outrun the bitstream ring");
 #else
-static_assert(311 + LS_K * 44 <= LS_ROUND_BYTES * 8, "LS_K: the cheap rounds could outrun the bitstream ring");
+static_assert(12 + 310 + (LS_K + 1) * 43 <= LS_ROUND_BYTES * 8 && 72 + (LS_K + 1) * (15 + 43) <= LS_ROUND_BYTES * 8, "LS_K: a round could outrun the bitstream ring");
 #endif
 
 struct LsCtx { // wave-uniform
