@@ -355,4 +355,81 @@ int mobi_lshost_compare(uint32_t w, uint32_t h, int version, const uint8_t *data
   mobi_lshost_destroy(C);
   return ok;
 }
+// ---- r06: what does a frame's PARSE need from the frame before it?  (measure before building frame-parallel lanes)
+// Every frame f of the clip is parsed twice: by parser A in stream order, and by a parser B that starts from A's state before the frame with
+// everything the frame header does not fix POISONED -- the 16 interior bytes of the intra-mode cache (Internal bytes 9..12, 17..20, 25..28,
+// 33..36: MD.cs:1840-1859, 2785-2843 only ever read a byte some block of the same macroblock wrote, or a border byte that
+// SetupQuantizationTables sets, :3913-3924) = 0xFF, and the MV predictor Internal[219], [220] (set per macroblock before it is read,
+// MD.cs:207-208).  stats: [0] frames compared (A's state before them is one the device parsers hold), [1] frames whose command list, rc and
+// Offset are the same from the poisoned state, [2] frames whose state AFTERWARDS is A's once the bytes B did not write (still 0xFF) are taken
+// from A's state before the frame, [3] frames skipped (host-only state), [4] the same comparison ([1] and [2] at once) for the lock-step
+// parser's lane functions, [5] lane-function frames that bailed out (not compared).
+int mobi_framedep_measure(uint32_t w, uint32_t h, int version, const uint8_t *data, const uint32_t *frame_off, int n_frames, long stats[6]) {
+  MobiStreamParser A(w, h, version);
+  Clip *C = (Clip *)mobi_lshost_create(w, h, version);
+  if (!C) return -1;
+  ParsedFrame pa, pb;
+  static const int interior[16] = {9, 10, 11, 12, 17, 18, 19, 20, 25, 26, 27, 28, 33, 34, 35, 36};
+  for (int k = 0; k < 6; k++) stats[k] = 0;
+  bool ready = true; // a new decoder's state is the device's
+  for (int f = 0; f < n_frames; f++) {
+    const uint8_t *d = data + frame_off[f];
+    const size_t len = frame_off[f + 1] - frame_off[f];
+    MobiDevState s0, s1;
+    MobiDevTail t0, t1;
+    A.export_state(s0, t0);
+    int32_t offa = 0, offb = 0;
+    const int rca = A.parse_frame(d, len, &offa, pa);
+    A.export_state(s1, t1);
+    if (!ready) { stats[3]++; ready = A.device_ready(); continue; }
+    MobiDevState sp = s0;
+    for (int i : interior) sp.mcache[i] = 0xFF;
+    sp.predx = 0x5A5A; sp.predy = -0x2525;
+    MobiStreamParser B(w, h, version);
+    B.import_state(sp, t0);
+    const int rcb = B.parse_frame(d, len, &offb, pb);
+    stats[0]++;
+    bool same = rca == rcb && offa == offb;
+    if (same && rca == MOBI_OK)
+      same = pa.payload == pb.payload && pa.intra_mbs == pb.intra_mbs && pa.intra_items == pb.intra_items && pa.desc.size() == pb.desc.size() &&
+             memcmp(pa.desc.data(), pb.desc.data(), pa.desc.size() * sizeof(MbDesc)) == 0 && memcmp(&pa.hdr, &pb.hdr, sizeof(FrameHdr)) == 0;
+    if (same) stats[1]++;
+    else fprintf(stderr, "framedep: frame %d parses differently from a poisoned state (rc %d / %d)\n", f, rca, rcb);
+    if (A.device_ready()) { // the state afterwards, merged the way a chain of frame-parallel lanes would merge it
+      MobiDevState sb;
+      MobiDevTail tb;
+      B.export_state(sb, tb);
+      for (int i : interior) if (sb.mcache[i] == 0xFF) sb.mcache[i] = s0.mcache[i];
+      if (pa.hdr.frame_type == 1 || rca != MOBI_OK) { if (sb.predx == 0x5A5A) sb.predx = s0.predx; if (sb.predy == -0x2525) sb.predy = s0.predy; }
+      if (memcmp(&sb, &s1, sizeof(sb)) == 0 && memcmp(&tb, &t1, sizeof(tb)) == 0) stats[2]++;
+      else fprintf(stderr, "framedep: frame %d leaves a different state from a poisoned start\n", f);
+    } else
+      stats[2]++; // (the host parser keeps the clip: nothing to merge)
+    // the lock-step parser's lane functions from the same poisoned state
+    {
+      C->quant = sp.quant; C->yuvfmt = sp.yuvfmt; C->tables_set = sp.tables_set; C->frames_started = sp.frames_started; C->predx = sp.predx; C->predy = sp.predy;
+      memcpy(C->m.mc_, sp.mcache, 40);
+      for (int i = 0; i < 2 * (C->g.mbw + 2); i++) C->m.mvc_[i] = t0.mvc[i];
+      int32_t used = 0;
+      uint32_t n_intra = 0, pay_words = 0, ftype = 0;
+      const int bail = mobi_lshost_parse(C, d, len, &used, &n_intra, &pay_words, &ftype);
+      if (bail) stats[5]++;
+      else {
+        bool eq = rca == MOBI_OK && used == offa && pay_words == pa.payload.size() && n_intra == pa.hdr.n_intra && C->quant == s1.quant && C->tables_set == s1.tables_set &&
+                  C->yuvfmt == s1.yuvfmt && memcmp(C->pay.data(), pa.payload.data(), pa.payload.size() * 4) == 0;
+        for (size_t mb = 0; eq && mb < pa.desc.size(); mb++) eq = C->desc[mb].payload_off == pa.desc[mb].payload_off && C->desc[mb].w1 == pa.desc[mb].w1 && C->desc[mb].w2 == pa.desc[mb].w2 && C->desc[mb].w3 == pa.desc[mb].w3;
+        uint8_t mc[40];
+        memcpy(mc, C->m.mc_, 40);
+        for (int i : interior) if (mc[i] == 0xFF) mc[i] = s0.mcache[i];
+        eq = eq && memcmp(mc, s1.mcache, 40) == 0;
+        if (ftype == 0) eq = eq && C->predx == s1.predx && C->predy == s1.predy;
+        if (eq) stats[4]++;
+        else fprintf(stderr, "framedep: frame %d: the lock-step lane functions differ from a poisoned state\n", f);
+      }
+    }
+    ready = A.device_ready();
+  }
+  mobi_lshost_destroy(C);
+  return 0;
+}
 }
