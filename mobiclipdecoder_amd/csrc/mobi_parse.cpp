@@ -142,7 +142,9 @@ void MobiStreamParser::export_state(MobiDevState &st, MobiDevTail &tail) {
 uint32_t MobiStreamParser::internal_word(uint32_t idx) { return internal_read(idx); }
 bool MobiStreamParser::device_ready() const {
   if (!last_frame_ok_ || frame_literal_ || frame_host_only_) return false;
-  if (tq_ != quant_ && tq_ != MOBI_TQ_NONE) return false; // (tables of another quantiser than Quantizer: the device's state has one field for both)
+  if (tq_ != quant_ && (tq_ != MOBI_TQ_NONE || quant_ != 0)) return false; // tables of another quantiser than Quantizer, or none at all under a Quantizer that is
+                                                                           // not 0 (a first SetupQuantizationTables that threw, ModsDS q >= 54): the device's state has
+                                                                           // one field for both and would name scale row `quant` where this parser names tq_
   for (uint32_t v : itail_)
     if (v) return false;
   return true;

@@ -424,7 +424,8 @@ int mobi_framedep_measure(uint32_t w, uint32_t h, int version, const uint8_t *da
         eq = eq && memcmp(mc, s1.mcache, 40) == 0;
         if (ftype == 0) eq = eq && C->predx == s1.predx && C->predy == s1.predy;
         if (eq) stats[4]++;
-        else fprintf(stderr, "framedep: frame %d: the lock-step lane functions differ from a poisoned state\n", f);
+        else fprintf(stderr, "framedep: frame %d: the lock-step lane functions differ from a poisoned state (rc %d, consumed %d / %d, payload %u / %zu, intra %u / %u, quant %u / %u, tables %u / %u)\n", f, rca, used, offa,
+                     pay_words, pa.payload.size(), n_intra, pa.hdr.n_intra, C->quant, s1.quant, C->tables_set, s1.tables_set);
       }
     }
     ready = A.device_ready();
