@@ -146,6 +146,29 @@ int mobi_batch_lockstep_finished(const mobi_batch *b);
 int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets);
 int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc);
 int mobi_batch_in_flight(const mobi_batch *b); /* steps submitted and not yet waited for: 0, 1 or 2 */
+/* Frame-parallel groups (r06): K = n_frames consecutive frames of EVERY clip in one call, 1 <= K <= 6 (the ring holds six pictures,
+ * MD.cs:19-20: every frame of the group is still there when the call returns -- frame k of the group at ring_idx K - 1 - k).  For callers
+ * that hold whole packets of a clip's next frames -- what the Moflex / Mods demuxers deliver (MoLiveDemux.cs:349-358, ModsDemuxer.cs:97-117);
+ * not for MOC5-style callers whose next Offset is only known once the frame before has been parsed.  All arrays are [k * n_clips + c]:
+ * frame k of clip c is data[..][offsets[..] .. len[..]), exactly what K calls of mobi_batch_decode would have been given; rc[..] and the
+ * Offsets after the frames come back the same way, and rc, Offset, Quantizer and planes ARE what those K calls give (tests: fuzzed
+ * streams, every parse mode).  What it buys: a frame's PARSE needs from the frame before it only what the frame headers determine
+ * (Quantizer, YuvFormat, the frame count: MD.cs:113-143, 224-236, 3884-3925; measured, profiles/r06_framedep.txt), so the device parsers
+ * run over n_clips * K frames side by side -- and their cost per frame falls with the number of lanes they are given -- while the
+ * reconstruction stays one step per frame, in order.  A start state predicted wrong, like a frame the device parsers do not finish,
+ * hands that clip's remaining frames to the host parser inside the same call (the prediction can cost time, never the result).
+ *   mobi_batch_decode_gop: the whole group, synchronously.  A batch that parses on the host (small batches; mobi_batch_set_parse_mode(b, 0))
+ *                          simply runs its K steps one after the other.
+ *   mobi_batch_gop_begin / mobi_batch_gop_finish: the same in two halves, for callers that keep the GPU fed: begin gathers and uploads a
+ *                          group (and starts its parse when no group is in front of it) and returns; finish reports the OLDEST group
+ *                          begun and not finished.  At most two groups may be begun: with group g + 1 begun before group g is finished,
+ *                          its upload and parse run beside group g's reconstruction.  The batch must parse on the GPU (as for
+ *                          mobi_batch_submit).  The ring turns in finish, K times; planes are read after finish.
+ * mobi_batch_decode / mobi_batch_submit are refused (MOBI_E_ARG) while a group is begun and not finished. */
+int mobi_batch_decode_gop(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
+int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, const int32_t *offsets);
+int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc);
+int mobi_batch_gop_in_flight(const mobi_batch *b); /* groups begun and not yet finished: 0, 1 or 2 */
 /* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
 float mobi_batch_last_decode_ms(const mobi_batch *b);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);

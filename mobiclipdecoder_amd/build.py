@@ -61,7 +61,7 @@ def build_hip(force=False, profiling=False):
     """profiling=True (python -m mobiclipdecoder_amd.build --profiling, tools/ only): a SECOND library, libmobiclip_hip_prof.so, with
     -DMOBI_PROFILING: the ablation / occupancy / stage-stop switches (MOBI_INTRA_DBG, MOBI_LDS_PAD, MOBI_INTRA_LDS_PAD, MOBI_STOP_STAGE,
     MOBI_DEBUG=9) and the mobi_debug_* test hooks.  The product library has none of them; tools select the other one with MOBI_LIB."""
-    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip", "mobi_dparse.hip", "mobi_lsparse.hip", "mobi_analysis.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("mobi_abi.cpp", "mobi_parse.cpp", "mobi_demux.cpp", "mobi_moflex.cpp", "mobi_kernels.hip", "mobi_rgb.hip", "mobi_dparse.hip", "mobi_lsparse.hip", "mobi_gop.hip", "mobi_analysis.hip")]
     deps = srcs + _hdrs(CSRC) + [os.path.join(ROOT, "include", "mobiclip_hip.h"), os.path.join(ROOT, "include", "mobiclip_demux.h"), os.path.abspath(__file__)]
     lib = LIB_HIP_PROF if profiling else LIB_HIP
     if not force and not _newer(lib, deps):

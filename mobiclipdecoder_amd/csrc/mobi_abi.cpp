@@ -20,6 +20,8 @@
 #include "../../include/mobiclip_hip.h"
 #include "mobi_cmd.h"
 #include "mobi_dparse.h"
+#define MOBI_GOP_DEVICE_DECLS
+#include "mobi_gop.h"
 #include "mobi_kernels.h"
 #include "mobi_tile.h"
 #include "mobi_parse.h"
@@ -310,6 +312,26 @@ struct mobi_batch {
     std::vector<uint32_t> host_quant, host_yuv; // Quantizer / YuvFormat behind that frame (the parser itself may be a step further by the time of wait)
   };
   AsyncSlot aslot[2];
+  // frame-parallel groups (mobi_batch_gop_begin / mobi_batch_gop_finish, mobi_gop.h): K frames of every clip parsed side by side as n * K
+  // virtual clips (v = k * n + c), reconstructed as K steps.  Two slots: the bytes of group g + 1 are gathered and uploaded, and its parse
+  // enqueued, while group g is reconstructed.
+  struct GopSlot {
+    PinnedBuf h_stage, h_res, h_fault, h_over[MOBI_GOP_MAX], h_seed, h_ret;
+    DevBuf d_bits, d_desc, d_pay, d_items, d_res, d_sin, d_sout, d_sls, d_tails, d_fault;
+    hipEvent_t ev_up = nullptr, ev_parsed = nullptr;
+    int K = 0;
+    size_t hdr_bytes = 0, bytes = 0, max_len = 0, cap_words = 0;
+    int n_iframes = 0;
+    bool parse_enqueued = false, lockstep = false;
+    int ring_in = 0;                 // the state ring entry the group's parse read
+    std::vector<uint64_t> boff;      // [v] where the frame's bytes start in the staged image (behind its header)
+    std::vector<uint32_t> lens;      // [v] their number (the header's copy carries MOBI_DP_SKIP for the host parser's clips)
+    std::vector<int32_t> offs;       // [v] Offset at submission
+    std::vector<uint8_t> is_host;    // [c] the host parser's clip when the parse was enqueued
+  };
+  GopSlot gslot[2];
+  int gop_head = 0, gop_count = 0;
+  std::vector<ParsedFrame> gop_frames; // host-parsed frames of the group being finished
   hipStream_t stream_p = nullptr;      // asynchronous steps: the parse kernels (upload on stream2, reconstruction on stream)
   int async_head = 0, async_count = 0; // oldest step in flight, number of steps in flight (<= 2)
   size_t dp_len_hint = 0;              // longest frame seen so far (+ 25 %): sizes the payload arena of the device-side parser
@@ -410,6 +432,10 @@ struct mobi_batch {
     drain_events();
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (ev_up) (void)hipEventDestroy(ev_up);
+    for (auto &gs : gslot) {
+      if (gs.ev_up) (void)hipEventDestroy(gs.ev_up);
+      if (gs.ev_parsed) (void)hipEventDestroy(gs.ev_parsed);
+    }
     for (auto &sl : aslot) {
       if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
       if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
@@ -791,12 +817,17 @@ static int dp_parse(mobi_batch *b, const uint8_t *d_bits, const DpStaged &st, bo
 // staged in pinned memory and copied into the clips' own rows of what the parse kernels leave -- descriptor rows, payload parts, item
 // rows, result records -- on stream s.  Runs of neighbouring clips (the hybrid mode's share) go as one copy per table.
 struct DpRows { uint8_t *desc, *pay, *items; MobiDevResult *res; size_t cap_words; };
-static int dp_override(mobi_batch *b, const std::vector<int> &clips, const int *rc, PinnedBuf &stage, const DpRows &d, hipStream_t s) {
+// frames != nullptr: frames[j] is clips[j]'s parsed frame (nullptr: it failed) and rcs[j] its rc -- both by POSITION in `clips` (the
+// frame-parallel path: a clip has K frames); else b->cur[c] and rc[c] by clip.
+static int dp_override(mobi_batch *b, const std::vector<int> &clips, const int *rc, PinnedBuf &stage, const DpRows &d, hipStream_t s,
+                       const ParsedFrame *const *frames = nullptr, const int *rcs = nullptr) {
   const int k = (int)clips.size(), n_mbs = b->g.mbw * b->g.mbh;
   if (k == 0) return MOBI_OK;
+  auto frame_of = [&](int j) -> const ParsedFrame * { return frames ? frames[j] : (rc[clips[j]] == MOBI_OK ? &b->cur[clips[j]] : nullptr); };
+  auto rc_of = [&](int j) { return frames ? rcs[j] : rc[clips[j]]; };
   size_t pitch_w = 0; // payload words per clip in the staging area
-  for (int c : clips)
-    if (rc[c] == MOBI_OK) pitch_w = std::max(pitch_w, b->cur[c].payload.size());
+  for (int j = 0; j < k; j++)
+    if (const ParsedFrame *f = frame_of(j)) pitch_w = std::max(pitch_w, f->payload.size());
   pitch_w = align_up(pitch_w + 4, 4);
   if (pitch_w > d.cap_words) return MOBI_E_DEVICE; // cannot happen: cap_words bounds any clip's payload
   const size_t desc_b = (size_t)n_mbs * sizeof(MbDesc), item_b = (size_t)n_mbs * 4, res_b = sizeof(MobiDevResult), pay_b = pitch_w * 4;
@@ -806,13 +837,12 @@ static int dp_override(mobi_batch *b, const std::vector<int> &clips, const int *
   const int groups = std::min(k, 32);
   b->pool->run(groups, [&](int g) {
     for (int j = (int)((long)k * g / groups), e = (int)((long)k * (g + 1) / groups); j < e; j++) {
-      const int c = clips[j];
-      const ParsedFrame *f = rc[c] == MOBI_OK ? &b->cur[c] : nullptr;
+      const ParsedFrame *f = frame_of(j);
       MbDesc *dd = (MbDesc *)(h + (size_t)j * desc_b);
       uint32_t *it = (uint32_t *)(h + o_item + (size_t)j * item_b);
       MobiDevResult *rr = (MobiDevResult *)(h + o_res + (size_t)j * res_b);
       memset(rr, 0, sizeof(*rr));
-      rr->rc = rc[c];
+      rr->rc = rc_of(j);
       if (!f) { // a failed clip: descriptors typed "intra" that no launch list references
         for (int m = 0; m < n_mbs; m++) dd[m] = MbDesc{0, MOBI_MB_INTRA, 0, 0, 0, 0, 0, 0};
         continue;
@@ -862,6 +892,7 @@ static void hybrid_share(mobi_batch *b) {
 // doubled with every hand-over (4, 8, ... 256: a clip whose every frame needs the host parser -- a ModsDS stream below quantiser 12 -- costs
 // a wasted device parse every few hundred frames, a glitch in an otherwise clean stream a handful of host-parsed frames).  The parser's state
 // goes into entry `entry` of the state ring -- the one the next step's parse reads -- on stream s, through `stage`.
+static int dp_return_list(mobi_batch *b, const std::vector<int> &back, int entry, PinnedBuf &stage, hipStream_t s);
 static int dp_return(mobi_batch *b, const std::vector<int> &host_clips, const int *rc, int entry, PinnedBuf &stage, hipStream_t s) {
   std::vector<int> back;
   for (int c : host_clips) {
@@ -870,6 +901,9 @@ static int dp_return(mobi_batch *b, const std::vector<int> &host_clips, const in
     else b->clean_run[c] = 0;
     if (b->clean_run[c] >= b->clean_need[c]) back.push_back(c);
   }
+  return dp_return_list(b, back, entry, stage, s);
+}
+static int dp_return_list(mobi_batch *b, const std::vector<int> &back, int entry, PinnedBuf &stage, hipStream_t s) {
   if (back.empty()) return MOBI_OK;
   const size_t rec = sizeof(MobiDevState) + sizeof(MobiDevTail);
   if (int e = stage.reserve(back.size() * rec)) return e;
@@ -905,7 +939,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     for (int i = 0; i < n; i++) rc[i] = MOBI_E_VERSION;
     return MOBI_OK; // DecodeFrame() returns before touching the ring (MD.cs:56-61)
   }
-  if (b->g.mbw > 64 || b->async_count) return MOBI_E_ARG; // (asynchronous steps in flight: mobi_batch_wait for them first)
+  if (b->g.mbw > 64 || b->async_count || b->gop_count) return MOBI_E_ARG; // (asynchronous steps / groups in flight: wait for them first)
   if (int e = dp_init(b)) return e;
   if (b->hybrid_host && b->frames_started == 0) // hybrid: the last clips are the host parsers' from the start (their state is a new decoder's: nothing to seed)
     for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = b->host_share[i] = 1;
@@ -1053,7 +1087,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (b->poisoned) return MOBI_E_DEVICE;
   if (b->parse_mode == 0) return MOBI_E_ARG; // the decoder state of this batch lives in the host parsers
   if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) return MOBI_E_VERSION;
-  if (b->g.mbw > 64 || b->async_count >= 2) return MOBI_E_ARG;
+  if (b->g.mbw > 64 || b->async_count >= 2 || b->gop_count) return MOBI_E_ARG;
   if (int e = dp_init(b)) return e;
   if (b->hybrid_host && b->frames_started == 0)
     for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = b->host_share[i] = 1;
@@ -1226,6 +1260,371 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
   return MOBI_OK;
 }
 
+// ---- frame-parallel groups (mobi_gop.h) -------------------------------------------------------------------------------------------
+// K consecutive frames of every clip in one call: data / len / offsets / rc are [k * n_clips + c].  The frames are parsed SIDE BY SIDE --
+// n * K virtual clips for the parse kernels, whose cost per frame falls with the number of lanes they are given -- and
+// reconstructed as K steps in order.  begin: gather + upload (and, when nothing else is in flight, the parse); finish: the host parser's
+// share and every hand-over, the K reconstruction steps, and the parse of the group begun behind it.
+static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S) {
+  const int n = b->n, K = S.K, n_mbs = b->g.mbw * b->g.mbh;
+  const size_t nv = (size_t)n * K;
+  S.is_host.assign(b->on_host.begin(), b->on_host.end());
+  uint32_t *blen = (uint32_t *)(S.h_stage.p + nv * 8);
+  DpStaged st;
+  for (size_t v = 0; v < nv; v++) {
+    if (S.is_host[v % n]) { blen[v] = MOBI_DP_SKIP; continue; }
+    blen[v] = S.lens[v];
+    st.n_dev++;
+    st.n_iframes += S.lens[v] >= 2 && (S.h_stage.p[S.hdr_bytes + S.boff[v] + 1] & 0x80) != 0;
+  }
+  S.lockstep = ls_decide(b, st);
+  if (S.max_len > b->dp_len_hint) b->dp_len_hint = S.max_len + S.max_len / 4;
+  const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448 + MOBI_WIDE_PARAMS, (size_t)n_mbs * 64 + (8 * b->dp_len_hint + 2) / 3) + 448 + 64; // (dp_parse has the bound's reasons)
+  S.cap_words = cap_words;
+  if (int e = S.d_desc.reserve(align_up(nv * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign))) return e;
+  if (int e = S.d_pay.reserve(align_up(nv * cap_words * 4 + kPaySlack, kAlign))) return e;
+  if (int e = S.d_items.reserve(nv * n_mbs * 4)) return e;
+  if (int e = S.d_res.reserve(nv * sizeof(MobiDevResult))) return e;
+  if (int e = S.d_sin.reserve(nv * sizeof(MobiDevState))) return e;
+  if (int e = S.d_sout.reserve(nv * sizeof(MobiDevState))) return e;
+  if (int e = S.d_sls.reserve(nv * sizeof(MobiDevState))) return e;
+  if (int e = S.d_tails.reserve(nv * sizeof(MobiDevTail))) return e;
+  if (int e = S.d_fault.reserve(nv * sizeof(int))) return e;
+  if (int e = S.h_res.reserve(nv * sizeof(MobiDevResult))) return e;
+  if (int e = S.h_fault.reserve(nv * sizeof(int))) return e;
+  hipStream_t ps = b->stream_p;
+  HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
+  HIP_TRY(hipMemcpyAsync(S.d_bits.p, S.h_stage.p, S.hdr_bytes, hipMemcpyHostToDevice, ps)); // offsets and lengths (with the host parser's clips marked)
+  MobiGopArgs G;
+  memset(&G, 0, sizeof(G));
+  MobiDevParseArgs &pa = G.P;
+  pa.bits = S.d_bits.p + S.hdr_bytes;
+  pa.bit_off = (const uint64_t *)S.d_bits.p;
+  pa.bit_len = (const uint32_t *)(S.d_bits.p + nv * 8);
+  pa.tables = b->d_ptables;
+  pa.state_in = (const MobiDevState *)S.d_sin.p; pa.state_out = (MobiDevState *)S.d_sout.p;
+  pa.tail_in = nullptr; pa.tail_out = (MobiDevTail *)S.d_tails.p;
+  pa.scale = b->d_scale;
+  pa.state_ls = (MobiDevState *)S.d_sls.p;
+  pa.lockstep = S.lockstep ? 2 : 0;
+  pa.pay_local = 1;
+  pa.clip_mod = n;
+  pa.skip_tail = 1;
+  pa.desc = (MbDesc *)S.d_desc.p;
+  pa.payload = (uint32_t *)S.d_pay.p;
+  pa.items = (uint32_t *)S.d_items.p;
+  pa.res = (MobiDevResult *)S.d_res.p;
+  pa.pay_cap = (uint32_t)cap_words;
+  pa.n_clips = (int)nv; pa.version = b->version;
+  pa.width = b->g.width; pa.height = b->g.height; pa.stride = b->g.stride; pa.lg = b->g.lg; pa.mbw = b->g.mbw; pa.mbh = b->g.mbh;
+  const int in = b->ps_cur, out = (b->ps_cur + 1) % 3;
+  G.ring_in = b->d_pstate[in]; G.ring_out = b->d_pstate[out];
+  G.rtail_in = b->d_ptail[in]; G.rtail_out = b->d_ptail[out];
+  G.n = n; G.K = K;
+  if (b->ktiming && !b->ev_p0) { (void)hipEventCreate(&b->ev_p0); (void)hipEventCreate(&b->ev_p1); }
+  const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1;
+  if (ptime) (void)hipEventRecord(b->ev_p0, ps);
+  if (mobi_launch_gop_prepare(&G, ps) != 0) return MOBI_E_DEVICE;
+  if (mobi_launch_parse(&pa, ps) != 0) return MOBI_E_DEVICE;
+  if (mobi_launch_gop_chain(&G, ps) != 0) return MOBI_E_DEVICE;
+  if (ptime) (void)hipEventRecord(b->ev_p1, ps);
+  HIP_TRY(hipMemcpyAsync(S.h_res.p, S.d_res.p, nv * sizeof(MobiDevResult), hipMemcpyDeviceToHost, ps));
+  HIP_TRY(hipEventRecord(S.ev_parsed, ps));
+  b->ps_cur = out;
+  S.ring_in = in;
+  S.parse_enqueued = true;
+  return MOBI_OK;
+}
+
+int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, const int32_t *offsets) {
+  if (!b || !data || !len || !offsets || n_frames < 1 || n_frames > MOBI_GOP_MAX) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  const int n = b->n, K = n_frames, n_mbs = b->g.mbw * b->g.mbh;
+  const size_t nv = (size_t)n * K;
+  if (b->frames_started == 0 && b->async_seq == 0 && b->gop_count == 0) { // a batch fed by groups parses on the GPU from its first frame
+    if (b->parse_auto) { b->parse_mode = 1; b->parse_auto = false; }
+    if (b->parse_mode == 2) hybrid_share(b);
+  }
+  if (b->poisoned) return MOBI_E_DEVICE;
+  if (b->parse_mode == 0) return MOBI_E_ARG; // the decoder state of this batch lives in the host parsers (mobi_batch_decode_gop serves those too)
+  if (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS) return MOBI_E_VERSION;
+  if (b->g.mbw > 64 || b->async_count || b->gop_count >= 2 || nv >= ((size_t)1 << 22)) return MOBI_E_ARG;
+  if (int e = dp_init(b)) return e;
+  if (b->hybrid_host && b->frames_started == 0 && b->gop_count == 0)
+    for (int i = n - b->hybrid_host; i < n; i++) b->on_host[i] = b->host_share[i] = 1;
+  mobi_batch::GopSlot &S = b->gslot[(b->gop_head + b->gop_count) & 1];
+  if (!S.ev_up) HIP_TRY(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
+  if (!S.ev_parsed) HIP_TRY(hipEventCreateWithFlags(&S.ev_parsed, hipEventDisableTiming));
+  if (!b->stream2) HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+  if (!b->stream_p) HIP_TRY(hipStreamCreateWithFlags(&b->stream_p, hipStreamNonBlocking));
+  const auto t_stage0 = std::chrono::steady_clock::now();
+  // the staged image: [bit_off u64 x nv][bit_len u32 x nv][bits: every frame 8-byte aligned, 32 zero bytes behind it]
+  constexpr size_t kBitPad = 32;
+  S.K = K;
+  S.boff.resize(nv); S.lens.resize(nv);
+  S.offs.assign(offsets, offsets + nv);
+  size_t pos = 0, max_len = 0;
+  const size_t frame_bound = (size_t)n_mbs * 4096 + 64; // (dp_stage: bytes beyond cannot influence the parse of one frame)
+  for (size_t v = 0; v < nv; v++) {
+    const int64_t o = offsets[v];
+    size_t l = (data[v] && o >= 0 && (uint64_t)o < len[v]) ? len[v] - (size_t)o : 0;
+    l = std::min(l, frame_bound);
+    max_len = std::max(max_len, l);
+    S.boff[v] = pos;
+    S.lens[v] = (uint32_t)l;
+    pos += align_up(l + kBitPad, 8);
+  }
+  pos += 64;
+  const size_t hdr_bytes = align_up(nv * 12, 16), need = hdr_bytes + pos;
+  if (need > S.h_stage.cap)
+    if (int e = S.h_stage.reserve(need + need / 4)) return e;
+  if (need > S.d_bits.cap)
+    if (int e = S.d_bits.reserve(need + need / 4)) return e;
+  uint8_t *hs = S.h_stage.p;
+  memcpy(hs, S.boff.data(), nv * 8);
+  memset(hs + hdr_bytes + pos - 64, 0, 64);
+  S.hdr_bytes = hdr_bytes; S.bytes = need; S.max_len = max_len;
+  auto gather = [&](size_t v) {
+    uint8_t *dst = hs + hdr_bytes + S.boff[v];
+    const size_t l = S.lens[v];
+    if (l) memcpy(dst, data[v] + offsets[v], l);
+    memset(dst + l, 0, align_up(l + kBitPad, 8) - l);
+  };
+  // gathered in chunks by the pool while one of its threads hands the chunk before to the copy engine (dp_stage)
+  {
+    const int chunks = nv >= 2048 ? 8 : 1;
+    std::atomic<int> up_err{0};
+    auto start_of = [&](size_t v) { return v < nv ? hdr_bytes + (size_t)S.boff[v] : need; };
+    for (int k = 0; k <= chunks; k++) {
+      const size_t c0 = k < chunks ? nv * k / chunks : nv, c1 = k < chunks ? nv * (k + 1) / chunks : nv;
+      const size_t u0 = k >= 1 ? nv * (k - 1) / chunks : 0, u1 = k >= 1 ? nv * k / chunks : 0;
+      const int n_up = u1 > u0 ? 1 : 0;
+      if (n_up + (c1 - c0) == 0) continue;
+      b->pool->run(n_up + (int)(c1 - c0), [&](int j) {
+        if (j < n_up) {
+          const size_t a = start_of(u0), e = start_of(u1);
+          if (e > a && (hipSetDevice(b->device) != hipSuccess || hipMemcpyAsync(S.d_bits.p + a, hs + a, e - a, hipMemcpyHostToDevice, b->stream2) != hipSuccess)) up_err = 1;
+          return;
+        }
+        gather(c0 + (size_t)(j - n_up));
+      });
+    }
+    if (up_err) { (void)hipStreamSynchronize(b->stream2); return MOBI_E_DEVICE; }
+  }
+  HIP_TRY(hipEventRecord(S.ev_up, b->stream2));
+  b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
+  S.parse_enqueued = false;
+  b->gop_count++;
+  if (b->gop_count == 1) // nothing in front: the parse may start at once (else mobi_batch_gop_finish of the group in front enqueues it, once it knows whose clips are whose)
+    if (int e = gop_enqueue_parse(b, S)) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamSynchronize(b->stream_p); b->gop_count--; return e; }
+  return MOBI_OK;
+}
+
+int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
+  if (!b || !rc) return MOBI_E_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->poisoned) return MOBI_E_DEVICE;
+  if (b->gop_count == 0) return MOBI_E_ARG;
+  mobi_batch::GopSlot &S = b->gslot[b->gop_head & 1];
+  const int n = b->n, K = S.K, n_mbs = b->g.mbw * b->g.mbh;
+  const size_t nv = (size_t)n * K;
+  // whatever fails from here on leaves rings, parsers and state ring out of step: the batch is drained and refuses further work
+  struct Poison {
+    mobi_batch *b; bool armed = true;
+    ~Poison() {
+      if (!armed) return;
+      if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+      if (b->stream_p) (void)hipStreamSynchronize(b->stream_p);
+      (void)hipStreamSynchronize(b->stream);
+      b->poisoned = true;
+    }
+  } poison{b};
+  if (!S.parse_enqueued)
+    if (int e = gop_enqueue_parse(b, S)) return e;
+  using clk = std::chrono::steady_clock;
+  const auto q0 = clk::now();
+  auto ms_since = [](clk::time_point x) { return std::chrono::duration<float, std::milli>(clk::now() - x).count(); };
+  // 1. the host parser's clips, all K frames of each, while the GPU parses the others
+  std::vector<int> host_from(n, K); // first frame of the group that is the host parser's
+  std::vector<int> hslot(n, -1);    // its place in gop_frames
+  std::vector<int> hrc(nv, MOBI_OK);
+  std::vector<int32_t> hoff(nv, 0);
+  std::vector<uint32_t> hq(n, 0), hy(n, 0);
+  std::vector<uint8_t> hready(nv, 0); // a host-parsed frame the device parsers would have finished too (MobiStreamParser::device_ready)
+  std::vector<int> host_clips;
+  for (int c = 0; c < n; c++)
+    if (S.is_host[c]) { host_from[c] = 0; hslot[c] = (int)host_clips.size(); host_clips.push_back(c); }
+  auto host_parse = [&](const std::vector<int> &cl) {
+    b->pool->run((int)cl.size(), [&](int j) {
+      const int c = cl[j];
+      for (int k = host_from[c]; k < K; k++) {
+        const size_t v = (size_t)k * n + c;
+        int32_t off = 0;
+        hrc[v] = b->parsers[c]->parse_frame(S.h_stage.p + S.hdr_bytes + S.boff[v], S.lens[v], &off, b->gop_frames[(size_t)hslot[c] * K + k]);
+        hoff[v] = S.offs[v] + off;
+        hready[v] = hrc[v] == MOBI_OK && b->parsers[c]->device_ready();
+      }
+      hq[c] = b->parsers[c]->quantizer();
+      hy[c] = b->parsers[c]->yuv_format();
+    });
+  };
+  if (b->gop_frames.size() < host_clips.size() * K) b->gop_frames.resize(host_clips.size() * K);
+  host_parse(host_clips);
+  // 2. what the device parsers finished
+  HIP_TRY(hipEventSynchronize(S.ev_parsed));
+  b->phase_ms[0] = ms_since(q0);
+  { const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1; float ms = 0; if (ptime && hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
+  const MobiDevResult *res = (const MobiDevResult *)S.h_res.p;
+  std::vector<int> fb;
+  for (int c = 0; c < n; c++) {
+    if (S.is_host[c]) continue;
+    for (int k = 0; k < K; k++)
+      if (res[(size_t)k * n + c].rc != MOBI_OK) { host_from[c] = k; fb.push_back(c); break; }
+  }
+  if (!fb.empty()) { // hand-overs: the state the first unfinished frame started from (mobi_gop_chain left the true one in its start slot) and the tail before it
+    const size_t rec = sizeof(MobiDevState) + sizeof(MobiDevTail);
+    if (int e = S.h_seed.reserve(fb.size() * rec)) return e;
+    for (size_t j = 0; j < fb.size(); j++) {
+      const int c = fb[j], k = host_from[c];
+      const size_t v = (size_t)k * n + c;
+      HIP_TRY(hipMemcpyAsync(S.h_seed.p + j * rec, (const MobiDevState *)S.d_sin.p + v, sizeof(MobiDevState), hipMemcpyDeviceToHost, b->stream_p));
+      const MobiDevTail *t = k == 0 ? b->d_ptail[S.ring_in] + c : (const MobiDevTail *)S.d_tails.p + (v - n);
+      HIP_TRY(hipMemcpyAsync(S.h_seed.p + j * rec + sizeof(MobiDevState), t, sizeof(MobiDevTail), hipMemcpyDeviceToHost, b->stream_p));
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream_p));
+    const size_t base = host_clips.size();
+    if (b->gop_frames.size() < (base + fb.size()) * K) b->gop_frames.resize((base + fb.size()) * K);
+    for (size_t j = 0; j < fb.size(); j++) {
+      const int c = fb[j];
+      hslot[c] = (int)(base + j);
+      b->parsers[c]->import_state(*(const MobiDevState *)(S.h_seed.p + j * rec), *(const MobiDevTail *)(S.h_seed.p + j * rec + sizeof(MobiDevState)));
+    }
+    host_parse(fb);
+    for (int c : fb) {
+      b->on_host[c] = 1;
+      b->clean_run[c] = 0;
+      b->clean_need[c] = (uint16_t)std::min(256, 2 * (int)b->clean_need[c]);
+    }
+    b->fallbacks += fb.size();
+  }
+  b->phase_ms[1] = ms_since(q0);
+  // 3. the host parser's command lists over the rows the parse kernels left, frame by frame
+  HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
+  std::vector<int> all_host(host_clips);
+  all_host.insert(all_host.end(), fb.begin(), fb.end());
+  std::sort(all_host.begin(), all_host.end());
+  const size_t desc_b = (size_t)n_mbs * sizeof(MbDesc), item_b = (size_t)n_mbs * 4;
+  for (int k = 0; k < K && !all_host.empty(); k++) {
+    std::vector<int> cl;
+    std::vector<const ParsedFrame *> fr;
+    std::vector<int> rcs;
+    for (int c : all_host)
+      if (host_from[c] <= k) {
+        const size_t v = (size_t)k * n + c;
+        cl.push_back(c);
+        rcs.push_back(hrc[v]);
+        fr.push_back(hrc[v] == MOBI_OK ? &b->gop_frames[(size_t)hslot[c] * K + k] : nullptr);
+      }
+    const size_t kn = (size_t)k * n;
+    const DpRows rows{S.d_desc.p + kn * desc_b, S.d_pay.p + kn * S.cap_words * 4, S.d_items.p + kn * item_b, (MobiDevResult *)S.d_res.p + kn, S.cap_words};
+    if (int e = dp_override(b, cl, nullptr, S.h_over[k], rows, b->stream, fr.data(), rcs.data())) return e;
+  }
+  // 4. K reconstruction steps from K consecutive command lists
+  HIP_TRY(hipMemsetAsync(S.d_fault.p, 0, nv * sizeof(int), b->stream));
+  for (int k = 0; k < K; k++) {
+    const size_t kn = (size_t)k * n;
+    uint32_t Kint = 0;
+    for (int c = 0; c < n; c++) {
+      const size_t v = kn + c;
+      if (k >= host_from[c]) { if (hrc[v] == MOBI_OK) Kint = std::max(Kint, b->gop_frames[(size_t)hslot[c] * K + k].hdr.n_intra); }
+      else Kint = std::max(Kint, res[v].n_intra);
+    }
+    b->ring_base = (b->ring_base + 1) % 6; // Y[i] = Y[i-1]; Y[0] = new (MD.cs:102-108) -- even if the parse threw
+    b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
+    b->argb_all_valid = false;
+    b->frames_started++;
+    MobiReconArgs a = b->args(S.d_desc.p + kn * desc_b, S.d_pay.p + kn * S.cap_words * 4);
+    a.pay_clip_words = (uint32_t)S.cap_words;
+    a.fault = (int *)S.d_fault.p + kn;
+    mobi_batch::EvPair ep{nullptr, nullptr, 0};
+    if (b->ktiming) { ep.a = b->get_event(); ep.b = b->get_event(); (void)hipEventRecord(ep.a, b->stream); }
+    if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
+    if (b->ktiming) { (void)hipEventRecord(ep.b, b->stream); b->evs.push_back(ep); }
+    const MobiDevResult *d_res_k = (const MobiDevResult *)S.d_res.p + kn;
+    if (Kint && mobi_launch_intra_cl(&a, (const uint32_t *)(S.d_items.p + kn * item_b), &d_res_k->n_intra, (int)(sizeof(MobiDevResult) / 4), (int)Kint, 0, b->stream) != 0)
+      return MOBI_E_DEVICE;
+  }
+  b->pay_clip_words = (uint32_t)S.cap_words;
+  HIP_TRY(hipMemcpyAsync(S.h_fault.p, S.d_fault.p, nv * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  b->phase_ms[2] = ms_since(q0);
+  // 5. clips that go back to the device parsers (dp_return's rule, counted in frames): their state into the entry the next parse reads
+  {
+    std::vector<int> back;
+    for (int c : all_host) {
+      if (b->host_share[c]) continue;
+      int run = b->clean_run[c]; // consecutive frames the device parsers would have finished too
+      for (int k = host_from[c]; k < K; k++) run = hready[(size_t)k * n + c] ? run + 1 : 0;
+      b->clean_run[c] = (uint16_t)std::min(60000, run);
+      if (run >= b->clean_need[c]) back.push_back(c);
+    }
+    if (int e = dp_return_list(b, back, b->ps_cur, S.h_ret, b->stream_p)) return e;
+  }
+  // 6. the group begun behind this one: its parse runs beside this group's reconstruction
+  if (b->gop_count == 2) {
+    mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
+    if (!N.parse_enqueued)
+      if (int e = gop_enqueue_parse(b, N)) return e;
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->phase_ms[3] = ms_since(q0);
+  b->drain_events();
+  poison.armed = false;
+  const int *fault = (const int *)S.h_fault.p;
+  b->ls_finished = S.lockstep ? 0 : -1;
+  b->lockstep = S.lockstep;
+  for (int k = 0; k < K; k++)
+    for (int c = 0; c < n; c++) {
+      const size_t v = (size_t)k * n + c;
+      if (k >= host_from[c]) {
+        rc[v] = hrc[v];
+        if (offsets_out) offsets_out[v] = hoff[v];
+      } else {
+        if (S.lockstep && res[v].pad == MOBI_LS_MAGIC) b->ls_finished++;
+        rc[v] = res[v].rc;
+        if (offsets_out) offsets_out[v] = S.offs[v] + (int32_t)res[v].consumed;
+      }
+      if (rc[v] == MOBI_OK && fault[v]) rc[v] = (fault[v] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+      if (k == K - 1) {
+        b->dev_quant[c] = k >= host_from[c] ? hq[c] : res[v].quant;
+        b->dev_yuvfmt[c] = k >= host_from[c] ? hy[c] : res[v].yuvfmt;
+      }
+    }
+  b->gop_head ^= 1;
+  b->gop_count--;
+  S.parse_enqueued = false;
+  return MOBI_OK;
+}
+int mobi_batch_gop_in_flight(const mobi_batch *b) { return b ? b->gop_count : 0; }
+
+int mobi_batch_decode_gop(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc) {
+  if (!b || !data || !len || !offsets || !rc || n_frames < 1 || n_frames > MOBI_GOP_MAX) return MOBI_E_ARG;
+  if (b->poisoned) return MOBI_E_DEVICE;
+  if (b->async_count || b->gop_count) return MOBI_E_ARG;
+  const int n = b->n;
+  if (b->parse_auto && b->frames_started == 0) { // as mobi_batch_decode chooses, with the lanes a group offers counted: n_clips * n_frames
+    b->parse_mode = (size_t)n * n_frames >= (size_t)std::max(640, 20 * (b->pool->size() + 1));
+    b->parse_auto = false;
+    if (b->parse_mode == 2) hybrid_share(b);
+  }
+  if (b->parse_mode == 0 || (size_t)n * n_frames >= ((size_t)1 << 22) || (b->version != MOBI_VERSION_MODSDS && b->version != MOBI_VERSION_MOFLEX3DS)) {
+    for (int k = 0; k < n_frames; k++) // the host parser's batch (or a version no parser knows): K calls, the same results
+      if (int e = mobi_batch_decode(b, data + (size_t)k * n, len + (size_t)k * n, offsets + (size_t)k * n, rc + (size_t)k * n)) return e;
+    return MOBI_OK;
+  }
+  if (int e = mobi_batch_gop_begin(b, n_frames, data, len, offsets)) return e;
+  return mobi_batch_gop_finish(b, offsets, rc);
+}
+
 int mobi_batch_in_flight(const mobi_batch *b) { return b ? b->async_count : 0; }
 int mobi_batch_host_clips(const mobi_batch *b) {
   if (!b) return 0;
@@ -1253,6 +1652,7 @@ int mobi_batch_decode(mobi_batch *b, const uint8_t *const *data, const size_t *l
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~CallTimer() { b->last_decode_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
   } call_timer{b};
+  if (b->gop_count) return MOBI_E_ARG; // (groups in flight: mobi_batch_gop_finish first)
   if (b->parse_auto && b->parse_mode && b->frames_started == 0) {
     // Chosen by batch size only: a caller that hands over whole files as Data (MOC5 style, Form1.cs:292-302) would make the
     // device path upload up to 4 KB per macroblock per clip and frame (the frame length is unknown before the parse).  Packets

@@ -50,6 +50,10 @@ struct MobiDevParseArgs {
   // pay_local != 0: MbDesc.payload_off is written relative to the clip's own part of the arena (MobiReconArgs.pay_clip_words = pay_cap), so
   // that n_clips * pay_cap may exceed 2^32 words; 0: relative to the arena (the hybrid mode, whose host-parsed clips sit behind the others)
   int pay_local;
+  // r06, frame-parallel parse (mobi_gop.h): the n_clips entries are VIRTUAL clips v = k * clip_mod + c (frame k of clip c); the intra items
+  // name the real clip (v mod clip_mod), which is what the reconstruction of frame k indexes its tables with.  0: clips are clips.
+  int clip_mod;
+  int skip_tail; // mobi_launch_parse leaves mobi_parse_tail out: mobi_gop_chain rebuilds the tails frame by frame
 };
 #define MOBI_DP_SKIP 0xFFFFFFFFu
 extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s); // the parse kernels, then mobi_parse_tail

@@ -738,7 +738,7 @@ extern "C" __global__ __launch_bounds__(64 * PWAVES) __attribute__((amdgpu_waves
     p.pay_cap = A.pay_cap;
     p.items = A.items + (size_t)clip * n_mbs;
     p.n_items = 0;
-    p.clip = (uint32_t)clip;
+    p.clip = (uint32_t)(A.clip_mod ? clip % A.clip_mod : clip);
     p.r.err = 0;
     p.cur_mb = 0; p.cur_x = p.cur_y = p.cur_off = 0; p.n_leaf_words = 0; p.mb_type = 0;
     p.cbp6 = p.t8mask = p.w3 = p.mb_pay = p.hdr_words = p.n_coefs = 0;
@@ -835,6 +835,6 @@ extern "C" int mobi_launch_parse(const MobiDevParseArgs *a, hipStream_t s) {
   if (a->lockstep)
     if (int e = mobi_launch_parse_ls(a, s)) return e;
   hipLaunchKernelGGL(mobi_parse_frames, dim3((unsigned)((a->n_clips + PWAVES - 1) / PWAVES)), dim3(64 * PWAVES), 0, s, *a);
-  hipLaunchKernelGGL(mobi_parse_tail, dim3((unsigned)((a->n_clips + 63) / 64)), dim3(64), 0, s, *a);
+  if (!a->skip_tail) hipLaunchKernelGGL(mobi_parse_tail, dim3((unsigned)((a->n_clips + 63) / 64)), dim3(64), 0, s, *a);
   return (int)hipGetLastError();
 }

@@ -111,7 +111,7 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
     s.pay = A.payload + (A.pay_local ? (size_t)clip * A.pay_cap : (size_t)0);
     s.pay_base = A.pay_local ? 0u : (uint32_t)clip * A.pay_cap;
     s.items = A.items + (size_t)clip * n_mbs;
-    s.clip = (uint32_t)clip;
+    s.clip = (uint32_t)(A.clip_mod ? clip % A.clip_mod : clip);
     base = A.bits + A.bit_off[clip];
     len = A.bit_len[clip];
     len2 = len & ~1u;

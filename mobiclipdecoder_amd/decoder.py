@@ -54,6 +54,10 @@ _SIGS = {
     "mobi_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_in_flight": (C.c_int, [C.c_void_p]),
+    "mobi_batch_decode_gop": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_gop_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_gop_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mobi_batch_gop_in_flight": (C.c_int, [C.c_void_p]),
     "mobi_batch_host_clips": (C.c_int, [C.c_void_p]),
     "mobi_batch_compare_clips": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mobi_forward_dct": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -273,6 +277,46 @@ class MobiclipBatch:
         e = self._lib.mobi_batch_submit(self._h, ptrs, lens, offs)
         if e != 0:
             raise MobiclipError(error_string(e))
+
+    # -- frame-parallel groups: K consecutive frames of every clip per call (mobiclip_hip.h, mobi_batch_decode_gop) -------------
+    def _gop_arrays(self, frames, offsets):
+        """frames[k][c] = byte buffer of frame k of clip c; offsets[k][c] (or None: all 0) -> the C arrays, [k * n + c]"""
+        K = len(frames)
+        bufs = [_as_u8(d) for fr in frames for d in fr]
+        assert len(bufs) == K * self.n
+        ptrs = (C.c_void_p * (K * self.n))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * (K * self.n))(*[b.size for b in bufs])
+        flat = [0] * (K * self.n) if offsets is None else [int(o) for row in offsets for o in row]
+        offs = (C.c_int32 * (K * self.n))(*flat)
+        return K, bufs, ptrs, lens, offs
+
+    def decode_gop(self, frames, offsets=None):
+        """K = len(frames) <= 6 DecodeFrame() calls per clip in one go, parsed side by side on the GPU.  -> (rc, offsets), each a list of
+        K lists of n: exactly what K decode() calls return."""
+        K, bufs, ptrs, lens, offs = self._gop_arrays(frames, offsets)
+        rcs = (C.c_int * (K * self.n))()
+        e = self._lib.mobi_batch_decode_gop(self._h, K, ptrs, lens, offs, rcs)
+        if e != 0:
+            raise MobiclipError(error_string(e))
+        return [list(rcs[k * self.n:(k + 1) * self.n]) for k in range(K)], [list(offs[k * self.n:(k + 1) * self.n]) for k in range(K)]
+
+    def gop_begin(self, frames, offsets=None):
+        """first half of decode_gop(): gather, upload (and parse, when no group is in front); at most two groups begun and not finished"""
+        K, bufs, ptrs, lens, offs = self._gop_arrays(frames, offsets)
+        e = self._lib.mobi_batch_gop_begin(self._h, K, ptrs, lens, offs)
+        if e != 0:
+            raise MobiclipError(error_string(e))
+        self._gop_k = getattr(self, "_gop_k", []) + [K]
+
+    def gop_finish(self):
+        """second half, for the OLDEST group begun: hand-overs, the K reconstruction steps; -> (rc, offsets) as decode_gop()"""
+        K = self._gop_k.pop(0)
+        offs = (C.c_int32 * (K * self.n))()
+        rcs = (C.c_int * (K * self.n))()
+        e = self._lib.mobi_batch_gop_finish(self._h, offs, rcs)
+        if e != 0:
+            raise MobiclipError(error_string(e))
+        return [list(rcs[k * self.n:(k + 1) * self.n]) for k in range(K)], [list(offs[k * self.n:(k + 1) * self.n]) for k in range(K)]
 
     def compare_clips(self, modulus):
         """clips whose newest frame differs from that of clip (index mod modulus), compared on the device (batches made of copies)"""

@@ -1,0 +1,267 @@
+"""Frame-parallel groups (mobi_batch_decode_gop / gop_begin / gop_finish, mobi_gop.h): K consecutive frames of every clip parsed SIDE BY
+SIDE on the GPU must give exactly what K calls of mobi_batch_decode give -- and what the oracle gives: rc, the Offset after every frame,
+Quantizer, YuvFormat and every plane of every frame of the group (frame k of a group of K sits at ring index K - 1 - k when the call returns).
+
+On intact streams of every kind, group sizes 1..6 in any order, both device parsers in front; on damaged streams (frames the device parsers
+do not finish, frames the reference throws on: the clip's remaining frames go to the host parser inside the same call); with the hybrid
+mode's host share; with two groups begun before the first is finished."""
+import numpy as np
+import pytest
+
+from mobiclipdecoder_amd import MobiclipBatch, default_params, generate_clip
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+from tests.gpu_streams import COVERAGE_SUITE
+from tests.oracle_binding import OracleDecoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(clips, f0, K):
+    """[k][c] -> the packet of frame f0 + k of clip c (empty when the clip has ended or its data was cut off)"""
+    out = []
+    for k in range(K):
+        row = []
+        for d, fo in clips:
+            f = f0 + k
+            a, e = (min(int(fo[f]), d.size), min(int(fo[f + 1]), d.size)) if f + 1 < len(fo) else (0, 0)
+            row.append(d[a:e])
+        out.append(row)
+    return out
+
+
+def _run_groups(clips, p0, groups, device_parse, oracle=True, pipelined=False, reference_batch=None):
+    """Decode the clips in groups of the given sizes; compare every frame with the oracle (and, if given, with a batch driven by plain
+    decode() calls: `reference_batch` = a device_parse value for it).  Returns (frames with rc != 0, batch.host_clips() at the end)."""
+    n = len(clips)
+    b = MobiclipBatch(n, p0.width, p0.height, p0.version, device_parse=device_parse)
+    rb = MobiclipBatch(n, p0.width, p0.height, p0.version, device_parse=reference_batch) if reference_batch is not None else None
+    oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(n)] if oracle else None
+    tainted = [0] * n  # a frame has failed and no I-frame has come by since: the reference keeps the failed frame's PARTIAL picture, this library the
+    # slot's old one (mobiclip_hip.h), so P-frames that predict from it, and from them, differ from the oracle's; the step-by-step batch's do not
+    history = [[] for _ in range(n)]
+    n_err = 0
+    f0 = 0
+    pending = []  # (f0, K, frames) of groups begun and not finished
+
+    def check(f0, K, frames, rcs, offs):
+        nonlocal n_err
+        for k in range(K):
+            if rb is not None:  # the step-by-step batch: one decode() per frame
+                rrc, roff = rb.decode(frames[k], [0] * n)
+                assert rcs[k] == rrc and offs[k] == roff, (f0 + k, rcs[k], rrc, offs[k], roff)
+            for c in range(n):
+                planes = None
+                if oras is not None:
+                    o = oras[c]
+                    o.Data, o.Offset = frames[k][c], 0
+                    planes = o.DecodeFrame()
+                    assert (rcs[k][c] == 0) == (o.last_error == 0), (f0 + k, c, rcs[k][c], o.last_error)
+                    if rcs[k][c] == 0:
+                        assert offs[k][c] == o.Offset, (f0 + k, c, offs[k][c], o.Offset)
+                if rcs[k][c] != 0:
+                    n_err += 1
+                    history[c].append(False)
+                    continue
+                # comparable with the oracle: an I-frame (it predicts from nothing; MD.cs:110-113: the frame's first bit), or a P-frame whose
+                # five possible references are all comparable
+                history[c].append(bool(frames[k][c][1] & 0x80) or all(history[c][-5:]))
+                tainted[c] = not history[c][-1]
+                got = b.planes(c, K - 1 - k)
+                if rb is not None:
+                    ry, ruv = rb.planes(c, 0)
+                    assert np.array_equal(got[0], ry) and np.array_equal(got[1], ruv), f"frame {f0 + k} clip {c} differs from the step-by-step batch"
+                if planes is not None and not tainted[c]:
+                    assert np.array_equal(got[0], planes[0]), f"Y mismatch frame {f0 + k} clip {c}: {np.argwhere(got[0] != planes[0])[:4].tolist()}"
+                    assert np.array_equal(got[1], planes[1]), f"UV mismatch frame {f0 + k} clip {c}"
+        for c in range(n):
+            if rcs[K - 1][c] == 0:
+                if oras is not None:
+                    assert b.quantizer(c) == oras[c].Quantizer and b.yuv_format(c) == oras[c].YuvFormat, (f0, c)
+                if rb is not None:
+                    assert b.quantizer(c) == rb.quantizer(c) and b.yuv_format(c) == rb.yuv_format(c), (f0, c)
+
+    for gi, K in enumerate(groups):
+        frames = _frames(clips, f0, K)
+        if not pipelined:
+            rcs, offs = b.decode_gop(frames)
+            check(f0, K, frames, rcs, offs)
+        else:
+            b.gop_begin(frames)
+            pending.append((f0, K, frames))
+            if len(pending) == 2:  # the second group is begun (gathered, uploaded) before the first is finished
+                g0 = pending.pop(0)
+                rcs, offs = b.gop_finish()
+                # (the planes of group g0 are read after its finish and before the next group's finish turns the ring again)
+                check(g0[0], g0[1], g0[2], rcs, offs)
+        f0 += K
+    while pending:
+        g0 = pending.pop(0)
+        rcs, offs = b.gop_finish()
+        check(g0[0], g0[1], g0[2], rcs, offs)
+    hc = b.host_clips()
+    b.close()
+    if rb is not None:
+        rb.close()
+    for o in oras or []:
+        o.close()
+    return n_err, hc
+
+
+@pytest.mark.parametrize("mode", [True, "lockstep"])
+@pytest.mark.parametrize("idx", range(len(COVERAGE_SUITE)))
+def test_coverage_suite_in_groups(idx, mode):
+    """every stream of the coverage suite (tests/gpu_streams.py), three clips with their own seeds, groups of 1..6 frames"""
+    cfg, seed, kw = COVERAGE_SUITE[idx]
+    kw = dict(kw, n_frames=12)
+    ps = [default_params(cfg, BASE_SEED + seed + 1000 * i, **kw) for i in range(3)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [3, 1, 6, 2], mode)
+    assert n_err == 0 and hc == 0  # nothing was handed to the host parser: every start state was predicted right
+
+
+def test_quantiser_deltas_and_iframes_in_every_position():
+    """the header chain: quantiser deltas in most P-frames, I-frames every other frame, both versions"""
+    for ver, cfg in ((1, "A"), (2, "A")):
+        ps = [default_params(cfg, BASE_SEED + 7100 + i, n_frames=18, width=128, height=96, version=ver, qdelta_prob=800, iframe_interval=2 + i % 3, pm_intra=200,
+                             intra_sub_prob=700, table1_prob=500) for i in range(6)]
+        clips = [generate_clip(p) for p in ps]
+        n_err, hc = _run_groups(clips, ps[0], [6, 6, 6], "lockstep")
+        assert n_err == 0 and hc == 0
+
+
+def test_first_frame_is_a_p_frame():
+    """a P-frame into an empty ring (a fresh decoder: Quantizer 0, no tables): Moflex3DS sets up quantiser 12 (MD.cs:119-126), ModsDS reads
+    zero tables; references to frames that were never decoded throw (MD.cs:413)"""
+    for ver in (1, 2):
+        ps = [default_params("A", BASE_SEED + 7200 + i, n_frames=8, width=64, height=48, version=ver, pm_intra=150) for i in range(4)]
+        clips = [generate_clip(p) for p in ps]
+        clips = [(d[int(fo[1]):], (fo[1:] - fo[1]).astype(np.uint32)) for d, fo in clips]  # drop the I-frame
+        _run_groups(clips, ps[0], [4, 3], True, reference_batch=False)
+
+
+@pytest.mark.parametrize("mode", [True, "lockstep", "hybrid"])
+def test_damaged_streams_hand_over_inside_the_group(mode):
+    """bit flips, garbage, truncation somewhere in the stream: rc / Offset / planes are the step-by-step HOST-parsed batch's, frame for
+    frame, and the oracle's wherever it decodes"""
+    rng = np.random.default_rng(0x6F70)
+    nfr = 18
+    ps = [default_params("A", BASE_SEED + 7300 + i, n_frames=nfr, width=96, height=64, pm_intra=120, pm_deep=120, pm_multiref=200,
+                         qdelta_prob=200, escape_prob=60, iframe_interval=5) for i in range(24)]
+    clips = []
+    for i, p in enumerate(ps):
+        d, fo = generate_clip(p)
+        d = np.array(d, copy=True)
+        kind = i % 4
+        if kind == 1:  # a few flipped bits in one frame of the middle
+            f = int(rng.integers(2, nfr - 2))
+            for pos in rng.integers(int(fo[f]) + 2, int(fo[f + 1]), 3):
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:  # 48 bytes of garbage
+            f = int(rng.integers(1, nfr - 1))
+            a = int(rng.integers(int(fo[f]), int(fo[f + 1])))
+            d[a:a + 48] = rng.integers(0, 256, d[a:a + 48].size, dtype=np.uint8)
+        elif kind == 3:  # a frame replaced by noise behind its first word
+            f = int(rng.integers(1, nfr - 1))
+            d[int(fo[f]) + 2:int(fo[f + 1])] = rng.integers(0, 256, int(fo[f + 1] - fo[f]) - 2, dtype=np.uint8)
+        clips.append((d, fo))
+    n_err, hc = _run_groups(clips, ps[0], [6, 5, 4, 3], mode, reference_batch=False)
+    assert n_err > 0  # (some frame was rejected: the hand-over paths ran)
+
+
+def test_moflex_damaged_streams():
+    rng = np.random.default_rng(0x6F71)
+    nfr = 12
+    ps = [default_params("B", BASE_SEED + 7400 + i, n_frames=nfr, width=96, height=64, pm_intra=120, pm_deep=120, pm_multiref=200, qdelta_prob=300, escape_prob=60,
+                         iframe_interval=4) for i in range(16)]
+    clips = []
+    for i, p in enumerate(ps):
+        d, fo = generate_clip(p)
+        d = np.array(d, copy=True)
+        if i % 2:
+            for pos in rng.integers(int(fo[1]), d.size, 4):
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+        clips.append((d, fo))
+    _run_groups(clips, ps[0], [6, 6], "lockstep", reference_batch=False)
+
+
+@pytest.mark.parametrize("mode", [True, "lockstep"])
+def test_two_groups_begun_before_the_first_is_finished(mode):
+    ps = [default_params("A", BASE_SEED + 7500 + i, n_frames=24, pm_intra=100, pm_multiref=300, iframe_interval=7) for i in range(5)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [3, 3, 2, 3, 1, 3, 3, 3, 3], mode, pipelined=True)
+    assert n_err == 0 and hc == 0
+
+
+def test_pipelined_groups_with_a_glitch_in_the_first():
+    """a clip that is handed to the host parser in group g must not be device-parsed in group g + 1, whose bytes were uploaded before
+    anybody knew"""
+    ps = [default_params("A", BASE_SEED + 7600 + i, n_frames=24, width=96, height=64, pm_intra=100, iframe_interval=6) for i in range(8)]
+    clips = []
+    for i, p in enumerate(ps):
+        d, fo = generate_clip(p)
+        d = np.array(d, copy=True)
+        if i in (2, 5):
+            d[int(fo[1 + i]) + 2:int(fo[2 + i])] = 0xA5
+        clips.append((d, fo))
+    n_err, hc = _run_groups(clips, ps[0], [3] * 8, "lockstep", pipelined=True, oracle=True)
+    assert n_err >= 2
+
+
+def test_host_parsed_batch_takes_groups_too():
+    ps = [default_params("A", BASE_SEED + 7700 + i, n_frames=9) for i in range(3)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [4, 5], False)
+    assert n_err == 0 and hc == 3  # (every clip is the host parser's: K calls one after the other)
+
+
+def test_640x480_long_gop_every_reference_slot():
+    ps = [default_params("B", BASE_SEED + 330 + i, n_frames=31, pm_multiref=300, pm_intra=60) for i in range(2)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [6, 6, 6, 6, 6], "lockstep")
+    assert n_err == 0 and hc == 0
+
+
+def test_group_calls_mix_with_single_steps():
+    """decode() between groups: the decoder state ring serves both"""
+    ps = [default_params("A", BASE_SEED + 7800 + i, n_frames=12, pm_intra=100) for i in range(4)]
+    clips = [generate_clip(p) for p in ps]
+    p0 = ps[0]
+    b = MobiclipBatch(4, p0.width, p0.height, p0.version, device_parse=True)
+    oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(4)]
+    f = 0
+    for step in ("gop3", "one", "gop2", "one", "one", "gop4"):
+        K = int(step[3:]) if step.startswith("gop") else 1
+        frames = _frames(clips, f, K)
+        if step == "one":
+            rcs, offs = b.decode(frames[0], [0] * 4)
+            rcs, offs = [rcs], [offs]
+        else:
+            rcs, offs = b.decode_gop(frames)
+        for k in range(K):
+            for c in range(4):
+                o = oras[c]
+                o.Data, o.Offset = frames[k][c], 0
+                planes = o.DecodeFrame()
+                assert rcs[k][c] == 0 == o.last_error and offs[k][c] == o.Offset
+                got = b.planes(c, K - 1 - k)
+                assert np.array_equal(got[0], planes[0]) and np.array_equal(got[1], planes[1]), (step, f + k, c)
+        f += K
+    b.close()
+    for o in oras:
+        o.close()
+
+
+def test_argument_checks():
+    p = default_params("A", BASE_SEED, n_frames=8)
+    clips = [generate_clip(p)]
+    b = MobiclipBatch(1, p.width, p.height, p.version, device_parse=True)
+    with pytest.raises(Exception):
+        b.decode_gop(_frames(clips, 0, 7))  # more frames than the ring holds
+    b.gop_begin(_frames(clips, 0, 2))
+    with pytest.raises(Exception):
+        b.decode(_frames(clips, 2, 1)[0], [0])  # a group is begun and not finished
+    b.gop_begin(_frames(clips, 2, 2))
+    with pytest.raises(Exception):
+        b.gop_begin(_frames(clips, 4, 2))  # at most two
+    assert b.gop_finish()[0] == [[0], [0]] and b.gop_finish()[0] == [[0], [0]]
+    b.close()

@@ -1,0 +1,101 @@
+"""Frame-parallel groups end to end (bitstreams in host memory -> planes in HBM): ms per frame step of mobi_batch_decode_gop and of the
+pipelined mobi_batch_gop_begin / mobi_batch_gop_finish, against the step-by-step calls.
+
+  python tools/exp_gop.py [clips] [K] [groups] [distinct] [config]
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import mobiclipdecoder_amd as m
+from mobiclipdecoder_amd.streamgen import BASE_SEED
+
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+groups = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+distinct = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+config = sys.argv[5] if len(sys.argv) > 5 else "B"
+mode = os.environ.get("GOP_MODE", "lockstep")
+mode = int(mode) if mode.isdigit() else mode
+
+n_frames = 1 + K * (groups + 2)
+streams = []
+for i in range(distinct):
+    p = m.default_params(config, BASE_SEED + 100 + i, n_frames=n_frames)
+    streams.append((p,) + m.generate_clip(p))
+p0 = streams[0][0]
+W, H = p0.width, p0.height
+
+
+def packed_group(f0, k):
+    bufs = [streams[c % distinct][1][streams[c % distinct][2][f0 + j]:streams[c % distinct][2][f0 + j + 1]] for j in range(k) for c in range(clips)]
+    return bufs, (C.c_void_p * len(bufs))(*[x.ctypes.data for x in bufs]), (C.c_size_t * len(bufs))(*[x.size for x in bufs])
+
+
+b = m.MobiclipBatch(clips, W, H, p0.version, device_parse=mode)
+lib, h = b._lib, b._h
+nv = clips * K
+offs, outo, rcs = (C.c_int32 * nv)(), (C.c_int32 * nv)(), (C.c_int * nv)()
+# the I-frame on its own, then groups
+g = packed_group(0, 1)
+assert lib.mobi_batch_decode_gop(h, 1, g[1], g[2], offs, rcs) == 0 and not any(rcs[:clips])
+packs = [packed_group(1 + K * i, K) for i in range(groups + 2)]
+ms = []
+for i in range(groups + 1):
+    for j in range(nv):
+        offs[j] = 0
+    t0 = time.perf_counter()
+    assert lib.mobi_batch_decode_gop(h, K, packs[i][1], packs[i][2], offs, rcs) == 0
+    ms.append((time.perf_counter() - t0) * 1e3)
+    assert not any(rcs), "stream error"
+sync_ms = float(np.median(ms[1:])) / K
+print(f"{clips} clips x K={K} ({config}, {distinct} distinct, mode {mode}): mobi_batch_decode_gop {sync_ms:.3f} ms per frame step = {clips * W * H / sync_ms / 1e6:.1f} Gpixels/s "
+      f"(groups: {[round(x, 1) for x in ms]} ms); host clips {b.host_clips()}, lock-step finished {b.lockstep_finished()} of {nv}")
+b.close()
+
+b = m.MobiclipBatch(clips, W, H, p0.version, device_parse=mode)
+lib, h = b._lib, b._h
+for j in range(nv):
+    offs[j] = 0
+assert lib.mobi_batch_decode_gop(h, 1, g[1], g[2], offs, rcs) == 0
+for j in range(nv):
+    offs[j] = 0
+assert lib.mobi_batch_decode_gop(h, K, packs[0][1], packs[0][2], offs, rcs) == 0 and not any(rcs)  # (allocations)
+for j in range(nv):
+    offs[j] = 0
+t0 = time.perf_counter()
+assert lib.mobi_batch_gop_begin(h, K, packs[1][1], packs[1][2], offs) == 0
+def finish():
+    e = lib.mobi_batch_gop_finish(h, outo, rcs)
+    bad = [(j, rcs[j]) for j in range(nv) if rcs[j]]
+    assert e == 0 and not bad, (e, b._lib.mobi_error_string(e), len(bad), bad[:8])
+
+
+for i in range(2, groups + 1):
+    assert lib.mobi_batch_gop_begin(h, K, packs[i][1], packs[i][2], offs) == 0
+    finish()
+finish()
+pipe_ms = (time.perf_counter() - t0) * 1e3 / (groups * K)
+print(f"  pipelined (gop_begin of group g + 1 before gop_finish of group g): {pipe_ms:.3f} ms per frame step = {clips * W * H / pipe_ms / 1e6:.1f} Gpixels/s")
+# the newest frame against a step-by-step batch's (a few clips)
+y = [b.planes(c, 0) for c in range(min(clips, 4))]
+b.close()
+if os.environ.get("GOP_STEPWISE", "1") != "0":
+    b = m.MobiclipBatch(clips, W, H, p0.version, device_parse=mode)
+    ms = []
+    last = 1 + K * (groups + 1)
+    for f in range(last):
+        datas = [streams[c % distinct][1][streams[c % distinct][2][f]:streams[c % distinct][2][f + 1]] for c in range(clips)]
+        r, _ = b.decode(datas, [0] * clips)
+        assert not any(r)
+        ms.append(b.last_decode_ms())
+    print(f"  step by step (mobi_batch_decode): {float(np.median(ms[2:])):.3f} ms per frame step")
+    for c in range(min(clips, 4)):
+        yy = b.planes(c, 0)
+        assert np.array_equal(y[c][0], yy[0]) and np.array_equal(y[c][1], yy[1]), "the pipelined groups' newest frame differs from the step-by-step batch's"
+    print("  newest frame identical to the step-by-step batch's (first clips)")
+    b.close()
