@@ -213,7 +213,7 @@ LS_FN void ls_begin_frame(LsLane &s, S &m, const LsCtx &c, uint32_t len) {
     if (c.version == MOBI_VERSION_MOFLEX3DS && q == 0) ls_setup_quant(s, m, c, q);
     else if (dq != 0) ls_setup_quant(s, m, c, q + (uint32_t)dq);
     s.vlc = 0;
-    for (int i = 0; i < 2 * (c.mbw + 2); i++) m.mvc(i) = 0;
+    for (int i = 0; i < c.mbw + 2; i++) m.mvp(i) = 0;
   }
 }
 
@@ -264,8 +264,7 @@ LS_FN void ls_cells(LsLane &s, int x, int y, int wi, int hi, uint32_t cell) {
 template <class S>
 LS_FN void ls_leaf(LsLane &s, S &m, const LsCtx &c, int wi, int hi, int x, int y, int ref, int dx, int dy) {
   const int w = 16 >> wi, h = 16 >> hi, S_ = c.stride;
-  m.mvc(s.mvslot) = dx;
-  m.mvc(s.mvslot + 1) = dy;
+  m.mvp(s.mvslot >> 1) = mobi_leaf_w1(dx, dy); // (r06: the row cache holds a vector as two int16 in one word -- a vector beyond +-8191 ends the lane right below)
   if (ref > ls_min(5, s.frames_started - 1)) { ls_bail(s, 6); return; }
   if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) { ls_bail(s, 7); return; }
   const int o = s.cur_off + y * S_ + x, ylen = S_ * c.height;
@@ -603,13 +602,14 @@ LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
         s.mb_type = MOBI_MB_INTRA;
         s.st = LS_I_HDR;
       } else {
-        const int e = 2 * s.mx; // left, top, top-right (MD.cs:163-169)
-        const int a0 = m.mvc(e), a1 = m.mvc(e + 1), b0 = m.mvc(e + 2), b1 = m.mvc(e + 3), c0 = m.mvc(e + 4), c1 = m.mvc(e + 5);
+        // left, top, top-right (MD.cs:163-169)
+        const uint32_t va = m.mvp(s.mx), vb = m.mvp(s.mx + 1), vc = m.mvp(s.mx + 2);
+        const int a0 = (int)(int16_t)(va & 0xFFFF), a1 = (int)(int16_t)(va >> 16), b0 = (int)(int16_t)(vb & 0xFFFF), b1 = (int)(int16_t)(vb >> 16),
+                  c0 = (int)(int16_t)(vc & 0xFFFF), c1 = (int)(int16_t)(vc >> 16);
         s.predx = ls_max(ls_min(a0, b0), ls_min(ls_max(a0, b0), c0));
         s.predy = ls_max(ls_min(a1, b1), ls_min(ls_max(a1, b1), c1));
         s.mvslot = 2 * (s.mx + 1);
-        m.mvc(s.mvslot) = 0;
-        m.mvc(s.mvslot + 1) = 0;
+        m.mvp(s.mx + 1) = 0;
         s.mb_type = MOBI_MB_INTER;
         m.stk(0) = 0;
         s.sp = 1;

@@ -32,11 +32,11 @@ namespace {
 enum { LS_SERVICE = LS_SERVICE_N, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
 struct DevStore { // L = clips per wave: the per-lane state is interleaved at that stride (element i of lane l at i * L + l)
-  int32_t *mvc_;
+  uint32_t *mvp_; // the MV row cache (Internal[221..]): one word per macroblock column, dx | dy << 16 (both within +-8191 in any frame a lane finishes)
   uint32_t *stk_, *rec_, *ring_;
   uint8_t *mc_;
   int lane, L;
-  __device__ __forceinline__ int32_t &mvc(int i) { return mvc_[i * L + lane]; }
+  __device__ __forceinline__ uint32_t &mvp(int i) { return mvp_[i * L + lane]; }
   __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * L + lane]; }
   __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * L + lane]; }
   __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * L + lane]; }
@@ -73,12 +73,12 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
   // the step before runs beside it (asynchronous steps: four of its waves on the same SIMD), the chain must not queue behind them.
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mvc_words = 2 * (A.mbw + 2);
+  const int mvp_words = A.mbw + 2;
   uint8_t *tab = lds;
   DevStore m;
   m.L = LS_CLIPS;
-  m.mvc_ = (int32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvc_words + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
-  m.stk_ = (uint32_t *)(m.mvc_ + mvc_words * LS_CLIPS);
+  m.mvp_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvp_words + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
+  m.stk_ = m.mvp_ + mvp_words * LS_CLIPS;
   m.rec_ = m.stk_ + 16 * LS_CLIPS;
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
   m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
@@ -170,7 +170,7 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
     st->predx = s.predx; st->predy = s.predy;
     if (!s.iframe) { // the MV row cache a P-frame leaves (Internal[221..]): a later I-frame's walk through Internal[] may read it (mobi_state.h)
       int32_t *mv = A.tail_out[clip].mvc;
-      for (int i = 0; i < mvc_words; i++) mv[i] = m.mvc(i);
+      for (int i = 0; i < mvp_words; i++) { const uint32_t v = m.mvp(i); mv[2 * i] = (int)(int16_t)(v & 0xFFFF); mv[2 * i + 1] = (int)(int16_t)(v >> 16); }
     }
   }
   A.res[clip] = r;
@@ -204,14 +204,22 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   // rounds -- 32768 clips: 68.9 ms per step against 39.9, 24576: 37.4 (16 per wave, r05's first rule) against 35.1, 16384: 34.8 against 28.7,
   // 40960: 55.3 against 47.7 (tools/exp_async.py, profiles/r05_experiments.txt).  49152 clips (24 per wave, what 288 GB hold at 640x480) only
   // fit a CU's LDS this way.
-  const int per_clip = 4 * (2 * (a->mbw + 2)) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
+  const int per_clip = 4 * (a->mbw + 2) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
   auto lds_of = [&](int w, int l) { return (size_t)MOBI_DT_BYTES + (size_t)w * l * per_clip; };
   const size_t lds_max = 160 * 1024;
   int L = (a->n_clips + 2047) / 2048;
   L = L < 1 ? 1 : L > 64 ? 64 : L;
-  while (L > 1 && lds_of(MOBI_LS_WAVES, L) > lds_max) L--; // (more than two waves per SIMD then: the launch takes turns, but runs)
   int W = MOBI_LS_WAVES;
   if ((a->n_clips + L - 1) / L > 1536 && lds_of(2 * W, L) <= lds_max) W *= 2;
+  // r06: more lanes than the chip holds as two waves per SIMD (frame-parallel groups: n_clips x K virtual clips) -- the launch takes turns.
+  // Beyond ~24 lanes a wave costs what its lanes bring (every lane is in a state of its own: the wave runs every part of the walk every
+  // round), and more than two waves per SIMD lose as they did in r05 (tools/exp_gop_lanes.sh, 147456 lanes, ms per launch by lanes x waves
+  // per workgroup: 24 x 8: 82, 28 x 8: 84, 35 x 8: 90, 46 x 6: 96, 64 x 4 -- one wave per SIMD -- 100; 15 x 8 twice per CU: 107, 12 x 8: 120)
+  if (L > 24) {
+    L = 24;
+    W = 2 * MOBI_LS_WAVES;
+    while (L > 1 && lds_of(W, L) > lds_max) L--;
+  }
 #if defined(MOBI_PROFILING)
   if (const char *e = getenv("MOBI_LS_CLIPS")) L = atoi(e);    // (tools/exp_lsab.sh, tests/test_lsparse_gpu.py)
   if (const char *e = getenv("MOBI_LS_WG_WAVES")) W = atoi(e);

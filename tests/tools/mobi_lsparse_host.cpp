@@ -12,13 +12,13 @@
 
 namespace {
 struct HostStore {
-  int32_t mvc_[2 * (64 + 2)];
+  uint32_t mvp_[64 + 2];
   uint32_t stk_[16];
   uint32_t rec_[MOBI_INTRA_RECORDS];
   uint8_t mc_[40];
   const uint8_t *data;
   uint32_t len2; // bytes that exist as whole 16-bit words
-  int32_t &mvc(int i) { return mvc_[i]; }
+  uint32_t &mvp(int i) { return mvp_[i]; }
   uint32_t &stk(int i) { return stk_[i]; }
   uint32_t &rec(int i) { return rec_[i]; }
   uint8_t &mc(int i) { return mc_[i]; }
@@ -409,7 +409,7 @@ int mobi_framedep_measure(uint32_t w, uint32_t h, int version, const uint8_t *da
     {
       C->quant = sp.quant; C->yuvfmt = sp.yuvfmt; C->tables_set = sp.tables_set; C->frames_started = sp.frames_started; C->predx = sp.predx; C->predy = sp.predy;
       memcpy(C->m.mc_, sp.mcache, 40);
-      for (int i = 0; i < 2 * (C->g.mbw + 2); i++) C->m.mvc_[i] = t0.mvc[i];
+      for (int i = 0; i < C->g.mbw + 2; i++) C->m.mvp_[i] = mobi_leaf_w1(t0.mvc[2 * i], t0.mvc[2 * i + 1]);
       int32_t used = 0;
       uint32_t n_intra = 0, pay_words = 0, ftype = 0;
       const int bail = mobi_lshost_parse(C, d, len, &used, &n_intra, &pay_words, &ftype);

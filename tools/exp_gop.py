@@ -22,7 +22,7 @@ config = sys.argv[5] if len(sys.argv) > 5 else "B"
 mode = os.environ.get("GOP_MODE", "lockstep")
 mode = int(mode) if mode.isdigit() else mode
 
-n_frames = 1 + K * (groups + 2)
+n_frames = 1 + K * (groups + 3)
 streams = []
 for i in range(distinct):
     p = m.default_params(config, BASE_SEED + 100 + i, n_frames=n_frames)
@@ -38,12 +38,14 @@ def packed_group(f0, k):
 
 b = m.MobiclipBatch(clips, W, H, p0.version, device_parse=mode)
 lib, h = b._lib, b._h
+if hasattr(lib, "mobi_debug_phase_ms"):
+    b.set_kernel_timing(1)
 nv = clips * K
 offs, outo, rcs = (C.c_int32 * nv)(), (C.c_int32 * nv)(), (C.c_int * nv)()
 # the I-frame on its own, then groups
 g = packed_group(0, 1)
 assert lib.mobi_batch_decode_gop(h, 1, g[1], g[2], offs, rcs) == 0 and not any(rcs[:clips])
-packs = [packed_group(1 + K * i, K) for i in range(groups + 2)]
+packs = [packed_group(1 + K * i, K) for i in range(groups + 3)]
 ms = []
 for i in range(groups + 1):
     for j in range(nv):
@@ -52,6 +54,15 @@ for i in range(groups + 1):
     assert lib.mobi_batch_decode_gop(h, K, packs[i][1], packs[i][2], offs, rcs) == 0
     ms.append((time.perf_counter() - t0) * 1e3)
     assert not any(rcs), "stream error"
+if hasattr(lib, "mobi_debug_phase_ms"):  # MOBI_LIB=mobiclipdecoder_amd/libmobiclip_hip_prof.so: where the last group's time went
+    for fn in ("mobi_debug_phase_ms", "mobi_debug_stage_ms", "mobi_debug_parse_ms"):
+        getattr(lib, fn).restype = C.c_float
+    lib.mobi_debug_phase_ms.argtypes = [C.c_void_p, C.c_int]
+    lib.mobi_debug_stage_ms.argtypes = [C.c_void_p]
+    lib.mobi_debug_parse_ms.argtypes = [C.c_void_p]
+    ph = [lib.mobi_debug_phase_ms(h, k) for k in range(4)]
+    print(f"  last group: gather + upload enqueue {lib.mobi_debug_stage_ms(h):.1f} ms; in finish: parse waited for at {ph[0]:.1f}, hand-overs done {ph[1]:.1f}, "
+          f"reconstruction enqueued {ph[2]:.1f}, all done {ph[3]:.1f} ms; parse kernels (events) {lib.mobi_debug_parse_ms(h):.1f} ms")
 sync_ms = float(np.median(ms[1:])) / K
 print(f"{clips} clips x K={K} ({config}, {distinct} distinct, mode {mode}): mobi_batch_decode_gop {sync_ms:.3f} ms per frame step = {clips * W * H / sync_ms / 1e6:.1f} Gpixels/s "
       f"(groups: {[round(x, 1) for x in ms]} ms); host clips {b.host_clips()}, lock-step finished {b.lockstep_finished()} of {nv}")
@@ -67,19 +78,22 @@ for j in range(nv):
 assert lib.mobi_batch_decode_gop(h, K, packs[0][1], packs[0][2], offs, rcs) == 0 and not any(rcs)  # (allocations)
 for j in range(nv):
     offs[j] = 0
-t0 = time.perf_counter()
-assert lib.mobi_batch_gop_begin(h, K, packs[1][1], packs[1][2], offs) == 0
 def finish():
     e = lib.mobi_batch_gop_finish(h, outo, rcs)
     bad = [(j, rcs[j]) for j in range(nv) if rcs[j]]
     assert e == 0 and not bad, (e, b._lib.mobi_error_string(e), len(bad), bad[:8])
 
 
-for i in range(2, groups + 1):
+# both slots' buffers exist before the clock starts: groups 1 and 2 are begun and group 1 finished untimed
+assert lib.mobi_batch_gop_begin(h, K, packs[1][1], packs[1][2], offs) == 0
+assert lib.mobi_batch_gop_begin(h, K, packs[2][1], packs[2][2], offs) == 0
+finish()
+t0 = time.perf_counter()
+for i in range(3, groups + 2):
     assert lib.mobi_batch_gop_begin(h, K, packs[i][1], packs[i][2], offs) == 0
     finish()
+pipe_ms = (time.perf_counter() - t0) * 1e3 / ((groups - 1) * K)
 finish()
-pipe_ms = (time.perf_counter() - t0) * 1e3 / (groups * K)
 print(f"  pipelined (gop_begin of group g + 1 before gop_finish of group g): {pipe_ms:.3f} ms per frame step = {clips * W * H / pipe_ms / 1e6:.1f} Gpixels/s")
 # the newest frame against a step-by-step batch's (a few clips)
 y = [b.planes(c, 0) for c in range(min(clips, 4))]
@@ -87,7 +101,7 @@ b.close()
 if os.environ.get("GOP_STEPWISE", "1") != "0":
     b = m.MobiclipBatch(clips, W, H, p0.version, device_parse=mode)
     ms = []
-    last = 1 + K * (groups + 1)
+    last = 1 + K * (groups + 2)
     for f in range(last):
         datas = [streams[c % distinct][1][streams[c % distinct][2][f]:streams[c % distinct][2][f + 1]] for c in range(clips)]
         r, _ = b.decode(datas, [0] * clips)
