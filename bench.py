@@ -75,7 +75,7 @@ def cpu_baseline(params, data, fo, budget_s):
                             "sample": f"{nb} clips including the YUV->ARGB Bitmap of every frame (MD.cs:260-323), {tb:.1f} s"}}
 
 
-def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse=True):
+def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse=True, groups=True):
     """Bitstreams in host memory -> planes in HBM: mobi_batch_decode with the parse on the GPU (row f3).  Reported next to
     the headline value, never as it: the timed region of `value` starts with the command lists already in HBM."""
     b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=device_parse)
@@ -119,6 +119,91 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
     out["async"] = {"value": round(n_clips * W * H / ta / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(ta, 3),
                     "how": "mobi_batch_submit / mobi_batch_wait, two steps in flight; wall time per step over the same P-frames",
                     "verified": verified_async}
+    if not groups:
+        return out
+    try:
+        # (device_parse=True names the one-wavefront-per-clip parser for EVERY step; a group offers n_clips * K lanes, and which parser is in front
+        # of those is the library's own choice, as in any batch created without a mode: mobi_abi.cpp ls_decide)
+        out["groups"] = gop_leg(m, streams, W, H, version, device, n_clips, None if device_parse is True else device_parse)
+    except Exception as e:  # (e.g. the six command lists of a group do not fit beside what is resident)
+        out["groups"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+GOP_K = 6  # frames per group: the ring holds six pictures (MD.cs:19-20), so every frame of a group is still readable when the call returns
+
+
+def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
+    """r06, frame-parallel groups: the same bitstreams, K consecutive P-frames of every clip per call (mobi_batch_decode_gop: the device
+    parsers run over n_clips * K frames side by side; the reconstruction stays one step per frame), and the same with group g + 1 begun
+    before group g is finished (mobi_batch_gop_begin / mobi_batch_gop_finish).  ms_per_step = wall time per FRAME step."""
+    import ctypes as C
+    import time as _t
+    if K is None:
+        # The lock-step parser is at its best from ~49152 lanes on (24 lanes x 8 waves on every CU; beyond that it takes turns: no gain), and a
+        # group's command lists cost HBM (worst-case payload room per frame): as many frames per group as it takes to get there, whole turns
+        K = GOP_K if n_clips * GOP_K <= 49152 else 4 if n_clips * 4 <= 98304 else 2
+    n_frames = min(len(s[2]) - 1 for s in streams)
+    G = (n_frames - 1) // K  # groups of P-frames a stream holds
+    if G < 3:
+        return {"error": f"streams of {n_frames} frames hold {G} groups of {K}"}
+    nv = n_clips * K
+
+    def pack(f0, k):
+        bufs = [streams[c % len(streams)][1][streams[c % len(streams)][2][f0 + j]:streams[c % len(streams)][2][f0 + j + 1]] for j in range(k) for c in range(n_clips)]
+        return bufs, (C.c_void_p * len(bufs))(*[x.ctypes.data for x in bufs]), (C.c_size_t * len(bufs))(*[x.size for x in bufs])
+
+    iframe = pack(0, 1)
+    packs = [pack(1 + K * g, K) for g in range(G)]
+    offs, outo, rcs = (C.c_int32 * nv)(), (C.c_int32 * nv)(), (C.c_int * nv)()
+
+    def zero():
+        C.memset(offs, 0, C.sizeof(offs))
+
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=device_parse)
+    lib, h = b._lib, b._h
+    zero()
+    assert lib.mobi_batch_decode_gop(h, 1, iframe[1], iframe[2], offs, rcs) == 0 and not any(rcs[:n_clips])
+    ms = []
+    for g in range(min(G, 4)):  # the first group untimed (allocations)
+        zero()
+        t0 = _t.perf_counter()
+        assert lib.mobi_batch_decode_gop(h, K, packs[g][1], packs[g][2], offs, rcs) == 0
+        ms.append((_t.perf_counter() - t0) * 1e3 / K)
+        assert not any(rcs), "stream error in the group leg"
+    host_clips = b.host_clips()
+    verified = verify_clips(b, streams, len(streams), n_clips, K * min(G, 4), W, H)
+    b.close()
+    t = float(np.median(ms[1:]))
+    out = {"value": round(n_clips * W * H / t / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(t, 3), "clips": n_clips, "frames_per_group": K,
+           "how": f"mobi_batch_decode_gop: {K} consecutive P-frames of every clip per call, parsed side by side as {nv} virtual clips (mobi_gop.h), reconstructed as {K} steps; "
+                  "wall time of the call / frames (host staging, H2D, parse, chain check, reconstruction, read-back, sync)",
+           "clips_handed_to_the_host_parser": int(host_clips), "verified": verified}
+    b = m.MobiclipBatch(n_clips, W, H, version, device=device, device_parse=device_parse)
+    lib, h = b._lib, b._h
+    zero()
+    assert lib.mobi_batch_decode_gop(h, 1, iframe[1], iframe[2], offs, rcs) == 0
+    zero()
+
+    def finish():
+        assert lib.mobi_batch_gop_finish(h, outo, rcs) == 0 and not any(rcs), "stream error in the pipelined group leg"
+
+    # groups 0 and 1 begun and group 0 finished untimed: both slots' buffers exist before the clock starts
+    assert lib.mobi_batch_gop_begin(h, K, packs[0][1], packs[0][2], offs) == 0
+    assert lib.mobi_batch_gop_begin(h, K, packs[1][1], packs[1][2], offs) == 0
+    finish()
+    t0 = _t.perf_counter()
+    for g in range(2, G):
+        assert lib.mobi_batch_gop_begin(h, K, packs[g][1], packs[g][2], offs) == 0
+        finish()
+    tp = (_t.perf_counter() - t0) * 1e3 / ((G - 2) * K)
+    finish()
+    verified_p = verify_clips(b, streams, len(streams), n_clips, K * G, W, H)
+    b.close()
+    out["pipelined"] = {"value": round(n_clips * W * H / tp / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(tp, 3), "groups_timed": G - 2,
+                        "how": "mobi_batch_gop_begin of group g + 1 (gather, upload) before mobi_batch_gop_finish of group g (hand-overs, reconstruction, then the parse of "
+                               "group g + 1 beside it); wall time per frame step in the steady state (one group's parse is under way when the clock starts and one when it stops)",
+                        "verified": verified_p}
     return out
 
 
@@ -564,7 +649,7 @@ def main():
             # and 34.4 with 64 or 128 (tools/exp_dparse.py, DISTINCT=...): this leg takes 64, so that no wave holds two copies of one.
             wide = list(streams)
             for i in range(len(streams), 64):
-                p = m.default_params(args.config, sharding.stream_seed(args.config, rank, i), n_frames=12, **gen_over)
+                p = m.default_params(args.config, sharding.stream_seed(args.config, rank, i), n_frames=1 + 5 * GOP_K, **gen_over)
                 wide.append((p,) + m.generate_clip(p))
             e2e_large = end_to_end(m, wide, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
         except Exception as e:  # (e.g. does not fit beside what the allocator still holds: reported beside the headline value, not fatal to it)
@@ -580,7 +665,7 @@ def main():
                 e2e_xl = {"error": f"{n_xl} clips need ~{(n_xl * 4.9e6 + 8e9) / 1e9:.0f} GB, {free / 1e9:.0f} GB free"}
                 continue
             try:
-                e2e_xl = end_to_end(m, wide, W, H, p0.version, local, n_xl, 6, device_parse="lockstep")
+                e2e_xl = end_to_end(m, wide, W, H, p0.version, local, n_xl, 6, device_parse="lockstep", groups=False)  # (rings of 218 GB leave no room for a second set of command lists)
                 break
             except Exception as e:
                 e2e_xl = {"error": f"{type(e).__name__}: {e}"}
