@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "mobi_gop.h"
 #include "mobi_lsparse.h"
 #include "mobi_parse.h"
 
@@ -429,6 +430,93 @@ int mobi_framedep_measure(uint32_t w, uint32_t h, int version, const uint8_t *da
       }
     }
     ready = A.device_ready();
+  }
+  mobi_lshost_destroy(C);
+  return 0;
+}
+// ---- r06: the frame-parallel chain (mobi_gop.h) on the CPU, with the same functions the two device kernels call -----------------------------
+// The clip's frames in groups of K: the start state of every frame of a group is PREDICTED from the group's true start state and the frame
+// headers (mobi_gop_next_guess, what mobi_gop_prepare does), every frame is parsed by the lock-step lane functions from its predicted state
+// (independently: nothing of frame k - 1's parse is used), and the chain (mobi_gop_chain) verifies each prediction against the merged truth and
+// merges.  The result -- command lists and the state behind every frame -- must be the host parser's, which parses in stream order.
+// stats: [0] frames parsed from a predicted state and verified, [1] predictions that did not hold (the rest of the group goes to the host
+// parser), [2] frames a lane bailed out of or the host parser rejected (same), [3] frames left to the host parser, [4] DIFFERENCES (must be 0).
+int mobi_gop_host_check(uint32_t w, uint32_t h, int version, const uint8_t *data, const uint32_t *frame_off, int n_frames, int K, long stats[5]) {
+  MobiStreamParser A(w, h, version);
+  Clip *C = (Clip *)mobi_lshost_create(w, h, version);
+  if (!C || K < 1 || K > MOBI_GOP_MAX) return -1;
+  for (int k = 0; k < 5; k++) stats[k] = 0;
+  ParsedFrame pa;
+  const int moflex = version == 2;
+  uint8_t hdr[8];
+  for (int f0 = 0; f0 < n_frames;) {
+    const int kk = std::min(K, n_frames - f0);
+    MobiDevState cur;
+    MobiDevTail t0;
+    A.export_state(cur, t0);
+    if (f0 > 0 && !A.device_ready()) { // the host parser's clip: it parses until its state is one the device holds again
+      int32_t off = 0;
+      A.parse_frame(data + frame_off[f0], frame_off[f0 + 1] - frame_off[f0], &off, pa);
+      stats[3]++;
+      f0++;
+      continue;
+    }
+    MobiDevState guess[MOBI_GOP_MAX];
+    guess[0] = cur;
+    for (int k = 1; k < kk; k++) {
+      const uint32_t len = frame_off[f0 + k] - frame_off[f0 + k - 1];
+      memset(hdr, 0, sizeof(hdr));
+      memcpy(hdr, data + frame_off[f0 + k - 1], std::min<uint32_t>(len, 8));
+      guess[k] = guess[k - 1];
+      mobi_gop_next_guess(moflex, hdr, len, guess[k]);
+    }
+    bool broken = false;
+    int k = 0;
+    for (; k < kk && !broken; k++) {
+      const uint8_t *d = data + frame_off[f0 + k];
+      const size_t len = frame_off[f0 + k + 1] - frame_off[f0 + k];
+      // the lane's parse, from the PREDICTED state (it does not know what the frame before left)
+      C->quant = guess[k].quant; C->yuvfmt = guess[k].yuvfmt; C->tables_set = guess[k].tables_set; C->frames_started = guess[k].frames_started;
+      C->predx = guess[k].predx; C->predy = guess[k].predy;
+      memcpy(C->m.mc_, guess[k].mcache, 40);
+      int32_t used = 0, offa = 0;
+      uint32_t n_intra = 0, pay_words = 0, ftype = 0;
+      const int bail = mobi_lshost_parse(C, d, len, &used, &n_intra, &pay_words, &ftype);
+      // the truth
+      const int rca = A.parse_frame(d, len, &offa, pa);
+      MobiDevState s1;
+      MobiDevTail t1;
+      A.export_state(s1, t1);
+      if (k > 0 && !mobi_gop_guess_ok(guess[k], cur)) { stats[1]++; broken = true; break; }
+      if (bail || rca != MOBI_OK) {
+        if (!bail) { fprintf(stderr, "gop check: frame %d finished by the lane functions, rejected (%d) by the host parser\n", f0 + k, rca); stats[4]++; }
+        stats[2]++;
+        broken = true;
+        break;
+      }
+      MobiDevState out;
+      memset(&out, 0, sizeof(out));
+      out.quant = C->quant; out.yuvfmt = C->yuvfmt; out.tables_set = C->tables_set; out.frames_started = C->frames_started; out.predx = C->predx; out.predy = C->predy;
+      memcpy(out.mcache, C->m.mc_, 40);
+      mobi_gop_merge(cur, ftype == 1, out);
+      bool eq = used == offa && pay_words == pa.payload.size() && n_intra == pa.hdr.n_intra && memcmp(C->pay.data(), pa.payload.data(), pa.payload.size() * 4) == 0;
+      for (size_t mb = 0; eq && mb < pa.desc.size(); mb++) eq = C->desc[mb].payload_off == pa.desc[mb].payload_off && C->desc[mb].w1 == pa.desc[mb].w1 && C->desc[mb].w2 == pa.desc[mb].w2 && C->desc[mb].w3 == pa.desc[mb].w3;
+      if (A.device_ready() && memcmp(&out, &s1, sizeof(out)) != 0) eq = false; // (a host-only state behind the frame: the host keeps the clip)
+      if (!eq) { fprintf(stderr, "gop check: frame %d differs when parsed from its predicted state\n", f0 + k); stats[4]++; }
+      stats[0]++;
+      cur = out;
+      if (!A.device_ready()) { k++; break; } // what follows starts from a state the device does not hold: the next group decides
+    }
+    if (broken) { // the frame at k and the ones behind it are the host parser's: A has parsed frame k already (above), the rest follows
+      stats[3]++;
+      for (int j = k + 1; j < kk; j++) {
+        int32_t off = 0;
+        A.parse_frame(data + frame_off[f0 + j], frame_off[f0 + j + 1] - frame_off[f0 + j], &off, pa);
+        stats[3]++;
+      }
+      f0 += kk;
+    } else
+      f0 += k;
   }
   mobi_lshost_destroy(C);
   return 0;
