@@ -225,7 +225,7 @@ def single_stream_leg(m, stream, W, H, version, device):
     res = {}
     for with_bitmap in (False, True):
         t_i, t_p = [], []
-        for rep in range(3):  # the first pass pays the allocations
+        for rep in range(10):  # the first pass pays the allocations; nine timed (a clip holds one I-frame: nine samples of it)
             h = lib.mobi_create(W, H, int(version), device)
             assert h
             for f in range(p.n_frames):
@@ -240,7 +240,8 @@ def single_stream_leg(m, stream, W, H, version, device):
                 if rep:
                     (t_i if f == 0 else t_p).append(dt)
             lib.mobi_destroy(h)
-        res["with_bitmap" if with_bitmap else "planes"] = {"p_frame_ms": round(float(np.median(t_p)), 4), "i_frame_ms": round(float(np.median(t_i)), 4)}
+        res["with_bitmap" if with_bitmap else "planes"] = {"p_frame_ms": round(float(np.median(t_p)), 4), "i_frame_ms": round(float(np.median(t_i)), 4),
+                                                              "p_frame_ms_max": round(float(np.max(t_p)), 4), "i_frame_ms_max": round(float(np.max(t_i)), 4), "i_frame_samples": len(t_i)}
     o = OracleDecoder(W, H, p.version)
     t0 = time.perf_counter()
     n = 0

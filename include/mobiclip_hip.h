@@ -125,7 +125,8 @@ int mobi_batch_host_clips(const mobi_batch *b);
 int mobi_batch_lockstep_finished(const mobi_batch *b);
 /* Asynchronous frame steps, for callers that already hold the next frame of every clip (demuxed Moflex / Mods packets: the Offset
  * to start from does not depend on the previous frame's parse).  The batch must parse on the GPU (the default for large batches, see above;
- * mobi_batch_set_parse_mode(b, 1) otherwise; not the hybrid mode) and at most two steps may be in flight.
+ * mobi_batch_set_parse_mode(b, 1), 2 or 3 otherwise: the hybrid mode's host share is parsed inside mobi_batch_submit) and at most two steps
+ * may be in flight.
  *   mobi_batch_submit: copies the bytes data[i][offsets[i] .. len[i]) of every clip into pinned memory and enqueues upload, parse and
  *                      reconstruction of one frame step behind the step before; returns without waiting for the GPU.  The caller's
  *                      buffers may be reused as soon as it returns.  The upload has a stream of its own, and so has the lock-step parser
@@ -141,7 +142,15 @@ int mobi_batch_lockstep_finished(const mobi_batch *b);
  * step is in flight).  The getters wait for everything enqueued before they copy, so reading results between submit and wait drains the
  * pipeline: read after the last wait, or accept the drain.  mobi_batch_quantizer / mobi_batch_yuv_format describe the step last
  * WAITED for.  If mobi_batch_submit fails after it has started to enqueue (MOBI_E_DEVICE), the batch is drained and refuses all
- * further steps: destroy it.  What it buys: the host gathers and uploads step n + 1 while the GPU parses step
+ * further steps: destroy it.  A frame the device parsers could not finish is repaired in mobi_batch_wait (every such clip of the step
+ * at once: their start states in one copy, their parses on the host threads, one reconstruction of those clips per affected step); rc,
+ * Offset, Quantizer and the frame's planes are then the host parser's, as in mobi_batch_decode.  ONE thing is unspecified in this mode
+ * only: when such a clip's NEXT frame was already in flight (parsed by the device from the state the failed frame left and reconstructed
+ * before anybody knew), that ring slot may hold what the wrong parse wrote -- so if the repaired parse of that next frame is itself
+ * rejected (rc != MOBI_OK) the slot's content is unspecified (mobi_batch_decode leaves the picture of six frames earlier there), and a
+ * repaired frame that predicts from the OLDEST ring picture (reference 5, the slot the step in flight was writing) may predict from it.
+ * Both need a damaged stream; intact streams, and damaged ones under mobi_batch_decode / mobi_batch_decode_gop, are exact.
+ * What it buys: the host gathers and uploads step n + 1 while the GPU parses step
  * n, and the GPU goes from parse to reconstruction without asking the host for launch sizes. */
 int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *len, const int32_t *offsets);
 int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc);

@@ -302,6 +302,7 @@ struct mobi_batch {
     hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_parsed = nullptr;
     std::vector<int32_t> offs; // Offset of every clip at submission
     int n_dev = 0;
+    bool lockstep = false;           // the lock-step parser was in front of THIS step (ls_decide at submission)
     bool parsed_recorded = false;    // ev_parsed has been recorded at least once
     int state_in = 0, ring_base = 0; // the entry of the state ring this step's parse read; the ring position its reconstruction wrote
     size_t hdr_bytes = 0;            // of the staged bitstream image (h_stage: offsets, lengths, bits)
@@ -869,13 +870,21 @@ static int dp_override(mobi_batch *b, const std::vector<int> &clips, const int *
   }
   return MOBI_OK;
 }
-// the decoder state clip c had when the step that read ring entry `in` started, into its host parser
-static int dp_seed_parser(mobi_batch *b, int c, int in) {
-  MobiDevState st;
-  MobiDevTail tail;
-  HIP_TRY(hipMemcpy(&st, b->d_pstate[in] + c, sizeof(st), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&tail, b->d_ptail[in] + c, sizeof(tail), hipMemcpyDeviceToHost));
-  b->parsers[c]->import_state(st, tail);
+// the decoder state the clips of `cl` had when the step that read ring entry `in` started, into their host parsers: two asynchronous copies per
+// clip into pinned memory, ONE wait, the imports on the pool (r05 issued two blocking copies per clip: a step in which every clip of a large
+// batch is handed over at once -- a ModsDS batch that cuts to a quantiser below 12 -- sat in tens of thousands of them)
+static int dp_seed_parsers(mobi_batch *b, const std::vector<int> &cl, int in, PinnedBuf &stage, hipStream_t s) {
+  if (cl.empty()) return MOBI_OK;
+  const size_t rec = sizeof(MobiDevState) + sizeof(MobiDevTail);
+  if (int e = stage.reserve(cl.size() * rec)) return e;
+  for (size_t j = 0; j < cl.size(); j++) {
+    HIP_TRY(hipMemcpyAsync(stage.p + j * rec, b->d_pstate[in] + cl[j], sizeof(MobiDevState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(stage.p + j * rec + sizeof(MobiDevState), b->d_ptail[in] + cl[j], sizeof(MobiDevTail), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  b->pool->run((int)cl.size(), [&](int j) {
+    b->parsers[cl[j]]->import_state(*(const MobiDevState *)(stage.p + (size_t)j * rec), *(const MobiDevTail *)(stage.p + (size_t)j * rec + sizeof(MobiDevState)));
+  });
   return MOBI_OK;
 }
 
@@ -982,8 +991,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   for (int i = 0; i < n; i++)
     if (!b->on_host[i] && res[i].rc != MOBI_OK) fb.push_back(i);
   if (!fb.empty()) {
-    for (int c : fb)
-      if (int e = dp_seed_parser(b, c, state_in)) return e;
+    if (int e = dp_seed_parsers(b, fb, state_in, b->h_ret, b->stream)) return e; // (the stream is idle: it was waited for above)
     host_parse(fb);
     for (int c : fb) {
       b->on_host[c] = 1;
@@ -995,7 +1003,7 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
     if (int e = dp_override(b, fb, rc, b->h_stage2, rows, b->stream)) return e; // (behind the parse kernels, which blanked these clips' rows)
   }
   uint32_t K = 0;
-  if (b->lockstep) b->ls_finished = 0;
+  b->ls_finished = b->lockstep ? 0 : -1;
   for (int i = 0; i < n; i++) {
     if (b->on_host[i]) {
       b->dev_quant[i] = b->parsers[i]->quantizer();
@@ -1035,35 +1043,59 @@ static int decode_device_parse(mobi_batch *b, const uint8_t *const *data, const 
   return MOBI_OK;
 }
 
-// One clip's frame through the reconstruction kernels on its own, into the ring slot `ring_base` names: the repair of a clip whose
-// asynchronous step had been enqueued before anybody knew that its frame was not the device parser's to finish (mobi_batch_wait).
-static int recon_one_clip(mobi_batch *b, int c, int ring_base, const ParsedFrame &pf, int *fault_out) {
-  const int n_mbs = b->g.mbw * b->g.mbh;
-  std::vector<const ParsedFrame *> one(1, &pf);
-  LevelPlan plan;
-  plan.build(one, b->g.mbw);
-  const size_t desc_bytes = align_up((size_t)n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), pay_bytes = align_up(pf.payload.size() * 4 + kPaySlack, kAlign);
-  const size_t item_off = desc_bytes + pay_bytes, total = item_off + align_up(plan.items.size() * 4 + 16, kAlign);
+// Frames of SOME clips through the reconstruction kernels on their own, into the ring slot `ring_base` names: the repair of clips whose
+// asynchronous step had been enqueued before anybody knew that their frame was not the device parser's to finish (mobi_batch_wait).
+// `clips` ascending, frames[j] = clips[j]'s parsed frame (nullptr: the host parser rejected it: nothing is written).  Neighbouring clips
+// form a run, and a run is one compact frame step of its own -- its descriptor table, its payload arena, its launch items, planes and
+// tags offset to its first clip -- so "every clip of the batch at once" is ONE set of launches and a lone glitch a set of its own.  One
+// upload, one read-back of the fault words, one wait for the lot (r05: a parse, an upload, launches and a wait PER CLIP, on the calling thread).
+static int recon_clips(mobi_batch *b, const std::vector<int> &clips, const ParsedFrame *const *frames, int ring_base, int *fault_out) {
+  const int n_mbs = b->g.mbw * b->g.mbh, k = (int)clips.size();
+  if (k == 0) return MOBI_OK;
+  struct Run { int j0, j1; size_t desc_off, pay_off, item_off; LevelPlan plan; };
+  std::vector<Run> runs;
+  size_t total = 0;
+  for (int j0 = 0; j0 < k;) {
+    int j1 = j0 + 1;
+    while (j1 < k && clips[j1] == clips[j1 - 1] + 1) j1++;
+    Run r;
+    r.j0 = j0; r.j1 = j1;
+    std::vector<const ParsedFrame *> fr(frames + j0, frames + j1);
+    r.plan.build(fr, b->g.mbw);
+    const size_t desc_bytes = align_up((size_t)(j1 - j0) * n_mbs * sizeof(MbDesc) + 8 * sizeof(MbDesc), kAlign), pay_bytes = align_up(step_payload_words(fr) * 4 + kPaySlack, kAlign);
+    if (step_payload_words(fr) + kPaySlack / 4 >= ((uint64_t)1 << 32)) return MOBI_E_ARG;
+    r.desc_off = total; r.pay_off = total + desc_bytes; r.item_off = r.pay_off + pay_bytes;
+    total = r.item_off + align_up(r.plan.items.size() * 4 + 16, kAlign);
+    runs.push_back(std::move(r));
+    j0 = j1;
+  }
   if (int e = b->h_fix.reserve(total)) return e;
   if (int e = b->d_fix.reserve(total)) return e;
-  memset(b->h_fix.p, 0, total);
-  step_write(one, n_mbs, (MbDesc *)b->h_fix.p, (uint32_t *)(b->h_fix.p + desc_bytes));
-  if (!plan.items.empty()) memcpy(b->h_fix.p + item_off, plan.items.data(), plan.items.size() * 4);
+  b->pool->run((int)runs.size(), [&](int i) {
+    const Run &r = runs[i];
+    std::vector<const ParsedFrame *> fr(frames + r.j0, frames + r.j1);
+    memset(b->h_fix.p + r.desc_off, 0, r.item_off - r.desc_off);
+    step_write(fr, n_mbs, (MbDesc *)(b->h_fix.p + r.desc_off), (uint32_t *)(b->h_fix.p + r.pay_off));
+    if (!r.plan.items.empty()) memcpy(b->h_fix.p + r.item_off, r.plan.items.data(), r.plan.items.size() * 4);
+  });
   HIP_TRY(hipMemcpyAsync(b->d_fix.p, b->h_fix.p, total, hipMemcpyHostToDevice, b->stream));
-  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1;
-  MobiReconArgs a = b->args(b->d_fix.p, b->d_fix.p + desc_bytes);
-  a.planes += (size_t)c * b->clip_bytes;
-  a.n_clips = 1;
-  a.fault = b->d_fault + c;
-  a.done = b->d_done + (size_t)c * n_mbs;
-  a.ring_base = ring_base;
-  if (int e = b->launch_plan(a, plan, (const uint32_t *)(b->d_fix.p + item_off), 1)) return e;
-  int fault = 0;
-  HIP_TRY(hipMemcpyAsync(&fault, b->d_fault + c, sizeof(int), hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipMemsetAsync(b->d_fault + c, 0, sizeof(int), b->stream));
+  b->step_tag = b->step_tag + 1 ? b->step_tag + 1 : 1; // (one tag for all runs: they touch different clips' tags)
+  for (const Run &r : runs) {
+    const int c0 = clips[r.j0], m = r.j1 - r.j0;
+    MobiReconArgs a = b->args(b->d_fix.p + r.desc_off, b->d_fix.p + r.pay_off);
+    a.planes += (size_t)c0 * b->clip_bytes;
+    a.n_clips = m;
+    a.fault = b->d_fault + c0;
+    a.done = b->d_done + (size_t)c0 * n_mbs;
+    a.ring_base = ring_base;
+    // (two launches, never the one-launch step: its give-up path -- fault bit 2, a dispatch order never seen -- has no retry here)
+    if (int e = b->launch_plan(a, r.plan, (const uint32_t *)(b->d_fix.p + r.item_off), m, false)) return e;
+  }
+  HIP_TRY(hipMemcpyAsync(b->h_fault.data(), b->d_fault, sizeof(int) * b->n, hipMemcpyDeviceToHost, b->stream));
+  for (const Run &r : runs) HIP_TRY(hipMemsetAsync(b->d_fault + clips[r.j0], 0, sizeof(int) * (r.j1 - r.j0), b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->drain_events();
-  *fault_out = fault;
+  for (int j = 0; j < k; j++) fault_out[j] = b->h_fault[clips[j]];
   return MOBI_OK;
 }
 
@@ -1108,7 +1140,7 @@ int mobi_batch_submit(mobi_batch *b, const uint8_t *const *data, const size_t *l
   if (int e = S.h_fault.reserve(sizeof(int) * n)) return e;
   S.offs.assign(offsets, offsets + n);
   S.n_dev = n;
-  b->lockstep = ls_decide(b, st);
+  b->lockstep = S.lockstep = ls_decide(b, st);
   S.hdr_bytes = st.hdr_bytes;
   S.is_host.assign(n, 0);
   S.host_rc.assign(n, MOBI_OK);
@@ -1196,33 +1228,45 @@ static int async_repair(mobi_batch *b, mobi_batch::AsyncSlot &S, const std::vect
   if (b->stream_p) HIP_TRY(hipStreamSynchronize(b->stream_p));
   HIP_TRY(hipStreamSynchronize(b->stream));
   mobi_batch::AsyncSlot *S1 = b->async_count == 2 ? &b->aslot[(b->async_head + 1) & 1] : nullptr;
-  const int n = b->n;
-  ParsedFrame pf;
-  for (int c : failed) {
-    if (int e = dp_seed_parser(b, c, S.state_in)) return e;
-    for (mobi_batch::AsyncSlot *T : {&S, S1}) {
-      if (!T) continue;
-      const uint64_t boff = ((const uint64_t *)T->h_stage.p)[c];
-      const uint32_t blen = ((const uint32_t *)(T->h_stage.p + (size_t)n * 8))[c];
+  const int n = b->n, k = (int)failed.size(), nT = S1 ? 2 : 1;
+  mobi_batch::AsyncSlot *const T[2] = {&S, S1};
+  // r06: a batch operation.  The start states in one go, the parses on the pool (a clip's two frames in order), then per affected step ONE
+  // reconstruction of the failed clips (recon_clips) -- r05 did all of it clip by clip on the calling thread: a GOP damaged in every clip of a
+  // batch, or a ModsDS batch that cuts to a quantiser below 12 in one frame, stalled mobi_batch_wait for ~1.5 ms x 2 x clips.
+  if (int e = dp_seed_parsers(b, failed, S.state_in, S.h_ret, b->stream)) return e;
+  if (b->gop_frames.size() < (size_t)k * 2) b->gop_frames.resize((size_t)k * 2);
+  std::vector<int> prc((size_t)k * 2, MOBI_OK);
+  b->pool->run(k, [&](int j) {
+    const int c = failed[j];
+    for (int t = 0; t < nT; t++) {
+      const uint64_t boff = ((const uint64_t *)T[t]->h_stage.p)[c];
+      const uint32_t blen = ((const uint32_t *)(T[t]->h_stage.p + (size_t)n * 8))[c];
       int32_t off = 0;
-      int rc = b->parsers[c]->parse_frame(T->h_stage.p + T->hdr_bytes + boff, blen, &off, pf);
-      T->is_host[c] = 1;
-      T->host_off[c] = T->offs[c] + off;
-      T->host_quant[c] = b->parsers[c]->quantizer();
-      T->host_yuv[c] = b->parsers[c]->yuv_format();
-      if (rc == MOBI_OK) {
-        int fault = 0;
-        if (int e = recon_one_clip(b, c, T->ring_base, pf, &fault)) return e;
-        if (fault) rc = (fault & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
-      }
-      T->host_rc[c] = rc;
-      ((int *)T->h_fault.p)[c] = 0;
+      prc[(size_t)j * 2 + t] = b->parsers[c]->parse_frame(T[t]->h_stage.p + T[t]->hdr_bytes + boff, blen, &off, b->gop_frames[(size_t)j * 2 + t]);
+      T[t]->is_host[c] = 1;
+      T[t]->host_off[c] = T[t]->offs[c] + off;
+      T[t]->host_quant[c] = b->parsers[c]->quantizer();
+      T[t]->host_yuv[c] = b->parsers[c]->yuv_format();
     }
+  });
+  std::vector<const ParsedFrame *> fr(k);
+  std::vector<int> fault(k);
+  for (int t = 0; t < nT; t++) {
+    for (int j = 0; j < k; j++) fr[j] = prc[(size_t)j * 2 + t] == MOBI_OK ? &b->gop_frames[(size_t)j * 2 + t] : nullptr;
+    if (int e = recon_clips(b, failed, fr.data(), T[t]->ring_base, fault.data())) return e;
+    for (int j = 0; j < k; j++) {
+      int rc = prc[(size_t)j * 2 + t];
+      if (rc == MOBI_OK && fault[j]) rc = (fault[j] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+      T[t]->host_rc[failed[j]] = rc;
+      ((int *)T[t]->h_fault.p)[failed[j]] = 0;
+    }
+  }
+  for (int c : failed) {
     b->on_host[c] = 1;
     b->clean_run[c] = 0;
     b->clean_need[c] = (uint16_t)std::min(256, 2 * (int)b->clean_need[c]);
-    b->fallbacks++;
   }
+  b->fallbacks += failed.size();
   return MOBI_OK;
 }
 int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
@@ -1239,7 +1283,7 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
     if (!S.is_host[i] && res[i].rc != MOBI_OK) failed.push_back(i);
   if (!failed.empty())
     if (int e = async_repair(b, S, failed)) { b->poisoned = true; return e; }
-  if (b->lockstep) b->ls_finished = 0;
+  b->ls_finished = S.lockstep ? 0 : -1; // (of the step being reported, not of the one submitted last: ADVICE r05)
   for (int i = 0; i < S.n_dev; i++) {
     if (S.is_host[i]) {
       rc[i] = S.host_rc[i];
@@ -1247,7 +1291,7 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
       b->dev_quant[i] = S.host_quant[i];
       b->dev_yuvfmt[i] = S.host_yuv[i];
     } else {
-      if (b->lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
+      if (S.lockstep && res[i].pad == MOBI_LS_MAGIC) b->ls_finished++;
       rc[i] = res[i].rc;
       if (offsets_out) offsets_out[i] = S.offs[i] + (int32_t)res[i].consumed;
       b->dev_quant[i] = res[i].quant;
@@ -1633,7 +1677,7 @@ int mobi_batch_host_clips(const mobi_batch *b) {
   for (uint8_t h : b->on_host) k += h;
   return k;
 }
-int mobi_batch_lockstep_finished(const mobi_batch *b) { return b && b->lockstep ? b->ls_finished : -1; }
+int mobi_batch_lockstep_finished(const mobi_batch *b) { return b ? b->ls_finished : -1; }
 
 int mobi_batch_set_parse_mode(mobi_batch *b, int device_parse) {
   if (!b || b->frames_started != 0) return MOBI_E_ARG; // the decoder state lives either in the host parsers or in HBM, not both
@@ -2076,6 +2120,9 @@ int mobi_batch_kernel_ms(mobi_batch *b, float *inter_ms, float *intra_ms, int *i
 mobi_dec *mobi_create(uint32_t width, uint32_t height, int version, int device) {
   mobi_batch *b = mobi_batch_create(1, width, height, version, device);
   if (!b) return nullptr;
+  // the Bitmap buffer of a single stream (1.2 MB at 640x480) exists from the start: the first mobi_get_argb is then a launch and a copy like
+  // every later one, not an allocation (r05: a first call that allocated right after another batch had freed 200 GB was once timed at 5 s)
+  if (ensure_argb(b, 1) != MOBI_OK) { mobi_batch_destroy(b); return nullptr; }
   return new mobi_dec{b};
 }
 void mobi_destroy(mobi_dec *d) {

@@ -456,6 +456,61 @@ def test_gpu_every_clip_of_a_batch_handed_over_at_once(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 2048])
+def test_gpu_every_clip_of_an_asynchronous_batch_handed_over_at_once(n):
+    """the same in asynchronous steps, two in flight: mobi_batch_wait learns that NO clip's frame 2 was the device parsers' to finish, and that
+    frame 3 of every clip -- already parsed from a wrong state and reconstructed -- has to be done again as well.  r06: the repair is a batch
+    operation (states in one go, parses on the pool, one reconstruction of the failed clips per affected step): 2048 clips well inside a
+    second, where r05's clip-by-clip repair took ~1.5 ms x 2 per clip"""
+    import time
+    from mobiclipdecoder_amd import MobiclipBatch
+    from tests.test_internal_walk import _set_quantizer
+    nfr = 6
+    ps = [default_params("A", BASE_SEED + 3005 + 100 * i, n_frames=nfr, width=64, height=48, quantizer=12, pm_intra=150, cbp_prob=500, iframe_interval=2) for i in range(3)]
+    src = []
+    for p in ps:
+        data, fo = generate_clip(p)
+        data = data.copy()
+        frame2 = data[fo[2]:fo[3]]
+        assert frame2[1] & 0x80
+        _set_quantizer(frame2, 5)
+        src.append((data, fo))
+    b = MobiclipBatch(n, 64, 48, 1, device_parse=True)
+    oras = [OracleDecoder(64, 48, 1) for _ in range(3)]
+    want = []
+    for f in range(nfr):
+        row = []
+        for i in range(3):
+            oras[i].Data, oras[i].Offset = src[i][0][src[i][1][f]:src[i][1][f + 1]], 0
+            ro = oras[i].DecodeFrame()
+            assert oras[i].last_error == 0
+            row.append((oras[i].Offset, oras[i].Quantizer, ro[0].copy(), ro[1].copy()))
+        want.append(row)
+    frames = [[src[i % 3][0][src[i % 3][1][f]:src[i % 3][1][f + 1]] for i in range(n)] for f in range(nfr)]
+    waits = []
+    b.submit(frames[0], [0] * n)
+    for f in range(1, nfr):
+        b.submit(frames[f], [0] * n)
+        t0 = time.perf_counter()
+        rcs, offs = b.wait()  # reports frame f - 1
+        waits.append((time.perf_counter() - t0) * 1e3)
+        assert not any(rcs) and all(offs[i] == want[f - 1][i % 3][0] for i in range(n)), (f - 1, [r for r in rcs if r][:4])
+    rcs, offs = b.wait()
+    assert not any(rcs) and all(offs[i] == want[nfr - 1][i % 3][0] for i in range(n))
+    assert b.host_clips() == n
+    for i in list(range(6)) + [n - 1]:
+        y, uv = b.planes(i)
+        assert b.quantizer(i) == want[nfr - 1][i % 3][1]
+        assert np.array_equal(y, want[nfr - 1][i % 3][2]) and np.array_equal(uv, want[nfr - 1][i % 3][3]), i
+    assert b.compare_clips(3) == 0  # every other clip against its source clip, on the device
+    print(f"asynchronous hand-over of {n} clips at once: the wait that repairs frames 2 and 3 took {waits[2]:.1f} ms (the other waits: {[round(w, 1) for w in waits[:2] + waits[3:]]})")
+    assert waits[2] < 1000.0, waits
+    b.close()
+    for o in oras:
+        o.close()
+
+
+@pytest.mark.gpu
 def test_gpu_hybrid_mode_in_asynchronous_steps():
     """r05: the hybrid mode's host share is parsed inside mobi_batch_submit, its command lists ride behind the parse kernels"""
     from mobiclipdecoder_amd import MobiclipBatch
