@@ -331,6 +331,47 @@ def bitmap_leg(m, streams, W, H, version, device, n_clips):
             "verified": {"clip": n_clips - 1, "ok": ok, "against": "CPU oracle's ARGB of the same frame"}}
 
 
+def rank_host_setup(rank, local, world, probe_gpu=True):
+    """One rank per GPU on ONE host: the ranks share its cores and its memory controllers.  Each rank takes cpus / world parse threads
+    (MOBI_PARSE_THREADS, unless the caller set it) and runs -- pool threads, pinned staging buffers (first touch) and all -- on the cpus of
+    its GPU's NUMA node when sysfs names one, else on its 1 / world share of the cpus this process may use.  Returns what it did, for the line."""
+    cpus = sorted(os.sched_getaffinity(0))
+    info = {"cpus_visible": len(cpus), "numa_node": None}
+    if world > 1:
+        mine, node = None, None
+        if probe_gpu:
+            try:
+                import torch
+                pr = torch.cuda.get_device_properties(local)
+                bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+                node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+                if node >= 0:
+                    txt = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+                    on_node = set()
+                    for part in txt.split(","):
+                        a, _, b = part.partition("-")
+                        on_node.update(range(int(a), int(b or a) + 1))
+                    sharing = max(1, world // max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])))
+                    cand = sorted(on_node & set(cpus))
+                    if cand:  # the ranks of one node split its cpus among themselves (by local rank order)
+                        k = local % sharing
+                        mine = cand[k * len(cand) // sharing:(k + 1) * len(cand) // sharing] or cand
+                        info["numa_node"] = node
+            except Exception as e:  # no sysfs entry, an older torch: the even split below
+                info["numa_probe"] = f"{type(e).__name__}: {e}"
+        if mine is None:
+            mine = cpus[rank * len(cpus) // world:(rank + 1) * len(cpus) // world] or cpus
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError as e:
+            info["affinity_error"] = str(e)
+        info["cpus_pinned"] = len(mine)
+        # (the library's own rule: a thread per two hardware threads, 64 at most -- applied to this rank's share)
+        os.environ.setdefault("MOBI_PARSE_THREADS", str(max(2, min(64, len(mine) // 2))))
+    info["parse_threads"] = int(os.environ["MOBI_PARSE_THREADS"]) if "MOBI_PARSE_THREADS" in os.environ else None
+    return info
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without an external launcher: start one worker per GPU (LOCAL_RANK = GPU index), each a copy of
     this command with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- exactly the environment `torch.distributed.run` would give
@@ -447,12 +488,15 @@ def dry_run(args, rank, world):
         dist.init_process_group("gloo")
         dist.barrier()
     elapsed = sharding.max_over_ranks(dist if group else None, 1.0 + rank)
-    gathered = [{"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes,
-                 "clips_per_gpu": int(args.clips), "verified_ok": None}]
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    host = rank_host_setup(rank, local, world, probe_gpu=False)
+    mine = {"rank": rank, "local_rank": local, "device": local, "seeds": seeds, "bytes": sizes, "clips_per_gpu": int(args.clips), "verified_ok": None, "host": host,
+            # world > 1: the product path too, all ranks at once (bitstreams in host memory -> planes, frame-parallel groups); None here: no HIP call
+            "end_to_end_groups": None}
+    gathered = [mine]
     if group:
         gathered = [None] * world
-        dist.all_gather_object(gathered, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": int(os.environ.get("LOCAL_RANK", "0")), "seeds": seeds, "bytes": sizes,
-                 "clips_per_gpu": int(args.clips), "verified_ok": None})
+        dist.all_gather_object(gathered, mine)
         dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "decoded Mpixels/s @ 640x480 P-frames", "value": 0.0, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
@@ -499,6 +543,7 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
     import torch
+    host_info = rank_host_setup(rank, local, world)  # (before the library creates its parse threads and pinned buffers)
     dist = None
     if world > 1:
         # no data-path collective exists (north_star: "no RCCL"): the process group only carries the barrier and the max of the
@@ -626,19 +671,43 @@ def main():
     # every rank checks its own clips (all of them: verify_clips) and says how many it ran: a rank that silently ran half the batch, or the
     # wrong pictures, shows in the one line
     verified = verify_clips(b, streams, distinct, args.clips, timed_frames[-1], W, H) if timed_frames else None
-    rank_report = [{"rank": rank, "device": local, "clips_per_gpu": int(args.clips), "verified_ok": bool(verified and verified["ok"]), "ms_per_step": round(my_elapsed * 1e3 / steps, 4)}]
+    rank_report = [{"rank": rank, "device": local, "clips_per_gpu": int(args.clips), "verified_ok": bool(verified and verified["ok"]), "ms_per_step": round(my_elapsed * 1e3 / steps, 4), "host": host_info}]
     if dist is not None:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, my_elapsed)
         rank_report = [None] * world
         dist.all_gather_object(rank_report, {"rank": rank, "device": local, "clips_per_gpu": int(args.clips), "verified_ok": bool(verified and verified["ok"]),
-                                             "ms_per_step": round(my_elapsed * 1e3 / steps, 4)})
+                                             "ms_per_step": round(my_elapsed * 1e3 / steps, 4), "host": host_info})
     cmd_bytes = sum(b.cmd_bytes(f) for f in timed_frames) / steps          # per step, all clips of this GPU
     stats = [b.intra_stats(f) for f in timed_frames]
     n_intra = sum(x[0] for x in stats) / steps
     intra_cmd = sum(x[1] for x in stats) / steps
     b.close()
     e2e = e2e_large = c4 = single = None
+    e2e_all = None
+    if world > 1 and args.e2e_clips > 0 and args.config == "B":
+        # N > 1: the PRODUCT path on every rank at once (the legs above only run at N = 1, so host staging x N ranks, N x PCIe and
+        # N parse pools on one host went unmeasured): frame-parallel groups at the headline batch, each rank on its own streams and cpus,
+        # behind the timed region's last barrier; per rank in ranks[], and the slowest rank's time for the whole job's rate.
+        n_e2e = min(args.e2e_large_clips, args.clips)
+        dist.barrier()
+        try:
+            mine = gop_leg(m, streams, W, H, p0.version, local, n_e2e, "lockstep")
+        except Exception as e:
+            mine = {"error": f"{type(e).__name__}: {e}"}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if rank == 0:
+            for r, g in enumerate(every):
+                rank_report[r]["end_to_end_groups"] = g if "error" in g else {"ms_per_step": g["ms_per_step"], "pipelined_ms_per_step": g["pipelined"]["ms_per_step"], "clips": g["clips"],
+                                                                                "frames_per_group": g["frames_per_group"], "verified_ok": bool(g["verified"]["ok"] and g["pipelined"]["verified"]["ok"])}
+            if all("error" not in g for g in every):
+                slow, slow_p = max(g["ms_per_step"] for g in every), max(g["pipelined"]["ms_per_step"] for g in every)
+                e2e_all = {"value": round(world * n_e2e * W * H / slow / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": slow, "n_gpus": world, "clips_per_gpu": n_e2e,
+                           "pipelined": {"value": round(world * n_e2e * W * H / slow_p / 1e3, 1), "ms_per_step": slow_p},
+                           "how": "every rank at once: mobi_batch_decode_gop / gop_begin + gop_finish on its own clips (bench.py gop_leg); the whole job's pixels per step / the slowest rank's ms per step"}
+            else:
+                e2e_all = {"error": [g.get("error") for g in every]}
     if world == 1 and args.single_stream and args.config == "B":
         single = single_stream_leg(m, streams[0], W, H, p0.version, local)
     if world == 1 and args.e2e_clips > 0 and args.config == "B":
@@ -757,7 +826,7 @@ def main():
                        "stream_ms_per_step": round(stream_ms / steps, 4)},
             # the part settles at a lower clock after about a second of this load: a short timed region flatters the number
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
-            "verified": verified, "ranks": rank_report, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "end_to_end_xl": e2e_xl, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
+            "verified": verified, "ranks": rank_report, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "end_to_end_xl": e2e_xl, "end_to_end_all_ranks": e2e_all, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -35,6 +35,23 @@ def test_gpus_2_spawns_two_ranks_with_disjoint_seeds():
     assert [x["device"] for x in out["ranks"]] == [0, 1] and all(x["clips_per_gpu"] == 24576 and "verified_ok" in x for x in out["ranks"])
 
 
+def test_ranks_split_the_host_and_announce_the_product_leg():
+    """N > 1: every rank takes its share of the host (cpus pinned, MOBI_PARSE_THREADS = a thread per two of ITS cpus) and runs the product
+    path too (frame-parallel groups, all ranks at once); the dry run shows the per-rank fields the real line fills"""
+    out = _line(_run(["--gpus", "2", "--dry-run"], drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MOBI_PARSE_THREADS")))
+    ncpu = len(os.sched_getaffinity(0))
+    for x in out["ranks"]:
+        assert "end_to_end_groups" in x and x["host"]["cpus_visible"] == ncpu
+        if ncpu >= 2:
+            assert x["host"]["cpus_pinned"] == ncpu // 2 and x["host"]["parse_threads"] == max(2, min(64, x["host"]["cpus_pinned"] // 2))
+
+
+def test_a_single_rank_on_another_device_ordinal():
+    """LOCAL_RANK names the device (one rank per GPU): a lone rank on GPU 1 reports device 1, not 0"""
+    out = _line(_run(["--gpus", "1", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "1"}, drop=()))
+    assert out["ranks"][0]["device"] == 1 and out["ranks"][0]["local_rank"] == 1
+
+
 def test_gpus_1_is_one_rank_and_the_line_is_unchanged_in_shape():
     out = _line(_run(["--gpus", "1", "--dry-run"]))
     assert out["n_gpus"] == 1 and len(out["ranks"]) == 1
