@@ -92,6 +92,38 @@ def _hand_made(kind, version):
     return 32, 32, version, np.concatenate(chunks), fo
 
 
+def _with_rejected_frames(cfg, version):
+    """r06: frames the reference REJECTS (DecodeFrame() swallows the exception and returns null, MD.cs:325-328) are part of what a green run
+    pins: a P-frame into an empty ring (its first copied leaf dereferences a null Y[ref], MD.cs:413), then the stream's own I / P / P, then a
+    P-frame whose bytes behind the first word are noise, then I / P / P again.  References reach one frame back only (pm_multiref = 0) and an
+    I-frame follows every rejected frame, so no accepted frame predicts from a picture the reference left half-written."""
+    p = default_params(cfg, BASE_SEED + 26000 + version, version=version, n_frames=7, width=64, height=48, pm_intra=120, pm_deep=120, pm_multiref=0, iframe_interval=3,
+                       qdelta_prob=300, mv_range=10)
+    data, fo = generate_clip(p)
+    pk = [np.array(data[fo[f]:fo[f + 1]], copy=True) for f in range(7)]
+    assert (pk[0][1] & 0x80) and (pk[3][1] & 0x80) and not (pk[1][1] & 0x80)
+    from tests.oracle_binding import OracleDecoder as _O
+    for fill in (0xA5, 0xFF, 0x5A, 0x3C, 0xC3, 0x00):  # noise the reference throws on (checked with the oracle, which restates its exceptions)
+        noise = np.array(pk[2], copy=True)
+        noise[2:] = fill
+        o = _O(p.width, p.height, p.version)
+        for q in (pk[0], pk[1]):
+            o.Data, o.Offset = q, 0
+            assert o.DecodeFrame() is not None
+        o.Data, o.Offset = noise, 0
+        rejected = o.DecodeFrame() is None
+        o.close()
+        if rejected:
+            break
+    else:
+        raise AssertionError("no noise pattern is rejected")
+    seq = [pk[1], pk[0], pk[1], noise, pk[3], pk[4], pk[5]]
+    off = [0]
+    for q in seq:
+        off.append(off[-1] + int(q.size))
+    return p.width, p.height, p.version, np.concatenate(seq), off
+
+
 RAW_CASES = [
     ("r05_walk_mods_64x48", lambda: _flipped("A", 1, 64, [(74, 4), (93, 7), (403, 0)])),              # a run past its block: literal frame
     ("r05_walk_moflex_64x48", lambda: _flipped("B", 2, 3, [(714, 0), (574, 4), (408, 6)])),
@@ -101,6 +133,8 @@ RAW_CASES = [
     ("r05_wide_plane_mods_32x32", lambda: _hand_made("wide_plane", 1)),
     ("r05_far_mv_mods_32x32", lambda: _hand_made("far_mv", 1)),
     ("r05_far_mv_moflex_32x32", lambda: _hand_made("far_mv", 2)),
+    ("r06_rejected_mods_64x48", lambda: _with_rejected_frames("A", 1)),                               # frames the reference returns null for
+    ("r06_rejected_moflex_64x48", lambda: _with_rejected_frames("B", 2)),
 ]
 
 
@@ -147,16 +181,21 @@ def main():
         for f in range(p.n_frames):
             o.Data, o.Offset = data[: fo[f + 1]], int(fo[f])
             r = o.DecodeFrame()
-            assert r is not None, (name, f, o.last_error)
+            rejected = r is None
+            assert not rejected or name.startswith("r06_rejected"), (name, f, o.last_error)
+            if rejected:  # what the reference leaves behind a swallowed exception: the PARTIAL picture (it pins where the throw happened), Offset, Quantizer
+                r = (o.y(0), o.uv(0))
             if L:
                 buf = np.ascontiguousarray(data[: fo[f + 1]])
                 off = C.c_int(int(fo[f]))
-                assert L.csref_decode(h, buf.ctypes.data, buf.size, C.byref(off)) == 0 and off.value == o.Offset
+                assert (L.csref_decode(h, buf.ctypes.data, buf.size, C.byref(off)) != 0) == rejected and off.value == o.Offset
                 S = o.Stride
                 assert np.array_equal(np.ctypeslib.as_array(L.csref_y(h, 0), (p.height, S)), r[0])
                 assert np.array_equal(np.ctypeslib.as_array(L.csref_uv(h, 0), (p.height // 2, S)), r[1])
-            frames.append({"y_sha256": hashlib.sha256(r[0].tobytes()).hexdigest(), "uv_sha256": hashlib.sha256(r[1].tobytes()).hexdigest(),
+            frames.append({"y_sha256": hashlib.sha256(np.ascontiguousarray(r[0]).tobytes()).hexdigest(), "uv_sha256": hashlib.sha256(np.ascontiguousarray(r[1]).tobytes()).hexdigest(),
                            "offset_after": o.Offset, "quantizer": o.Quantizer})
+            if rejected:
+                frames[-1]["rejected"] = True
         cov = np.zeros(363, np.uint64)  # MOBI_COV_WORDS (oracle/mobi_oracle.h): what this fixture exercises = what a green VerifyGolden run pins
         OL.mobi_oracle_coverage(cov.ctypes.data, 1)
         manifest["cases"].append({"name": name, "width": p.width, "height": p.height, "version": p.version, "stride": o.Stride,
@@ -184,10 +223,66 @@ def write_text_manifest(manifest):
             if c.get("covers"):
                 f.write(f"covers {c['covers']}\n")
             for i, fr in enumerate(c["frames"]):
-                f.write(f"frame {c['frame_off'][i]} {c['frame_off'][i + 1]} {fr['y_sha256']} {fr['uv_sha256']} {fr['offset_after']} {fr['quantizer']}\n")
+                # "reject": the reference returns null for this frame (MD.cs:325-328); the hashes are those of the partial picture it keeps
+                f.write(f"{'reject' if fr.get('rejected') else 'frame'} {c['frame_off'][i]} {c['frame_off'][i + 1]} {fr['y_sha256']} {fr['uv_sha256']} {fr['offset_after']} {fr['quantizer']}\n")
+
+
+def selftest():
+    """Nothing regenerated: (1) golden_manifest.txt is golden.json line for line; (2) every fixture decodes in the oracle to the recorded
+    hashes / Offset / Quantizer / rejections; (3) every `covers` line -- what a green run of tests/golden/verify pins -- is what the oracle's
+    coverage counters (the ones tests/test_coverage.py reads) say the fixture exercises TODAY, so "pins X" is never stale.  Exit code 0 / 1."""
+    import io
+    from tests import oracle_binding
+    g = json.load(open(os.path.join(HERE, "golden.json")))
+    bad = 0
+    want = io.StringIO()
+    real_open = open
+
+    class _Capture:  # write_text_manifest into memory
+        def __enter__(self): return want
+        def __exit__(self, *a): return False
+    import builtins
+    builtins_open = builtins.open
+    try:
+        builtins.open = lambda path, mode="r", *a, **k: _Capture() if str(path).endswith("golden_manifest.txt") and "w" in mode else builtins_open(path, mode, *a, **k)
+        write_text_manifest(g)
+    finally:
+        builtins.open = builtins_open
+    if want.getvalue() != real_open(os.path.join(HERE, "golden_manifest.txt")).read():
+        print("golden_manifest.txt is not what golden.json says (python tests/golden/make_golden.py --text-only)")
+        bad += 1
+    OL = oracle_binding.lib()
+    OL.mobi_oracle_coverage.argtypes = [C.c_void_p, C.c_int]
+    OL.mobi_oracle_coverage.restype = None
+    n_frames = n_rej = 0
+    for c in g["cases"]:
+        data = np.fromfile(os.path.join(HERE, c["name"] + ".bin"), dtype=np.uint8)
+        o = OracleDecoder(c["width"], c["height"], c["version"])
+        OL.mobi_oracle_coverage(None, 1)
+        for f, exp in enumerate(c["frames"]):
+            o.Data, o.Offset = data[: c["frame_off"][f + 1]], c["frame_off"][f]
+            r = o.DecodeFrame()
+            y, uv = (o.y(0), o.uv(0)) if r is None else r
+            ok = ((r is None) == bool(exp.get("rejected")) and o.Offset == exp["offset_after"] and o.Quantizer == exp["quantizer"] and
+                  hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest() == exp["y_sha256"] and hashlib.sha256(np.ascontiguousarray(uv).tobytes()).hexdigest() == exp["uv_sha256"])
+            n_frames += 1
+            n_rej += r is None
+            if not ok:
+                print(f"{c['name']} frame {f}: the oracle no longer gives what the fixture records")
+                bad += 1
+        cov = np.zeros(363, np.uint64)
+        OL.mobi_oracle_coverage(cov.ctypes.data, 1)
+        if covers(cov) != c.get("covers"):
+            print(f"{c['name']}: 'covers' is stale:\n  recorded {c.get('covers')}\n  today    {covers(cov)}")
+            bad += 1
+        o.close()
+    print(f"selftest: {len(g['cases'])} fixtures, {n_frames} frames ({n_rej} of them rejected by the reference's restatement), {bad} problems")
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
+    if "--selftest" in sys.argv:
+        sys.exit(selftest())
     if "--text-only" in sys.argv:  # golden_manifest.txt from the committed golden.json, nothing regenerated
         write_text_manifest(json.load(open(os.path.join(HERE, "golden.json"))))
     else:

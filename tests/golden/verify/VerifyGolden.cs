@@ -45,6 +45,7 @@ public static class VerifyGolden
         //   case <name> <width> <height> <version 1=ModsDS 2=Moflex3DS> <n_frames>
         //   covers <what the fixture exercises, from the oracle's coverage counters: what a run without differences pins>
         //   frame <start offset> <end offset> <sha256 of Y[0]> <sha256 of UV[0]> <Offset after DecodeFrame> <Quantizer>
+        //   reject <the same fields>: DecodeFrame() returns null for this frame; the hashes are those of the partial picture it leaves
         string[] lines = File.ReadAllLines(Path.Combine(dir, "golden_manifest.txt"));
         for (int li = 0; li <= lines.Length; li++)
         {
@@ -67,16 +68,19 @@ public static class VerifyGolden
             {
                 covers = line.Substring(line.IndexOf(' ') + 1);
             }
-            else if (t[0] == "frame")
+            else if (t[0] == "frame" || t[0] == "reject")
             {
+                // "reject": a frame the reference returns null for (the exception is swallowed, MobiclipDecoder.cs:325-328).  The hashes are those of
+                // the PARTIAL picture it keeps in Y[0] / UV[0] -- they pin where the throw happened -- and Offset is where the reader stood.
                 int start = int.Parse(t[1], CultureInfo.InvariantCulture), end = int.Parse(t[2], CultureInfo.InvariantCulture);
                 byte[] frame = new byte[end];                 // Data = the stream up to the end of this frame, Offset = where it starts
                 Array.Copy(data, frame, end);                 // (what tests/golden/make_golden.py handed the oracle)
                 d.Data = frame;
                 d.Offset = start;
-                d.DecodeFrame();
+                object bitmap = d.DecodeFrame();
                 string y = Sha(d.Y[0]), uv = Sha(d.UV[0]);
                 bool ok = y == t[3] && uv == t[4] && d.Offset == int.Parse(t[5]) && d.Quantizer == uint.Parse(t[6]);
+                if (t[0] == "reject" && bitmap != null) ok = false;   // (the converse is not checked: without libgdiplus every frame returns null, see above)
                 frames++;
                 if (!ok)
                 {
