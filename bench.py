@@ -778,6 +778,9 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_ms, 5),
                     "launches": km["inter_launches"],
+                    # pixel bytes only (the inter macroblocks' 384 B read + 384 B written, no command bytes): a fatter command list cannot flatter it
+                    "frac_pixel_bytes": round((args.clips * n_mbs - n_intra) * 768.0 / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "command_kb_per_frame": round(cmd_bytes / args.clips / 1e3, 2),
                     "whole_step_frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "whole_step_bytes": int(step_bytes), "whole_step_ms": round(step_ms, 5),
                     "intra_macroblocks_per_step": round(n_intra, 1),
