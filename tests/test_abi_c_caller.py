@@ -56,6 +56,25 @@ def test_c_caller_asynchronous_batch_reproduces_golden(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mods_256x192_A", "moflex_640x480_B", "mods_64x48_rich", "moflex_64x48_rich_iint"])
+def test_c_caller_frame_parallel_groups_reproduce_golden(name):
+    """The golden streams through mobi_batch_decode_gop from C (r06): three clips, groups of 4, 1, 6, 2 frames parsed side by side on the
+    GPU, every frame of a group read back from the ring afterwards."""
+    case = [c for c in MAN["cases"] if c["name"] == name][0]
+    args = [CALLER, "--batch-gop", os.path.join(GOLD, name + ".bin"), str(case["width"]), str(case["height"]), str(int(case["version"])),
+            str(len(case["frames"]))] + [str(o) for o in case["frame_off"][: len(case["frames"]) + 1]]
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "mobiclipdecoder_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(lines) == len(case["frames"])
+    for l, exp in zip(lines, case["frames"]):
+        assert int(l[1]) == 0 and int(l[2]) == exp["offset_after"] and int(l[3]) in (0, exp["quantizer"]), (name, l)
+        assert l[4] == exp["y_sha256"] and l[5] == exp["uv_sha256"], (name, l[0])
+    assert any(int(l[3]) for l in lines)
+
+
+@pytest.mark.gpu
 def test_batches_on_two_devices_in_one_process():
     """mobi_batch_create(..., device) with device != 0: a batch on GPU 0 and one on GPU 1, driven alternately from one thread
     (config 4 of BASELINE.json shards clips over the GPUs of a node; one process may own several).  Skipped on a 1-GPU box."""

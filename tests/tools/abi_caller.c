@@ -11,6 +11,10 @@
  *
  * The same stream as three clips of a batch that parses on the GPU, through mobi_batch_submit / mobi_batch_wait with two frame steps
  * in flight; prints the same lines (for clip 2).
+ *   abi_caller --batch-gop <the same arguments>
+ *
+ * ... through mobi_batch_decode_gop, groups of 4, 1, 6, 2, ... frames per call (parsed side by side on the GPU); the same lines (Quantizer only
+ * on a group's last frame, 0 elsewhere).
  * tests/test_abi_c_caller.py compares the lines with tests/golden/golden.json.  Test tool: not part of the product. */
 #include <stdint.h>
 #include <stdio.h>
@@ -98,9 +102,52 @@ static int run_batch_async(const uint8_t *data, uint32_t w, uint32_t hgt, int ve
   return bad;
 }
 
+/* --batch-gop: the same stream as three clips through mobi_batch_decode_gop, up to MOBI_GOP frames per call (r06: the frames of a group
+ * are parsed side by side on the GPU); every frame of a group is read back from the ring afterwards (frame k of K at ring index K - 1 - k) */
+static int run_batch_gop(const uint8_t *data, uint32_t w, uint32_t hgt, int version, int nf, char **offs) {
+  enum { N = 3, MAXK = 6 };
+  mobi_batch *b = mobi_batch_create(N, w, hgt, version, test_device());
+  if (!b) { fprintf(stderr, "mobi_batch_create failed\n"); return 3; }
+  if (mobi_batch_set_parse_mode(b, 3) != MOBI_OK) return 3;             /* parse on the GPU, the lock-step parser in front */
+  const size_t ysz = (size_t)mobi_batch_stride(b) * hgt;
+  uint8_t *y = (uint8_t *)malloc(ysz), *uv = (uint8_t *)malloc(ysz / 2);
+  char hy[65], huv[65];
+  int f0 = 0, bad = 0, turn = 0;
+  while (f0 < nf) {
+    static const int sizes[4] = {4, 1, 6, 2};
+    int K = sizes[turn++ & 3], k, c;
+    if (K > nf - f0) K = nf - f0;
+    const uint8_t *ptrs[N * MAXK];
+    size_t lens[N * MAXK];
+    int32_t off[N * MAXK];
+    int rc[N * MAXK];
+    for (k = 0; k < K; k++)
+      for (c = 0; c < N; c++) {                                         /* [k * n_clips + c]: frame k of the group, clip c */
+        ptrs[k * N + c] = data;
+        lens[k * N + c] = (size_t)atol(offs[f0 + k + 1]);
+        off[k * N + c] = atoi(offs[f0 + k]);
+      }
+    if (mobi_batch_decode_gop(b, K, ptrs, lens, off, rc) != MOBI_OK) { fprintf(stderr, "decode_gop at frame %d failed\n", f0); return 3; }
+    for (k = 0; k < K; k++) {
+      hy[0] = huv[0] = '-'; hy[1] = huv[1] = 0;
+      if (rc[k * N + 2] == MOBI_OK && mobi_batch_get_planes(b, 2, K - 1 - k, y, uv) == MOBI_OK) {
+        sha256_hex(y, ysz, hy);
+        sha256_hex(uv, ysz / 2, huv);
+      } else bad = 1;
+      /* (Quantizer is the decoder's field: it describes the group's last frame) */
+      printf("%d %d %d %u %s %s\n", f0 + k, rc[k * N + 2], (int)off[k * N + 2], k == K - 1 ? mobi_batch_quantizer(b, 2) : 0u, hy, huv);
+    }
+    f0 += K;
+  }
+  mobi_batch_destroy(b);
+  free(y); free(uv);
+  return bad;
+}
+
 int main(int argc, char **argv) {
   const int batch_async = argc > 1 && strcmp(argv[1], "--batch-async") == 0;
-  if (batch_async) { argv++; argc--; }
+  const int batch_gop = argc > 1 && strcmp(argv[1], "--batch-gop") == 0;
+  if (batch_async || batch_gop) { argv++; argc--; }
   if (argc < 7) { fprintf(stderr, "usage: abi_caller stream.bin width height version n_frames off_0 .. off_n\n"); return 2; }
   const uint32_t w = (uint32_t)atoi(argv[2]), hgt = (uint32_t)atoi(argv[3]);
   const int version = atoi(argv[4]), nf = atoi(argv[5]);
@@ -115,6 +162,7 @@ int main(int argc, char **argv) {
   fclose(f);
 
   if (batch_async) { const int e = run_batch_async(data, w, hgt, version, nf, argv + 6); free(data); return e; }
+  if (batch_gop) { const int e = run_batch_gop(data, w, hgt, version, nf, argv + 6); free(data); return e; }
   mobi_dec *d = mobi_create(w, hgt, version, test_device());                    /* new MobiclipDecoder(Width, Height, Version) */
   if (!d) { fprintf(stderr, "mobi_create failed: %s\n", mobi_error_string(MOBI_E_DEVICE)); return 3; }
   const int stride = mobi_stride(d);
