@@ -6,7 +6,7 @@
      quantiser 12 on the device parsers;
   2. every clip of a batch glitches in the same frame, under asynchronous steps: mobi_batch_wait repairs them all (r06: one batch operation).
 
-  python tools/exp_allhost.py [clips]        (256x192 ModsDS; default 2048)
+  python tools/exp_allhost.py [clips]        (64x48 ModsDS; default 16384)
 """
 import os
 import sys
@@ -19,19 +19,32 @@ import mobiclipdecoder_amd as m
 from mobiclipdecoder_amd.streamgen import BASE_SEED
 from tests.test_internal_walk import _set_quantizer
 
-clips = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-W, H, NFR, DISTINCT = 256, 192, 14, 8
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+W, H, NFR, DISTINCT = 64, 48, 14, 8  # (at real picture sizes the reference throws on practically every P-frame below quantiser 12 -- some walk leaves
+# Internal[] or wrecks a table the frame still needs; 64x48 at quantiser 10 decodes: profiles/r06_experiments.txt)
 
 
 def streams(q):
-    out = []
-    for i in range(DISTINCT):
-        p = m.default_params("A", BASE_SEED + 600 + i, n_frames=NFR, quantizer=12)
+    """DISTINCT streams that the reference decodes at quantiser q (checked with the oracle, the checker: below 12 a walk through Internal[]
+    can also run into something the reference throws on -- such a stream is not content, it is skipped)"""
+    from tests.oracle_binding import OracleDecoder
+    out, seed = [], 0
+    while len(out) < DISTINCT and seed < 400:
+        p = m.default_params("A", BASE_SEED + 600 + seed, n_frames=NFR, width=W, height=H, quantizer=12, pm_intra=100, cbp_prob=400)
+        seed += 1
         data, fo = m.generate_clip(p)
         data = data.copy()
         if q != 12:
             _set_quantizer(data[fo[0]:fo[1]], q)  # the I-frame names the quantiser; the P-frames keep it (delta 0)
-        out.append((data, fo))
+        o = OracleDecoder(W, H, 1)
+        ok = True
+        for f in range(NFR):
+            o.Data, o.Offset = data[fo[f]:fo[f + 1]], 0
+            ok = ok and o.DecodeFrame() is not None
+        o.close()
+        if ok:
+            out.append((data, fo))
+    assert len(out) == DISTINCT, f"only {len(out)} streams decode at quantiser {q}"
     return out
 
 
@@ -45,13 +58,13 @@ def run(q, label):
         assert not any(rcs), (q, f, [r for r in rcs if r][:4])
         ms.append(b.last_decode_ms())
     t = float(np.median(ms[3:]))
-    print(f"{label}: {clips} clips 256x192 ModsDS, quantiser {q}: {t:.2f} ms per step = {clips * W * H / t / 1e6:.1f} Gpixels/s; clips with the host parser at the end: {b.host_clips()}")
+    print(f"{label}: {clips} clips {W}x{H} ModsDS, quantiser {q}: {t:.2f} ms per step = {clips * W * H / t / 1e6:.1f} Gpixels/s; clips with the host parser at the end: {b.host_clips()}")
     b.close()
     return t
 
 
 run(12, "device parsers (quantiser 12)")
-run(8, "all-host steady state (quantiser 8: every block walks through Internal[])")
+run(10, "all-host steady state (quantiser 10: every block walks through Internal[])")
 
 # every clip glitches in frame 2 (its I-frame header re-written to quantiser 5), two asynchronous steps in flight
 src = []
