@@ -41,5 +41,11 @@ bash $REPO/tools/exp_fused.sh $TAG/fused_raw > "$OUT/fused.txt" 2>&1
 { timeout 600 python $REPO/tools/exp_dparse.py 4096 8192 24576 --device-both; } > "$OUT/lsparse.txt" 2>&1
 timeout 300 python $REPO/tools/exp_async.py 4096 12 > "$OUT/async.txt" 2>&1
 { for N in 8192 24576 49152; do echo "== $N clips, lock-step parser in front"; LOCKSTEP=1 timeout 300 python $REPO/tools/exp_async.py $N 8 | grep -E "^asynchronous|^synchronous"; done; } >> "$OUT/async.txt" 2>&1
+# r06: frame-parallel groups (mobi_batch_decode_gop / gop_begin + gop_finish) end to end, the lock-step parser's lanes x waves under n * K virtual clips,
+# and the two all-host situations (a ModsDS batch below quantiser 12; every clip handed over in one frame of an asynchronous batch)
+{ export MOBI_LIB=$REPO/mobiclipdecoder_amd/libmobiclip_hip_prof.so; for NK in "1024 6" "4096 6" "8192 6" "24576 4" "24576 2"; do set -- $NK; timeout 400 python $REPO/tools/exp_gop.py $1 $2 4 64; done; unset MOBI_LIB; } > "$OUT/gop.txt" 2>&1
+( cd $REPO && LW="24,8 28,8 35,8 64,4 15,8 24,4" timeout 900 tools/exp_gop_lanes.sh 24576 6 ) > "$OUT/gop_lanes.txt" 2>&1
+timeout 600 python $REPO/tools/exp_allhost.py > "$OUT/allhost.txt" 2>&1
+{ timeout 900 python $REPO/tools/soak_parity.py 4096 B gop | tail -8; } > "$OUT/soak_gop.txt" 2>&1
 { timeout 600 python $REPO/tools/fuzz_intra_gpu.py 2000 100; timeout 600 python $REPO/tools/fuzz_inter_gpu.py 3000 100; timeout 900 python $REPO/tools/soak_parity.py 4096 B; timeout 900 python $REPO/tools/soak_parity.py 8192 B lockstep; timeout 900 python $REPO/tools/exp_refusals.py 1500 --gpu; } > "$OUT/fuzz.txt" 2>&1
 ls "$OUT" > /dev/null
