@@ -186,6 +186,9 @@ int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out,
  * just that clip first if the whole-batch conversion has not been run for the current frame. */
 int mobi_batch_convert_argb(mobi_batch *b);
 int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out);
+/* ... of the frame at ring index ring_idx (0 = the newest; MOBI_E_NULLREF for a slot never produced): the Bitmap DecodeFrame() returned
+ * ring_idx calls ago.  For callers that decode in groups and want every frame's Bitmap: frame k of a group of K is ring index K - 1 - k. */
+int mobi_batch_get_argb_at(mobi_batch *b, int clip, int ring_idx, uint32_t *out);
 /* Encoder-side analysis: Analyzer.InterPredict2x2 (Analyzer.cs:608-681) for every 2x2 luma block of
  * every macroblock of every clip, as SolveInterPredictionPuzzle calls it (:683-693): three-step search (6, 3, 1 pels) in up
  * to five past frames = ring slots 0..4 of this batch (the encoder's PastFramesY, MobiEncoder.cs:138-144).

@@ -1894,6 +1894,24 @@ int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out) {
   HIP_TRY(hipMemcpy(out, b->d_argb + src_clip * words, words * 4, hipMemcpyDeviceToHost));
   return MOBI_OK;
 }
+// the Bitmap of the frame at ring index ring_idx (0 = the newest): what DecodeFrame() returned `ring_idx` calls ago -- for callers that decode
+// in groups (mobi_batch_decode_gop: frame k of a group of K sits at ring index K - 1 - k) and want every frame's Bitmap, as a converter does
+// (MobiConverter/Program.cs:57-71).  YuvFormat is the decoder's current one (an I-frame inside the group may have changed it: MD.cs:227).
+int mobi_batch_get_argb_at(mobi_batch *b, int clip, int ring_idx, uint32_t *out) {
+  if (!b || clip < 0 || clip >= b->n || !out || ring_idx < 0 || ring_idx > 5) return MOBI_E_ARG;
+  if (ring_idx >= b->frames_started) return MOBI_E_NULLREF;
+  if (ring_idx == 0) return mobi_batch_get_argb(b, clip, out);
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t words = (size_t)b->g.width * b->g.height;
+  if (int e = ensure_argb(b, 1)) return e;
+  b->argb_all_valid = false; // (the front of the buffer is this frame's now)
+  MobiReconArgs a = b->args(nullptr, nullptr);
+  a.ring_base = (b->ring_base + 6 - ring_idx) % 6;
+  if (mobi_launch_argb(&a, b->version, clip, 1, b->d_argb, b->stream) != 0) return MOBI_E_DEVICE;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->d_argb, words * 4, hipMemcpyDeviceToHost));
+  return MOBI_OK;
+}
 // ---- encoder-side analysis: Analyzer.InterPredict2x2 over the ring this batch keeps in HBM (Analyzer.cs:608-693) ----
 int mobi_batch_motion_search(mobi_batch *b, const uint8_t *const *src_y, uint32_t *out) {
   if (!b || !src_y || !out) return MOBI_E_ARG;

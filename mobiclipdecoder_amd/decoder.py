@@ -64,6 +64,7 @@ _SIGS = {
     "mobi_batch_get_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mobi_batch_convert_argb": (C.c_int, [C.c_void_p]),
     "mobi_batch_get_argb": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mobi_batch_get_argb_at": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mobi_batch_quantizer": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_yuv_format": (C.c_uint32, [C.c_void_p, C.c_int]),
     "mobi_batch_set_parse_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -360,9 +361,10 @@ class MobiclipBatch:
         if rc != 0:
             raise MobiclipError(error_string(rc))
 
-    def bitmap(self, clip):
+    def bitmap(self, clip, idx=0):
+        """the Bitmap of the frame at ring index idx (0 = the newest)"""
         out = np.empty((self.Height, self.Width), np.uint32)
-        rc = self._lib.mobi_batch_get_argb(self._h, clip, out.ctypes.data)
+        rc = self._lib.mobi_batch_get_argb_at(self._h, clip, idx, out.ctypes.data) if idx else self._lib.mobi_batch_get_argb(self._h, clip, out.ctypes.data)
         if rc != 0:
             raise MobiclipError(error_string(rc))
         return out

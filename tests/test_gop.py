@@ -251,6 +251,32 @@ def test_group_calls_mix_with_single_steps():
         o.close()
 
 
+def test_bitmaps_of_every_frame_of_a_group():
+    """mobi_batch_get_argb_at: the Bitmap DecodeFrame() would have returned for each frame of the group (MD.cs:260-323), against the oracle's"""
+    for cfg in ("A", "B"):
+        ps = [default_params(cfg, BASE_SEED + 7900 + i, n_frames=7, width=64, height=48, pm_intra=100) for i in range(2)]
+        clips = [generate_clip(p) for p in ps]
+        p0 = ps[0]
+        b = MobiclipBatch(2, p0.width, p0.height, p0.version, device_parse="lockstep")
+        oras = [OracleDecoder(p0.width, p0.height, p0.version) for _ in range(2)]
+        want = []
+        for f in range(7):
+            row = []
+            for c in range(2):
+                oras[c].Data, oras[c].Offset = clips[c][0][clips[c][1][f]:clips[c][1][f + 1]], 0
+                assert oras[c].DecodeFrame() is not None
+                row.append(oras[c].argb().copy())
+            want.append(row)
+        assert b.decode_gop(_frames(clips, 0, 1))[0] == [[0, 0]]
+        assert b.decode_gop(_frames(clips, 1, 6))[0] == [[0, 0]] * 6
+        for k in range(6):
+            for c in range(2):
+                assert np.array_equal(b.bitmap(c, 5 - k), want[1 + k][c]), (cfg, k, c)
+        b.close()
+        for o in oras:
+            o.close()
+
+
 def test_argument_checks():
     p = default_params("A", BASE_SEED, n_frames=8)
     clips = [generate_clip(p)]
