@@ -1896,7 +1896,7 @@ int mobi_batch_get_argb(mobi_batch *b, int clip, uint32_t *out) {
 }
 // the Bitmap of the frame at ring index ring_idx (0 = the newest): what DecodeFrame() returned `ring_idx` calls ago -- for callers that decode
 // in groups (mobi_batch_decode_gop: frame k of a group of K sits at ring index K - 1 - k) and want every frame's Bitmap, as a converter does
-// (MobiConverter/Program.cs:57-71).  YuvFormat is the decoder's current one (an I-frame inside the group may have changed it: MD.cs:227).
+// (MobiConverter/Program.cs:57-71).  (The conversion depends on Version alone, MD.cs:260-323: any frame still in the ring converts the same way.)
 int mobi_batch_get_argb_at(mobi_batch *b, int clip, int ring_idx, uint32_t *out) {
   if (!b || clip < 0 || clip >= b->n || !out || ring_idx < 0 || ring_idx > 5) return MOBI_E_ARG;
   if (ring_idx >= b->frames_started) return MOBI_E_NULLREF;
