@@ -47,6 +47,20 @@ e2x = B.get("end_to_end_xl") or {}
 xl_text = (f" With as many clips as HBM holds (`end_to_end_xl`, {e2x['clips']} clips): {e2x['ms_per_step']:.1f} ms per step = **{e2x['value'] / 1e3:.0f} Gpixels/s**, "
            f"asynchronous {e2x['async']['ms_per_step']:.1f} ms = **{e2x['async']['value'] / 1e3:.0f} Gpixels/s** (the lock-step parser's cost per clip falls with the batch).") if "value" in e2x else ""
 xl_readme = f" and {e2x['value'] / 1e3:.0f} ({e2x['async']['value'] / 1e3:.0f}) at {e2x['clips']}" if "value" in e2x else ""
+def groups_text(e, what):
+    g = e.get("groups") or {}
+    if "value" not in g:
+        return ""
+    return (f" In frame-parallel groups of {g['frames_per_group']} (`{what}.groups`, `mobi_batch_decode_gop`): {g['ms_per_step']:.1f} ms per frame step = **{g['value'] / 1e3:.0f} Gpixels/s**, "
+            f"with the next group begun before the last is finished (`gop_begin` / `gop_finish`) {g['pipelined']['ms_per_step']:.1f} ms = **{g['pipelined']['value'] / 1e3:.0f} Gpixels/s**.")
+
+
+# a figure that is an outlier of its own kind does not go into three documents (a 2.5 s "I-frame with the Bitmap" that was one
+# stalled sample of two): the Bitmap adds a launch and a 1.2 MB copy to a call, never an order of magnitude
+for kind in ("p_frame_ms", "i_frame_ms"):
+    a_, b_ = ss["planes"][kind], ss["with_bitmap"][kind]
+    if b_ > 10 * a_ + 1.0:
+        raise SystemExit(f"sync_docs: single_stream.with_bitmap.{kind} = {b_} ms against {a_} ms without the Bitmap: an outlier, not a result; re-run the bench")
 lf = B.get("content_lowfreq") or {}
 ver = B.get("verified") or {}
 text = f'''Results, MI355X, {RND} build (`profiles/{RND}_{{A,B,C}}_bench.json`; the rocprofv3 kernel-trace average of the same command,
@@ -93,9 +107,9 @@ the Bitmap conversion {cb['with_bitmap']['value']:.0f} Mpixels/s (`with_bitmap`)
 
 End to end (`mobi_batch_decode`: bitstream bytes in host memory → planes in HBM; staging, H2D, device parse, reconstruction,
 read-back of 32 B per clip, synchronisation): {e2e['ms_per_step']:.1f} ms per step of 4096 clips = {e2e['value'] / 1e3:.0f} Gpixels/s (`end_to_end`);
-`mobi_batch_submit` / `mobi_batch_wait` with two steps in flight: {e2e['async']['ms_per_step']:.1f} ms = {e2e['async']['value'] / 1e3:.0f} Gpixels/s (`end_to_end.async`).
+`mobi_batch_submit` / `mobi_batch_wait` with two steps in flight: {e2e['async']['ms_per_step']:.1f} ms = {e2e['async']['value'] / 1e3:.0f} Gpixels/s (`end_to_end.async`).{groups_text(e2e, 'end_to_end')}
 At the headline batch with the lock-step parser in front (`end_to_end_large`, {e2l['clips']} clips): {e2l['ms_per_step']:.1f} ms per step = **{e2l['value'] / 1e3:.0f} Gpixels/s**,
-asynchronous {e2l['async']['ms_per_step']:.1f} ms = **{e2l['async']['value'] / 1e3:.0f} Gpixels/s**.{xl_text} The parse is what such a step waits for (`HISTORY.md`, parsers). PCIe-inclusive rate of the
+asynchronous {e2l['async']['ms_per_step']:.1f} ms = **{e2l['async']['value'] / 1e3:.0f} Gpixels/s**.{groups_text(e2l, 'end_to_end_large')}{xl_text} The parse is what such a step waits for (`HISTORY.md`, parsers). PCIe-inclusive rate of the
 *reconstruction* path fed with host-parsed command lists: ≈90 KB of commands per 640×480 frame, 10 % of the pixel bytes, 35 Gpixels/s with
 64 parse threads at 1024 clips (`profiles/{RND}_ubench.txt`, hostparse: parse, staging and upload pipelined; the parse, not PCIe, limits).
 '''
@@ -113,12 +127,17 @@ def n(v):
     return format(v, ",.0f").replace(",", " ")
 
 
+def gshort(e):
+    g = e.get("groups") or {}
+    return f"; in frame-parallel groups {n(g['value'])}, pipelined {n(g['pipelined']['value'])}" if "value" in g else ""
+
+
 def pct(d):
     return f"{d['roofline']['frac'] * 100:.1f} / {d['roofline']['whole_step_frac'] * 100:.1f}"
 
 
 rows = [f"| A 256×192 Mods P-stream | 1 | {A['config']['clips_per_gpu']} | {n(A['value'])} | {gb(A, 'A')} | {pct(A)} | — | {A['cpu_baseline']['value']:.0f} / — | yes |",
-        f"| B 640×480 Moflex P-stream | 1 | {B['config']['clips_per_gpu']} | {n(B['value'])} | {gb(B, 'B')} | {pct(B)} | {n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous) (4096 clips, device parse); {n(e2l['value'])} ({n(e2l['async']['value'])}) at {e2l['clips']} clips, lock-step parse" + (f"; {n(e2x['value'])} ({n(e2x['async']['value'])}) at {e2x['clips']}" if 'value' in e2x else '') + f" | {cb['value']:.0f} / {cb['all_cpus']['value']:.0f} (N = {cb['all_cpus']['cores']}) | yes |",
+        f"| B 640×480 Moflex P-stream | 1 | {B['config']['clips_per_gpu']} | {n(B['value'])} | {gb(B, 'B')} | {pct(B)} | {n(e2e['value'])} ({n(e2e['async']['value'])} asynchronous{gshort(e2e)}) (4096 clips, device parse); {n(e2l['value'])} ({n(e2l['async']['value'])}{gshort(e2l)}) at {e2l['clips']} clips, lock-step parse" + (f"; {n(e2x['value'])} ({n(e2x['async']['value'])}) at {e2x['clips']}" if 'value' in e2x else '') + f" | {cb['value']:.0f} / {cb['all_cpus']['value']:.0f} (N = {cb['all_cpus']['cores']}) | yes |",
         f"| B, DC / low-frequency content profile (`content_lowfreq`) | 1 | {lf.get('clips', 0)} | {n(lf.get('value', 0))} | — | {lf.get('inter_frac', 0) * 100:.1f} / {lf.get('whole_step_frac', 0) * 100:.1f} | — | | yes |",
         f"| C 848×480 Moflex P-stream | 1 | {C['config']['clips_per_gpu']} | {n(C['value'])} | {gb(C, 'C')} | {pct(C)} | — | {C['cpu_baseline']['value']:.0f} / — | yes |",
         f"| B ×8 clips (64 over 8 GPUs) | 1 | 8 | {n(c4['value'])} | — | — | — | | yes |"]
@@ -147,14 +166,19 @@ GPUs run N copies of the 1-GPU row. Earlier rounds: r03 B 908 067 Mpix/s (41.2 /
 |---|---|---|---|---|---|---|---|---|
 '''
 open("BASELINE.md", "w").write(s[:a] + head + "\n".join(rows) + "\n")
+def greadme(e):
+    g = e.get("groups") or {}
+    return f"; {g['pipelined']['value'] / 1e3:.0f} with {g['frames_per_group']} frames of every clip parsed side by side, r06" if "value" in g else ""
+
+
 s = open("README.md").read()
 a, b = s.index("<!-- measured:begin -->") + len("<!-- measured:begin -->\n"), s.index("<!-- measured:end -->")
 s = s[:a] + f'''Measured on one MI355X (round {int(RND[1:])}, `python bench.py`, 640×480 Moflex3DS P-frames in stream order, {B['config']['clips_per_gpu']} resident clips, {B['timed_region_s']:.1f} s
 timed): {B['value'] / 1e3:.0f} Gpixels/s of reconstruction (command lists resident in HBM), the dominant kernel at {B['roofline']['frac'] * 100:.0f} % of the 8 TB/s HBM
 roofline counting only its own macroblocks' bytes, the whole step at {B['roofline']['whole_step_frac'] * 100:.0f} %, HBM traffic {ratio:.2f} × the algorithmic bytes, bit-exact
 (every clip of the batch checked after the timed region: the distinct streams against the oracle, the copies against their source on the device);
-{e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight) at 4096
-clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}) at {e2l['clips']} clips with the lock-step parser{xl_readme}, {hp1024} with the parse on 64 host threads at 1024 clips;
+{e2e['value'] / 1e3:.0f} Gpixels/s end to end from bitstreams in host memory with the parse on the GPU ({e2e['async']['value'] / 1e3:.0f} with two steps in flight{greadme(e2e)}) at 4096
+clips, {e2l['value'] / 1e3:.0f} ({e2l['async']['value'] / 1e3:.0f}{greadme(e2l)}) at {e2l['clips']} clips with the lock-step parser{xl_readme}, {hp1024} with the parse on 64 host threads at 1024 clips;
 ''' + (f'''the Bitmap of every clip (`mobi_yuv_to_argb`) at {B['bitmap']['roofline']['frac'] * 100:.0f} % of the roofline on its own 5.5 bytes per pixel; ''' if B.get('bitmap') and 'ms' in B['bitmap'] else '') + f'''one
 stream through `mobi_decode`: {ss['planes']['p_frame_ms']:.2f} ms per P-frame; {cb['value'] / 1e3:.2f} Gpixels/s for the CPU restatement of the reference on one host
 core ({cb['all_cpus']['value'] / 1e3:.1f} on all {cb['all_cpus']['cores']}). The planes live in HBM as macroblock tiles (`mobi_tile.h`): the reference's linear
