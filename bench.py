@@ -143,10 +143,15 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
         # The lock-step parser is at its best from ~49152 lanes on (24 lanes x 8 waves on every CU; beyond that it takes turns: no gain), and a
         # group's command lists cost HBM (worst-case payload room per frame): as many frames per group as it takes to get there, whole turns
         K = GOP_K if n_clips * GOP_K <= 49152 else 4 if n_clips * 4 <= 98304 else 2
-    n_frames = min(len(s[2]) - 1 for s in streams)
-    G = (n_frames - 1) // K  # groups of P-frames a stream holds
-    if G < 3:
-        return {"error": f"streams of {n_frames} frames hold {G} groups of {K}"}
+    # its own streams of the same seeds and mix, long enough for eight groups: one to warm up and six timed in the pipelined part (three
+    # timed groups, as the 33-frame clips of the replay give, start on a GPU whose clocks have just sat through the checker's seconds)
+    G = 8
+    longer = []
+    for p, _, _ in streams:
+        q = type(p).from_buffer_copy(p)
+        q.n_frames = 1 + K * G
+        longer.append((q,) + m.generate_clip(q))
+    streams = longer
     nv = n_clips * K
 
     def pack(f0, k):
@@ -719,7 +724,7 @@ def main():
             # and 34.4 with 64 or 128 (tools/exp_dparse.py, DISTINCT=...): this leg takes 64, so that no wave holds two copies of one.
             wide = list(streams)
             for i in range(len(streams), 64):
-                p = m.default_params(args.config, sharding.stream_seed(args.config, rank, i), n_frames=1 + 5 * GOP_K, **gen_over)
+                p = m.default_params(args.config, sharding.stream_seed(args.config, rank, i), n_frames=12, **gen_over)
                 wide.append((p,) + m.generate_clip(p))
             e2e_large = end_to_end(m, wide, W, H, p0.version, local, min(args.e2e_large_clips, args.clips), 6, device_parse="lockstep")
         except Exception as e:  # (e.g. does not fit beside what the allocator still holds: reported beside the headline value, not fatal to it)
