@@ -172,12 +172,18 @@ int mobi_batch_in_flight(const mobi_batch *b); /* steps submitted and not yet wa
  *                          group (and starts its parse when no group is in front of it) and returns; finish reports the OLDEST group
  *                          begun and not finished.  At most two groups may be begun: with group g + 1 begun before group g is finished,
  *                          its upload and parse run beside group g's reconstruction.  The batch must parse on the GPU (as for
- *                          mobi_batch_submit).  The ring turns in finish, K times; planes are read after finish.
+ *                          mobi_batch_submit).  The ring turns in finish, once per frame; planes are read after finish.
+ *                          A group begun this way may hold up to 12 frames -- what is parsed side by side is not bound by the ring, and
+ *                          a small batch fills the parsers' lanes only with that many -- and finish hands them out SIX AT A TIME, oldest
+ *                          first: every call reconstructs and reports min(6, mobi_batch_gop_frames_pending(b)) frames of the oldest group
+ *                          (rc / offsets_out [j * n_clips + c], j counted from the part's first frame; that part's frame j sits at ring
+ *                          index part_size - 1 - j afterwards), so a group of 12 is finished by two calls.
  * mobi_batch_decode / mobi_batch_submit are refused (MOBI_E_ARG) while a group is begun and not finished. */
 int mobi_batch_decode_gop(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
 int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, const int32_t *offsets);
 int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc);
 int mobi_batch_gop_in_flight(const mobi_batch *b); /* groups begun and not yet finished: 0, 1 or 2 */
+int mobi_batch_gop_frames_pending(const mobi_batch *b); /* frames of the oldest such group that no finish has reported yet (0: none begun) */
 /* Wall-clock milliseconds the last mobi_batch_decode call spent inside the library (parse or upload, launches, sync). */
 float mobi_batch_last_decode_ms(const mobi_batch *b);
 int mobi_batch_get_planes(mobi_batch *b, int clip, int ring_idx, uint8_t *y_out, uint8_t *uv_out);

@@ -317,7 +317,7 @@ struct mobi_batch {
   // virtual clips (v = k * n + c), reconstructed as K steps.  Two slots: the bytes of group g + 1 are gathered and uploaded, and its parse
   // enqueued, while group g is reconstructed.
   struct GopSlot {
-    PinnedBuf h_stage, h_res, h_fault, h_over[MOBI_GOP_MAX], h_seed, h_ret;
+    PinnedBuf h_stage, h_res, h_fault, h_over[MOBI_GOP_PARSE_MAX], h_seed, h_ret;
     DevBuf d_bits, d_desc, d_pay, d_items, d_res, d_sin, d_sout, d_sls, d_tails, d_fault;
     hipEvent_t ev_up = nullptr, ev_parsed = nullptr;
     int K = 0;
@@ -329,6 +329,13 @@ struct mobi_batch {
     std::vector<uint32_t> lens;      // [v] their number (the header's copy carries MOBI_DP_SKIP for the host parser's clips)
     std::vector<int32_t> offs;       // [v] Offset at submission
     std::vector<uint8_t> is_host;    // [c] the host parser's clip when the parse was enqueued
+    // what the group's first mobi_batch_gop_finish settles for all K frames (a group of more than six is finished in two calls)
+    bool resolved = false;
+    int done = 0;                    // frames reconstructed and reported so far
+    std::vector<int> host_from, hslot, hrc, all_host;
+    std::vector<int32_t> hoff;
+    std::vector<uint32_t> hq, hy;
+    std::vector<uint8_t> hready;
   };
   GopSlot gslot[2];
   int gop_head = 0, gop_count = 0;
@@ -1381,7 +1388,7 @@ static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S) {
 }
 
 int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, const int32_t *offsets) {
-  if (!b || !data || !len || !offsets || n_frames < 1 || n_frames > MOBI_GOP_MAX) return MOBI_E_ARG;
+  if (!b || !data || !len || !offsets || n_frames < 1 || n_frames > MOBI_GOP_PARSE_MAX) return MOBI_E_ARG;
   HIP_TRY(hipSetDevice(b->device));
   const int n = b->n, K = n_frames, n_mbs = b->g.mbw * b->g.mbh;
   const size_t nv = (size_t)n * K;
@@ -1458,6 +1465,8 @@ int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data
   HIP_TRY(hipEventRecord(S.ev_up, b->stream2));
   b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
   S.parse_enqueued = false;
+  S.resolved = false;
+  S.done = 0;
   b->gop_count++;
   if (b->gop_count == 1) // nothing in front: the parse may start at once (else mobi_batch_gop_finish of the group in front enqueues it, once it knows whose clips are whose)
     if (int e = gop_enqueue_parse(b, S)) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamSynchronize(b->stream_p); b->gop_count--; return e; }
@@ -1488,94 +1497,105 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
   using clk = std::chrono::steady_clock;
   const auto q0 = clk::now();
   auto ms_since = [](clk::time_point x) { return std::chrono::duration<float, std::milli>(clk::now() - x).count(); };
-  // 1. the host parser's clips, all K frames of each, while the GPU parses the others
-  std::vector<int> host_from(n, K); // first frame of the group that is the host parser's
-  std::vector<int> hslot(n, -1);    // its place in gop_frames
-  std::vector<int> hrc(nv, MOBI_OK);
-  std::vector<int32_t> hoff(nv, 0);
-  std::vector<uint32_t> hq(n, 0), hy(n, 0);
-  std::vector<uint8_t> hready(nv, 0); // a host-parsed frame the device parsers would have finished too (MobiStreamParser::device_ready)
-  std::vector<int> host_clips;
-  for (int c = 0; c < n; c++)
-    if (S.is_host[c]) { host_from[c] = 0; hslot[c] = (int)host_clips.size(); host_clips.push_back(c); }
-  auto host_parse = [&](const std::vector<int> &cl) {
-    b->pool->run((int)cl.size(), [&](int j) {
-      const int c = cl[j];
-      for (int k = host_from[c]; k < K; k++) {
-        const size_t v = (size_t)k * n + c;
-        int32_t off = 0;
-        hrc[v] = b->parsers[c]->parse_frame(S.h_stage.p + S.hdr_bytes + S.boff[v], S.lens[v], &off, b->gop_frames[(size_t)hslot[c] * K + k]);
-        hoff[v] = S.offs[v] + off;
-        hready[v] = hrc[v] == MOBI_OK && b->parsers[c]->device_ready();
-      }
-      hq[c] = b->parsers[c]->quantizer();
-      hy[c] = b->parsers[c]->yuv_format();
-    });
-  };
-  if (b->gop_frames.size() < host_clips.size() * K) b->gop_frames.resize(host_clips.size() * K);
-  host_parse(host_clips);
-  // 2. what the device parsers finished
-  HIP_TRY(hipEventSynchronize(S.ev_parsed));
-  b->phase_ms[0] = ms_since(q0);
-  { const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1; float ms = 0; if (ptime && hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
-  const MobiDevResult *res = (const MobiDevResult *)S.h_res.p;
-  std::vector<int> fb;
-  for (int c = 0; c < n; c++) {
-    if (S.is_host[c]) continue;
-    for (int k = 0; k < K; k++)
-      if (res[(size_t)k * n + c].rc != MOBI_OK) { host_from[c] = k; fb.push_back(c); break; }
-  }
-  if (!fb.empty()) { // hand-overs: the state the first unfinished frame started from (mobi_gop_chain left the true one in its start slot) and the tail before it
-    const size_t rec = sizeof(MobiDevState) + sizeof(MobiDevTail);
-    if (int e = S.h_seed.reserve(fb.size() * rec)) return e;
-    for (size_t j = 0; j < fb.size(); j++) {
-      const int c = fb[j], k = host_from[c];
-      const size_t v = (size_t)k * n + c;
-      HIP_TRY(hipMemcpyAsync(S.h_seed.p + j * rec, (const MobiDevState *)S.d_sin.p + v, sizeof(MobiDevState), hipMemcpyDeviceToHost, b->stream_p));
-      const MobiDevTail *t = k == 0 ? b->d_ptail[S.ring_in] + c : (const MobiDevTail *)S.d_tails.p + (v - n);
-      HIP_TRY(hipMemcpyAsync(S.h_seed.p + j * rec + sizeof(MobiDevState), t, sizeof(MobiDevTail), hipMemcpyDeviceToHost, b->stream_p));
-    }
-    HIP_TRY(hipStreamSynchronize(b->stream_p));
-    const size_t base = host_clips.size();
-    if (b->gop_frames.size() < (base + fb.size()) * K) b->gop_frames.resize((base + fb.size()) * K);
-    for (size_t j = 0; j < fb.size(); j++) {
-      const int c = fb[j];
-      hslot[c] = (int)(base + j);
-      b->parsers[c]->import_state(*(const MobiDevState *)(S.h_seed.p + j * rec), *(const MobiDevTail *)(S.h_seed.p + j * rec + sizeof(MobiDevState)));
-    }
-    host_parse(fb);
-    for (int c : fb) {
-      b->on_host[c] = 1;
-      b->clean_run[c] = 0;
-      b->clean_need[c] = (uint16_t)std::min(256, 2 * (int)b->clean_need[c]);
-    }
-    b->fallbacks += fb.size();
-  }
-  b->phase_ms[1] = ms_since(q0);
-  // 3. the host parser's command lists over the rows the parse kernels left, frame by frame
-  HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
-  std::vector<int> all_host(host_clips);
-  all_host.insert(all_host.end(), fb.begin(), fb.end());
-  std::sort(all_host.begin(), all_host.end());
+  std::vector<int> &host_from = S.host_from, &hslot = S.hslot, &hrc = S.hrc, &all_host = S.all_host;
+  std::vector<int32_t> &hoff = S.hoff;
+  std::vector<uint32_t> &hq = S.hq, &hy = S.hy;
+  std::vector<uint8_t> &hready = S.hready;
   const size_t desc_b = (size_t)n_mbs * sizeof(MbDesc), item_b = (size_t)n_mbs * 4;
-  for (int k = 0; k < K && !all_host.empty(); k++) {
-    std::vector<int> cl;
-    std::vector<const ParsedFrame *> fr;
-    std::vector<int> rcs;
-    for (int c : all_host)
-      if (host_from[c] <= k) {
+  if (!S.resolved) { // the group's first finish: whose frames are whose, for all K of them
+    // 1. the host parser's clips, all K frames of each, while the GPU parses the others
+    host_from.assign(n, K); // first frame of the group that is the host parser's
+    hslot.assign(n, -1);    // its place in gop_frames
+    hrc.assign(nv, MOBI_OK);
+    hoff.assign(nv, 0);
+    hq.assign(nv, 0); hy.assign(nv, 0); // Quantizer / YuvFormat behind a host-parsed frame
+    hready.assign(nv, 0);               // a host-parsed frame the device parsers would have finished too (MobiStreamParser::device_ready)
+    std::vector<int> host_clips;
+    for (int c = 0; c < n; c++)
+      if (S.is_host[c]) { host_from[c] = 0; hslot[c] = (int)host_clips.size(); host_clips.push_back(c); }
+    auto host_parse = [&](const std::vector<int> &cl) {
+      b->pool->run((int)cl.size(), [&](int j) {
+        const int c = cl[j];
+        for (int k = host_from[c]; k < K; k++) {
+          const size_t v = (size_t)k * n + c;
+          int32_t off = 0;
+          hrc[v] = b->parsers[c]->parse_frame(S.h_stage.p + S.hdr_bytes + S.boff[v], S.lens[v], &off, b->gop_frames[(size_t)hslot[c] * K + k]);
+          hoff[v] = S.offs[v] + off;
+          hready[v] = hrc[v] == MOBI_OK && b->parsers[c]->device_ready();
+          hq[v] = b->parsers[c]->quantizer();
+          hy[v] = b->parsers[c]->yuv_format();
+        }
+      });
+    };
+    if (b->gop_frames.size() < host_clips.size() * K) b->gop_frames.resize(host_clips.size() * K);
+    host_parse(host_clips);
+    // 2. what the device parsers finished
+    HIP_TRY(hipEventSynchronize(S.ev_parsed));
+    b->phase_ms[0] = ms_since(q0);
+    { const bool ptime = b->ktiming && b->ev_p0 && b->ev_p1; float ms = 0; if (ptime && hipEventElapsedTime(&ms, b->ev_p0, b->ev_p1) == hipSuccess) b->last_parse_ms = ms; }
+    const MobiDevResult *res = (const MobiDevResult *)S.h_res.p;
+    std::vector<int> fb;
+    for (int c = 0; c < n; c++) {
+      if (S.is_host[c]) continue;
+      for (int k = 0; k < K; k++)
+        if (res[(size_t)k * n + c].rc != MOBI_OK) { host_from[c] = k; fb.push_back(c); break; }
+    }
+    if (!fb.empty()) { // hand-overs: the state the first unfinished frame started from (mobi_gop_chain left the true one in its start slot) and the tail before it
+      const size_t rec = sizeof(MobiDevState) + sizeof(MobiDevTail);
+      if (int e = S.h_seed.reserve(fb.size() * rec)) return e;
+      for (size_t j = 0; j < fb.size(); j++) {
+        const int c = fb[j], k = host_from[c];
         const size_t v = (size_t)k * n + c;
-        cl.push_back(c);
-        rcs.push_back(hrc[v]);
-        fr.push_back(hrc[v] == MOBI_OK ? &b->gop_frames[(size_t)hslot[c] * K + k] : nullptr);
+        HIP_TRY(hipMemcpyAsync(S.h_seed.p + j * rec, (const MobiDevState *)S.d_sin.p + v, sizeof(MobiDevState), hipMemcpyDeviceToHost, b->stream_p));
+        const MobiDevTail *t = k == 0 ? b->d_ptail[S.ring_in] + c : (const MobiDevTail *)S.d_tails.p + (v - n);
+        HIP_TRY(hipMemcpyAsync(S.h_seed.p + j * rec + sizeof(MobiDevState), t, sizeof(MobiDevTail), hipMemcpyDeviceToHost, b->stream_p));
       }
-    const size_t kn = (size_t)k * n;
-    const DpRows rows{S.d_desc.p + kn * desc_b, S.d_pay.p + kn * S.cap_words * 4, S.d_items.p + kn * item_b, (MobiDevResult *)S.d_res.p + kn, S.cap_words};
-    if (int e = dp_override(b, cl, nullptr, S.h_over[k], rows, b->stream, fr.data(), rcs.data())) return e;
+      HIP_TRY(hipStreamSynchronize(b->stream_p));
+      const size_t base = host_clips.size();
+      if (b->gop_frames.size() < (base + fb.size()) * K) b->gop_frames.resize((base + fb.size()) * K);
+      for (size_t j = 0; j < fb.size(); j++) {
+        const int c = fb[j];
+        hslot[c] = (int)(base + j);
+        b->parsers[c]->import_state(*(const MobiDevState *)(S.h_seed.p + j * rec), *(const MobiDevTail *)(S.h_seed.p + j * rec + sizeof(MobiDevState)));
+      }
+      host_parse(fb);
+      for (int c : fb) {
+        b->on_host[c] = 1;
+        b->clean_run[c] = 0;
+        b->clean_need[c] = (uint16_t)std::min(256, 2 * (int)b->clean_need[c]);
+      }
+      b->fallbacks += fb.size();
+    }
+    b->phase_ms[1] = ms_since(q0);
+    // 3. the host parser's command lists over the rows the parse kernels left, frame by frame
+    HIP_TRY(hipStreamWaitEvent(b->stream, S.ev_parsed, 0));
+    all_host = host_clips;
+    all_host.insert(all_host.end(), fb.begin(), fb.end());
+    std::sort(all_host.begin(), all_host.end());
+    for (int k = 0; k < K && !all_host.empty(); k++) {
+      std::vector<int> cl;
+      std::vector<const ParsedFrame *> fr;
+      std::vector<int> rcs;
+      for (int c : all_host)
+        if (host_from[c] <= k) {
+          const size_t v = (size_t)k * n + c;
+          cl.push_back(c);
+          rcs.push_back(hrc[v]);
+          fr.push_back(hrc[v] == MOBI_OK ? &b->gop_frames[(size_t)hslot[c] * K + k] : nullptr);
+        }
+      const size_t kn = (size_t)k * n;
+      const DpRows rows{S.d_desc.p + kn * desc_b, S.d_pay.p + kn * S.cap_words * 4, S.d_items.p + kn * item_b, (MobiDevResult *)S.d_res.p + kn, S.cap_words};
+      if (int e = dp_override(b, cl, nullptr, S.h_over[k], rows, b->stream, fr.data(), rcs.data())) return e;
+    }
+    HIP_TRY(hipMemsetAsync(S.d_fault.p, 0, nv * sizeof(int), b->stream));
+    S.resolved = true;
+    S.done = 0;
   }
-  // 4. K reconstruction steps from K consecutive command lists
-  HIP_TRY(hipMemsetAsync(S.d_fault.p, 0, nv * sizeof(int), b->stream));
-  for (int k = 0; k < K; k++) {
+  const MobiDevResult *res = (const MobiDevResult *)S.h_res.p;
+  // 4. the reconstruction steps of this part -- at most six: the ring holds six pictures -- from consecutive command lists
+  const int k0 = S.done, k1 = std::min(K, k0 + 6);
+  const bool last = k1 == K;
+  for (int k = k0; k < k1; k++) {
     const size_t kn = (size_t)k * n;
     uint32_t Kint = 0;
     for (int c = 0; c < n; c++) {
@@ -1599,54 +1619,66 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
       return MOBI_E_DEVICE;
   }
   b->pay_clip_words = (uint32_t)S.cap_words;
-  HIP_TRY(hipMemcpyAsync(S.h_fault.p, S.d_fault.p, nv * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemcpyAsync(S.h_fault.p + (size_t)k0 * n * sizeof(int), S.d_fault.p + (size_t)k0 * n * sizeof(int), (size_t)(k1 - k0) * n * sizeof(int), hipMemcpyDeviceToHost, b->stream));
   b->phase_ms[2] = ms_since(q0);
-  // 5. clips that go back to the device parsers (dp_return's rule, counted in frames): their state into the entry the next parse reads
-  {
-    std::vector<int> back;
-    for (int c : all_host) {
-      if (b->host_share[c]) continue;
-      int run = b->clean_run[c]; // consecutive frames the device parsers would have finished too
-      for (int k = host_from[c]; k < K; k++) run = hready[(size_t)k * n + c] ? run + 1 : 0;
-      b->clean_run[c] = (uint16_t)std::min(60000, run);
-      if (run >= b->clean_need[c]) back.push_back(c);
+  if (last) {
+    // 5. clips that go back to the device parsers (dp_return's rule, counted in frames): their state into the entry the next parse reads
+    {
+      std::vector<int> back;
+      for (int c : all_host) {
+        if (b->host_share[c]) continue;
+        int run = b->clean_run[c]; // consecutive frames the device parsers would have finished too
+        for (int k = host_from[c]; k < K; k++) run = hready[(size_t)k * n + c] ? run + 1 : 0;
+        b->clean_run[c] = (uint16_t)std::min(60000, run);
+        if (run >= b->clean_need[c]) back.push_back(c);
+      }
+      if (int e = dp_return_list(b, back, b->ps_cur, S.h_ret, b->stream_p)) return e;
     }
-    if (int e = dp_return_list(b, back, b->ps_cur, S.h_ret, b->stream_p)) return e;
-  }
-  // 6. the group begun behind this one: its parse runs beside this group's reconstruction
-  if (b->gop_count == 2) {
-    mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
-    if (!N.parse_enqueued)
-      if (int e = gop_enqueue_parse(b, N)) return e;
+    // 6. the group begun behind this one: its parse runs beside this group's reconstruction
+    if (b->gop_count == 2) {
+      mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
+      if (!N.parse_enqueued)
+        if (int e = gop_enqueue_parse(b, N)) return e;
+    }
   }
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->phase_ms[3] = ms_since(q0);
   b->drain_events();
   poison.armed = false;
   const int *fault = (const int *)S.h_fault.p;
-  b->ls_finished = S.lockstep ? 0 : -1;
+  if (k0 == 0) b->ls_finished = S.lockstep ? 0 : -1;
   b->lockstep = S.lockstep;
-  for (int k = 0; k < K; k++)
+  for (int k = k0; k < k1; k++)
     for (int c = 0; c < n; c++) {
-      const size_t v = (size_t)k * n + c;
+      const size_t v = (size_t)k * n + c, o = (size_t)(k - k0) * n + c; // (the part's results count from its first frame)
       if (k >= host_from[c]) {
-        rc[v] = hrc[v];
-        if (offsets_out) offsets_out[v] = hoff[v];
+        rc[o] = hrc[v];
+        if (offsets_out) offsets_out[o] = hoff[v];
       } else {
         if (S.lockstep && res[v].pad == MOBI_LS_MAGIC) b->ls_finished++;
-        rc[v] = res[v].rc;
-        if (offsets_out) offsets_out[v] = S.offs[v] + (int32_t)res[v].consumed;
+        rc[o] = res[v].rc;
+        if (offsets_out) offsets_out[o] = S.offs[v] + (int32_t)res[v].consumed;
       }
-      if (rc[v] == MOBI_OK && fault[v]) rc[v] = (fault[v] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
-      if (k == K - 1) {
-        b->dev_quant[c] = k >= host_from[c] ? hq[c] : res[v].quant;
-        b->dev_yuvfmt[c] = k >= host_from[c] ? hy[c] : res[v].yuvfmt;
+      if (rc[o] == MOBI_OK && fault[v]) rc[o] = (fault[v] & 2) ? MOBI_E_DEVICE : MOBI_E_CLAMP;
+      if (k == k1 - 1) {
+        b->dev_quant[c] = k >= host_from[c] ? hq[v] : res[v].quant;
+        b->dev_yuvfmt[c] = k >= host_from[c] ? hy[v] : res[v].yuvfmt;
       }
     }
-  b->gop_head ^= 1;
-  b->gop_count--;
-  S.parse_enqueued = false;
+  S.done = k1;
+  if (last) {
+    b->gop_head ^= 1;
+    b->gop_count--;
+    S.parse_enqueued = false;
+    S.resolved = false;
+  }
   return MOBI_OK;
+}
+// frames of the OLDEST group begun that mobi_batch_gop_finish has not reported yet (0: no group is begun); the next finish reports min(6, that)
+int mobi_batch_gop_frames_pending(const mobi_batch *b) {
+  if (!b || b->gop_count == 0) return 0;
+  const mobi_batch::GopSlot &S = b->gslot[b->gop_head & 1];
+  return S.K - (S.resolved ? S.done : 0);
 }
 int mobi_batch_gop_in_flight(const mobi_batch *b) { return b ? b->gop_count : 0; }
 

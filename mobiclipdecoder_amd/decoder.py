@@ -58,6 +58,7 @@ _SIGS = {
     "mobi_batch_gop_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_gop_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mobi_batch_gop_in_flight": (C.c_int, [C.c_void_p]),
+    "mobi_batch_gop_frames_pending": (C.c_int, [C.c_void_p]),
     "mobi_batch_host_clips": (C.c_int, [C.c_void_p]),
     "mobi_batch_compare_clips": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mobi_forward_dct": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -307,17 +308,20 @@ class MobiclipBatch:
         e = self._lib.mobi_batch_gop_begin(self._h, K, ptrs, lens, offs)
         if e != 0:
             raise MobiclipError(error_string(e))
-        self._gop_k = getattr(self, "_gop_k", []) + [K]
 
     def gop_finish(self):
-        """second half, for the OLDEST group begun: hand-overs, the K reconstruction steps; -> (rc, offsets) as decode_gop()"""
-        K = self._gop_k.pop(0)
+        """second half, for the OLDEST group begun: hand-overs, the reconstruction steps; -> (rc, offsets) as decode_gop().  A group of more
+        than six frames (gop_begin takes up to 12) is handed out six at a time: call again while gop_frames_pending() > 0."""
+        K = min(6, self._lib.mobi_batch_gop_frames_pending(self._h))
         offs = (C.c_int32 * (K * self.n))()
         rcs = (C.c_int * (K * self.n))()
         e = self._lib.mobi_batch_gop_finish(self._h, offs, rcs)
         if e != 0:
             raise MobiclipError(error_string(e))
         return [list(rcs[k * self.n:(k + 1) * self.n]) for k in range(K)], [list(offs[k * self.n:(k + 1) * self.n]) for k in range(K)]
+
+    def gop_frames_pending(self):
+        return self._lib.mobi_batch_gop_frames_pending(self._h)
 
     def compare_clips(self, modulus):
         """clips whose newest frame differs from that of clip (index mod modulus), compared on the device (batches made of copies)"""

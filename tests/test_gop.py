@@ -80,6 +80,17 @@ def _run_groups(clips, p0, groups, device_parse, oracle=True, pipelined=False, r
                 if rb is not None:
                     assert b.quantizer(c) == rb.quantizer(c) and b.yuv_format(c) == rb.yuv_format(c), (f0, c)
 
+    def finish_oldest():
+        # a group of more than six frames comes back six at a time; each part's planes are read before the next finish turns the ring again
+        g0 = pending.pop(0)
+        done = 0
+        while done < g0[1]:
+            assert b.gop_frames_pending() == g0[1] - done
+            rcs, offs = b.gop_finish()
+            check(g0[0] + done, len(rcs), g0[2][done:done + len(rcs)], rcs, offs)
+            done += len(rcs)
+        assert done == g0[1]
+
     for gi, K in enumerate(groups):
         frames = _frames(clips, f0, K)
         if not pipelined:
@@ -89,15 +100,10 @@ def _run_groups(clips, p0, groups, device_parse, oracle=True, pipelined=False, r
             b.gop_begin(frames)
             pending.append((f0, K, frames))
             if len(pending) == 2:  # the second group is begun (gathered, uploaded) before the first is finished
-                g0 = pending.pop(0)
-                rcs, offs = b.gop_finish()
-                # (the planes of group g0 are read after its finish and before the next group's finish turns the ring again)
-                check(g0[0], g0[1], g0[2], rcs, offs)
+                finish_oldest()
         f0 += K
     while pending:
-        g0 = pending.pop(0)
-        rcs, offs = b.gop_finish()
-        check(g0[0], g0[1], g0[2], rcs, offs)
+        finish_oldest()
     hc = b.host_clips()
     b.close()
     if rb is not None:
@@ -190,6 +196,28 @@ def test_two_groups_begun_before_the_first_is_finished(mode):
     clips = [generate_clip(p) for p in ps]
     n_err, hc = _run_groups(clips, ps[0], [3, 3, 2, 3, 1, 3, 3, 3, 3], mode, pipelined=True)
     assert n_err == 0 and hc == 0
+
+
+@pytest.mark.parametrize("mode", [True, "lockstep"])
+def test_groups_of_twelve_parsed_at_once_finished_six_at_a_time(mode):
+    """gop_begin takes up to 12 frames (what is parsed side by side is not bound by the ring); finish hands them out six at a time"""
+    ps = [default_params("A", BASE_SEED + 7550 + i, n_frames=40, width=128, height=96, pm_intra=100, pm_multiref=300, iframe_interval=9, qdelta_prob=300) for i in range(5)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [12, 12, 7, 8], mode, pipelined=True)
+    assert n_err == 0 and hc == 0
+
+
+def test_a_glitch_in_the_second_half_of_a_group_of_twelve():
+    ps = [default_params("A", BASE_SEED + 7650 + i, n_frames=25, width=96, height=64, pm_intra=100, iframe_interval=6) for i in range(6)]
+    clips = []
+    for i, p in enumerate(ps):
+        d, fo = generate_clip(p)
+        d = np.array(d, copy=True)
+        if i in (1, 4):
+            d[int(fo[8 + i]) + 2:int(fo[9 + i])] = 0xA5
+        clips.append((d, fo))
+    n_err, hc = _run_groups(clips, ps[0], [12, 12], "lockstep", pipelined=True, reference_batch=False)
+    assert n_err >= 2
 
 
 def test_pipelined_groups_with_a_glitch_in_the_first():
@@ -290,4 +318,6 @@ def test_argument_checks():
     with pytest.raises(Exception):
         b.gop_begin(_frames(clips, 4, 2))  # at most two
     assert b.gop_finish()[0] == [[0], [0]] and b.gop_finish()[0] == [[0], [0]]
+    with pytest.raises(Exception):
+        b.gop_begin(_frames(clips * 1, 0, 1) * 13)  # more than twelve frames
     b.close()
