@@ -52,7 +52,8 @@ def groups_text(e, what):
     if "value" not in g:
         return ""
     return (f" In frame-parallel groups of {g['frames_per_group']} (`{what}.groups`, `mobi_batch_decode_gop`): {g['ms_per_step']:.1f} ms per frame step = **{g['value'] / 1e3:.0f} Gpixels/s**, "
-            f"with the next group begun before the last is finished (`gop_begin` / `gop_finish`) {g['pipelined']['ms_per_step']:.1f} ms = **{g['pipelined']['value'] / 1e3:.0f} Gpixels/s**.")
+            f"with the next group begun before the last is finished (`gop_begin` / `gop_finish`, {g['pipelined'].get('frames_per_group', g['frames_per_group'])} frames per group) "
+            f"{g['pipelined']['ms_per_step']:.1f} ms = **{g['pipelined']['value'] / 1e3:.0f} Gpixels/s**.")
 
 
 # a figure that is an outlier of its own kind does not go into three documents (a 2.5 s "I-frame with the Bitmap" that was one
@@ -168,7 +169,7 @@ GPUs run N copies of the 1-GPU row. Earlier rounds: r03 B 908 067 Mpix/s (41.2 /
 open("BASELINE.md", "w").write(s[:a] + head + "\n".join(rows) + "\n")
 def greadme(e):
     g = e.get("groups") or {}
-    return f"; {g['pipelined']['value'] / 1e3:.0f} with {g['frames_per_group']} frames of every clip parsed side by side, r06" if "value" in g else ""
+    return f"; {g['pipelined']['value'] / 1e3:.0f} with {g['pipelined'].get('frames_per_group', g['frames_per_group'])} frames of every clip parsed side by side, r06" if "value" in g else ""
 
 
 s = open("README.md").read()
