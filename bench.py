@@ -146,10 +146,14 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     # its own streams of the same seeds and mix, long enough for eight groups: one to warm up and six timed in the pipelined part (three
     # timed groups, as the 33-frame clips of the replay give, start on a GPU whose clocks have just sat through the checker's seconds)
     G = 12 if K == GOP_K else 8
+    # ... and 64 distinct ones: the lock-step parser's lanes are consecutive clips, up to 24 per wave under a group, and a wave that holds two
+    # copies of one stream diverges less than content allows (16 distinct streams: 330 instead of 240 Gpixels/s at 4096 clips x 12 -- flattery)
     longer = []
-    for p, _, _ in streams:
+    for j in range(max(64, len(streams))):
+        p = streams[j % len(streams)][0]
         q = type(p).from_buffer_copy(p)
         q.n_frames = 1 + K * G
+        q.seed = p.seed + 1000003 * (j // len(streams))
         longer.append((q,) + m.generate_clip(q))
     streams = longer
     nv = n_clips * K

@@ -330,7 +330,7 @@ struct mobi_batch {
     std::vector<int32_t> offs;       // [v] Offset at submission
     std::vector<uint8_t> is_host;    // [c] the host parser's clip when the parse was enqueued
     // what the group's first mobi_batch_gop_finish settles for all K frames (a group of more than six is finished in two calls)
-    bool resolved = false;
+    bool resolved = false, returned = false; // (returned: the clips that go back to the device parsers have been sent)
     int done = 0;                    // frames reconstructed and reported so far
     std::vector<int> host_from, hslot, hrc, all_host;
     std::vector<int32_t> hoff;
@@ -1465,7 +1465,7 @@ int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data
   HIP_TRY(hipEventRecord(S.ev_up, b->stream2));
   b->last_stage_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_stage0).count();
   S.parse_enqueued = false;
-  S.resolved = false;
+  S.resolved = S.returned = false;
   S.done = 0;
   b->gop_count++;
   if (b->gop_count == 1) // nothing in front: the parse may start at once (else mobi_batch_gop_finish of the group in front enqueues it, once it knows whose clips are whose)
@@ -1621,7 +1621,10 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
   b->pay_clip_words = (uint32_t)S.cap_words;
   HIP_TRY(hipMemcpyAsync(S.h_fault.p + (size_t)k0 * n * sizeof(int), S.d_fault.p + (size_t)k0 * n * sizeof(int), (size_t)(k1 - k0) * n * sizeof(int), hipMemcpyDeviceToHost, b->stream));
   b->phase_ms[2] = ms_since(q0);
-  if (last) {
+  // (behind this part's reconstruction in the queue, but in the group's FIRST part: everything the next parse needs to know -- whose clips are
+  // whose -- is settled once the group is resolved, and a parse enqueued only with the last part would leave the GPU waiting for the host between the parts)
+  if (!S.returned) {
+    S.returned = true;
     // 5. clips that go back to the device parsers (dp_return's rule, counted in frames): their state into the entry the next parse reads
     {
       std::vector<int> back;
@@ -1634,12 +1637,12 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
       }
       if (int e = dp_return_list(b, back, b->ps_cur, S.h_ret, b->stream_p)) return e;
     }
-    // 6. the group begun behind this one: its parse runs beside this group's reconstruction
-    if (b->gop_count == 2) {
-      mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
-      if (!N.parse_enqueued)
-        if (int e = gop_enqueue_parse(b, N)) return e;
-    }
+  }
+  // 6. the group begun behind this one: its parse runs beside this group's reconstruction
+  if (b->gop_count == 2) {
+    mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
+    if (!N.parse_enqueued)
+      if (int e = gop_enqueue_parse(b, N)) return e;
   }
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->phase_ms[3] = ms_since(q0);
@@ -1670,7 +1673,7 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
     b->gop_head ^= 1;
     b->gop_count--;
     S.parse_enqueued = false;
-    S.resolved = false;
+    S.resolved = S.returned = false;
   }
   return MOBI_OK;
 }
