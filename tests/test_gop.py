@@ -135,6 +135,15 @@ def test_quantiser_deltas_and_iframes_in_every_position():
         assert n_err == 0 and hc == 0
 
 
+def test_geometries_from_one_macroblock_to_the_widest_picture():
+    """16x16 (one macroblock), 1024 wide (Stride == Width: the linear offsets wrap rows), a width that is not a multiple of the octet, both versions"""
+    for i, (w, h, ver, q) in enumerate([(16, 16, 1, 12), (64, 48, 2, 52), (1024, 32, 2, 20), (272, 160, 1, 16), (512, 64, 2, 30)]):
+        ps = [default_params("A", BASE_SEED + 7950 + 10 * i + c, n_frames=13, width=w, height=h, version=ver, quantizer=q, pm_intra=200, mv_range=12, iframe_interval=5) for c in range(3)]
+        clips = [generate_clip(p) for p in ps]
+        n_err, hc = _run_groups(clips, ps[0], [6, 1, 5], "lockstep" if i & 1 else True)
+        assert n_err == 0 and hc == 0, (w, h, ver)
+
+
 def test_first_frame_is_a_p_frame():
     """a P-frame into an empty ring (a fresh decoder: Quantizer 0, no tables): Moflex3DS sets up quantiser 12 (MD.cs:119-126), ModsDS reads
     zero tables; references to frames that were never decoded throw (MD.cs:413)"""
