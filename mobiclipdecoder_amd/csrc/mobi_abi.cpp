@@ -319,7 +319,7 @@ struct mobi_batch {
   struct GopSlot {
     PinnedBuf h_stage, h_res, h_fault, h_over[MOBI_GOP_PARSE_MAX], h_seed, h_ret;
     DevBuf d_bits, d_desc, d_pay, d_items, d_res, d_sin, d_sout, d_sls, d_tails, d_fault;
-    hipEvent_t ev_up = nullptr, ev_parsed = nullptr;
+    hipEvent_t ev_up = nullptr, ev_parsed = nullptr, ev_recon = nullptr;
     int K = 0;
     size_t hdr_bytes = 0, bytes = 0, max_len = 0, cap_words = 0;
     int n_iframes = 0;
@@ -443,6 +443,7 @@ struct mobi_batch {
     for (auto &gs : gslot) {
       if (gs.ev_up) (void)hipEventDestroy(gs.ev_up);
       if (gs.ev_parsed) (void)hipEventDestroy(gs.ev_parsed);
+      if (gs.ev_recon) (void)hipEventDestroy(gs.ev_recon);
     }
     for (auto &sl : aslot) {
       if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
@@ -1316,7 +1317,7 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
 // n * K virtual clips for the parse kernels, whose cost per frame falls with the number of lanes they are given -- and
 // reconstructed as K steps in order.  begin: gather + upload (and, when nothing else is in flight, the parse); finish: the host parser's
 // share and every hand-over, the K reconstruction steps, and the parse of the group begun behind it.
-static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S) {
+static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S, hipEvent_t after = nullptr) {
   const int n = b->n, K = S.K, n_mbs = b->g.mbw * b->g.mbh;
   const size_t nv = (size_t)n * K;
   S.is_host.assign(b->on_host.begin(), b->on_host.end());
@@ -1345,6 +1346,11 @@ static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S) {
   if (int e = S.h_fault.reserve(nv * sizeof(int))) return e;
   hipStream_t ps = b->stream_p;
   HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
+  // `after`: the reconstruction steps just enqueued for the group in front go FIRST.  A full parse workgroup takes a CU's whole LDS (36 lanes x
+  // 8 waves), the octet kernel's workgroups the rest: left to the dispatcher, the parse got in first, the reconstruction the caller is waiting
+  // for sat behind it, and by the time mobi_batch_gop_finish returned the GPU had nothing left to do while the host gathered the next group
+  // (24576 clips x 6: 147 ms per group against 62 + 50 of kernels).  In this order the host's turn overlaps the parse.
+  if (after) HIP_TRY(hipStreamWaitEvent(ps, after, 0));
   HIP_TRY(hipMemcpyAsync(S.d_bits.p, S.h_stage.p, S.hdr_bytes, hipMemcpyHostToDevice, ps)); // offsets and lengths (with the host parser's clips marked)
   MobiGopArgs G;
   memset(&G, 0, sizeof(G));
@@ -1638,11 +1644,14 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
       if (int e = dp_return_list(b, back, b->ps_cur, S.h_ret, b->stream_p)) return e;
     }
   }
-  // 6. the group begun behind this one: its parse runs beside this group's reconstruction
+  // 6. the group begun behind this one: its parse goes out now, behind this part's reconstruction steps
   if (b->gop_count == 2) {
     mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
-    if (!N.parse_enqueued)
-      if (int e = gop_enqueue_parse(b, N)) return e;
+    if (!N.parse_enqueued) {
+      if (!S.ev_recon) HIP_TRY(hipEventCreateWithFlags(&S.ev_recon, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(S.ev_recon, b->stream));
+      if (int e = gop_enqueue_parse(b, N, S.ev_recon)) return e;
+    }
   }
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->phase_ms[3] = ms_since(q0);

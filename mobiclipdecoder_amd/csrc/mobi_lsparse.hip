@@ -211,14 +211,20 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   L = L < 1 ? 1 : L > 64 ? 64 : L;
   int W = MOBI_LS_WAVES;
   if ((a->n_clips + L - 1) / L > 1536 && lds_of(2 * W, L) <= lds_max) W *= 2;
-  // r06: more lanes than the chip holds as two waves per SIMD (frame-parallel groups: n_clips x K virtual clips) -- the launch takes turns.
-  // Beyond ~24 lanes a wave costs what its lanes bring (every lane is in a state of its own: the wave runs every part of the walk every
-  // round), and more than two waves per SIMD lose as they did in r05 (tools/exp_gop_lanes.sh, 147456 lanes, ms per launch by lanes x waves
-  // per workgroup: 24 x 8: 82, 28 x 8: 84, 35 x 8: 90, 46 x 6: 96, 64 x 4 -- one wave per SIMD -- 100; 15 x 8 twice per CU: 107, 12 x 8: 120)
-  if (L > 24) {
-    L = 24;
+  // r06: more lanes than the chip holds as two waves per SIMD (frame-parallel groups: n_clips x K virtual clips) -- the launch takes TURNS
+  // of 256 workgroups of eight waves, and a turn lasts as long as one workgroup lives, however few workgroups the last one has.  A wave's
+  // life grows slowly with its lanes (640x480 P-frames, ms: 12 lanes 22.9, 24: 27.3, 36: 30.7 -- about 20 + 0.3 per lane), so a lane is the
+  // cheaper the fuller its wave, and what counts is WHOLE turns: the fewest turns that an eight-wave workgroup's LDS allows (36 lanes per
+  // wave at 640 wide), the lanes dealt evenly over them.  147456 lanes: 36 x 8 in two turns 62 ms; 24 x 8 in three turns 82; 35 x 8 -- two
+  // turns and fifteen workgroups of a third -- 90 (tools/exp_gop_lanes.sh; r06's first sweep read that as "beyond 24 lanes a wave costs what
+  // its lanes bring": it had measured the tail).  More than two waves per SIMD lose as they did in r05 (15 x 8 twice per CU: 107).
+  if (lds_of(W, L) > lds_max || L > 24) {
     W = 2 * MOBI_LS_WAVES;
-    while (L > 1 && lds_of(W, L) > lds_max) L--;
+    int Lmax = 64;
+    while (Lmax > 1 && lds_of(W, Lmax) > lds_max) Lmax--;
+    const long per_turn = 256L * W; // waves of one turn (one workgroup per CU)
+    const long turns = (a->n_clips + Lmax * per_turn - 1) / (Lmax * per_turn);
+    L = (int)((a->n_clips + turns * per_turn - 1) / (turns * per_turn));
   }
 #if defined(MOBI_PROFILING)
   if (const char *e = getenv("MOBI_LS_CLIPS")) L = atoi(e);    // (tools/exp_lsab.sh, tests/test_lsparse_gpu.py)
