@@ -139,13 +139,28 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     before group g is finished (mobi_batch_gop_begin / mobi_batch_gop_finish).  ms_per_step = wall time per FRAME step."""
     import ctypes as C
     import time as _t
+    # How many frames per group.  The lock-step parser works in TURNS of 2048 waves (eight per CU), a wave is the cheaper per lane the fuller it
+    # is, and a workgroup's LDS holds 36 lanes per wave at 640 wide (mobi_launch_parse_ls): the frames in flight should fill whole turns --
+    # n_clips x K close to a multiple of 2048 x 36 -- as far as K (6 per call, 12 per gop_begin) and HBM allow: a group's command lists
+    # are resident until it is reconstructed, worst-case payload room per frame (mobi_abi.cpp, gop_enqueue_parse).
+    mbw, n_mbs = W // 16, (W // 16) * (H // 16)
+    turn = 2048 * ((160 * 1024 - 18400) // (8 * (4 * (mbw + 2) + 64 + 96 + 128 + 40)))
+    frame_len = max(int(s[2][f + 1] - s[2][f]) for s in streams for f in range(1, len(s[2]) - 1))
+    per_frame = 32 * n_mbs + 4 * (64 * n_mbs + (8 * frame_len * 5 // 4 + 2) // 3 + 512) + 4 * n_mbs + 1200 + 2 * frame_len  # descriptors, payload part, items, states, bits
+    import torch
+    room = torch.cuda.mem_get_info(device)[0] - n_clips * (W if W > 512 else 512 if W > 256 else 256) * H * 9 - (12 << 30)  # free HBM less the rings and a margin
+
+    def pick(kmax, slots):
+        fits = [k for k in range(1, kmax + 1) if slots * n_clips * k * per_frame <= room] or [1]
+        fill = {k: n_clips * k / (-(-n_clips * k // turn) * turn) for k in fits}
+        return max(k for k in fits if fill[k] >= 0.9 * max(fill.values()))
+
     if K is None:
-        # The lock-step parser is at its best from ~49152 lanes on (24 lanes x 8 waves on every CU; beyond that it takes turns: no gain), and a
-        # group's command lists cost HBM (worst-case payload room per frame): as many frames per group as it takes to get there, whole turns
-        K = GOP_K if n_clips * GOP_K <= 49152 else 4 if n_clips * 4 <= 98304 else 2
-    # its own streams of the same seeds and mix, long enough for eight groups: one to warm up and six timed in the pipelined part (three
+        K = pick(GOP_K, 1)
+    Kp = pick(2 * GOP_K, 2)
+    # its own streams of the same seeds and mix, long enough for a warm-up group and at least four timed ones in the pipelined part (three
     # timed groups, as the 33-frame clips of the replay give, start on a GPU whose clocks have just sat through the checker's seconds)
-    G = 12 if K == GOP_K else 8
+    G = max(8, -(-6 * Kp // K))
     # ... and 64 distinct ones: the lock-step parser's lanes are consecutive clips, up to 24 per wave under a group, and a wave that holds two
     # copies of one stream diverges less than content allows (16 distinct streams: 330 instead of 240 Gpixels/s at 4096 clips x 12 -- flattery)
     longer = []
@@ -189,8 +204,7 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
                   "wall time of the call / frames (host staging, H2D, parse, chain check, reconstruction, read-back, sync)",
            "clips_handed_to_the_host_parser": int(host_clips), "verified": verified}
     # Pipelined: what is PARSED side by side is not bound by the ring -- mobi_batch_gop_begin takes up to 12 frames, mobi_batch_gop_finish hands
-    # them out six at a time -- so a batch too small to fill the parsers' lanes with six frames per clip begins twelve.
-    Kp = 2 * K if K == GOP_K and n_clips * 2 * K <= 49152 else K
+    # them out six at a time -- so a batch too small to fill the parsers' lanes with six frames per clip begins up to twelve (Kp, above).
     Gp = G * K // Kp
     del packs
     packs = [pack(1 + Kp * g, Kp) for g in range(Gp)]
