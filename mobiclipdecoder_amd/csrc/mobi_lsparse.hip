@@ -8,8 +8,9 @@
 //   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
 //                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
 //
-// LDS per workgroup: ONE copy of the table blob (18 KB) for its waves, and per wave and lane the motion-vector row cache (2 (mbw + 2)
-// words), the partition-tree stack (16), the intra records (24), the mode cache (40 bytes), a 128-byte ring of bitstream -- all
+// LDS per workgroup: ONE copy of the table blob (18 KB) for its waves, and per wave and lane the motion-vector row cache (mbw + 2
+// words: a vector as two int16, r06), the intra records (24 words; the partition-tree stack of an inter macroblock lives in the same
+// words, r06), the mode cache (40 bytes), a 128-byte ring of bitstream -- 432 bytes at 640 wide (r05: 664) -- all
 // lane-interleaved (element i of lane l at i * ls_clips + l), so that the lanes reading "their" element i hit different banks.
 // How many clips a wave carries is a launch argument (mobi_launch_parse_ls, with the measurements): a wave's life grows with the number of
 // DIFFERENT clips it holds -- it runs until its slowest lane is done, a round costs what its lanes' different states need -- and alone on a
@@ -77,9 +78,11 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
   uint8_t *tab = lds;
   DevStore m;
   m.L = LS_CLIPS;
-  m.mvp_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvp_words + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
-  m.stk_ = m.mvp_ + mvp_words * LS_CLIPS;
-  m.rec_ = m.stk_ + 16 * LS_CLIPS;
+  m.mvp_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvp_words + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
+  // (r06: the partition-tree stack lives in the intra records' words -- a macroblock is intra only by its ROOT node's code (mobi_lsparse.h,
+  // LS_NODE: any deeper "intra" code ends the lane), when the stack is empty, and the records are zeroed behind that: never both at once)
+  m.rec_ = m.mvp_ + mvp_words * LS_CLIPS;
+  m.stk_ = m.rec_;
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
   m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
   m.lane = lane;
@@ -204,7 +207,7 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   // rounds -- 32768 clips: 68.9 ms per step against 39.9, 24576: 37.4 (16 per wave, r05's first rule) against 35.1, 16384: 34.8 against 28.7,
   // 40960: 55.3 against 47.7 (tools/exp_async.py, profiles/r05_experiments.txt).  49152 clips (24 per wave, what 288 GB hold at 640x480) only
   // fit a CU's LDS this way.
-  const int per_clip = 4 * (a->mbw + 2) + 4 * 16 + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
+  const int per_clip = 4 * (a->mbw + 2) + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
   auto lds_of = [&](int w, int l) { return (size_t)MOBI_DT_BYTES + (size_t)w * l * per_clip; };
   const size_t lds_max = 160 * 1024;
   int L = (a->n_clips + 2047) / 2048;
@@ -214,7 +217,7 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   // r06: more lanes than the chip holds as two waves per SIMD (frame-parallel groups: n_clips x K virtual clips) -- the launch takes TURNS
   // of 256 workgroups of eight waves, and a turn lasts as long as one workgroup lives, however few workgroups the last one has.  A wave's
   // life grows slowly with its lanes (640x480 P-frames, ms: 12 lanes 22.9, 24: 27.3, 36: 30.7 -- about 20 + 0.3 per lane), so a lane is the
-  // cheaper the fuller its wave, and what counts is WHOLE turns: the fewest turns that an eight-wave workgroup's LDS allows (36 lanes per
+  // cheaper the fuller its wave, and what counts is WHOLE turns: the fewest turns that an eight-wave workgroup's LDS allows (42 lanes per
   // wave at 640 wide), the lanes dealt evenly over them.  147456 lanes: 36 x 8 in two turns 62 ms; 24 x 8 in three turns 82; 35 x 8 -- two
   // turns and fifteen workgroups of a third -- 90 (tools/exp_gop_lanes.sh; r06's first sweep read that as "beyond 24 lanes a wave costs what
   // its lanes bring": it had measured the tail).  More than two waves per SIMD lose as they did in r05 (15 x 8 twice per CU: 107).

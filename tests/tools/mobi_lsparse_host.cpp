@@ -14,13 +14,12 @@
 namespace {
 struct HostStore {
   uint32_t mvp_[64 + 2];
-  uint32_t stk_[16];
-  uint32_t rec_[MOBI_INTRA_RECORDS];
+  uint32_t rec_[MOBI_INTRA_RECORDS]; // (the partition-tree stack shares these words, as on the device: mobi_lsparse.hip)
   uint8_t mc_[40];
   const uint8_t *data;
   uint32_t len2; // bytes that exist as whole 16-bit words
   uint32_t &mvp(int i) { return mvp_[i]; }
-  uint32_t &stk(int i) { return stk_[i]; }
+  uint32_t &stk(int i) { return rec_[i]; }
   uint32_t &rec(int i) { return rec_[i]; }
   uint8_t &mc(int i) { return mc_[i]; }
   uint32_t ring32(uint32_t rd) const {
