@@ -140,11 +140,11 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     import ctypes as C
     import time as _t
     # How many frames per group.  The lock-step parser works in TURNS of 2048 waves (eight per CU), a wave is the cheaper per lane the fuller it
-    # is, and a workgroup's LDS holds 42 lanes per wave at 640 wide (mobi_launch_parse_ls): the frames in flight should fill whole turns --
-    # n_clips x K close to a multiple of 2048 x 36 -- as far as K (6 per call, 12 per gop_begin) and HBM allow: a group's command lists
+    # is, and a workgroup's LDS holds full waves of 64 lanes since the MV row cache left it (mobi_launch_parse_ls): the frames in flight should fill whole turns --
+    # n_clips x K close to a multiple of 2048 x 64 -- as far as K (6 per call, 12 per gop_begin) and HBM allow: a group's command lists
     # are resident until it is reconstructed, worst-case payload room per frame (mobi_abi.cpp, gop_enqueue_parse).
     mbw, n_mbs = W // 16, (W // 16) * (H // 16)
-    turn = 2048 * ((160 * 1024 - 18400) // (8 * (4 * (mbw + 2) + 96 + 128 + 40)))
+    turn = 2048 * min(64, (160 * 1024 - 18400) // (8 * (96 + 128 + 40)))
     frame_len = max(int(s[2][f + 1] - s[2][f]) for s in streams for f in range(1, len(s[2]) - 1))
     per_frame = 32 * n_mbs + 4 * (64 * n_mbs + (8 * frame_len * 5 // 4 + 2) // 3 + 512) + 4 * n_mbs + 1200 + 2 * frame_len  # descriptors, payload part, items, states, bits
     import torch

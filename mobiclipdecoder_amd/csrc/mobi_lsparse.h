@@ -78,7 +78,14 @@ struct LsLane {
   uint32_t quant, yuvfmt, tables_set;
   int vlc, frames_started, iframe;
   // macroblock
-  int mb, mx, my, cur_off, mb_type, predx, predy, mvslot;
+  int mb, mx, my, cur_off, mb_type, predx, predy;
+  // The MV row cache (Internal[221..], MD.cs:145-208: macroblock mx reads entries mx, mx + 1, mx + 2 -- left, top, top right -- and owns entry
+  // mx + 1), r06: NOT in LDS.  A vector is dx | dy << 16 (both within +-8191 in any frame a lane finishes).  What a macroblock needs sits in
+  // registers -- mv_left (the macroblock before it in the row), mv_a / mv_b (entries mx + 1, mx + 2 as the row above left them) -- the entry
+  // it owns (mv_cur) goes to the store's global copy when the macroblock ends, and the one word per macroblock that has to come back from
+  // there (entry mx + 3 of the row above: the NEXT macroblock's top right) is asked for a macroblock ahead (mv_pref).  The first two entries
+  // of the row being written (row_e1, row_e2) are the next row's first top and top right.
+  uint32_t mv_left, mv_a, mv_b, mv_cur, mv_pref, row_e1, row_e2;
   uint32_t pay_pos, mb_pay, hdr_words, n_coefs, cbp6, t8mask, w3, n_items;
   // partition tree
   int sp, nleaf;
@@ -185,7 +192,8 @@ template <class S>
 LS_FN void ls_begin_frame(LsLane &s, S &m, const LsCtx &c, uint32_t len) {
   s.W = 0; s.navail = 0; s.cbits = 0; s.rd = 0;
   s.bail = 0; s.st = LS_MB_BEGIN; s.ret = LS_DONE;
-  s.mb = 0; s.mx = 0; s.my = 0; s.cur_off = 0; s.mb_type = MOBI_MB_INTER; s.mvslot = 2; // (predx, predy: loaded with the state, Internal[219], [220])
+  s.mb = 0; s.mx = 0; s.my = 0; s.cur_off = 0; s.mb_type = MOBI_MB_INTER; // (predx, predy: loaded with the state, Internal[219], [220])
+  s.mv_left = s.mv_a = s.mv_b = s.mv_cur = s.mv_pref = s.row_e1 = s.row_e2 = 0;
   s.pay_pos = 0; s.mb_pay = 0; s.hdr_words = 0; s.n_coefs = 0; s.cbp6 = s.t8mask = s.w3 = 0; s.n_items = 0;
   s.sp = 0; s.nleaf = 0; s.l0a = s.l0b = s.l1a = s.l1b = 0;
   s.area_mask = s.sub_mask = 0; s.cur_area = 0; s.blk_p = s.blk_n = s.blk_tile = 0; s.blk_flags = 0;
@@ -213,7 +221,10 @@ LS_FN void ls_begin_frame(LsLane &s, S &m, const LsCtx &c, uint32_t len) {
     if (c.version == MOBI_VERSION_MOFLEX3DS && q == 0) ls_setup_quant(s, m, c, q);
     else if (dq != 0) ls_setup_quant(s, m, c, q + (uint32_t)dq);
     s.vlc = 0;
-    for (int i = 0; i < c.mbw + 2; i++) m.mvp(i) = 0;
+    // (the cache is zeroed here in the reference, MD.cs:144-154: the top row reads zeros without looking -- my == 0 -- every entry 1 .. mbw is
+    // written before a later row reads it, and the two that no macroblock owns are written now: what the frame leaves is the whole cache)
+    m.mvp_store(0, 0);
+    m.mvp_store(c.mbw + 1, 0);
   }
 }
 
@@ -264,7 +275,7 @@ LS_FN void ls_cells(LsLane &s, int x, int y, int wi, int hi, uint32_t cell) {
 template <class S>
 LS_FN void ls_leaf(LsLane &s, S &m, const LsCtx &c, int wi, int hi, int x, int y, int ref, int dx, int dy) {
   const int w = 16 >> wi, h = 16 >> hi, S_ = c.stride;
-  m.mvp(s.mvslot >> 1) = mobi_leaf_w1(dx, dy); // (r06: the row cache holds a vector as two int16 in one word -- a vector beyond +-8191 ends the lane right below)
+  s.mv_cur = mobi_leaf_w1(dx, dy); // (the row cache holds a vector as two int16 in one word -- a vector beyond +-8191 ends the lane right below)
   if (ref > ls_min(5, s.frames_started - 1)) { ls_bail(s, 6); return; }
   if (dx < -MOBI_MV_LIMIT || dx > MOBI_MV_LIMIT || dy < -MOBI_MV_LIMIT || dy > MOBI_MV_LIMIT) { ls_bail(s, 7); return; }
   const int o = s.cur_off + y * S_ + x, ylen = S_ * c.height;
@@ -582,6 +593,16 @@ LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
     d.w2 = w2; d.w3 = w3; d.w4 = w4; d.w5 = w5; d.w6 = w6; d.w7 = w7;
     s.desc[s.mb] = d;
     s.pay_pos = s.mb_pay + s.hdr_words + s.n_coefs;
+    if (!s.iframe) { // the row cache: this macroblock's entry, and what the next macroblock will find as its left, top and top right
+      m.mvp_store(s.mx + 1, s.mv_cur);
+      s.row_e1 = s.mx == 0 ? s.mv_cur : s.row_e1;
+      s.row_e2 = s.mx == 1 ? s.mv_cur : s.row_e2;
+      const bool row_end = s.mx + 1 == c.mbw;
+      const uint32_t top = row_end ? s.row_e1 : s.mv_b, tr = row_end ? (c.mbw >= 2 ? s.row_e2 : 0u) : s.mv_pref;
+      s.mv_left = row_end ? 0u : s.mv_cur;
+      s.mv_a = top;
+      s.mv_b = tr;
+    }
     s.mb++;
     if (++s.mx == c.mbw) { s.mx = 0; s.my++; }
     s.st = LS_MB_BEGIN;
@@ -603,13 +624,13 @@ LS_FN void ls_step_main(LsLane &s, S &m, const LsCtx &c) {
         s.st = LS_I_HDR;
       } else {
         // left, top, top-right (MD.cs:163-169)
-        const uint32_t va = m.mvp(s.mx), vb = m.mvp(s.mx + 1), vc = m.mvp(s.mx + 2);
+        const uint32_t va = s.mv_left, vb = s.mv_a, vc = s.mv_b;
+        s.mv_cur = 0; // (an intra macroblock leaves 0: MD.cs:205-206)
+        s.mv_pref = (s.my > 0 && s.mx + 3 <= c.mbw) ? m.mvp_load(s.mx + 3) : 0u; // the next macroblock's top right, as the row above left it
         const int a0 = (int)(int16_t)(va & 0xFFFF), a1 = (int)(int16_t)(va >> 16), b0 = (int)(int16_t)(vb & 0xFFFF), b1 = (int)(int16_t)(vb >> 16),
                   c0 = (int)(int16_t)(vc & 0xFFFF), c1 = (int)(int16_t)(vc >> 16);
         s.predx = ls_max(ls_min(a0, b0), ls_min(ls_max(a0, b0), c0));
         s.predy = ls_max(ls_min(a1, b1), ls_min(ls_max(a1, b1), c1));
-        s.mvslot = 2 * (s.mx + 1);
-        m.mvp(s.mx + 1) = 0;
         s.mb_type = MOBI_MB_INTER;
         m.stk(0) = 0;
         s.sp = 1;

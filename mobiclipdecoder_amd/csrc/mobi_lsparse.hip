@@ -33,11 +33,12 @@ namespace {
 enum { LS_SERVICE = LS_SERVICE_N, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
 struct DevStore { // L = clips per wave: the per-lane state is interleaved at that stride (element i of lane l at i * L + l)
-  uint32_t *mvp_; // the MV row cache (Internal[221..]): one word per macroblock column, dx | dy << 16 (both within +-8191 in any frame a lane finishes)
+  int32_t *mvg; // the MV row cache (Internal[221..]) in HBM: this clip's MobiDevTail.mvc, two int32 per entry -- what a P-frame leaves IS the tail
   uint32_t *stk_, *rec_, *ring_;
   uint8_t *mc_;
   int lane, L;
-  __device__ __forceinline__ uint32_t &mvp(int i) { return mvp_[i * L + lane]; }
+  __device__ __forceinline__ uint32_t mvp_load(int i) const { const int2 v = ((const int2 *)mvg)[i]; return ((uint32_t)v.x & 0xFFFFu) | ((uint32_t)v.y << 16); }
+  __device__ __forceinline__ void mvp_store(int i, uint32_t v) { ((int2 *)mvg)[i] = int2{(int)(int16_t)(v & 0xFFFFu), (int)(int16_t)(v >> 16)}; }
   __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * L + lane]; }
   __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * L + lane]; }
   __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * L + lane]; }
@@ -74,14 +75,13 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
   // the step before runs beside it (asynchronous steps: four of its waves on the same SIMD), the chain must not queue behind them.
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mvp_words = A.mbw + 2;
   uint8_t *tab = lds;
   DevStore m;
   m.L = LS_CLIPS;
-  m.mvp_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvp_words + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
+  m.mvg = nullptr;
   // (r06: the partition-tree stack lives in the intra records' words -- a macroblock is intra only by its ROOT node's code (mobi_lsparse.h,
   // LS_NODE: any deeper "intra" code ends the lane), when the stack is empty, and the records are zeroed behind that: never both at once)
-  m.rec_ = m.mvp_ + mvp_words * LS_CLIPS;
+  m.rec_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * MOBI_INTRA_RECORDS + LS_RING + 40));
   m.stk_ = m.rec_;
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
   m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
@@ -115,6 +115,7 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
     s.pay_base = A.pay_local ? 0u : (uint32_t)clip * A.pay_cap;
     s.items = A.items + (size_t)clip * n_mbs;
     s.clip = (uint32_t)(A.clip_mod ? clip % A.clip_mod : clip);
+    m.mvg = A.tail_out[clip].mvc;
     base = A.bits + A.bit_off[clip];
     len = A.bit_len[clip];
     len2 = len & ~1u;
@@ -171,10 +172,8 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
     st->quant = s.quant; st->yuvfmt = s.yuvfmt; st->tables_set = s.tables_set; st->frames_started = s.frames_started;
     for (int i = 0; i < 40; i++) st->mcache[i] = m.mc(i);
     st->predx = s.predx; st->predy = s.predy;
-    if (!s.iframe) { // the MV row cache a P-frame leaves (Internal[221..]): a later I-frame's walk through Internal[] may read it (mobi_state.h)
-      int32_t *mv = A.tail_out[clip].mvc;
-      for (int i = 0; i < mvp_words; i++) { const uint32_t v = m.mvp(i); mv[2 * i] = (int)(int16_t)(v & 0xFFFF); mv[2 * i + 1] = (int)(int16_t)(v >> 16); }
-    }
+    // (the MV row cache a P-frame leaves, Internal[221..] -- a later I-frame's walk through Internal[] may read it, mobi_state.h -- is where
+    // the walk kept it: tail_out[clip].mvc)
   }
   A.res[clip] = r;
 }
@@ -207,7 +206,7 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   // rounds -- 32768 clips: 68.9 ms per step against 39.9, 24576: 37.4 (16 per wave, r05's first rule) against 35.1, 16384: 34.8 against 28.7,
   // 40960: 55.3 against 47.7 (tools/exp_async.py, profiles/r05_experiments.txt).  49152 clips (24 per wave, what 288 GB hold at 640x480) only
   // fit a CU's LDS this way.
-  const int per_clip = 4 * (a->mbw + 2) + 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
+  const int per_clip = 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
   auto lds_of = [&](int w, int l) { return (size_t)MOBI_DT_BYTES + (size_t)w * l * per_clip; };
   const size_t lds_max = 160 * 1024;
   int L = (a->n_clips + 2047) / 2048;

@@ -18,7 +18,8 @@ struct HostStore {
   uint8_t mc_[40];
   const uint8_t *data;
   uint32_t len2; // bytes that exist as whole 16-bit words
-  uint32_t &mvp(int i) { return mvp_[i]; }
+  uint32_t mvp_load(int i) const { return mvp_[i]; } // (on the device: the clip's MobiDevTail.mvc in HBM)
+  void mvp_store(int i, uint32_t v) { mvp_[i] = v; }
   uint32_t &stk(int i) { return rec_[i]; }
   uint32_t &rec(int i) { return rec_[i]; }
   uint8_t &mc(int i) { return mc_[i]; }
@@ -315,6 +316,13 @@ int mobi_lshost_compare(uint32_t w, uint32_t h, int version, const uint8_t *data
       break;
     }
     bool same = used == off && pay_words == pf.payload.size() && ftype == pf.hdr.frame_type && n_intra == pf.hdr.n_intra && C->quant == hp.quantizer();
+    if (same && ftype == 0 && hp.device_ready()) { // the MV row cache a P-frame leaves (r06: the lanes keep it in registers and in the tail itself)
+      MobiDevState st;
+      MobiDevTail tl;
+      hp.export_state(st, tl);
+      for (int i = 0; i < C->g.mbw + 2 && same; i++)
+        if (C->m.mvp_[i] != mobi_leaf_w1(tl.mvc[2 * i], tl.mvc[2 * i + 1])) { fprintf(stderr, "frame %d: MV row cache entry %d: %08x vs host (%d, %d)\n", f, i, C->m.mvp_[i], tl.mvc[2 * i], tl.mvc[2 * i + 1]); same = false; }
+    }
     if (!same) fprintf(stderr, "frame %d: consumed %d/%d payload %u/%zu type %u/%u intra %u/%u quant %u/%u\n", f, used, off, pay_words, pf.payload.size(), ftype,
                        pf.hdr.frame_type, n_intra, pf.hdr.n_intra, C->quant, hp.quantizer());
     for (size_t mb = 0; same && mb < pf.desc.size(); mb++) {
