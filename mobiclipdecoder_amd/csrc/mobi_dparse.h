@@ -47,6 +47,7 @@ struct MobiDevParseArgs {
   MobiDevState *state_ls;
   int lockstep;
   int ls_clips; // clips per wave of mobi_parse_frames_ls (filled in by mobi_launch_parse_ls)
+  int ls_mv_lds; // ... and whether its lanes keep the MV row cache in LDS (room to spare) or in the clips' tails in HBM
   // pay_local != 0: MbDesc.payload_off is written relative to the clip's own part of the arena (MobiReconArgs.pay_clip_words = pay_cap), so
   // that n_clips * pay_cap may exceed 2^32 words; 0: relative to the arena (the hybrid mode, whose host-parsed clips sit behind the others)
   int pay_local;

@@ -33,12 +33,23 @@ namespace {
 enum { LS_SERVICE = LS_SERVICE_N, LS_RING_WORDS = LS_RING / 4 }; // every LS_SERVICE rounds a lane with 32 bytes of room in its ring asks for 32 more
 
 struct DevStore { // L = clips per wave: the per-lane state is interleaved at that stride (element i of lane l at i * L + l)
-  int32_t *mvg; // the MV row cache (Internal[221..]) in HBM: this clip's MobiDevTail.mvc, two int32 per entry -- what a P-frame leaves IS the tail
+  // The MV row cache (Internal[221..]) beyond the registers that hold its working set (mobi_lsparse.h): in HBM -- this clip's MobiDevTail.mvc, two
+  // int32 per entry: what a P-frame leaves IS the tail -- or, when the launch has LDS to spare (mobi_launch_parse_ls), in LDS like everything
+  // else (mvl != nullptr, wave-uniform; written out at the end): one macroblock's word costs a round trip either way, but a shorter one
+  int32_t *mvg;
+  uint32_t *mvl;
   uint32_t *stk_, *rec_, *ring_;
   uint8_t *mc_;
   int lane, L;
-  __device__ __forceinline__ uint32_t mvp_load(int i) const { const int2 v = ((const int2 *)mvg)[i]; return ((uint32_t)v.x & 0xFFFFu) | ((uint32_t)v.y << 16); }
-  __device__ __forceinline__ void mvp_store(int i, uint32_t v) { ((int2 *)mvg)[i] = int2{(int)(int16_t)(v & 0xFFFFu), (int)(int16_t)(v >> 16)}; }
+  __device__ __forceinline__ uint32_t mvp_load(int i) const {
+    if (mvl) return mvl[i * L + lane];
+    const int2 v = ((const int2 *)mvg)[i];
+    return ((uint32_t)v.x & 0xFFFFu) | ((uint32_t)v.y << 16);
+  }
+  __device__ __forceinline__ void mvp_store(int i, uint32_t v) {
+    if (mvl) mvl[i * L + lane] = v;
+    else ((int2 *)mvg)[i] = int2{(int)(int16_t)(v & 0xFFFFu), (int)(int16_t)(v >> 16)};
+  }
   __device__ __forceinline__ uint32_t &stk(int i) { return stk_[i * L + lane]; }
   __device__ __forceinline__ uint32_t &rec(int i) { return rec_[i * L + lane]; }
   __device__ __forceinline__ uint8_t &mc(int i) { return mc_[i * L + lane]; }
@@ -79,12 +90,14 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
   DevStore m;
   m.L = LS_CLIPS;
   m.mvg = nullptr;
+  const int mvp_words = A.ls_mv_lds ? A.mbw + 2 : 0;
   // (r06: the partition-tree stack lives in the intra records' words -- a macroblock is intra only by its ROOT node's code (mobi_lsparse.h,
   // LS_NODE: any deeper "intra" code ends the lane), when the stack is empty, and the records are zeroed behind that: never both at once)
-  m.rec_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * MOBI_INTRA_RECORDS + LS_RING + 40));
+  m.rec_ = (uint32_t *)(lds + MOBI_DT_BYTES + (size_t)wave * LS_CLIPS * (4 * mvp_words + 4 * MOBI_INTRA_RECORDS + LS_RING + 40));
   m.stk_ = m.rec_;
   m.ring_ = m.rec_ + MOBI_INTRA_RECORDS * LS_CLIPS;
   m.mc_ = (uint8_t *)(m.ring_ + LS_RING_WORDS * LS_CLIPS);
+  m.mvl = mvp_words ? (uint32_t *)(m.mc_ + 40 * LS_CLIPS) : nullptr;
   m.lane = lane;
   for (int i = threadIdx.x; i < MOBI_DT_BYTES / 16; i += (int)blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)A.tables)[i];
   __syncthreads();
@@ -172,8 +185,12 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
     st->quant = s.quant; st->yuvfmt = s.yuvfmt; st->tables_set = s.tables_set; st->frames_started = s.frames_started;
     for (int i = 0; i < 40; i++) st->mcache[i] = m.mc(i);
     st->predx = s.predx; st->predy = s.predy;
-    // (the MV row cache a P-frame leaves, Internal[221..] -- a later I-frame's walk through Internal[] may read it, mobi_state.h -- is where
-    // the walk kept it: tail_out[clip].mvc)
+    // the MV row cache a P-frame leaves, Internal[221..] -- a later I-frame's walk through Internal[] may read it, mobi_state.h: where the walk
+    // kept it (tail_out[clip].mvc) or, from LDS, written there now
+    if (!s.iframe && m.mvl) {
+      int32_t *mv = A.tail_out[clip].mvc;
+      for (int i = 0; i < mvp_words; i++) { const uint32_t v = m.mvl[i * LS_CLIPS + lane]; mv[2 * i] = (int)(int16_t)(v & 0xFFFF); mv[2 * i + 1] = (int)(int16_t)(v >> 16); }
+    }
   }
   A.res[clip] = r;
 }
@@ -206,36 +223,50 @@ extern "C" int mobi_launch_parse_ls(const MobiDevParseArgs *a, hipStream_t s) {
   // rounds -- 32768 clips: 68.9 ms per step against 39.9, 24576: 37.4 (16 per wave, r05's first rule) against 35.1, 16384: 34.8 against 28.7,
   // 40960: 55.3 against 47.7 (tools/exp_async.py, profiles/r05_experiments.txt).  49152 clips (24 per wave, what 288 GB hold at 640x480) only
   // fit a CU's LDS this way.
-  const int per_clip = 4 * MOBI_INTRA_RECORDS + LS_RING + 40;
-  auto lds_of = [&](int w, int l) { return (size_t)MOBI_DT_BYTES + (size_t)w * l * per_clip; };
+  // LDS per lane without / with the MV row cache's words (r06: the walk keeps the cache's working set in registers and the rest in HBM -- 264 B
+  // per lane, full waves of 64 -- or, when the lanes asked for fit with it, in LDS: 432 B at 640 wide, 42 lanes per wave)
+  const int per_g = 4 * MOBI_INTRA_RECORDS + LS_RING + 40, per_s = per_g + 4 * (a->mbw + 2);
   const size_t lds_max = 160 * 1024;
-  int L = (a->n_clips + 2047) / 2048;
-  L = L < 1 ? 1 : L > 64 ? 64 : L;
-  int W = MOBI_LS_WAVES;
-  if ((a->n_clips + L - 1) / L > 1536 && lds_of(2 * W, L) <= lds_max) W *= 2;
-  // r06: more lanes than the chip holds as two waves per SIMD (frame-parallel groups: n_clips x K virtual clips) -- the launch takes TURNS
-  // of 256 workgroups of eight waves, and a turn lasts as long as one workgroup lives, however few workgroups the last one has.  A wave's
-  // life grows slowly with its lanes (640x480 P-frames, ms: 12 lanes 22.9, 24: 27.3, 36: 30.7 -- about 20 + 0.3 per lane), so a lane is the
-  // cheaper the fuller its wave, and what counts is WHOLE turns: the fewest turns that an eight-wave workgroup's LDS allows (42 lanes per
-  // wave at 640 wide), the lanes dealt evenly over them.  147456 lanes: 36 x 8 in two turns 62 ms; 24 x 8 in three turns 82; 35 x 8 -- two
-  // turns and fifteen workgroups of a third -- 90 (tools/exp_gop_lanes.sh; r06's first sweep read that as "beyond 24 lanes a wave costs what
-  // its lanes bring": it had measured the tail).  More than two waves per SIMD lose as they did in r05 (15 x 8 twice per CU: 107).
-  if (lds_of(W, L) > lds_max || L > 24) {
-    W = 2 * MOBI_LS_WAVES;
-    int Lmax = 64;
-    while (Lmax > 1 && lds_of(W, Lmax) > lds_max) Lmax--;
-    const long per_turn = 256L * W; // waves of one turn (one workgroup per CU)
-    const long turns = (a->n_clips + Lmax * per_turn - 1) / (Lmax * per_turn);
-    L = (int)((a->n_clips + turns * per_turn - 1) / (turns * per_turn));
-  }
+  struct Plan { int L, W, turns; double cost; };
+  // r06 (frame-parallel groups: n_clips x K virtual clips): more lanes than one such launch holds take TURNS of 256 workgroups, a turn lasts as
+  // long as one workgroup lives however few workgroups the last one has, and a wave's life grows slowly with its lanes (640x480 P-frames, ms:
+  // 12 lanes 22.9, 24: 27.3, 36: 30.7, 60: 38 -- about 20 + 0.3 per lane): a lane is the cheaper the fuller its wave, and what counts is WHOLE
+  // turns -- the fewest that LDS allows, the lanes dealt evenly.  147456 lanes: 36 x 8 in two turns 62 ms; 24 x 8 in three 82; 35 x 8 -- two turns
+  // and fifteen workgroups of a third -- 90 (tools/exp_gop_lanes.sh; r06's first sweep read that as "beyond 24 lanes a wave costs what its lanes
+  // bring": it had measured the tail).  More than two waves per SIMD lose what they gain (15 x 8 twice per CU: 107: the walk is issue-bound at two).
+  auto plan = [&](int per_lane, double penalty) {
+    auto lds_of = [&](int w, int l) { return (size_t)MOBI_DT_BYTES + (size_t)w * l * per_lane; };
+    Plan p;
+    p.L = (a->n_clips + 2047) / 2048;
+    p.L = p.L < 1 ? 1 : p.L > 64 ? 64 : p.L;
+    p.W = MOBI_LS_WAVES;
+    p.turns = 1;
+    if ((a->n_clips + p.L - 1) / p.L > 1536 && lds_of(2 * p.W, p.L) <= lds_max) p.W *= 2;
+    if (lds_of(p.W, p.L) > lds_max || p.L > 24) {
+      p.W = 2 * MOBI_LS_WAVES;
+      int Lmax = 64;
+      while (Lmax > 1 && lds_of(p.W, Lmax) > lds_max) Lmax--;
+      const long per_turn = 256L * p.W; // waves of one turn (one workgroup per CU)
+      p.turns = (int)((a->n_clips + Lmax * per_turn - 1) / (Lmax * per_turn));
+      p.L = (int)((a->n_clips + p.turns * per_turn - 1) / (p.turns * per_turn));
+    }
+    p.cost = p.turns * (20.0 + 0.3 * p.L) * penalty;
+    return p;
+  };
+  // (the round trip to HBM for one word per macroblock costs a wave ~5 % of its life: 49152 lanes 29.4 against 28.0 ms, 73728: 32.3 against 30.8)
+  const Plan pg = plan(per_g, 1.05), ps = plan(per_s, 1.0);
+  int mv_lds = ps.cost <= pg.cost;
+  int L = mv_lds ? ps.L : pg.L, W = mv_lds ? ps.W : pg.W;
 #if defined(MOBI_PROFILING)
   if (const char *e = getenv("MOBI_LS_CLIPS")) L = atoi(e);    // (tools/exp_lsab.sh, tests/test_lsparse_gpu.py)
   if (const char *e = getenv("MOBI_LS_WG_WAVES")) W = atoi(e);
 #endif
   if (L < 1 || L > 64 || W < 1 || W > 8) return (int)hipErrorInvalidValue;
+  if ((size_t)MOBI_DT_BYTES + (size_t)W * L * per_s > lds_max) mv_lds = 0; // (a forced shape that only fits without the cache)
   MobiDevParseArgs b = *a;
   b.ls_clips = L;
-  const size_t lds = lds_of(W, L);
+  b.ls_mv_lds = mv_lds;
+  const size_t lds = (size_t)MOBI_DT_BYTES + (size_t)W * L * (mv_lds ? per_s : per_g);
   if (lds > lds_max) return (int)hipErrorInvalidValue;
   if (lds > 64 * 1024) // (per device and per size; cheap)
     if (hipFuncSetAttribute((const void *)mobi_parse_frames_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
