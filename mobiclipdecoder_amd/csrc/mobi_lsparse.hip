@@ -8,9 +8,10 @@
 //   mobi_parse_frames      (mobi_dparse.hip) runs afterwards, one wave per clip as always: a finished clip's wave only moves the new decoder
 //                          state from its shadow copy into place; every other clip is parsed as if the first kernel had not run.
 //
-// LDS per workgroup: ONE copy of the table blob (18 KB) for its waves, and per wave and lane the motion-vector row cache (mbw + 2
-// words: a vector as two int16, r06), the intra records (24 words; the partition-tree stack of an inter macroblock lives in the same
-// words, r06), the mode cache (40 bytes), a 128-byte ring of bitstream -- 432 bytes at 640 wide (r05: 664) -- all
+// LDS per workgroup: ONE copy of the table blob (18 KB) for its waves, and per wave and lane the intra records (24 words; the
+// partition-tree stack of an inter macroblock lives in the same words, r06), the mode cache (40 bytes), a 128-byte ring of bitstream --
+// 264 bytes (r05: 664) -- and, when the launch has room (mobi_launch_parse_ls), the motion-vector row cache (mbw + 2 words: a vector as two
+// int16; else its working set is in registers and the rest in the clip's tail in HBM: mobi_lsparse.h, LsLane) -- all
 // lane-interleaved (element i of lane l at i * ls_clips + l), so that the lanes reading "their" element i hit different banks.
 // How many clips a wave carries is a launch argument (mobi_launch_parse_ls, with the measurements): a wave's life grows with the number of
 // DIFFERENT clips it holds -- it runs until its slowest lane is done, a round costs what its lanes' different states need -- and alone on a
