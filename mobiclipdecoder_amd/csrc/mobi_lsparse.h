@@ -910,10 +910,12 @@ LS_FN void ls_step_intra(LsLane &s, S &m, const LsCtx &c) {
 LS_FN bool ls_in_intra(const LsLane &s) { return s.st >= LS_I_HDR && s.st <= LS_I_FSUB; }
 // One round as the kernel runs it: the whole walk once, then the cheap rounds (per lane here; on the GPU each part runs while any lane of the
 // wave is in it)
+// with_intra: the kernel leaves the intra part out of some rounds of a wave that holds P-frames only (mobi_lsparse.hip, LS_INTRA_PERIOD): its
+// lanes wait there for the next round that has it -- nothing else changes for them
 template <class S>
-LS_FN void ls_round(LsLane &s, S &m, const LsCtx &c) {
+LS_FN void ls_round(LsLane &s, S &m, const LsCtx &c, bool with_intra = true) {
   ls_step_main(s, m, c);
-  ls_step_intra(s, m, c);
+  if (with_intra) ls_step_intra(s, m, c);
   ls_next_fast(s, m, c);
   ls_token_fast(s, m, c);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LS_CHEAP_LOOP)

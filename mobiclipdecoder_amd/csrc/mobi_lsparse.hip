@@ -77,6 +77,9 @@ __device__ __forceinline__ uint4 ls_chunk(const uint8_t *base, uint32_t o, uint3
 }
 } // namespace
 
+#ifndef LS_INTRA_PERIOD
+#define LS_INTRA_PERIOD 3
+#endif
 #ifndef MOBI_LS_WAVES
 #define MOBI_LS_WAVES 4 // waves per workgroup: they share one copy of the table blob in LDS (18 KB), everything else is a wave's own
 #endif             // (the launch's choice: 4, or 8 where two workgroups of four would not fit a CU's LDS -- mobi_launch_parse_ls)
@@ -145,6 +148,10 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
   }
   uint4 pend0 = uint4{0, 0, 0, 0}, pend1 = uint4{0, 0, 0, 0};
   bool pending = false;
+  // The intra part of the walk is half of a round's instructions for one macroblock in twenty of a P-frame, and a full wave has a lane in it
+  // nine rounds out of ten: a wave of P-frames runs it every LS_INTRA_PERIOD-th round only -- its lanes wait, and each run serves three times
+  // as many (simulated, tools/exp_lssched.py at 60 lanes: 10.9 -> 9.3 M instructions per P-frame).  A wave that holds an I-frame keeps every round.
+  const bool intra_every_round = __builtin_amdgcn_ballot_w64(live && s.iframe) != 0;
   for (uint32_t round = 0;; round++) {
     if ((round & (LS_SERVICE - 1)) == 0) {
       if (pending) { // what the last service asked for has had LS_SERVICE rounds to arrive
@@ -163,7 +170,7 @@ extern "C" __global__ __launch_bounds__(512) void mobi_parse_frames_ls(MobiDevPa
       }
     }
     if (s.st != LS_DONE && wr - s.rd >= LS_ROUND_BYTES) {
-      ls_round(s, m, c);
+      ls_round(s, m, c, intra_every_round || round % LS_INTRA_PERIOD == 0);
     }
     if (__builtin_amdgcn_ballot_w64(s.st != LS_DONE) == 0) break;
   }
