@@ -146,7 +146,7 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     mbw, n_mbs = W // 16, (W // 16) * (H // 16)
     turn = 2048 * min(64, (160 * 1024 - 18400) // (8 * (96 + 128 + 40)))
     frame_len = max(int(s[2][f + 1] - s[2][f]) for s in streams for f in range(1, len(s[2]) - 1))
-    per_frame = 32 * n_mbs + 4 * (64 * n_mbs + (8 * frame_len * 5 // 4 + 2) // 3 + 512) + 4 * n_mbs + 1200 + 2 * frame_len  # descriptors, payload part, items, states, bits
+    per_frame = 32 * n_mbs + 4 * (64 * n_mbs + (8 * frame_len * 5 // 4 + 2) // 3 + 512) + 4 * n_mbs + 16 * n_mbs + 1200 + 2 * frame_len  # descriptors, payload part, items, sorted items, states, bits
     import torch
     room = torch.cuda.mem_get_info(device)[0] - n_clips * (W if W > 512 else 512 if W > 256 else 256) * H * 9 - (12 << 30)  # free HBM less the rings and a margin
 

@@ -331,6 +331,10 @@ struct mobi_batch {
     std::vector<uint8_t> is_host;    // [c] the host parser's clip when the parse was enqueued
     // what the group's first mobi_batch_gop_finish settles for all K frames (a group of more than six is finished in two calls)
     bool resolved = false, returned = false; // (returned: the clips that go back to the device parsers have been sent)
+    bool sorted = false;             // the group's intra macroblocks were put in wavefront order on the device (mobi_launch_gop_sort)
+    DevBuf d_sorted, d_hist;
+    uint64_t sorted_off[MOBI_GOP_PARSE_MAX] = {0};
+    uint32_t sorted_items[MOBI_GOP_PARSE_MAX] = {0};
     int done = 0;                    // frames reconstructed and reported so far
     std::vector<int> host_from, hslot, hrc, all_host;
     std::vector<int32_t> hoff;
@@ -1342,6 +1346,11 @@ static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S, hipEvent_t a
   if (int e = S.d_sls.reserve(nv * sizeof(MobiDevState))) return e;
   if (int e = S.d_tails.reserve(nv * sizeof(MobiDevTail))) return e;
   if (int e = S.d_fault.reserve(nv * sizeof(int))) return e;
+  if (b->g.width < b->g.stride) { // the wavefront-ordered intra items (mobi_launch_gop_sort), for the most a group can hold: sized here, not when the
+    // counts are known -- mobi_batch_gop_finish would sit in a hipFree + hipMalloc with the GPU idle whenever a group held more than the last
+    if (int e = S.d_sorted.reserve((nv * n_mbs + (size_t)K * (3 * MOBI_SORT_LEVELS + 8)) * 16)) return e;
+    if (int e = S.d_hist.reserve((size_t)3 * MOBI_GOP_PARSE_MAX * MOBI_SORT_LEVELS * 4)) return e;
+  }
   if (int e = S.h_res.reserve(nv * sizeof(MobiDevResult))) return e;
   if (int e = S.h_fault.reserve(nv * sizeof(int))) return e;
   hipStream_t ps = b->stream_p;
@@ -1594,6 +1603,45 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
       if (int e = dp_override(b, cl, nullptr, S.h_over[k], rows, b->stream, fr.data(), rcs.data())) return e;
     }
     HIP_TRY(hipMemsetAsync(S.d_fault.p, 0, nv * sizeof(int), b->stream));
+    // 3b. the intra macroblocks of every frame of the group as launch items in wavefront order, built on the device behind the overrides (mobi_gop.h)
+    // (the wavefront order holds where the halo's linear addresses do not wrap: in a picture as wide as its stride -- 256, 512, 1024 -- the
+    // first macroblock of a row reads the LAST one of the row above, MD.cs:212-217 with Stride == Width; those keep the raster-order launch)
+    S.sorted = b->g.width < b->g.stride;
+#if defined(MOBI_PROFILING)
+    if (const char *e = getenv("MOBI_GOP_INTRA_SORT")) S.sorted = S.sorted && atoi(e) != 0; // (A/B: 0 = the raster-order launch, mobi_recon_intra_cl)
+#endif
+    if (S.sorted) {
+      MobiGopSortArgs A;
+      memset(&A, 0, sizeof(A));
+      uint64_t off = 0;
+      for (int k = 0; k < K; k++) {
+        uint64_t sum = 0;
+        for (int c = 0; c < n; c++) {
+          const size_t v = (size_t)k * n + c;
+          sum += k >= host_from[c] ? (hrc[v] == MOBI_OK ? b->gop_frames[(size_t)hslot[c] * K + k].hdr.n_intra : 0u) : res[v].n_intra;
+        }
+        S.sorted_items[k] = sum ? (uint32_t)(align_up(sum, 4) + 3 * MOBI_SORT_LEVELS + 4) & ~3u : 0u; // (every wavefront starts on a wave of four: at most three rows of padding each)
+        S.sorted_off[k] = off;
+        A.sorted_off[k] = off;
+        A.sorted_cap[k] = S.sorted_items[k];
+        off += S.sorted_items[k];
+      }
+      if (off) {
+        const size_t hist_b = (size_t)K * MOBI_SORT_LEVELS * 4;
+        if (int e = S.d_sorted.reserve(off * 16)) return e;
+        if (int e = S.d_hist.reserve(3 * hist_b)) return e;
+        HIP_TRY(hipMemsetAsync(S.d_hist.p, 0, 2 * hist_b, b->stream));
+        A.desc = (const MbDesc *)S.d_desc.p;
+        A.items = (const uint32_t *)S.d_items.p;
+        A.res = (const MobiDevResult *)S.d_res.p;
+        A.hist = (uint32_t *)S.d_hist.p;
+        A.cursor = (uint32_t *)(S.d_hist.p + hist_b);
+        A.start = (uint32_t *)(S.d_hist.p + 2 * hist_b);
+        A.sorted = (uint32_t *)S.d_sorted.p;
+        A.n = n; A.K = K; A.n_mbs = n_mbs; A.mbw = b->g.mbw;
+        if (mobi_launch_gop_sort(&A, b->stream) != 0) return MOBI_E_DEVICE;
+      }
+    }
     S.resolved = true;
     S.done = 0;
   }
@@ -1621,7 +1669,9 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
     if (mobi_launch_inter(&a, b->stream) != 0) return MOBI_E_DEVICE;
     if (b->ktiming) { (void)hipEventRecord(ep.b, b->stream); b->evs.push_back(ep); }
     const MobiDevResult *d_res_k = (const MobiDevResult *)S.d_res.p + kn;
-    if (Kint && mobi_launch_intra_cl(&a, (const uint32_t *)(S.d_items.p + kn * item_b), &d_res_k->n_intra, (int)(sizeof(MobiDevResult) / 4), (int)Kint, 0, b->stream) != 0)
+    if (S.sorted) {
+      if (S.sorted_items[k] && mobi_launch_intra(&a, (const uint32_t *)S.d_sorted.p + S.sorted_off[k] * 4, (int)S.sorted_items[k], b->stream) != 0) return MOBI_E_DEVICE;
+    } else if (Kint && mobi_launch_intra_cl(&a, (const uint32_t *)(S.d_items.p + kn * item_b), &d_res_k->n_intra, (int)(sizeof(MobiDevResult) / 4), (int)Kint, 0, b->stream) != 0)
       return MOBI_E_DEVICE;
   }
   b->pay_clip_words = (uint32_t)S.cap_words;

@@ -106,6 +106,30 @@ struct MobiGopArgs {
   MobiDevTail *rtail_out;
   int n, K;
 };
+// The intra macroblocks of the group's frames as launch items in WAVEFRONT order (mobi_recon_intra's own format: mobi_kernels.h), built on
+// the device from what the parsers left -- per virtual clip raster-order lists and the descriptors -- behind the host parser's overrides.
+// The raster-order launch (mobi_recon_intra_cl: a wave = the same list slot of four clips, every row polling the rows it depends on) takes
+// 1.5 - 1.7 ms per P-frame step of 24576 clips and 25 ms per I-frame step; the host-built dependency-level order 1.0 and 20.  Levels proper
+// are a chain through every clip's list (a lane per clip walking it: 28 ms per group of 5 x 24576, tried); the wavefront mbx + 2 * mby is
+// a valid order as well -- whatever a halo reads (left, above left, above, above right, and at the picture's right edge the first macroblock
+// of the same row: ls_intra_deps, mobi_lsparse.h) lies on an earlier one -- and needs the macroblock's index only: with thousands of clips
+// every wavefront holds many rows, which is all the order is for.  NOT valid where Width == Stride (256, 512, 1024 wide): there the halo of a
+// row's first macroblock wraps to the last one of the row above (a later wavefront); the caller keeps the raster-order launch for those.
+//   hist / cursor / start  [K][MOBI_SORT_LEVELS] uint32 (hist and cursor zeroed by the caller)
+//   sorted  frame k's items at sorted + sorted_off[k] * 4 words, sorted_cap[k] items of room, the frames back to back (every wavefront
+//           starts on a wave of four items; the padding, and what is left behind the last one, are MOBI_ITEM_NONE rows that do nothing)
+#define MOBI_SORT_LEVELS 1024 /* mbw + 2 * mbh of the largest picture (1024 x 2048: 64 + 256) and room */
+struct MobiGopSortArgs {
+  const MbDesc *desc;          // [v][n_mbs]
+  const uint32_t *items;       // [v][n_mbs] raster-order MOBI_ITEM(clip, mb)
+  const MobiDevResult *res;    // [v] n_intra
+  uint32_t *hist, *cursor, *start;
+  uint32_t *sorted;
+  uint64_t sorted_off[MOBI_GOP_PARSE_MAX];
+  uint32_t sorted_cap[MOBI_GOP_PARSE_MAX];
+  int n, K, n_mbs, mbw;
+};
+extern "C" int mobi_launch_gop_sort(const MobiGopSortArgs *a, hipStream_t s);
 extern "C" int mobi_launch_gop_prepare(const MobiGopArgs *a, hipStream_t s); // start states of the n * K virtual clips (before the parse kernels)
 extern "C" int mobi_launch_gop_chain(const MobiGopArgs *a, hipStream_t s);   // verify, merge, tails (behind them)
 #endif

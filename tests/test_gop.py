@@ -144,6 +144,18 @@ def test_geometries_from_one_macroblock_to_the_widest_picture():
         assert n_err == 0 and hc == 0, (w, h, ver)
 
 
+@pytest.mark.parametrize("mode", [True, "lockstep"])
+def test_dense_intra_in_wavefront_order(mode):
+    """pictures narrower than their stride take the wavefront-ordered intra launch (mobi_launch_gop_sort): P-frames that are mostly intra
+    macroblocks (every halo reads intra neighbours of the same frame) and I-frames in every other position, against the oracle; a
+    power-of-two width beside them keeps the raster-order launch"""
+    for i, (w, h) in enumerate([(96, 64), (176, 144), (336, 48), (128, 64)]):
+        ps = [default_params("A", BASE_SEED + 8100 + 10 * i + c, n_frames=14, width=w, height=h, pm_intra=850, intra_sub_prob=600, iframe_interval=2 + c % 3) for c in range(9)]
+        clips = [generate_clip(p) for p in ps]
+        n_err, hc = _run_groups(clips, ps[0], [6, 1, 4, 3], mode)
+        assert n_err == 0 and hc == 0, (w, h)
+
+
 def test_first_frame_is_a_p_frame():
     """a P-frame into an empty ring (a fresh decoder: Quantizer 0, no tables): Moflex3DS sets up quantiser 12 (MD.cs:119-126), ModsDS reads
     zero tables; references to frames that were never decoded throw (MD.cs:413)"""
