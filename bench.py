@@ -130,6 +130,7 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
     return out
 
 
+GOP_PARSE_MAX = 32  # frames per mobi_batch_gop_begin (MOBI_GOP_PARSE_MAX, mobi_gop.h)
 GOP_K = 6  # frames per group: the ring holds six pictures (MD.cs:19-20), so every frame of a group is still readable when the call returns
 
 
@@ -141,7 +142,7 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     import time as _t
     # How many frames per group.  The lock-step parser works in TURNS of 2048 waves (eight per CU), a wave is the cheaper per lane the fuller it
     # is, and a workgroup's LDS holds full waves of 64 lanes since the MV row cache left it (mobi_launch_parse_ls): the frames in flight should fill whole turns --
-    # n_clips x K close to a multiple of 2048 x 64 -- as far as K (6 per call, 12 per gop_begin) and HBM allow: a group's command lists
+    # n_clips x K close to a multiple of 2048 x 64 -- as far as K (6 per call, 32 per gop_begin) and HBM allow: a group's command lists
     # are resident until it is reconstructed, worst-case payload room per frame (mobi_abi.cpp, gop_enqueue_parse).
     mbw, n_mbs = W // 16, (W // 16) * (H // 16)
     turn = 2048 * min(64, (160 * 1024 - 18400) // (8 * (96 + 128 + 40)))
@@ -157,10 +158,10 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
 
     if K is None:
         K = pick(GOP_K, 1)
-    Kp = pick(2 * GOP_K, 2)
+    Kp = pick(GOP_PARSE_MAX, 2)
     # its own streams of the same seeds and mix, long enough for a warm-up group and at least four timed ones in the pipelined part (three
     # timed groups, as the 33-frame clips of the replay give, start on a GPU whose clocks have just sat through the checker's seconds)
-    G = max(8, -(-6 * Kp // K))
+    G = max(8, -(-(6 if Kp <= 16 else 5) * Kp // K))  # (groups of more than 16 frames: three timed ones are a third of a second)
     # ... and 64 distinct ones: the lock-step parser's lanes are consecutive clips, up to 24 per wave under a group, and a wave that holds two
     # copies of one stream diverges less than content allows (16 distinct streams: 330 instead of 240 Gpixels/s at 4096 clips x 12 -- flattery)
     longer = []
@@ -203,8 +204,8 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
            "how": f"mobi_batch_decode_gop: {K} consecutive P-frames of every clip per call, parsed side by side as {nv} virtual clips (mobi_gop.h), reconstructed as {K} steps; "
                   "wall time of the call / frames (host staging, H2D, parse, chain check, reconstruction, read-back, sync)",
            "clips_handed_to_the_host_parser": int(host_clips), "verified": verified}
-    # Pipelined: what is PARSED side by side is not bound by the ring -- mobi_batch_gop_begin takes up to 12 frames, mobi_batch_gop_finish hands
-    # them out six at a time -- so a batch too small to fill the parsers' lanes with six frames per clip begins up to twelve (Kp, above).
+    # Pipelined: what is PARSED side by side is not bound by the ring -- mobi_batch_gop_begin takes up to 32 frames, mobi_batch_gop_finish hands
+    # them out six at a time -- so a batch too small to fill the parsers' lanes with six frames per clip begins more (Kp, above: 4096 clips x 32).
     Gp = G * K // Kp
     del packs
     packs = [pack(1 + Kp * g, Kp) for g in range(Gp)]
@@ -436,18 +437,26 @@ def verify_clips(b, streams, distinct, clips, frame, W, H):
     its source clip on the device, byte for byte (mobi_batch_compare_clips) -- the bench line says whether the pixels it counted were the
     right ones, all of them.  (The checker, used as the checker.)"""
     from tests.oracle_binding import OracleDecoder
+    from concurrent.futures import ThreadPoolExecutor
     n_src = min(distinct, clips)
-    bad_sources = []
-    for sidx in range(n_src):
+
+    def oracle_frame(sidx):  # (the C oracle runs outside the GIL: the sources side by side on a few host threads)
         p, data, fo = streams[sidx]
         o = OracleDecoder(W, H, p.version)
         for f in range(frame + 1):
             o.Data, o.Offset = data[fo[f]:fo[f + 1]], 0
             assert o.DecodeFrame() is not None
-        got = b.planes(sidx)
-        if got is None or not np.array_equal(got[0][:, :W], o.y(0)[:, :W]) or not np.array_equal(got[1], o.uv(0)):
-            bad_sources.append(sidx)
+        want = (np.array(o.y(0)[:, :W], copy=True), np.array(o.uv(0), copy=True))
         o.close()
+        return want
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        wants = list(pool.map(oracle_frame, range(n_src)))
+    bad_sources = []
+    for sidx in range(n_src):
+        got = b.planes(sidx)
+        if got is None or not np.array_equal(got[0][:, :W], wants[sidx][0]) or not np.array_equal(got[1], wants[sidx][1]):
+            bad_sources.append(sidx)
     differing_copies = b.compare_clips(n_src)
     return {"clips": int(clips), "frame": int(frame), "ok": not bad_sources and differing_copies == 0,
             "sources_against_oracle": n_src, "sources_that_differ": bad_sources,

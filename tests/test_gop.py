@@ -228,6 +228,15 @@ def test_groups_of_twelve_parsed_at_once_finished_six_at_a_time(mode):
     assert n_err == 0 and hc == 0
 
 
+@pytest.mark.parametrize("mode", [True, "lockstep"])
+def test_groups_of_thirty_two(mode):
+    """the most mobi_batch_gop_begin takes (MOBI_GOP_PARSE_MAX): 32 frames parsed side by side, handed out by six finish calls (33 are refused: test_argument_checks)"""
+    ps = [default_params("A", BASE_SEED + 8200 + i, n_frames=72, width=96, height=64, pm_intra=100, pm_multiref=300, iframe_interval=11, qdelta_prob=300) for i in range(5)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [32, 32, 7], mode, pipelined=True)
+    assert n_err == 0 and hc == 0
+
+
 def test_a_glitch_in_the_second_half_of_a_group_of_twelve():
     ps = [default_params("A", BASE_SEED + 7650 + i, n_frames=25, width=96, height=64, pm_intra=100, iframe_interval=6) for i in range(6)]
     clips = []
@@ -340,5 +349,5 @@ def test_argument_checks():
         b.gop_begin(_frames(clips, 4, 2))  # at most two
     assert b.gop_finish()[0] == [[0], [0]] and b.gop_finish()[0] == [[0], [0]]
     with pytest.raises(Exception):
-        b.gop_begin(_frames(clips * 1, 0, 1) * 13)  # more than twelve frames
+        b.gop_begin(_frames(clips * 1, 0, 1) * 33)  # more than MOBI_GOP_PARSE_MAX frames
     b.close()
