@@ -61,7 +61,7 @@ for cfg in "BAC":
     print(cfg, "value", bench["value"], "ms/step", bench["ms_per_step"], "inter ms", r["avg_launch_ms"], "frac", r["frac"], "whole", r["whole_step_frac"], "traffic", traffic.get(f"{cfg}:{clips}", {}).get("hbm_bytes_per_launch"))
 json.dump(traffic, open(tj, "w"), indent=1)
 with open(os.path.join(dst, f"{RND}_ubench.txt"), "w") as o:
-    for name in ("stages_inter", "stages_intra", "intra_ablate", "iframe", "fused", "hostparse", "lsparse", "async", "gop", "gop_lanes", "allhost", "soak_gop", "fuzz"):
+    for name in ("stages_inter", "stages_intra", "intra_ablate", "iframe", "fused", "hostparse", "lsparse", "async", "gop", "gop_lanes", "gop_sort_ab", "allhost", "soak_gop", "fuzz"):
         p = os.path.join(src, name + ".txt")
         if os.path.exists(p):
             o.write(f"==== {name} ====\n" + open(p).read() + "\n")
