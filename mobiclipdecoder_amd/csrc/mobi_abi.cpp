@@ -535,7 +535,7 @@ long long mobi_debug_read_parse(mobi_batch *b, uint32_t *desc_out, uint32_t *ite
 #pragma GCC visibility pop
 #endif // MOBI_PROFILING
 
-const char *mobi_build_info(void) { return "libmobiclip_hip 0.5 (gfx950, macroblock-tiled planes; HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_step, mobi_recon_intra_cl, mobi_recon_intra_walk, mobi_parse_frames, mobi_parse_frames_ls, mobi_ls_deps, mobi_parse_tail, mobi_untile, mobi_yuv_to_argb, mobi_motion_search_2x2, mobi_fwd_dct8, mobi_fwd_dct4; no CPU reconstruction path)"; }
+const char *mobi_build_info(void) { return "libmobiclip_hip 0.6 (gfx950, macroblock-tiled planes; HIP kernels: mobi_recon_inter8, mobi_recon_intra, mobi_recon_step, mobi_recon_intra_cl, mobi_recon_intra_walk, mobi_parse_frames, mobi_parse_frames_ls, mobi_ls_deps, mobi_parse_tail, mobi_gop_prepare, mobi_gop_chain, mobi_gop_fronts, mobi_gop_front_starts, mobi_gop_scatter, mobi_untile, mobi_yuv_to_argb, mobi_motion_search_2x2, mobi_fwd_dct8, mobi_fwd_dct4; no CPU reconstruction path)"; }
 
 const char *mobi_error_string(int rc) {
   switch (rc) {
