@@ -1677,8 +1677,7 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
   b->pay_clip_words = (uint32_t)S.cap_words;
   HIP_TRY(hipMemcpyAsync(S.h_fault.p + (size_t)k0 * n * sizeof(int), S.d_fault.p + (size_t)k0 * n * sizeof(int), (size_t)(k1 - k0) * n * sizeof(int), hipMemcpyDeviceToHost, b->stream));
   b->phase_ms[2] = ms_since(q0);
-  // (behind this part's reconstruction in the queue, but in the group's FIRST part: everything the next parse needs to know -- whose clips are
-  // whose -- is settled once the group is resolved, and a parse enqueued only with the last part would leave the GPU waiting for the host between the parts)
+  // (what the next parse needs to know -- whose clips are whose -- is settled once the group is resolved: the clips that go back are sent with the first part)
   if (!S.returned) {
     S.returned = true;
     // 5. clips that go back to the device parsers (dp_return's rule, counted in frames): their state into the entry the next parse reads
@@ -1694,8 +1693,18 @@ int mobi_batch_gop_finish(mobi_batch *b, int32_t *offsets_out, int *rc) {
       if (int e = dp_return_list(b, back, b->ps_cur, S.h_ret, b->stream_p)) return e;
     }
   }
-  // 6. the group begun behind this one: its parse goes out now, behind this part's reconstruction steps
-  if (b->gop_count == 2) {
+  // 6. the group begun behind this one: its parse goes out behind the reconstruction steps of this group's LAST part.  Parse and reconstruction
+  // do not share the GPU (a full parse workgroup takes a CU's whole LDS), so the parse belongs where only the host is busy: a part's steps
+  // are waited for before the call returns, the caller's next move behind the last part is the gather and upload of the group after next
+  // (mobi_batch_gop_begin: tens of ms at 131 072 frames) -- with the parse in the queue the GPU works through that; with the parse sent out
+  // with the FIRST part (r06 until its last hours) it ran while the host sat in the second part's wait, and the GPU idled through the gather
+  // (4096 clips x 32 frames: 3.4 -> 2.9 - 3.2 ms per frame step; groups of one part are the same either way).
+  bool parse_now = last;
+#if defined(MOBI_PROFILING)
+  static const int parse_first = getenv("MOBI_GOP_PARSE_FIRST") ? atoi(getenv("MOBI_GOP_PARSE_FIRST")) : 0; // (A/B: with the group's first part)
+  if (parse_first) parse_now = true;
+#endif
+  if (b->gop_count == 2 && parse_now) {
     mobi_batch::GopSlot &N = b->gslot[(b->gop_head + 1) & 1];
     if (!N.parse_enqueued) {
       if (!S.ev_recon) HIP_TRY(hipEventCreateWithFlags(&S.ev_recon, hipEventDisableTiming));
