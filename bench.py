@@ -238,7 +238,7 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     b.close()
     out["pipelined"] = {"value": round(n_clips * W * H / tp / 1e3, 1), "unit": "Mpixels/s", "ms_per_step": round(tp, 3), "groups_timed": Gp - 2, "frames_per_group": Kp,
                         "how": f"mobi_batch_gop_begin of group g + 1 ({Kp} frames of every clip: gather, upload) before the mobi_batch_gop_finish calls of group g (hand-overs, "
-                               "reconstruction six frames per call, then the parse of group g + 1 beside it); wall time per frame step in the steady state (one group's parse is "
+                               "reconstruction six frames per call, the parse of group g + 1 behind the last part's); wall time per frame step in the steady state (one group's parse is "
                                "under way when the clock starts and one when it stops)",
                         "verified": verified_p}
     return out
