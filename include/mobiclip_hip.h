@@ -171,7 +171,8 @@ int mobi_batch_in_flight(const mobi_batch *b); /* steps submitted and not yet wa
  *   mobi_batch_gop_begin / mobi_batch_gop_finish: the same in two halves, for callers that keep the GPU fed: begin gathers and uploads a
  *                          group (and starts its parse when no group is in front of it) and returns; finish reports the OLDEST group
  *                          begun and not finished.  At most two groups may be begun: with group g + 1 begun before group g is finished,
- *                          its upload and parse run beside group g's reconstruction.  The batch must parse on the GPU (as for
+ *                          its upload runs beside group g's reconstruction and its parse goes out behind the steps of g's last part:
+ *                          the GPU parses while the caller gathers the group after next.  The batch must parse on the GPU (as for
  *                          mobi_batch_submit).  The ring turns in finish, once per frame; planes are read after finish.
  *                          A group begun this way may hold up to 32 frames -- what is parsed side by side is not bound by the ring, and
  *                          a small batch fills the parsers' lanes only with that many -- and finish hands them out SIX AT A TIME, oldest
