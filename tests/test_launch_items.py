@@ -64,3 +64,38 @@ def test_items_say_what_the_descriptors_say(cfg, kw):
             assert level[int(mb)] == 1 + max([level[x] for x in intra_deps], default=0)
             seen_deps += bool(flags & 2); seen_dependents += bool(flags & 4); seen_edge += bool(flags & 8)
     assert seen_deps and seen_dependents and seen_edge and len(seen_classes) >= 3
+
+
+def _intra_deps_by_frame(p):
+    data, fo = generate_clip(p)
+    d = InterpDecoder(p.width, p.height, p.version)
+    for f in range(p.n_frames):
+        d.Data, d.Offset = data[: fo[f + 1]], int(fo[f])
+        assert d.DecodeFrame() is not None
+        desc, mbs, _, _ = d.command_list()
+        for mb in mbs:
+            w = desc[mb, 4:8]
+            for dep in np.concatenate([w & 0xFFFF, w >> 16]):
+                if dep != DEP_NONE:
+                    yield int(mb), int(dep & 0x1FFF)
+
+
+@pytest.mark.parametrize("w,h,ver", [(96, 64, 1), (176, 144, 2), (336, 48, 1), (640, 480, 2), (848, 480, 2)])
+def test_every_halo_lies_on_an_earlier_wavefront_when_the_picture_is_narrower_than_its_stride(w, h, ver):
+    """what mobi_launch_gop_sort (mobi_gop.hip) relies on: ordered by mbx + 2 * mby, every macroblock a halo reads -- inter or intra -- comes
+    before the one that reads it (the lock-step parser's descriptors are these, tests/test_lsparse.py)"""
+    p = default_params("A", BASE_SEED + 6300, n_frames=3 if w < 600 else 2, width=w, height=h, version=ver, pm_intra=800, intra_sub_prob=600, iframe_interval=2)
+    mbw, n = w // 16, 0
+    for mb, dep in _intra_deps_by_frame(p):
+        assert dep % mbw + 2 * (dep // mbw) < mb % mbw + 2 * (mb // mbw), (mb, dep)
+        n += 1
+    assert n > 100
+
+
+def test_a_picture_as_wide_as_its_stride_wraps_to_a_later_wavefront():
+    """... and why 256-, 512-, 1024-wide pictures keep the raster-order launch: the first macroblock of a row reads the LAST one of the row
+    above (the reference's linear offsets with Stride == Width, MD.cs:212-217)"""
+    p = default_params("A", BASE_SEED + 6301, n_frames=2, width=256, height=64, pm_intra=900, iframe_interval=1)
+    mbw = p.width // 16
+    later = [(mb, dep) for mb, dep in _intra_deps_by_frame(p) if dep % mbw + 2 * (dep // mbw) >= mb % mbw + 2 * (mb // mbw)]
+    assert later and all(mb % mbw == 0 and dep == mb - 1 for mb, dep in later)
