@@ -1,7 +1,7 @@
 """Frame-parallel groups end to end (bitstreams in host memory -> planes in HBM): ms per frame step of mobi_batch_decode_gop and of the
 pipelined mobi_batch_gop_begin / mobi_batch_gop_finish, against the step-by-step calls.
 
-  python tools/exp_gop.py [clips] [K] [groups] [distinct] [config]
+  python tools/exp_gop.py [clips] [K] [groups] [distinct] [config]        (GOP_KP, GOP_GEN, GOP_MODE, GOP_STEPWISE: below)
 """
 import ctypes as C
 import os
@@ -23,9 +23,11 @@ mode = os.environ.get("GOP_MODE", "lockstep")
 mode = int(mode) if mode.isdigit() else mode
 
 n_frames = 1 + K * (groups + 3)
+# GOP_GEN="iframe_interval=30,pm_intra=100": generator overrides (an I-frame every 30 frames -- the same frames in every clip -- instead of P-frames only)
+gen_over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("GOP_GEN", "").split(",") if kv)}
 streams = []
 for i in range(distinct):
-    p = m.default_params(config, BASE_SEED + 100 + i, n_frames=n_frames)
+    p = m.default_params(config, BASE_SEED + 100 + i, n_frames=n_frames, **gen_over)
     streams.append((p,) + m.generate_clip(p))
 p0 = streams[0][0]
 W, H = p0.width, p0.height
