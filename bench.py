@@ -130,7 +130,8 @@ def end_to_end(m, streams, W, H, version, device, n_clips, n_steps, device_parse
     return out
 
 
-GOP_PARSE_MAX = 32  # frames per mobi_batch_gop_begin (MOBI_GOP_PARSE_MAX, mobi_gop.h)
+GOP_PARSE_MAX = 32  # frames per mobi_batch_gop_begin in this bench (the library takes up to MOBI_GOP_PARSE_MAX = 128, mobi_gop.h: batches of 1024 clips fill a turn
+# of the parser with that many; the two batches measured here fill one with 32 and with 5)
 GOP_K = 6  # frames per group: the ring holds six pictures (MD.cs:19-20), so every frame of a group is still readable when the call returns
 
 
@@ -142,7 +143,7 @@ def gop_leg(m, streams, W, H, version, device, n_clips, device_parse, K=None):
     import time as _t
     # How many frames per group.  The lock-step parser works in TURNS of 2048 waves (eight per CU), a wave is the cheaper per lane the fuller it
     # is, and a workgroup's LDS holds full waves of 64 lanes since the MV row cache left it (mobi_launch_parse_ls): the frames in flight should fill whole turns --
-    # n_clips x K close to a multiple of 2048 x 64 -- as far as K (6 per call, 32 per gop_begin) and HBM allow: a group's command lists
+    # n_clips x K close to a multiple of 2048 x 64 -- as far as K (6 per call, 32 per gop_begin here) and HBM allow: a group's command lists
     # are resident until it is reconstructed, worst-case payload room per frame (mobi_abi.cpp, gop_enqueue_parse).
     mbw, n_mbs = W // 16, (W // 16) * (H // 16)
     turn = 2048 * min(64, (160 * 1024 - 18400) // (8 * (96 + 128 + 40)))

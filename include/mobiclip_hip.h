@@ -174,11 +174,11 @@ int mobi_batch_in_flight(const mobi_batch *b); /* steps submitted and not yet wa
  *                          its upload runs beside group g's reconstruction and its parse goes out behind the steps of g's last part:
  *                          the GPU parses while the caller gathers the group after next.  The batch must parse on the GPU (as for
  *                          mobi_batch_submit).  The ring turns in finish, once per frame; planes are read after finish.
- *                          A group begun this way may hold up to 32 frames -- what is parsed side by side is not bound by the ring, and
+ *                          A group begun this way may hold up to 128 frames -- what is parsed side by side is not bound by the ring, and
  *                          a small batch fills the parsers' lanes only with that many -- and finish hands them out SIX AT A TIME, oldest
  *                          first: every call reconstructs and reports min(6, mobi_batch_gop_frames_pending(b)) frames of the oldest group
  *                          (rc / offsets_out [j * n_clips + c], j counted from the part's first frame; that part's frame j sits at ring
- *                          index part_size - 1 - j afterwards), so a group of 12 is finished by two calls, one of 32 by six.
+ *                          index part_size - 1 - j afterwards), so a group of 12 is finished by two calls, one of 32 by six, one of 128 by 22.
  * mobi_batch_decode / mobi_batch_submit are refused (MOBI_E_ARG) while a group is begun and not finished. */
 int mobi_batch_decode_gop(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
 int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, const int32_t *offsets);

@@ -28,7 +28,7 @@
 #include "mobi_state.h"
 
 #define MOBI_GOP_MAX 6 /* the ring holds six pictures (MD.cs:19-20): every frame of a group is still there when the call returns */
-#define MOBI_GOP_PARSE_MAX 32 /* mobi_batch_gop_begin: frames parsed side by side (4096 clips x 32 = one turn of full waves of the lock-step parser); mobi_batch_gop_finish hands them out six at a time */
+#define MOBI_GOP_PARSE_MAX 128 /* mobi_batch_gop_begin: frames parsed side by side (one turn of full waves of the lock-step parser = 131 072: 4096 clips x 32, 1024 x 128); mobi_batch_gop_finish hands them out six at a time */
 #define MOBI_GOP_RC_CHAIN (-99) /* MobiDevResult.rc of a frame whose start state was predicted wrong (device-private: the host parser takes over) */
 #define MOBI_MC_UNWRITTEN 0xFFu
 

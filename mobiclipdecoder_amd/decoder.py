@@ -311,7 +311,7 @@ class MobiclipBatch:
 
     def gop_finish(self):
         """second half, for the OLDEST group begun: hand-overs, the reconstruction steps; -> (rc, offsets) as decode_gop().  A group of more
-        than six frames (gop_begin takes up to 32) is handed out six at a time: call again while gop_frames_pending() > 0."""
+        than six frames (gop_begin takes up to 128) is handed out six at a time: call again while gop_frames_pending() > 0."""
         K = min(6, self._lib.mobi_batch_gop_frames_pending(self._h))
         offs = (C.c_int32 * (K * self.n))()
         rcs = (C.c_int * (K * self.n))()

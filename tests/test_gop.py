@@ -229,11 +229,16 @@ def test_groups_of_twelve_parsed_at_once_finished_six_at_a_time(mode):
 
 
 @pytest.mark.parametrize("mode", [True, "lockstep"])
-def test_groups_of_thirty_two(mode):
-    """the most mobi_batch_gop_begin takes (MOBI_GOP_PARSE_MAX): 32 frames parsed side by side, handed out by six finish calls (33 are refused: test_argument_checks)"""
+def test_groups_of_thirty_two_and_of_a_hundred_and_twenty_eight(mode):
+    """32 frames parsed side by side, handed out by six finish calls; and the most mobi_batch_gop_begin takes (MOBI_GOP_PARSE_MAX): 128, by
+    22 calls (129 are refused: test_argument_checks)"""
     ps = [default_params("A", BASE_SEED + 8200 + i, n_frames=72, width=96, height=64, pm_intra=100, pm_multiref=300, iframe_interval=11, qdelta_prob=300) for i in range(5)]
     clips = [generate_clip(p) for p in ps]
     n_err, hc = _run_groups(clips, ps[0], [32, 32, 7], mode, pipelined=True)
+    assert n_err == 0 and hc == 0
+    ps = [default_params("A", BASE_SEED + 8300 + i, n_frames=1 + 128 + 128 + 20, width=96, height=64, pm_intra=100, pm_multiref=300, iframe_interval=37, qdelta_prob=300) for i in range(3)]
+    clips = [generate_clip(p) for p in ps]
+    n_err, hc = _run_groups(clips, ps[0], [1, 128, 128, 20], mode, pipelined=True)
     assert n_err == 0 and hc == 0
 
 
@@ -349,5 +354,5 @@ def test_argument_checks():
         b.gop_begin(_frames(clips, 4, 2))  # at most two
     assert b.gop_finish()[0] == [[0], [0]] and b.gop_finish()[0] == [[0], [0]]
     with pytest.raises(Exception):
-        b.gop_begin(_frames(clips * 1, 0, 1) * 33)  # more than MOBI_GOP_PARSE_MAX frames
+        b.gop_begin(_frames(clips * 1, 0, 1) * 129)  # more than MOBI_GOP_PARSE_MAX frames
     b.close()

@@ -70,7 +70,7 @@ print(f"{clips} clips x K={K} ({config}, {distinct} distinct, mode {mode}): mobi
       f"(groups: {[round(x, 1) for x in ms]} ms); host clips {b.host_clips()}, lock-step finished {b.lockstep_finished()} of {nv}")
 b.close()
 
-# pipelined: GOP_KP frames per group (default K; up to 32: what is parsed side by side is not bound by the ring, finish hands out six at a time)
+# pipelined: GOP_KP frames per group (default K; up to 128: what is parsed side by side is not bound by the ring, finish hands out six at a time)
 KP = int(os.environ.get("GOP_KP", K))
 GP = (groups + 3) * K // KP
 ppacks = packs if KP == K else [packed_group(1 + KP * i, KP) for i in range(GP)]

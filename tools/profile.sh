@@ -44,7 +44,7 @@ timeout 300 python $REPO/tools/exp_async.py 4096 12 > "$OUT/async.txt" 2>&1
 # r06: frame-parallel groups (mobi_batch_decode_gop / gop_begin + gop_finish) end to end, the lock-step parser's lanes x waves under n * K virtual clips,
 # and the two all-host situations (a ModsDS batch below quantiser 12; every clip handed over in one frame of an asynchronous batch)
 # (the product library: the profiling twin's kernels carry their stage-stop tests; one run on the twin for where a group's time goes)
-{ for NK in "1024 6 32 24" "1024 6 12 9" "2048 6 32 24" "4096 6 32 24" "4096 6 12 9" "4096 6 6 9" "8192 6 15 12" "8192 6 6 9" "16384 4 8 9" "24576 5 5 9" "24576 4 4 9" "24576 6 6 9"; do set -- $NK; GOP_KP=$3 timeout 400 python $REPO/tools/exp_gop.py $1 $2 $4 64; done; # (clips, K of the synchronous call, frames per gop_begin, groups of K: at least three timed groups of the pipelined part)
+{ for NK in "256 6 128 107" "512 6 128 107" "1024 6 128 107" "1024 6 32 24" "1024 6 12 9" "2048 6 64 64" "2048 6 32 24" "4096 6 32 24" "4096 6 12 9" "4096 6 6 9" "8192 6 15 12" "8192 6 6 9" "16384 4 8 9" "24576 5 5 9" "24576 4 4 9" "24576 6 6 9"; do set -- $NK; GOP_KP=$3 timeout 400 python $REPO/tools/exp_gop.py $1 $2 $4 64; done; # (clips, K of the synchronous call, frames per gop_begin, groups of K: at least three timed groups of the pipelined part)
   echo "== on the profiling twin (events around the parse kernels)"; MOBI_LIB=$REPO/mobiclipdecoder_amd/libmobiclip_hip_prof.so GOP_STEPWISE=0 timeout 400 python $REPO/tools/exp_gop.py 24576 5 5 64;
   MOBI_LIB=$REPO/mobiclipdecoder_amd/libmobiclip_hip_prof.so GOP_STEPWISE=0 timeout 400 python $REPO/tools/exp_gop.py 4096 6 5 64; } > "$OUT/gop.txt" 2>&1
 ( cd $REPO && LW="24,8 28,8 35,8 64,4 15,8 24,4" timeout 900 tools/exp_gop_lanes.sh 24576 6 ) > "$OUT/gop_lanes.txt" 2>&1
