@@ -179,6 +179,9 @@ int mobi_batch_in_flight(const mobi_batch *b); /* steps submitted and not yet wa
  *                          first: every call reconstructs and reports min(6, mobi_batch_gop_frames_pending(b)) frames of the oldest group
  *                          (rc / offsets_out [j * n_clips + c], j counted from the part's first frame; that part's frame j sits at ring
  *                          index part_size - 1 - j afterwards), so a group of 12 is finished by two calls, one of 32 by six, one of 128 by 22.
+ *                          What a group writes lives in HBM until it is reconstructed (per frame of it about 40 KB of descriptors and
+ *                          items and the worst-case payload part, 0.3 - 0.5 MB at 640x480): a group that does not fit is refused by
+ *                          mobi_batch_gop_begin (the allocator's error, nothing enqueued, the batch goes on).
  * mobi_batch_decode / mobi_batch_submit are refused (MOBI_E_ARG) while a group is begun and not finished. */
 int mobi_batch_decode_gop(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, int32_t *offsets, int *rc);
 int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data, const size_t *len, const int32_t *offsets);

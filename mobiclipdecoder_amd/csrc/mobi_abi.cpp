@@ -1321,19 +1321,12 @@ int mobi_batch_wait(mobi_batch *b, int32_t *offsets_out, int *rc) {
 // n * K virtual clips for the parse kernels, whose cost per frame falls with the number of lanes they are given -- and
 // reconstructed as K steps in order.  begin: gather + upload (and, when nothing else is in flight, the parse); finish: the host parser's
 // share and every hand-over, the K reconstruction steps, and the parse of the group begun behind it.
-static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S, hipEvent_t after = nullptr) {
+// Everything a group's parse and reconstruction write, sized when the group is BEGUN: a group that does not fit is refused by
+// mobi_batch_gop_begin, with nothing enqueued (the parse of a group begun behind another goes out inside that one's mobi_batch_gop_finish:
+// an allocation failing there would leave rings and parsers out of step).
+static int gop_reserve(mobi_batch *b, mobi_batch::GopSlot &S) {
   const int n = b->n, K = S.K, n_mbs = b->g.mbw * b->g.mbh;
   const size_t nv = (size_t)n * K;
-  S.is_host.assign(b->on_host.begin(), b->on_host.end());
-  uint32_t *blen = (uint32_t *)(S.h_stage.p + nv * 8);
-  DpStaged st;
-  for (size_t v = 0; v < nv; v++) {
-    if (S.is_host[v % n]) { blen[v] = MOBI_DP_SKIP; continue; }
-    blen[v] = S.lens[v];
-    st.n_dev++;
-    st.n_iframes += S.lens[v] >= 2 && (S.h_stage.p[S.hdr_bytes + S.boff[v] + 1] & 0x80) != 0;
-  }
-  S.lockstep = ls_decide(b, st);
   if (S.max_len > b->dp_len_hint) b->dp_len_hint = S.max_len + S.max_len / 4;
   const size_t cap_words = std::min<size_t>((size_t)n_mbs * 448 + MOBI_WIDE_PARAMS, (size_t)n_mbs * 64 + (8 * b->dp_len_hint + 2) / 3) + 448 + 64; // (dp_parse has the bound's reasons)
   S.cap_words = cap_words;
@@ -1353,6 +1346,22 @@ static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S, hipEvent_t a
   }
   if (int e = S.h_res.reserve(nv * sizeof(MobiDevResult))) return e;
   if (int e = S.h_fault.reserve(nv * sizeof(int))) return e;
+  return MOBI_OK;
+}
+static int gop_enqueue_parse(mobi_batch *b, mobi_batch::GopSlot &S, hipEvent_t after = nullptr) {
+  const int n = b->n, K = S.K;
+  const size_t nv = (size_t)n * K;
+  S.is_host.assign(b->on_host.begin(), b->on_host.end());
+  uint32_t *blen = (uint32_t *)(S.h_stage.p + nv * 8);
+  DpStaged st;
+  for (size_t v = 0; v < nv; v++) {
+    if (S.is_host[v % n]) { blen[v] = MOBI_DP_SKIP; continue; }
+    blen[v] = S.lens[v];
+    st.n_dev++;
+    st.n_iframes += S.lens[v] >= 2 && (S.h_stage.p[S.hdr_bytes + S.boff[v] + 1] & 0x80) != 0;
+  }
+  S.lockstep = ls_decide(b, st);
+  const size_t cap_words = S.cap_words; // (gop_reserve, when the group was begun)
   hipStream_t ps = b->stream_p;
   HIP_TRY(hipStreamWaitEvent(ps, S.ev_up, 0));
   // `after`: the reconstruction steps just enqueued for the group in front go FIRST.  A full parse workgroup takes a CU's whole LDS (36 lanes x
@@ -1482,6 +1491,7 @@ int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data
   S.parse_enqueued = false;
   S.resolved = S.returned = false;
   S.done = 0;
+  if (int e = gop_reserve(b, S)) { (void)hipStreamSynchronize(b->stream2); return e; } // (does not fit: refused, nothing of it is in flight)
   b->gop_count++;
   if (b->gop_count == 1) // nothing in front: the parse may start at once (else mobi_batch_gop_finish of the group in front enqueues it, once it knows whose clips are whose)
     if (int e = gop_enqueue_parse(b, S)) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamSynchronize(b->stream_p); b->gop_count--; return e; }

@@ -242,6 +242,37 @@ def test_groups_of_thirty_two_and_of_a_hundred_and_twenty_eight(mode):
     assert n_err == 0 and hc == 0
 
 
+def test_a_group_that_does_not_fit_is_refused_when_it_is_begun():
+    """8192 clips x 128 frames of 640x480 command lists are 380 GB: mobi_batch_gop_begin says so (out of memory) with nothing enqueued --
+    not the mobi_batch_gop_finish of the group in front, which would have to give the batch up -- and the batch goes on"""
+    from mobiclipdecoder_amd.decoder import MobiclipError
+    n = 8192
+    p = default_params("B", BASE_SEED + 8400, n_frames=4)
+    d, fo = generate_clip(p)
+    b = MobiclipBatch(n, p.width, p.height, p.version, device_parse="lockstep")
+    row = lambda f: [d[int(fo[f]):int(fo[f + 1])]] * n
+    rcs, _ = b.decode_gop([row(0)])
+    assert not any(rcs[0])
+    b.gop_begin([row(1)])  # a group in front: the next one's parse would go out inside its finish
+    tiny = np.zeros(2, np.uint8)
+    with pytest.raises(MobiclipError, match="memory"):
+        b.gop_begin([[tiny] * n] * 128)
+    assert b.gop_frames_pending() == 1
+    rcs, _ = b.gop_finish()
+    assert not any(rcs[0]) and b.gop_frames_pending() == 0
+    rcs, _ = b.decode_gop([row(2), row(3)])
+    assert not any(rcs[0]) and not any(rcs[1])
+    o = OracleDecoder(p.width, p.height, p.version)
+    for f in range(4):
+        o.Data, o.Offset = d[int(fo[f]):int(fo[f + 1])], 0
+        assert o.DecodeFrame() is not None
+    for c in (0, n - 1):
+        y, uv = b.planes(c, 0)
+        assert np.array_equal(y[:, :p.width], o.y(0)[:, :p.width]) and np.array_equal(uv, o.uv(0))
+    o.close()
+    b.close()
+
+
 def test_a_glitch_in_the_second_half_of_a_group_of_twelve():
     ps = [default_params("A", BASE_SEED + 7650 + i, n_frames=25, width=96, height=64, pm_intra=100, iframe_interval=6) for i in range(6)]
     clips = []
