@@ -87,8 +87,8 @@ def finish():
     while pending > 0:
         part = min(6, pending)
         e = lib.mobi_batch_gop_finish(h, outo, rcs)
-        bad = [(j, rcs[j]) for j in range(part * clips) if rcs[j]]
-        assert e == 0 and not bad, (e, b._lib.mobi_error_string(e), len(bad), bad[:8])
+        bad = np.flatnonzero(np.frombuffer(rcs, dtype=np.int32)[:part * clips])
+        assert e == 0 and not bad.size, (e, b._lib.mobi_error_string(e), bad.size, [(int(j), rcs[j]) for j in bad[:8]])
         pending -= part
 
 
