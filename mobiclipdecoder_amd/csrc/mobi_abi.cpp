@@ -1475,13 +1475,14 @@ int mobi_batch_gop_begin(mobi_batch *b, int n_frames, const uint8_t *const *data
       const size_t u0 = k >= 1 ? nv * (k - 1) / chunks : 0, u1 = k >= 1 ? nv * k / chunks : 0;
       const int n_up = u1 > u0 ? 1 : 0;
       if (n_up + (c1 - c0) == 0) continue;
-      b->pool->run(n_up + (int)(c1 - c0), [&](int j) {
+      constexpr size_t kRun = 64; // frames per task: one per frame had the pool's threads queue at its counter (122 880 frames of 256x192: 8 ms)
+      b->pool->run(n_up + (int)((c1 - c0 + kRun - 1) / kRun), [&](int j) {
         if (j < n_up) {
           const size_t a = start_of(u0), e = start_of(u1);
           if (e > a && (hipSetDevice(b->device) != hipSuccess || hipMemcpyAsync(S.d_bits.p + a, hs + a, e - a, hipMemcpyHostToDevice, b->stream2) != hipSuccess)) up_err = 1;
           return;
         }
-        gather(c0 + (size_t)(j - n_up));
+        for (size_t v = c0 + (size_t)(j - n_up) * kRun, e = std::min(c1, v + kRun); v < e; v++) gather(v);
       });
     }
     if (up_err) { (void)hipStreamSynchronize(b->stream2); return MOBI_E_DEVICE; }
