@@ -744,8 +744,9 @@ static int dp_stage(mobi_batch *b, const uint8_t *const *data, const size_t *len
     if (blen[i]) memcpy(dst, data[i] + offsets[i], blen[i]);
     memset(dst + blen[i], 0, align_up(blen[i] + kBitPad, 8) - blen[i]);
   };
+  constexpr int kRun = 32; // frames per pool task (one per frame has the pool's threads queue at its counter: gop_begin measured it)
   if (!dev) {
-    b->pool->run(nd, gather);
+    b->pool->run((nd + kRun - 1) / kRun, [&](int j) { for (int i = j * kRun, e = std::min(nd, i + kRun); i < e; i++) gather(i); });
   } else {
     const size_t need = hdr_bytes + pos;
     if (need > dev->cap) // growing frees and allocates (a device-wide stall): asynchronous steps leave room for the longer frames to come
@@ -758,13 +759,13 @@ static int dp_stage(mobi_batch *b, const uint8_t *const *data, const size_t *len
       const int u0 = k >= 1 ? (int)((long)nd * (k - 1) / chunks) : 0, u1 = k >= 1 ? (int)((long)nd * k / chunks) : 0; // gathered in the round before
       const int n_up = u1 > u0 ? 1 : 0;
       if (n_up + (c1 - c0) == 0) continue;
-      b->pool->run(n_up + (c1 - c0), [&](int j) {
+      b->pool->run(n_up + (c1 - c0 + kRun - 1) / kRun, [&](int j) {
         if (j < n_up) {
           const size_t a = u0 == 0 ? 0 : end_of(u0), e = end_of(u1); // (the first chunk takes the header along)
           if (e > a && (hipSetDevice(b->device) != hipSuccess || hipMemcpyAsync(dev->p + a, hs + a, e - a, hipMemcpyHostToDevice, up) != hipSuccess)) up_err = 1;
           return;
         }
-        gather(c0 + (j - n_up));
+        for (int i = c0 + (j - n_up) * kRun, e = std::min(c1, i + kRun); i < e; i++) gather(i);
       });
     }
     if (up_err) return MOBI_E_DEVICE;
