@@ -879,6 +879,14 @@ def main():
             "timed_region_s": round(elapsed, 3), "clock_state": "sustained" if elapsed >= 1.0 else "unsettled (timed region < 1 s)",
             "verified": verified, "ranks": rank_report, "roofline": roof, "cpu_baseline": base, "end_to_end": e2e, "end_to_end_large": e2e_large, "end_to_end_xl": e2e_xl, "end_to_end_all_ranks": e2e_all, "config4": c4, "single_stream": single, "bitmap": bitmap, "content_lowfreq": content,
         }
+        # the end-to-end legs in one place (Mpixels/s from bitstreams in host memory; each leg's own entry says how it was measured)
+        def _leg(e):
+            if not e or "value" not in e:
+                return None
+            g = e.get("groups") or {}
+            return {"clips": e.get("clips"), "call_per_frame": e.get("value"), "two_steps_in_flight": (e.get("async") or {}).get("value"),
+                    "groups": g.get("value"), "groups_pipelined": (g.get("pipelined") or {}).get("value"), "frames_per_gop_begin": (g.get("pipelined") or {}).get("frames_per_group")}
+        out["end_to_end_summary"] = {k: _leg(v) for k, v in (("end_to_end", e2e), ("end_to_end_large", e2e_large), ("end_to_end_xl", e2e_xl)) if _leg(v)} or None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
